@@ -1,0 +1,353 @@
+"""halo2_regex_amd — MI355X-native batched DFA witness generator for the halo2-regex chip.
+
+Python here is a thin ctypes binding over the C ABI in include/hrx.h (libhrx.so, built from
+halo2_regex_amd/csrc by hipcc for gfx950).  The class and method names mirror the reference's
+Rust surface for the path (src/defs.rs, src/table.rs, src/lib.rs:96-113,311-318,766-888) so that the
+parity tests read like the reference's own tests.  There is no CPU implementation of the compute
+path: without the HIP library the import fails, and without a gfx950 device RegexVerifyConfig raises.
+"""
+import ctypes as C
+import os
+
+# torch must be imported before libhrx.so: both need libamdhip64.so.7 and the process must end up with
+# ONE HIP runtime (torch's bundled copy wins by SONAME when it is loaded first), otherwise device
+# pointers of torch tensors would belong to a different runtime than the one launching the kernels.
+import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhrx.so")
+
+HRX_OK = 0
+HRX_ERR_PARSE, HRX_ERR_BOUNDS, HRX_ERR_ARG, HRX_ERR_HIP, HRX_ERR_STATE = 1, 2, 3, 4, 5
+HRX_ERR_INVALID_TRANSITION, HRX_ERR_OUT_OF_CONTRACT, HRX_ERR_IO = 6, 7, 8
+
+#: every symbol include/hrx.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = [
+    "hrx_defs_create", "hrx_defs_destroy", "hrx_defs_push_allstr_text", "hrx_defs_push_allstr_file",
+    "hrx_defs_push_substr_text", "hrx_defs_push_substr_file", "hrx_defs_push_allstr", "hrx_defs_push_substr",
+    "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
+    "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
+    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count",
+    "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_host",
+    "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
+]
+
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_u16p = C.POINTER(C.c_uint16)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class HrxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "halo2_regex_amd: %s is missing — build it with `make -C halo2_regex_amd/csrc` "
+            "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u64, i = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
+    sig = {
+        "hrx_defs_create": (i, [C.POINTER(vp)]),
+        "hrx_defs_destroy": (None, [vp]),
+        "hrx_defs_push_allstr_text": (i, [vp, C.c_char_p, sz]),
+        "hrx_defs_push_allstr_file": (i, [vp, C.c_char_p]),
+        "hrx_defs_push_substr_text": (i, [vp, C.c_char_p, sz]),
+        "hrx_defs_push_substr_file": (i, [vp, C.c_char_p]),
+        "hrx_defs_push_allstr": (i, [vp, u64, u64, u64, sz, _u64p, _u64p, _u8p, _u64p]),
+        "hrx_defs_push_substr": (i, [vp, sz, _u64p, _u64p, sz, _u64p, sz, _u64p]),
+        "hrx_defs_finalize": (i, [vp]),
+        "hrx_defs_num_defs": (sz, [vp]),
+        "hrx_defs_num_substrs": (sz, [vp, sz]),
+        "hrx_defs_first_state": (u64, [vp, sz]),
+        "hrx_defs_accepted_state": (u64, [vp, sz]),
+        "hrx_defs_largest_state": (u64, [vp, sz]),
+        "hrx_defs_num_transitions": (sz, [vp, sz]),
+        "hrx_defs_substr_id_offset": (u64, [vp, sz]),
+        "hrx_defs_table_bytes": (sz, [vp]),
+        "hrx_table_transition_rows": (sz, [vp, sz, _u64p, sz]),
+        "hrx_table_endpoint_rows": (sz, [vp, sz, _u64p, sz]),
+        "hrx_device_count": (i, [C.POINTER(i)]),
+        "hrx_ctx_create": (i, [vp, i, C.POINTER(vp)]),
+        "hrx_ctx_destroy": (None, [vp]),
+        "hrx_last_error": (C.c_char_p, []),
+        "hrx_witness_batch_device": (i, [vp, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
+        "hrx_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
+        "hrx_shard_range": (None, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
+        "hrx_derive_states": (i, [vp, _u8p, sz, _u64p]),
+        "hrx_derive_substr_ids": (i, [vp, _u64p, sz, _u64p]),
+        "hrx_derive_is_start_end": (i, [vp, _u64p, _u64p, sz, _u8p, _u8p]),
+        "hrx_match_substrs": (i, [vp, _u8p, sz, sz] + [_u64p] * 9),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc):
+    if rc != HRX_OK:
+        raise HrxError(rc, lib.hrx_last_error().decode("utf-8", "replace"))
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+# ---------------------------------------------------------------------------------------------
+# data model — src/defs.rs
+# ---------------------------------------------------------------------------------------------
+class AllstrRegexDef:
+    """AllstrRegexDef (src/defs.rs:26-36): holds the definition text; parsing happens in C."""
+
+    def __init__(self, text):
+        self.text = text.encode() if isinstance(text, str) else bytes(text)
+
+    @classmethod
+    def read_from_text(cls, file_path):  # defs.rs:54-58
+        with open(file_path, "rb") as f:
+            return cls(f.read())
+
+
+class SubstrRegexDef:
+    """SubstrRegexDef (src/defs.rs:115-132)."""
+
+    def __init__(self, text):
+        self.text = text.encode() if isinstance(text, str) else bytes(text)
+
+    @classmethod
+    def read_from_text(cls, file_path):  # defs.rs:184-188
+        with open(file_path, "rb") as f:
+            return cls(f.read())
+
+    @classmethod
+    def new(cls, max_length, min_position, max_position, valid_state_transitions, start_states, end_states):
+        """SubstrRegexDef::new (defs.rs:147-163), rendered to the text format of defs.rs:165-177."""
+        lines = [str(max_length), str(min_position), str(max_position),
+                 " ".join(str(s) for s in start_states), " ".join(str(s) for s in end_states)]
+        lines += ["%d %d" % (a, b) for a, b in sorted(valid_state_transitions)]
+        return cls("\n".join(lines) + "\n")
+
+
+class RegexDefs:
+    """RegexDefs { allstr, substrs } (src/defs.rs:17-22)."""
+
+    def __init__(self, allstr, substrs):
+        self.allstr = allstr
+        self.substrs = list(substrs)
+
+
+class _DefsHandle:
+    def __init__(self, regex_defs):
+        self.h = C.c_void_p()
+        _check(lib.hrx_defs_create(C.byref(self.h)))
+        try:
+            for rd in regex_defs:
+                _check(lib.hrx_defs_push_allstr_text(self.h, rd.allstr.text, len(rd.allstr.text)))
+                for sd in rd.substrs:
+                    _check(lib.hrx_defs_push_substr_text(self.h, sd.text, len(sd.text)))
+            _check(lib.hrx_defs_finalize(self.h))
+        except Exception:
+            lib.hrx_defs_destroy(self.h)
+            self.h = None
+            raise
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.hrx_defs_destroy(self.h)
+            self.h = None
+
+
+class RegexTableConfig:
+    """The integer rows RegexTableConfig::load assigns (src/table.rs:61-198)."""
+
+    def __init__(self, defs_handle, def_idx):
+        self._d = defs_handle
+        self.def_idx = def_idx
+
+    def transition_rows(self):
+        n = lib.hrx_table_transition_rows(self._d.h, self.def_idx, None, 0)
+        rows = np.zeros((n, 4), np.uint64)
+        lib.hrx_table_transition_rows(self._d.h, self.def_idx, _ptr(rows, _u64p), n)
+        return rows
+
+    def endpoint_rows(self):
+        n = lib.hrx_table_endpoint_rows(self._d.h, self.def_idx, None, 0)
+        rows = np.zeros((n, 3), np.uint64)
+        lib.hrx_table_endpoint_rows(self._d.h, self.def_idx, _ptr(rows, _u64p), n)
+        return rows
+
+
+class AssignedRegexResult:
+    """Integer content of AssignedRegexResult (src/lib.rs:79-93) plus the per-def advice columns."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib.hrx_device_count(C.byref(n)))
+    return n.value
+
+
+def shard_range(B, world, rank):
+    b, c = C.c_size_t(0), C.c_size_t(0)
+    lib.hrx_shard_range(B, world, rank, C.byref(b), C.byref(c))
+    return b.value, c.value
+
+
+class RegexVerifyConfig:
+    """Witness-side mirror of RegexVerifyConfig (src/lib.rs:96-113).
+
+    configure() takes what the reference's configure (lib.rs:126-131) takes minus the halo2 objects
+    (ConstraintSystem, FlexGateConfig): max_chars_size and the Vec<RegexDefs>.  `device=None` builds the
+    host-side tables only (table rows, constants); any compute call then raises.
+    """
+
+    def __init__(self, max_chars_size, regex_defs, device=0):
+        self.max_chars_size = int(max_chars_size)
+        self.regex_defs = list(regex_defs)      # pub field, lib.rs:112
+        self._defs = _DefsHandle(self.regex_defs)
+        self.num_defs = lib.hrx_defs_num_defs(self._defs.h)
+        self.table_array = [RegexTableConfig(self._defs, d) for d in range(self.num_defs)]
+        self._ctx = None
+        self.device = device
+        if device is not None:
+            ctx = C.c_void_p()
+            _check(lib.hrx_ctx_create(self._defs.h, int(device), C.byref(ctx)))
+            self._ctx = ctx
+
+    @classmethod
+    def configure(cls, max_chars_size, regex_defs, device=0):
+        return cls(max_chars_size, regex_defs, device)
+
+    def __del__(self):
+        if getattr(self, "_ctx", None):
+            lib.hrx_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def _need_ctx(self):
+        if not self._ctx:
+            raise HrxError(HRX_ERR_HIP, "no device context: the witness path runs on a gfx950 GPU only")
+        return self._ctx
+
+    # -- lookup tables: RegexVerifyConfig::load (lib.rs:779-785) ---------------------------------
+    def load(self):
+        """Returns per def (transition_rows, endpoint_rows) in table.rs assignment order."""
+        return [(t.transition_rows(), t.endpoint_rows()) for t in self.table_array]
+
+    def substr_id_offset(self, d):
+        return lib.hrx_defs_substr_id_offset(self._defs.h, d)
+
+    def accepted_state(self, d):
+        return lib.hrx_defs_accepted_state(self._defs.h, d)
+
+    def table_bytes(self):
+        return lib.hrx_defs_table_bytes(self._defs.h)
+
+    # -- the three derive_* of lib.rs:804-888 -----------------------------------------------------
+    def derive_states(self, characters):
+        ch = np.frombuffer(bytes(characters), dtype=np.uint8)
+        n = len(ch)
+        states = np.zeros((self.num_defs, n + 1), np.uint64)
+        _check(lib.hrx_derive_states(self._need_ctx(), _ptr(ch, _u8p) if n else None, n, _ptr(states, _u64p)))
+        return states
+
+    def derive_substr_ids(self, states):
+        states = _np(states, np.uint64)
+        n = states.shape[1] - 1
+        out = np.zeros((self.num_defs, n), np.uint64)
+        _check(lib.hrx_derive_substr_ids(self._need_ctx(), _ptr(states, _u64p), n, _ptr(out, _u64p)))
+        return out
+
+    def derive_is_start_end(self, states, substr_ids):
+        states = _np(states, np.uint64)
+        substr_ids = _np(substr_ids, np.uint64)
+        n = states.shape[1] - 1
+        st = np.zeros((self.num_defs, n + 1), np.uint8)
+        en = np.zeros((self.num_defs, n + 1), np.uint8)
+        _check(lib.hrx_derive_is_start_end(self._need_ctx(), _ptr(states, _u64p), _ptr(substr_ids, _u64p), n,
+                                           _ptr(st, _u8p), _ptr(en, _u8p)))
+        return st.astype(bool), en.astype(bool)
+
+    # -- match_substrs (lib.rs:311-773), integer columns ------------------------------------------
+    def match_substrs(self, characters):
+        ch = np.frombuffer(bytes(characters), dtype=np.uint8)
+        n, M, D = len(ch), self.max_chars_size, self.num_defs
+        cols = {k: np.zeros(M, np.uint64) for k in ("enable", "character", "masked_char", "masked_substr_id")}
+        for k in ("state", "substr_id", "start_enable", "end_enable"):
+            cols[k] = np.zeros((D, M), np.uint64)
+        status = np.zeros(1, np.uint64)
+        _check(lib.hrx_match_substrs(self._need_ctx(), _ptr(ch, _u8p) if n else None, n, M,
+                                     *[_ptr(cols[k], _u64p) for k in ("enable", "character", "state", "substr_id",
+                                                                       "start_enable", "end_enable", "masked_char",
+                                                                       "masked_substr_id")], _ptr(status, _u64p)))
+        return AssignedRegexResult(all_enable_flags=cols["enable"], all_characters=cols["character"],
+                                   all_substr_ids=cols["masked_substr_id"], masked_characters=cols["masked_char"],
+                                   states=cols["state"], substr_ids=cols["substr_id"],
+                                   start_enables=cols["start_enable"], end_enables=cols["end_enable"],
+                                   status=int(status[0]))
+
+    # -- the batch surface (the build's addition; parity is per string with match_substrs) --------
+    def witness_batch_host(self, chars2d, lens):
+        """chars2d (B, stride) uint8 numpy, lens (B,) -> records (B,M,D) u32, masked (B,M) u16, status (B,) u64."""
+        chars2d = _np(chars2d, np.uint8)
+        lens = _np(lens, np.uint32)
+        B, stride = chars2d.shape
+        M, D = self.max_chars_size, self.num_defs
+        rec = np.zeros((B, M, D), np.uint32)
+        msk = np.zeros((B, M), np.uint16)
+        st = np.zeros(B, np.uint64)
+        _check(lib.hrx_witness_batch_host(self._need_ctx(), _ptr(chars2d, _u8p), stride, _ptr(lens, _u32p), B, M,
+                                          _ptr(rec, _u32p), _ptr(msk, _u16p), _ptr(st, _u64p)))
+        return rec, msk, st
+
+    def alloc_outputs(self, B, device=None):
+        """Device buffers for witness_batch: records int32 (B,M,D), masked int16 (B,M), status int64 (B,)."""
+        dev = torch.device("cuda", self.device) if device is None else device
+        M, D = self.max_chars_size, self.num_defs
+        return (torch.empty((B, M, D), dtype=torch.int32, device=dev),
+                torch.empty((B, M), dtype=torch.int16, device=dev),
+                torch.empty((B,), dtype=torch.int64, device=dev))
+
+    def witness_batch(self, chars, lens, out=None, stream=None):
+        """Device-resident batch: chars (B, stride) uint8 CUDA tensor (stride % 16 == 0), lens (B,) int32 CUDA tensor.
+        Asynchronous on `stream` (default: torch's current stream).  Returns (records, masked, status) tensors whose
+        bit patterns are the u32/u16/u64 layouts of include/hrx.h."""
+        assert chars.is_cuda and lens.is_cuda and chars.dtype == torch.uint8 and lens.dtype == torch.int32
+        assert chars.is_contiguous() and lens.is_contiguous()
+        B, stride = chars.shape
+        if out is None:
+            out = self.alloc_outputs(B, chars.device)
+        rec, msk, st = out
+        s = torch.cuda.current_stream(chars.device) if stream is None else stream
+        _check(lib.hrx_witness_batch_device(self._need_ctx(), chars.data_ptr(), stride, lens.data_ptr(), B,
+                                            self.max_chars_size, rec.data_ptr(), msk.data_ptr(), st.data_ptr(),
+                                            s.cuda_stream))
+        return rec, msk, st
+
+
+def decode_status(s):
+    s = int(s) & 0xFFFFFFFFFFFFFFFF
+    code = s & 0xff
+    if code == 0:
+        return {"code": 0, "accept": (s >> 8) & 0xff}
+    if code == 1:
+        return {"code": 1, "def": (s >> 8) & 0xff, "char": (s >> 16) & 0xff, "state": (s >> 24) & 0xffff, "pos": s >> 40}
+    if code == 2:
+        return {"code": 2, "pos": s >> 40}
+    return {"code": code}

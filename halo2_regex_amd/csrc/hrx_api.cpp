@@ -1,0 +1,456 @@
+// hrx_api.cpp — the C ABI (include/hrx.h) over the host data model and the HIP kernels.
+// There is deliberately no CPU implementation of the compute entry points: without a gfx950
+// device they fail with HRX_ERR_HIP.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/hrx.h"
+#include "hrx_defs.hpp"
+#include "hrx_kernel.hpp"
+#include "hrx_lane.h"
+
+using namespace hrx;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(HRX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct hrx_defs {
+    DefsSet s;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct hrx_ctx {
+    DefsSet s;  // private copy: the ctx outlives / is independent of the hrx_defs it was made from
+    int device = 0;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+    uint32_t *d_table = nullptr;
+    std::vector<uint16_t *> d_pair;
+    std::vector<uint8_t *> d_member;
+    std::mutex mu;
+    DevBuf chars, lens, records, masked, status, states, tags;
+};
+
+extern "C" {
+
+const char *hrx_last_error(void) { return g_err.c_str(); }
+
+/* ------------------------------ data model ------------------------------ */
+
+int hrx_defs_create(hrx_defs **out) {
+    if (!out) return fail(HRX_ERR_ARG, "out is NULL");
+    *out = new hrx_defs();
+    return HRX_OK;
+}
+
+void hrx_defs_destroy(hrx_defs *defs) { delete defs; }
+
+int hrx_defs_push_allstr_text(hrx_defs *defs, const char *text, size_t len) {
+    if (!defs || (!text && len)) return fail(HRX_ERR_ARG, "NULL argument");
+    if (defs->s.finalized) return fail(HRX_ERR_STATE, "defs already finalized");
+    RegexDefs rd;
+    const int rc = parse_allstr_text(text, len, rd.allstr);
+    if (rc) return fail(HRX_ERR_PARSE, "allstr definition: cannot parse line " + std::to_string(-rc - 1));
+    defs->s.defs.push_back(std::move(rd));
+    return HRX_OK;
+}
+
+int hrx_defs_push_substr_text(hrx_defs *defs, const char *text, size_t len) {
+    if (!defs || (!text && len)) return fail(HRX_ERR_ARG, "NULL argument");
+    if (defs->s.finalized) return fail(HRX_ERR_STATE, "defs already finalized");
+    if (defs->s.defs.empty()) return fail(HRX_ERR_STATE, "push an allstr definition first");
+    SubstrRegexDef sd;
+    const int rc = parse_substr_text(text, len, sd);
+    if (rc) return fail(HRX_ERR_PARSE, "substr definition: cannot parse line " + std::to_string(-rc - 1));
+    defs->s.defs.back().substrs.push_back(std::move(sd));
+    return HRX_OK;
+}
+
+static int read_file(const char *path, std::string &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return fail(HRX_ERR_IO, std::string("cannot open ") + (path ? path : "(null)"));  // File::open(..).unwrap()
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return HRX_OK;
+}
+
+int hrx_defs_push_allstr_file(hrx_defs *defs, const char *path) {
+    std::string t;
+    if (int rc = read_file(path, t)) return rc;
+    return hrx_defs_push_allstr_text(defs, t.data(), t.size());
+}
+
+int hrx_defs_push_substr_file(hrx_defs *defs, const char *path) {
+    std::string t;
+    if (int rc = read_file(path, t)) return rc;
+    return hrx_defs_push_substr_text(defs, t.data(), t.size());
+}
+
+int hrx_defs_push_allstr(hrx_defs *defs, uint64_t first_state_val, uint64_t accepted_state_val,
+                         uint64_t largest_state_val, size_t n, const uint64_t *cur, const uint64_t *next,
+                         const uint8_t *chr, const uint64_t *line_idx) {
+    if (!defs || (n && (!cur || !next || !chr))) return fail(HRX_ERR_ARG, "NULL argument");
+    if (defs->s.finalized) return fail(HRX_ERR_STATE, "defs already finalized");
+    RegexDefs rd;
+    rd.allstr.first_state_val = first_state_val;
+    rd.allstr.accepted_state_val = accepted_state_val;
+    rd.allstr.largest_state_val = largest_state_val;
+    for (size_t i = 0; i < n; ++i)
+        rd.allstr.state_lookup[{(uint64_t)chr[i], cur[i]}] = AllstrRegexDef::Val{line_idx ? line_idx[i] : (uint64_t)(i + 3), next[i]};
+    defs->s.defs.push_back(std::move(rd));
+    return HRX_OK;
+}
+
+int hrx_defs_push_substr(hrx_defs *defs, size_t n_pairs, const uint64_t *pair_cur, const uint64_t *pair_next,
+                         size_t n_start, const uint64_t *start_states, size_t n_end, const uint64_t *end_states) {
+    if (!defs) return fail(HRX_ERR_ARG, "NULL argument");
+    if (defs->s.finalized) return fail(HRX_ERR_STATE, "defs already finalized");
+    if (defs->s.defs.empty()) return fail(HRX_ERR_STATE, "push an allstr definition first");
+    SubstrRegexDef sd;
+    for (size_t i = 0; i < n_pairs; ++i) sd.valid_state_transitions.insert({pair_cur[i], pair_next[i]});
+    sd.start_states.assign(start_states, start_states + n_start);
+    sd.end_states.assign(end_states, end_states + n_end);
+    defs->s.defs.back().substrs.push_back(std::move(sd));
+    return HRX_OK;
+}
+
+int hrx_defs_finalize(hrx_defs *defs) {
+    if (!defs) return fail(HRX_ERR_ARG, "NULL argument");
+    std::string err;
+    const int rc = finalize_defs(defs->s, err);
+    return rc ? fail(rc, err) : HRX_OK;
+}
+
+size_t hrx_defs_num_defs(const hrx_defs *defs) { return defs ? defs->s.defs.size() : 0; }
+size_t hrx_defs_num_substrs(const hrx_defs *defs, size_t d) { return defs && d < defs->s.defs.size() ? defs->s.defs[d].substrs.size() : 0; }
+uint64_t hrx_defs_first_state(const hrx_defs *defs, size_t d) { return defs->s.defs[d].allstr.first_state_val; }
+uint64_t hrx_defs_accepted_state(const hrx_defs *defs, size_t d) { return defs->s.defs[d].allstr.accepted_state_val; }
+uint64_t hrx_defs_largest_state(const hrx_defs *defs, size_t d) { return defs->s.defs[d].allstr.largest_state_val; }
+size_t hrx_defs_num_transitions(const hrx_defs *defs, size_t d) { return defs->s.defs[d].allstr.state_lookup.size(); }
+uint64_t hrx_defs_substr_id_offset(const hrx_defs *defs, size_t d) {
+    uint64_t off = 1;
+    for (size_t i = 0; i < d && i < defs->s.defs.size(); ++i) off += defs->s.defs[i].substrs.size();
+    return off;
+}
+size_t hrx_defs_table_bytes(const hrx_defs *defs) { return defs && defs->s.finalized ? defs->s.table_image.size() * 4 : 0; }
+
+size_t hrx_table_transition_rows(const hrx_defs *defs, size_t d, uint64_t *rows4, size_t cap_rows) {
+    if (!defs || !defs->s.finalized || d >= defs->s.defs.size()) return 0;
+    return table_transition_rows(defs->s, d, rows4, cap_rows);
+}
+
+size_t hrx_table_endpoint_rows(const hrx_defs *defs, size_t d, uint64_t *rows3, size_t cap_rows) {
+    if (!defs || !defs->s.finalized || d >= defs->s.defs.size()) return 0;
+    return table_endpoint_rows(defs->s, d, rows3, cap_rows);
+}
+
+/* ------------------------------ device ------------------------------ */
+
+int hrx_device_count(int *count) {
+    if (!count) return fail(HRX_ERR_ARG, "NULL argument");
+    *count = 0;
+    HIP_TRY(hipGetDeviceCount(count));
+    return HRX_OK;
+}
+
+void hrx_shard_range(size_t B, int world, int rank, size_t *begin, size_t *count) {
+    if (world < 1) world = 1;
+    const size_t per = (B + (size_t)world - 1) / (size_t)world;  // ceil(B / G) strings per device
+    size_t b = per * (size_t)rank;
+    if (b > B) b = B;
+    size_t e = b + per;
+    if (e > B) e = B;
+    if (begin) *begin = b;
+    if (count) *count = e - b;
+}
+
+int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
+    if (!defs || !out) return fail(HRX_ERR_ARG, "NULL argument");
+    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(HRX_ERR_ARG, "no such device");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HRX_ERR_HIP, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+    hrx_ctx *c = new hrx_ctx();
+    c->s = defs->s;
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_table, c->s.table_image.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(c->d_table, c->s.table_image.data(), c->s.table_image.size() * 4, hipMemcpyHostToDevice);
+    for (size_t d = 0; e == hipSuccess && d < c->s.pair_tags.size(); ++d) {
+        uint16_t *p = nullptr;
+        e = hipMalloc((void **)&p, c->s.pair_tags[d].size() * 2);
+        if (e == hipSuccess) {
+            c->d_pair.push_back(p);
+            e = hipMemcpy(p, c->s.pair_tags[d].data(), c->s.pair_tags[d].size() * 2, hipMemcpyHostToDevice);
+        }
+    }
+    for (size_t d = 0; e == hipSuccess && d < c->s.endpoint_member.size(); ++d) {
+        uint8_t *p = nullptr;
+        e = hipMalloc((void **)&p, c->s.endpoint_member[d].size());
+        if (e == hipSuccess) {
+            c->d_member.push_back(p);
+            e = hipMemcpy(p, c->s.endpoint_member[d].data(), c->s.endpoint_member[d].size(), hipMemcpyHostToDevice);
+        }
+    }
+    if (e != hipSuccess) {
+        hrx_ctx_destroy(c);
+        return fail(HRX_ERR_HIP, std::string("ctx setup: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return HRX_OK;
+}
+
+void hrx_ctx_destroy(hrx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->d_table) (void)hipFree(c->d_table);
+    for (uint16_t *p : c->d_pair) (void)hipFree(p);
+    for (uint8_t *p : c->d_member) (void)hipFree(p);
+    c->chars.release(); c->lens.release(); c->records.release(); c->masked.release();
+    c->status.release(); c->states.release(); c->tags.release();
+    delete c;
+}
+
+/* ------------------------------ the hot path ------------------------------ */
+
+static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                        uint32_t *records, uint16_t *masked, uint64_t *status, hipStream_t st) {
+    if (B == 0) return HRX_OK;
+    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (M == 0 || M > (1u << 24)) return fail(HRX_ERR_ARG, "max_chars_size must be in 1..2^24");
+    if (B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "batch too large");
+    if ((stride & 15) || ((uintptr_t)chars & 15)) return fail(HRX_ERR_ARG, "chars must be 16-byte aligned with stride % 16 == 0");
+    if (((uintptr_t)records & 15) || ((uintptr_t)masked & 15) || ((uintptr_t)status & 7) || ((uintptr_t)lens & 3))
+        return fail(HRX_ERR_ARG, "output buffers must be 16-byte aligned");
+    WitnessArgs a{};
+    a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
+    a.records = records; a.masked = masked; a.status = status;
+    a.table_image = ctx->d_table; a.table_bytes = (uint32_t)(ctx->s.table_image.size() * 4);
+    a.n_groups = (uint32_t)((B + 63) / 64);
+    a.D = (uint32_t)ctx->s.defs.size();
+    for (uint32_t d = 0; d < a.D; ++d) a.dc[d] = ctx->s.consts[d];
+    LaunchInfo li;
+    if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+    HIP_TRY(launch_witness(a, li, st));
+    return HRX_OK;
+}
+
+int hrx_witness_batch_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                             uint32_t *records, uint16_t *masked, uint64_t *status, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                             uint32_t *records, uint16_t *masked, uint64_t *status) {
+    if (B == 0) return HRX_OK;
+    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
+    const size_t D = ctx->s.defs.size();
+    const size_t dstride = (stride + 15) & ~(size_t)15;
+    HIP_TRY(ctx->chars.reserve(dstride * B + 16));
+    HIP_TRY(ctx->lens.reserve(4 * B));
+    HIP_TRY(ctx->records.reserve(4 * B * M * D));
+    HIP_TRY(ctx->masked.reserve(2 * B * M));
+    HIP_TRY(ctx->status.reserve(8 * B));
+    hipStream_t st = ctx->stream;
+    if (dstride != stride) HIP_TRY(hipMemsetAsync(ctx->chars.p, 0, dstride * B, st));
+    if (stride) HIP_TRY(hipMemcpy2DAsync(ctx->chars.p, dstride, chars, stride, stride, B, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->lens.p, lens, 4 * B, hipMemcpyHostToDevice, st));
+    if (int rc = launch_batch(ctx, (const uint8_t *)ctx->chars.p, dstride ? dstride : 16, (const uint32_t *)ctx->lens.p, B, M,
+                              (uint32_t *)ctx->records.p, (uint16_t *)ctx->masked.p, (uint64_t *)ctx->status.p, st))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(records, ctx->records.p, 4 * B * M * D, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(masked, ctx->masked.p, 2 * B * M, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status, ctx->status.p, 8 * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HRX_OK;
+}
+
+int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                           uint32_t *records, uint16_t *masked, uint64_t *status) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return batch_host_locked(ctx, chars, stride, lens, B, M, records, masked, status);
+}
+
+/* ------------------------------ single-string entry points ------------------------------ */
+
+static int status_to_error(uint64_t sw) {
+    switch (sw & 0xff) {
+        case kStatusOk: return HRX_OK;
+        case kStatusInvalidTransition: {
+            char buf[96];
+            // the reference's panic text, lib.rs:817
+            std::snprintf(buf, sizeof buf, "The transition from %u by %u is invalid!", (unsigned)((sw >> 24) & 0xffff),
+                          (unsigned)((sw >> 16) & 0xff));
+            return fail(HRX_ERR_INVALID_TRANSITION, buf);
+        }
+        case kStatusFlagOverlap:
+            return fail(HRX_ERR_OUT_OF_CONTRACT, "two regex defs raise a start/end flag on row " + std::to_string(sw >> 40));
+        default: return fail(HRX_ERR_OUT_OF_CONTRACT, "input longer than max_chars_size");
+    }
+}
+
+// one string through the batch kernel with M rows; returns host copies of the compact outputs
+static int run_one(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t M, std::vector<uint32_t> &rec,
+                   std::vector<uint16_t> &msk, uint64_t &sw) {
+    const size_t D = ctx->s.defs.size();
+    rec.assign(M * D, 0);
+    msk.assign(M, 0);
+    const uint32_t len = (uint32_t)n;
+    std::vector<uint8_t> tmp((n + 15) & ~(size_t)15, 0);
+    if (n) std::memcpy(tmp.data(), characters, n);
+    if (tmp.empty()) tmp.resize(16, 0);
+    return batch_host_locked(ctx, tmp.data(), tmp.size(), &len, 1, M, rec.data(), msk.data(), &sw);
+}
+
+int hrx_derive_states(hrx_ctx *ctx, const uint8_t *characters, size_t n, uint64_t *states) {
+    if (!ctx || (!characters && n) || !states) return fail(HRX_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t D = ctx->s.defs.size(), M = n + 1;  // row n holds states[d][n] (lib.rs:406-411)
+    std::vector<uint32_t> rec;
+    std::vector<uint16_t> msk;
+    uint64_t sw = 0;
+    if (int rc = run_one(ctx, characters, n, M, rec, msk, sw)) return rc;
+    if ((sw & 0xff) == kStatusInvalidTransition) return status_to_error(sw);
+    for (size_t d = 0; d < D; ++d)
+        for (size_t i = 0; i <= n; ++i) states[d * (n + 1) + i] = rec[i * D + d] & 0xffffu;
+    return HRX_OK;
+}
+
+static int pair_tags_host(hrx_ctx *ctx, const uint64_t *states, size_t n, std::vector<uint16_t> &tags) {
+    const size_t D = ctx->s.defs.size();
+    tags.assign(n * D, 0);
+    if (n == 0) return HRX_OK;
+    HIP_TRY(ctx->states.reserve(8 * D * (n + 1)));
+    HIP_TRY(ctx->tags.reserve(2 * D * n));
+    HIP_TRY(hipMemcpyAsync(ctx->states.p, states, 8 * D * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t ns[3];
+    const uint16_t *pt[3];
+    for (size_t d = 0; d < D; ++d) { ns[d] = (uint32_t)ctx->s.defs[d].allstr.largest_state_val + 1; pt[d] = ctx->d_pair[d]; }
+    HIP_TRY(launch_pair_tags((const uint64_t *)ctx->states.p, n, (uint32_t)D, pt, ns, (uint16_t *)ctx->tags.p, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(tags.data(), ctx->tags.p, 2 * D * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return HRX_OK;
+}
+
+int hrx_derive_substr_ids(hrx_ctx *ctx, const uint64_t *states, size_t n, uint64_t *substr_ids) {
+    if (!ctx || !states || (!substr_ids && n)) return fail(HRX_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint16_t> tags;
+    if (int rc = pair_tags_host(ctx, states, n, tags)) return rc;
+    for (size_t i = 0; i < tags.size(); ++i) substr_ids[i] = tags[i] & 0xffu;
+    return HRX_OK;
+}
+
+int hrx_derive_is_start_end(hrx_ctx *ctx, const uint64_t *states, const uint64_t *substr_ids, size_t n,
+                            uint8_t *is_start, uint8_t *is_end) {
+    if (!ctx || !states || !is_start || !is_end || (!substr_ids && n)) return fail(HRX_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t D = ctx->s.defs.size();
+    std::vector<uint8_t> flags(n * D, 0);
+    if (n) {
+        HIP_TRY(ctx->states.reserve(8 * D * (n + 1)));
+        HIP_TRY(ctx->tags.reserve(8 * D * n + D * n));
+        uint64_t *d_sids = (uint64_t *)ctx->tags.p;
+        uint8_t *d_flags = (uint8_t *)ctx->tags.p + 8 * D * n;
+        HIP_TRY(hipMemcpyAsync(ctx->states.p, states, 8 * D * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_sids, substr_ids, 8 * D * n, hipMemcpyHostToDevice, ctx->stream));
+        EndpointArgs a{};
+        a.states = (const uint64_t *)ctx->states.p; a.substr_ids = d_sids; a.n = n; a.D = (uint32_t)D; a.flags = d_flags;
+        for (size_t d = 0; d < D; ++d) {
+            a.member[d] = ctx->d_member[d];
+            a.n_states[d] = (uint32_t)ctx->s.defs[d].allstr.largest_state_val + 1;
+            a.n_substrs[d] = (uint32_t)ctx->s.defs[d].substrs.size();
+            a.id_offset[d] = ctx->s.consts[d].substr_id_offset;
+        }
+        HIP_TRY(launch_endpoint_flags(a, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(flags.data(), d_flags, D * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    for (size_t d = 0; d < D; ++d) {
+        for (size_t i = 0; i < n; ++i) {
+            is_start[d * (n + 1) + i] = flags[d * n + i] & 1;
+            is_end[d * (n + 1) + i + 1] = (flags[d * n + i] >> 1) & 1;
+        }
+        is_start[d * (n + 1) + n] = 0;  // lib.rs:869
+        is_end[d * (n + 1)] = 0;        // lib.rs:882
+    }
+    return HRX_OK;
+}
+
+int hrx_match_substrs(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t M, uint64_t *enable, uint64_t *character,
+                      uint64_t *state, uint64_t *substr_id, uint64_t *start_enable, uint64_t *end_enable,
+                      uint64_t *masked_char, uint64_t *masked_substr_id, uint64_t *status) {
+    if (!ctx || (!characters && n)) return fail(HRX_ERR_ARG, "NULL argument");
+    if (n > M) return fail(HRX_ERR_OUT_OF_CONTRACT, "input longer than max_chars_size");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t D = ctx->s.defs.size();
+    std::vector<uint32_t> rec;
+    std::vector<uint16_t> msk;
+    uint64_t sw = 0;
+    if (int rc = run_one(ctx, characters, n, M, rec, msk, sw)) return rc;
+    if (status) *status = sw;
+    if (int rc = status_to_error(sw)) return rc;
+    for (size_t r = 0; r < M; ++r) {
+        if (enable) enable[r] = r < n ? 1 : 0;                          // lib.rs:339-348
+        if (character) character[r] = r < n ? characters[r] : 0;
+        for (size_t d = 0; d < D; ++d) {
+            const uint32_t w = rec[r * D + d];
+            if (state) state[d * M + r] = w & 0xffffu;
+            if (substr_id) substr_id[d * M + r] = (w >> 16) & 0xffu;
+            if (start_enable) start_enable[d * M + r] = (w >> 24) & 1u;
+            if (end_enable) end_enable[d * M + r] = (w >> 25) & 1u;
+        }
+        if (masked_char) masked_char[r] = msk[r] & 0xffu;
+        if (masked_substr_id) masked_substr_id[r] = msk[r] >> 8;
+    }
+    return HRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+// hrx_defs.cpp — text parsers of src/defs.rs and the dense fused-table builder.
+#include "hrx_defs.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "../../include/hrx.h"
+#include "hrx_lane.h"
+
+namespace hrx {
+
+// One line -> Vec<u64>, like `line.split_whitespace().map(|s| s.parse::<u64>())` (defs.rs:86-92).
+// false where the reference's parse().expect() panics.
+static bool split_u64(const char *p, const char *end, std::vector<uint64_t> &out) {
+    out.clear();
+    auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
+    while (p < end) {
+        while (p < end && is_ws(*p)) ++p;
+        if (p >= end) break;
+        if (*p == '+') ++p;
+        if (p >= end || *p < '0' || *p > '9') return false;
+        uint64_t v = 0;
+        while (p < end && *p >= '0' && *p <= '9') {
+            const uint64_t d = (uint64_t)(*p - '0');
+            if (v > (UINT64_MAX - d) / 10) return false;
+            v = v * 10 + d;
+            ++p;
+        }
+        if (p < end && !is_ws(*p)) return false;
+        out.push_back(v);
+    }
+    return true;
+}
+
+template <class F>
+static int for_each_line(const char *text, size_t len, F &&f) {
+    const char *p = text, *end = text + len;
+    uint64_t idx = 0;
+    std::vector<uint64_t> el;
+    while (p < end) {  // BufRead::lines(): no extra empty line after a trailing '\n'
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        if (!split_u64(p, le, el)) return -(int)(idx + 1);
+        if (!f(idx, el)) return -(int)(idx + 1);
+        ++idx;
+        p = nl ? nl + 1 : end;
+    }
+    return 0;
+}
+
+// AllstrRegexDef::read_from_reader — src/defs.rs:75-110
+int parse_allstr_text(const char *text, size_t len, AllstrRegexDef &out) {
+    out = AllstrRegexDef();
+    return for_each_line(text, len, [&](uint64_t idx, const std::vector<uint64_t> &el) {
+        if (idx <= 2) {
+            if (el.empty()) return false;
+            if (idx == 0) out.first_state_val = el[0];
+            else if (idx == 1) out.accepted_state_val = el[0];
+            else out.largest_state_val = el[0];
+        } else {
+            if (el.size() < 3) return false;
+            // insert((elements[2] as u8, elements[0]), (idx, elements[1])): a later duplicate overwrites (defs.rs:100)
+            out.state_lookup[{(uint64_t)(uint8_t)el[2], el[0]}] = AllstrRegexDef::Val{idx, el[1]};
+        }
+        return true;
+    });
+}
+
+// SubstrRegexDef::read_from_reader — src/defs.rs:209-265
+int parse_substr_text(const char *text, size_t len, SubstrRegexDef &out) {
+    out = SubstrRegexDef();
+    return for_each_line(text, len, [&](uint64_t idx, const std::vector<uint64_t> &el) {
+        if (idx <= 2) {
+            if (el.empty()) return false;
+            if (idx == 0) out.max_length = el[0];
+            else if (idx == 1) out.min_position = el[0];
+            else out.max_position = el[0];
+        } else if (idx == 3) {
+            out.start_states = el;
+        } else if (idx == 4) {
+            out.end_states = el;
+        } else {
+            if (el.size() < 2) return false;
+            out.valid_state_transitions.insert({el[0], el[1]});
+        }
+        return true;
+    });
+}
+
+// tag of the transition (cur -> next) of def `rd`: substr id of the FIRST substring whose
+// valid_state_transitions holds the pair (lib.rs:831-840, table.rs:110-120), start flag if cur is one of
+// that substring's start_states (lib.rs:861-866), end flag if next is one of its end_states (lib.rs:874-879).
+static uint32_t pair_tag(const RegexDefs &rd, uint64_t off, uint64_t cur, uint64_t next) {
+    for (size_t j = 0; j < rd.substrs.size(); ++j) {
+        const SubstrRegexDef &sd = rd.substrs[j];
+        if (sd.valid_state_transitions.count({cur, next})) {
+            uint32_t tag = (uint32_t)(off + j);
+            if (std::find(sd.start_states.begin(), sd.start_states.end(), cur) != sd.start_states.end()) tag |= kTagStart;
+            if (std::find(sd.end_states.begin(), sd.end_states.end(), next) != sd.end_states.end()) tag |= kTagEnd;
+            return tag;
+        }
+    }
+    return 0;
+}
+
+int finalize_defs(DefsSet &s, std::string &err) {
+    if (s.finalized) return HRX_OK;
+    if (s.defs.empty()) { err = "no RegexDefs pushed"; return HRX_ERR_STATE; }
+    if (s.defs.size() > 3) { err = "at most 3 RegexDefs per config are supported"; return HRX_ERR_BOUNDS; }
+    s.consts.clear();
+    s.pair_tags.clear();
+    s.endpoint_member.clear();
+    size_t total_rows = 0;
+    uint64_t off = 1;          // substr_id_offset, lib.rs:780,827,854
+    uint64_t max_sid_sum = 0;  // largest value Σ_d substr_id_d can take (masked_substr_id is a u8)
+    for (size_t d = 0; d < s.defs.size(); ++d) {
+        const RegexDefs &rd = s.defs[d];
+        const uint64_t L = rd.allstr.largest_state_val;
+        if (L > 60000) { err = "largest_state_val too large for a u16 state record"; return HRX_ERR_BOUNDS; }
+        if (rd.allstr.first_state_val > L || rd.allstr.accepted_state_val > L) {
+            err = "first/accepted state exceeds largest_state_val"; return HRX_ERR_BOUNDS;
+        }
+        for (const auto &kv : rd.allstr.state_lookup) {
+            if (kv.first.second > L || kv.second.next > L) { err = "a transition references a state above largest_state_val"; return HRX_ERR_BOUNDS; }
+        }
+        DefConsts c{};
+        c.n_rows = (uint32_t)L + 3;
+        c.row_base = (uint32_t)total_rows;
+        c.first_entry = (uint32_t)(total_rows + rd.allstr.first_state_val) << kNextShift;
+        c.dummy_entry = (uint32_t)(total_rows + L + 1) << kNextShift;
+        c.dead_entry = (uint32_t)(total_rows + L + 2) << kNextShift;
+        c.accepted_state = (uint32_t)rd.allstr.accepted_state_val;
+        c.substr_id_offset = (uint32_t)off;
+        s.consts.push_back(c);
+        total_rows += c.n_rows;
+        if (!rd.substrs.empty()) max_sid_sum += off + rd.substrs.size() - 1;
+        off += rd.substrs.size();
+    }
+    if (max_sid_sum > 255) { err = "substring ids do not fit the u8 masked_substr_id"; return HRX_ERR_BOUNDS; }
+    if (total_rows * 1024 > kMaxTableBytes) {
+        err = "fused (state,char) tables need " + std::to_string(total_rows) + " KiB of LDS; limit is " +
+              std::to_string(kMaxTableBytes / 1024) + " KiB";
+        return HRX_ERR_BOUNDS;
+    }
+    s.table_image.assign(total_rows * 256, 0);
+    for (size_t d = 0; d < s.defs.size(); ++d) {
+        const RegexDefs &rd = s.defs[d];
+        const DefConsts &c = s.consts[d];
+        const uint64_t L = rd.allstr.largest_state_val;
+        uint32_t *T = s.table_image.data() + (size_t)c.row_base * 256;
+        // undefined (state,char) -> dead (the reference panics, lib.rs:817); dummy and dead rows absorb.
+        for (uint64_t st = 0; st <= L; ++st)
+            for (int ch = 0; ch < 256; ++ch) T[st * 256 + ch] = c.dead_entry;
+        for (int ch = 0; ch < 256; ++ch) {
+            T[(L + 1) * 256 + ch] = c.dummy_entry;
+            T[(L + 2) * 256 + ch] = c.dead_entry;
+        }
+        std::vector<uint16_t> pt((L + 1) * (L + 1), 0);
+        for (const auto &kv : rd.allstr.state_lookup) {
+            const uint64_t ch = kv.first.first, cur = kv.first.second, next = kv.second.next;
+            const uint32_t tag = pair_tag(rd, c.substr_id_offset, cur, next);
+            T[cur * 256 + ch] = ((uint32_t)(c.row_base + next) << kNextShift) | tag;
+        }
+        for (uint64_t cur = 0; cur <= L; ++cur)
+            for (uint64_t next = 0; next <= L; ++next) pt[cur * (L + 1) + next] = (uint16_t)pair_tag(rd, c.substr_id_offset, cur, next);
+        s.pair_tags.push_back(std::move(pt));
+        std::vector<uint8_t> mem(rd.substrs.size() * (L + 1) + 1, 0);
+        for (size_t j = 0; j < rd.substrs.size(); ++j) {
+            for (uint64_t st : rd.substrs[j].start_states) if (st <= L) mem[j * (L + 1) + st] |= 1;
+            for (uint64_t en : rd.substrs[j].end_states) if (en <= L) mem[j * (L + 1) + en] |= 2;
+        }
+        s.endpoint_member.push_back(std::move(mem));
+    }
+    s.finalized = true;
+    return HRX_OK;
+}
+
+// RegexTableConfig::load, transition table — src/table.rs:68-125
+size_t table_transition_rows(const DefsSet &s, size_t d, uint64_t *rows, size_t cap_rows) {
+    const RegexDefs &rd = s.defs[d];
+    const uint64_t dummy = rd.allstr.largest_state_val + 1;  // table.rs:67
+    const uint64_t off = s.consts[d].substr_id_offset;
+    const size_t n = 1 + rd.allstr.state_lookup.size();
+    if (!rows) return n;
+    struct Row { uint64_t line, ch, cur, next; };
+    std::vector<Row> v;
+    v.reserve(rd.allstr.state_lookup.size());
+    for (const auto &kv : rd.allstr.state_lookup) v.push_back({kv.second.line_idx, kv.first.first, kv.first.second, kv.second.next});
+    std::sort(v.begin(), v.end(), [](const Row &a, const Row &b) { return a.line < b.line; });  // table.rs:108
+    size_t k = 0;
+    auto put = [&](uint64_t a, uint64_t b, uint64_t c, uint64_t e) {
+        if (k < cap_rows) { rows[4 * k] = a; rows[4 * k + 1] = b; rows[4 * k + 2] = c; rows[4 * k + 3] = e; }
+        ++k;
+    };
+    put(0, dummy, dummy, 0);  // table.rs:101
+    for (const Row &r : v) put(r.ch, r.cur, r.next, pair_tag(rd, off, r.cur, r.next) & 0xff);
+    return n;
+}
+
+// RegexTableConfig::load, endpoint table — src/table.rs:126-196
+size_t table_endpoint_rows(const DefsSet &s, size_t d, uint64_t *rows, size_t cap_rows) {
+    const RegexDefs &rd = s.defs[d];
+    const uint64_t dummy = rd.allstr.largest_state_val + 1;
+    const uint64_t off = s.consts[d].substr_id_offset;
+    size_t k = 0;
+    auto put = [&](uint64_t a, uint64_t b, uint64_t c) {
+        if (rows && k < cap_rows) { rows[3 * k] = a; rows[3 * k + 1] = b; rows[3 * k + 2] = c; }
+        ++k;
+    };
+    put(0, dummy, dummy);
+    for (size_t j = 0; j < rd.substrs.size(); ++j) {
+        for (uint64_t st : rd.substrs[j].start_states) put(off + j, st, dummy);
+        for (uint64_t en : rd.substrs[j].end_states) put(off + j, dummy, en);
+    }
+    return k;
+}
+
+}  // namespace hrx

@@ -1,0 +1,79 @@
+// hrx_defs.hpp — host data model (src/defs.rs) and the dense fused-table builder.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace hrx {
+
+struct PairHash {
+    size_t operator()(const std::pair<uint64_t, uint64_t> &p) const noexcept {
+        uint64_t x = p.first * 0x9e3779b97f4a7c15ull ^ (p.second + 0x7f4a7c15ull + (p.first << 6));
+        x ^= x >> 31;
+        return (size_t)(x * 0xff51afd7ed558ccdull);
+    }
+};
+
+// SubstrRegexDef — src/defs.rs:115-132
+struct SubstrRegexDef {
+    uint64_t max_length = 0, min_position = 0, max_position = 0;  // unused by the chip (defs.rs:118-125)
+    std::unordered_set<std::pair<uint64_t, uint64_t>, PairHash> valid_state_transitions;
+    std::vector<uint64_t> start_states, end_states;
+};
+
+// AllstrRegexDef — src/defs.rs:26-36.  state_lookup keyed (char, state) -> (line idx, next).
+struct AllstrRegexDef {
+    struct Val {
+        uint64_t line_idx, next;
+    };
+    std::unordered_map<std::pair<uint64_t, uint64_t>, Val, PairHash> state_lookup;  // key = (char as u8, cur state)
+    uint64_t first_state_val = 0, accepted_state_val = 0, largest_state_val = 0;
+};
+
+// RegexDefs — src/defs.rs:17-22
+struct RegexDefs {
+    AllstrRegexDef allstr;
+    std::vector<SubstrRegexDef> substrs;
+};
+
+// Per-def constants the kernel needs.  The tables of all defs are stacked into one LDS image of
+// 256-entry rows; entries hold ABSOLUTE row numbers (row_base + state) << 10, so the next lookup
+// address is (entry & ~0x3ff) | 4*byte for every def (hrx_lane.h).
+struct DefConsts {
+    uint32_t row_base;     // first row of this def's table inside the image
+    uint32_t n_rows;       // largest + 3: real states, dummy (largest+1), dead (largest+2)
+    uint32_t first_entry;  // (row_base + first_state_val) << 10
+    uint32_t dummy_entry;  // (row_base + largest+1) << 10 : padding rows (lib.rs:413)
+    uint32_t dead_entry;   // (row_base + largest+2) << 10 : absorbing sink of undefined transitions (lib.rs:817)
+    uint32_t accepted_state;
+    uint32_t substr_id_offset;
+};
+
+struct DefsSet {
+    std::vector<RegexDefs> defs;
+    bool finalized = false;
+    // dense image: for def d, n_rows x 256 u32 entries at table_base (see hrx_lane.h for the entry format)
+    std::vector<uint32_t> table_image;
+    std::vector<DefConsts> consts;
+    // (cur,next) -> {sid, is_start(cur), is_end(next)} per def, for the states-in entry points (lib.rs:825-888)
+    std::vector<std::vector<uint16_t>> pair_tags;  // [(largest+1)^2], entry = tag bits as in the fused table
+    // membership bytes per def: [n_substrs][largest+1]; bit0: state in start_states, bit1: state in end_states
+    std::vector<std::vector<uint8_t>> endpoint_member;
+};
+
+// Parsers return 0 or -(line_idx+1) where the reference would panic.
+int parse_allstr_text(const char *text, size_t len, AllstrRegexDef &out);
+int parse_substr_text(const char *text, size_t len, SubstrRegexDef &out);
+// Returns HRX_* status; message in err.
+int finalize_defs(DefsSet &s, std::string &err);
+
+size_t table_transition_rows(const DefsSet &s, size_t d, uint64_t *rows4, size_t cap_rows);
+size_t table_endpoint_rows(const DefsSet &s, size_t d, uint64_t *rows3, size_t cap_rows);
+
+// LDS budget for the table image (the rest of the 160 KiB holds the per-wave staging)
+constexpr size_t kMaxTableBytes = 96 * 1024;
+
+}  // namespace hrx

@@ -1,0 +1,58 @@
+// hrx_kernel.hpp — host-visible launch interface of the HIP kernels (hrx_kernel.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "hrx_defs.hpp"
+
+namespace hrx {
+
+struct WitnessArgs {
+    const uint8_t *chars;
+    uint64_t stride;
+    const uint32_t *lens;
+    uint32_t B, M;
+    uint32_t *records;
+    uint16_t *masked;
+    uint64_t *status;
+    const uint32_t *table_image;  // device copy of DefsSet::table_image
+    uint32_t table_bytes;
+    uint32_t n_groups;            // ceil(B / 64)
+    uint32_t D;
+    DefConsts dc[3];
+};
+
+struct LaunchInfo {
+    int waves_per_wg;
+    int grid;
+    size_t lds_bytes;
+};
+
+// LDS bytes one wave stages per 64-string x 64-row tile
+constexpr size_t wave_stage_bytes(int D) { return 64 * (256 * (size_t)D + 16) + 64 * 80 + 64 * 8; }
+constexpr size_t kLdsLimit = 160 * 1024;
+
+// Picks the launch geometry for `a` on a device with `num_cus` CUs; returns false if nothing fits.
+bool plan_witness_launch(const WitnessArgs &a, int num_cus, LaunchInfo &out);
+hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
+
+// states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])
+hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,
+                            const uint32_t *n_states, uint16_t *tags, hipStream_t stream);
+
+// derive_is_start_end (lib.rs:847-888) for caller-supplied states AND substr ids:
+// flags[d*n+i] bit0 = is_start[d][i], bit1 = is_end[d][i+1]
+struct EndpointArgs {
+    const uint64_t *states;
+    const uint64_t *substr_ids;
+    uint64_t n;
+    uint32_t D;
+    const uint8_t *member[3];
+    uint32_t n_states[3], n_substrs[3], id_offset[3];
+    uint8_t *flags;
+};
+hipError_t launch_endpoint_flags(const EndpointArgs &a, hipStream_t stream);
+
+}  // namespace hrx

@@ -1,0 +1,160 @@
+// hrx_lane.h — per-string ("per-lane") integer logic of the witness generator.
+//
+// One GPU lane owns one input string.  Everything a lane needs to know about a
+// 64-row tile of its string is kept as 64-bit position bitvectors in its own
+// registers (bit p <-> witness row t0+p), so the reference's two sequential
+// "last event wins" mask scans (src/lib.rs:598-645 forward, 663-714 backward)
+// become a handful of 64-bit adds per tile instead of ~24 field-gate calls per
+// row.  The header is plain C++ so that the same code is compiled by hipcc for
+// the kernel and by g++ for the CPU algorithm test (tests/sim); it is not a
+// CPU fallback — the product path only ever runs it on the device.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIP__)  // clang in HIP mode (hipcc), host and device passes alike
+#define HRX_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
+#else
+#define HRX_HD inline
+#endif
+
+namespace hrx {
+
+constexpr int kTile = 64;  // witness rows per tile = width of the position bitvectors
+
+// ---------------------------------------------------------------------------
+// Fused dense-table entry: one u32 per (state, byte).
+//   bits 10..31  next_state * 1024  = byte offset of the next state's 256-entry row
+//   bits  0.. 7  substr_id of the transition (state,next)   table.rs:110-120 / lib.rs:831-840
+//   bit   8      is_start: substr_id != 0 && state in start_states     lib.rs:861-866
+//   bit   9      is_end of the NEXT row: substr_id != 0 && next in end_states   lib.rs:874-879
+// so  (entry & ~0x3ff) + 4*byte  is the LDS address of the next lookup (one v_and_or),
+// and (entry & 0x3ff) << 16 | state is the compact witness record of the row.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kTagMask = 0x3ffu;
+constexpr int kNextShift = 10;
+constexpr uint32_t kTagStart = 1u << 8;
+constexpr uint32_t kTagEnd = 1u << 9;
+
+// compact witness record (u32): state | substr_id << 16 | start_enable << 24 | end_enable << 25
+constexpr uint32_t kRecEndBit = 1u << 25;
+
+// per-string status word (u64), shared with the oracle (oracle/hrx_oracle.c pack_status)
+constexpr uint64_t kStatusOk = 0, kStatusInvalidTransition = 1, kStatusFlagOverlap = 2, kStatusBadLength = 3;
+
+HRX_HD uint64_t brev64(uint64_t x) {
+#if defined(__clang__)
+    return __builtin_bitreverse64(x);  // s_brev_b64 / v_bfrev_b32 on gfx950
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+    x = ((x >> 8) & 0x00ff00ff00ff00ffull) | ((x & 0x00ff00ff00ff00ffull) << 8);
+    x = ((x >> 16) & 0x0000ffff0000ffffull) | ((x & 0x0000ffff0000ffffull) << 16);
+    return (x >> 32) | (x << 32);
+#endif
+}
+
+HRX_HD int ctz64(uint64_t x) { return __builtin_ctzll(x); }        // x != 0
+HRX_HD int msb64(uint64_t x) { return 63 - __builtin_clzll(x); }   // index of the highest set bit, x != 0
+
+// "Last event wins" scan towards higher bit positions.
+//   out[i] = set[i] ? 1 : rst[i] ? 0 : out[i-1],   out[-1] = cin        (set & rst == 0)
+// which is the recurrence  new = select(0, select(1, last, is_set), is_reset)  of
+// src/lib.rs:631-642.  Ripple-carry identity: with generate G = set and propagate
+// P = ~(set|rst), out[i] is the carry OUT of bit i of (P|G) + G + cin; the carry INTO
+// bit i is ((P|G) + G + cin) ^ P.
+HRX_HD uint64_t fill_up(uint64_t set, uint64_t rst, uint32_t cin) {
+    const uint64_t P = ~(set | rst);
+    const uint64_t sum = (P | set) + set + (uint64_t)cin;
+    return set | (P & (sum ^ P));
+}
+
+// Same towards lower bit positions: out[i] = set[i] ? 1 : rst[i] ? 0 : out[i+1], out[64] = cin
+// (src/lib.rs:699-710 runs this from the last row down).
+HRX_HD uint64_t fill_down(uint64_t set, uint64_t rst, uint32_t cin) {
+    return brev64(fill_up(brev64(set), brev64(rst), cin));
+}
+
+// What a lane carries from one tile of its string to the next.
+struct MaskCarry {
+    uint32_t sm;          // start_mask of the previous row                      (last_start_mask, lib.rs:598,644)
+    uint32_t en;          // EN[t0]: an is_end flag lands on the first row of the next tile
+    uint32_t pend;        // rows [pend_start, t0) were written assuming end_mask = 1
+    uint32_t pend_start;
+};
+
+// Bitvectors of one tile, bit p <-> row r = t0 + p  (SURVEY App. A.2/A.3 notation):
+//   st  : ST[r]   = sum_d is_start_d[r]  != 0           (0 for r >= n)
+//   en1 : EN[r+1] = sum_d is_end_d[r+1]  != 0           (0 unless r < n and r <= M-2; lib.rs:501-519)
+//   ch  : SID[r] != SID[r-1],  SID = sum_d substr_id_d, SID[-1] = 0, SID[r>=n] = 0
+struct TileBits {
+    uint64_t st, en1, ch;
+};
+
+struct TileMasks {
+    uint64_t mask;        // start_mask & end_mask for rows r < n
+    uint32_t fix;         // 1: zero masked rows [fix_start, t0) — an earlier optimistic end_mask = 1 was wrong
+    uint32_t fix_start;
+};
+
+// Reveal mask of one tile (src/lib.rs:598-764 on integers).
+//
+// The backward scan (end_mask) of row p depends on rows > p.  The backward event that
+// decides position q-1 is made of row q's own quantities (lib.rs:665-698):
+//     set   = EN[q] & (SID[q] != SID[q-1]),   reset = !EN[q] & ST[q] & (SID[q] != SID[q-1])
+// so all events of positions t0-1 .. t0+62 are known inside the tile; what is not
+// known is the first event at or after t0+63.  `exact` says there is none
+// (the string or the region ends inside/before this tile: no events at rows > n, none at row M).
+// Otherwise the rows after the tile's last event are emitted optimistically with
+// end_mask = 1 (the common case: a substring that ends in the next tile) and the lane
+// remembers where they start; the first event of a later tile confirms them or asks for
+// them to be zeroed (`fix`).  Each row is fixed at most once.
+HRX_HD TileMasks tile_masks(const TileBits &b, MaskCarry &c, uint32_t t0, bool exact, uint64_t valid) {
+    TileMasks out;
+    const uint64_t en0 = (b.en1 << 1) | (uint64_t)c.en;  // bit p = EN[t0+p]
+    c.en = (uint32_t)(b.en1 >> 63);
+    // forward: start_mask                                                     lib.rs:598-645
+    const uint64_t setF = b.st & b.ch;
+    const uint64_t rstF = ~b.st & en0 & b.ch;
+    const uint64_t sm = fill_up(setF, rstF, c.sm);
+    c.sm = (uint32_t)(sm >> 63);
+    // backward: end_mask; bit j of setB/rstB is the event of position t0+j-1   lib.rs:663-714
+    const uint64_t setB = en0 & b.ch;
+    const uint64_t rstB = ~en0 & b.st & b.ch;
+    const uint32_t cin = exact ? 0u : 1u;
+    const uint64_t F = fill_down(setB, rstB, cin);      // F[j]: first event at bit >= j is a set (cin if none)
+    const uint64_t em = (F >> 1) | ((uint64_t)cin << 63);  // end_mask[t0+p] = F[p+1]
+    out.mask = sm & em & valid;                          // lib.rs:740-745
+    const uint64_t any = setB | rstB;
+    out.fix = 0;
+    out.fix_start = 0;
+    if (c.pend && (any != 0 || exact)) {
+        if (!(F & 1)) { out.fix = 1; out.fix_start = c.pend_start; }
+        c.pend = 0;
+    }
+    if (!exact) {
+        const uint64_t suffix = any ? (~0ull << msb64(any)) : ~0ull;  // rows whose end_mask came from cin
+        const uint64_t opt = out.mask & suffix;
+        if (opt != 0 && !c.pend) { c.pend = 1; c.pend_start = t0 + (uint32_t)ctz64(opt); }
+    }
+    return out;
+}
+
+// No backward event can exist beyond this tile (rows > n carry no flags, row M does not exist).
+HRX_HD bool tile_is_exact(uint32_t t0, uint32_t n, uint32_t M) { return n <= t0 + 63u || t0 + 64u >= M; }
+
+// rows r = t0+p with r < n, as a bitvector
+HRX_HD uint64_t rows_below(uint32_t t0, uint32_t n) {
+    if (n <= t0) return 0;
+    const uint32_t k = n - t0;
+    return k >= 64 ? ~0ull : ((1ull << k) - 1);
+}
+
+HRX_HD uint64_t status_ok(uint32_t accept_mask) { return (uint64_t)(accept_mask & 0xff) << 8; }
+HRX_HD uint64_t status_invalid(uint32_t def, uint32_t pos, uint32_t state, uint32_t ch) {
+    return kStatusInvalidTransition | (uint64_t)(def & 0xff) << 8 | (uint64_t)(ch & 0xff) << 16 |
+           (uint64_t)(state & 0xffff) << 24 | (uint64_t)(pos & 0xffffff) << 40;
+}
+HRX_HD uint64_t status_overlap(uint32_t row) { return kStatusFlagOverlap | (uint64_t)(row & 0xffffff) << 40; }
+
+}  // namespace hrx

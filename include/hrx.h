@@ -1,0 +1,155 @@
+/*
+ * hrx.h — C ABI of the MI355X-native batched DFA witness generator for halo2-regex.
+ *
+ * The reference (zkemail/halo2-regex) has no FFI: the seam this library replaces is
+ * Rust-internal — the three pub(crate) methods RegexVerifyConfig::derive_states /
+ * derive_substr_ids / derive_is_start_end (src/lib.rs:804-888) called at the top of
+ * RegexVerifyConfig::match_substrs (src/lib.rs:316-318), the integer content of the
+ * reveal-mask scan in match_substrs (src/lib.rs:593-764), the data model and text
+ * parsers of src/defs.rs, and the fixed-table rows of RegexTableConfig::load
+ * (src/table.rs:61-198).  Every entry point below cites the reference interface it
+ * stands in for.  INTEGRATION.md shows the Rust binding a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, caller-owned buffers, integer status
+ * returns (0 = HRX_OK), nothing unwinds.  Text of the last error: hrx_last_error().
+ * Compute entry points need a gfx950 device; there is no CPU fallback.
+ */
+#ifndef HRX_H
+#define HRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hrx_defs hrx_defs; /* Vec<RegexDefs> (src/defs.rs:17-22) + the dense fused tables built from it */
+typedef struct hrx_ctx hrx_ctx;   /* one device: tables resident in HBM, a stream, staging buffers */
+
+enum {
+    HRX_OK = 0,
+    HRX_ERR_PARSE = 1,              /* where AllstrRegexDef/SubstrRegexDef::read_from_reader panics (defs.rs:85-91, 219-225) */
+    HRX_ERR_BOUNDS = 2,             /* state / substr-id ranges the compact record or the LDS table cannot hold */
+    HRX_ERR_ARG = 3,
+    HRX_ERR_HIP = 4,
+    HRX_ERR_STATE = 5,              /* call order (e.g. push after finalize) */
+    HRX_ERR_INVALID_TRANSITION = 6, /* single-string API: the reference's panic at src/lib.rs:817 */
+    HRX_ERR_OUT_OF_CONTRACT = 7,    /* single-string API: two defs flag the same row or n > max_chars_size */
+    HRX_ERR_IO = 8
+};
+
+/* ------------------------------------------------------------------ */
+/* Data model — src/defs.rs                                            */
+/* ------------------------------------------------------------------ */
+
+int hrx_defs_create(hrx_defs **out);
+void hrx_defs_destroy(hrx_defs *defs);
+
+/* AllstrRegexDef::read_from_reader (defs.rs:75-110) on an in-memory text; begins a new
+ * RegexDefs { allstr, substrs: vec![] }.  Line 0 first state, line 1 accepted state,
+ * line 2 largest state, then "cur next char" per line; the char is taken `as u8`. */
+int hrx_defs_push_allstr_text(hrx_defs *defs, const char *text, size_t len);
+/* AllstrRegexDef::read_from_text (defs.rs:54-58) */
+int hrx_defs_push_allstr_file(hrx_defs *defs, const char *path);
+/* SubstrRegexDef::read_from_reader (defs.rs:209-265); appended to the last RegexDefs.substrs. */
+int hrx_defs_push_substr_text(hrx_defs *defs, const char *text, size_t len);
+/* SubstrRegexDef::read_from_text (defs.rs:184-188) */
+int hrx_defs_push_substr_file(hrx_defs *defs, const char *path);
+/* Already-parsed forms for a Rust caller that holds the structs:
+ * AllstrRegexDef { state_lookup, first_state_val, accepted_state_val, largest_state_val } (defs.rs:26-36);
+ * entry i is state_lookup[(chr[i], cur[i])] = (line_idx[i], next[i]). */
+int hrx_defs_push_allstr(hrx_defs *defs, uint64_t first_state_val, uint64_t accepted_state_val,
+                         uint64_t largest_state_val, size_t n_transitions, const uint64_t *cur,
+                         const uint64_t *next, const uint8_t *chr, const uint64_t *line_idx);
+/* SubstrRegexDef::new (defs.rs:147-163); max_length / min_position / max_position are unused by the chip. */
+int hrx_defs_push_substr(hrx_defs *defs, size_t n_pairs, const uint64_t *pair_cur, const uint64_t *pair_next,
+                         size_t n_start, const uint64_t *start_states, size_t n_end, const uint64_t *end_states);
+/* Validate and build the dense fused (state,char) tables.  Required before any call below. */
+int hrx_defs_finalize(hrx_defs *defs);
+
+size_t hrx_defs_num_defs(const hrx_defs *defs);
+size_t hrx_defs_num_substrs(const hrx_defs *defs, size_t def);
+uint64_t hrx_defs_first_state(const hrx_defs *defs, size_t def);
+uint64_t hrx_defs_accepted_state(const hrx_defs *defs, size_t def);
+uint64_t hrx_defs_largest_state(const hrx_defs *defs, size_t def);
+size_t hrx_defs_num_transitions(const hrx_defs *defs, size_t def);
+/* substr_id of the first substring of `def`: the offset rule of lib.rs:780-783 / 827,842 */
+uint64_t hrx_defs_substr_id_offset(const hrx_defs *defs, size_t def);
+/* bytes of LDS the fused tables of all defs occupy */
+size_t hrx_defs_table_bytes(const hrx_defs *defs);
+
+/* RegexTableConfig::load (table.rs:61-198), rows as integers in assignment order.
+ * transition rows: (char, cur_state, next_state, substr_id), row 0 = (0,dummy,dummy,0), then one row per
+ * state_lookup entry sorted by line index.  endpoint rows: (substr_id, start_state, end_state).
+ * Returns the number of rows; writes min(rows, cap) of them. */
+size_t hrx_table_transition_rows(const hrx_defs *defs, size_t def, uint64_t *rows4, size_t cap_rows);
+size_t hrx_table_endpoint_rows(const hrx_defs *defs, size_t def, uint64_t *rows3, size_t cap_rows);
+
+/* ------------------------------------------------------------------ */
+/* Device context                                                      */
+/* ------------------------------------------------------------------ */
+
+int hrx_device_count(int *count);
+/* Uploads the tables to `device` and creates a stream.  The handle may be shared by clones of a
+ * RegexVerifyConfig (lib.rs:96 derives Clone); calls on one ctx are serialised internally. */
+int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out);
+void hrx_ctx_destroy(hrx_ctx *ctx);
+/* thread-local text of the last failing call (any entry point) */
+const char *hrx_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* The hot path: witness rows for a batch of strings                    */
+/* ------------------------------------------------------------------ */
+/*
+ * One call = match_substrs' integer content (lib.rs:316-318, 339-348, 387-519, 593-764) for B strings.
+ *   chars    B strings, string b at chars + b*stride, stride % 16 == 0, base 16-byte aligned
+ *   lens     n_b (bytes of string b), n_b <= M
+ *   M        max_chars_size (lib.rs:128): witness rows per string
+ *   records  [B][M][D] u32: state_d[r] | substr_id_d[r] << 16 | start_enable_d[r] << 24 | end_enable_d[r] << 25
+ *            (the states / substr_ids / start_enable / end_enable advice columns, lib.rs:419-519)
+ *   masked   [B][M] u16:   masked_char[r] | masked_substr_id[r] << 8
+ *            (AssignedRegexResult.masked_characters / .all_substr_ids, lib.rs:766-771)
+ *   status   [B] u64: bits 0..7 code
+ *            0 ok: bits 8..15 = accept mask (bit d: state at row n == accepted_state_val of def d, lib.rs:442-457)
+ *            1 invalid transition (lib.rs:817): bits 8..15 def, 16..23 char, 24..39 state, 40..63 position;
+ *              lowest def, then lowest position, like the reference's loop order
+ *            2 two defs flag the same row (out of contract): bits 40..63 row
+ *            3 n_b > M
+ *            records/masked of a string whose code != 0 are unspecified.
+ * All five pointers are DEVICE pointers on ctx's device; `stream` is a hipStream_t (NULL = ctx's own stream).
+ * The call is asynchronous on that stream.
+ */
+int hrx_witness_batch_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
+                             size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream);
+/* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers; synchronous. */
+int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
+                           size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);
+
+/* Contiguous shard [begin, begin+count) of a batch of B strings for `rank` of `world` devices
+ * (strings are independent given the RegexDefs; no collective on the path). */
+void hrx_shard_range(size_t B, int world, int rank, size_t *begin, size_t *count);
+
+/* ------------------------------------------------------------------ */
+/* Reference-shaped single-string entry points — src/lib.rs:804-888     */
+/* ------------------------------------------------------------------ */
+/* derive_states(&self, characters:&[u8]) -> Vec<Vec<u64>>: states[d*(n+1) + i].  On the reference's panic
+ * returns HRX_ERR_INVALID_TRANSITION and hrx_last_error() is exactly
+ * "The transition from {state} by {char} is invalid!" (lib.rs:817). */
+int hrx_derive_states(hrx_ctx *ctx, const uint8_t *characters, size_t n, uint64_t *states);
+/* derive_substr_ids(&self, states) -> Vec<Vec<usize>>: substr_ids[d*n + i] */
+int hrx_derive_substr_ids(hrx_ctx *ctx, const uint64_t *states, size_t n, uint64_t *substr_ids);
+/* derive_is_start_end(&self, states, substr_ids) -> (Vec<Vec<bool>>, Vec<Vec<bool>>): each [d*(n+1) + i] */
+int hrx_derive_is_start_end(hrx_ctx *ctx, const uint64_t *states, const uint64_t *substr_ids, size_t n,
+                            uint8_t *is_start, uint8_t *is_end);
+/* match_substrs(&self, ctx, characters) integer columns for one string (lib.rs:311-773); any pointer may be NULL.
+ * enable/character/masked_char/masked_substr_id: [M]; state/substr_id/start_enable/end_enable: [D][M]. */
+int hrx_match_substrs(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t M, uint64_t *enable,
+                      uint64_t *character, uint64_t *state, uint64_t *substr_id, uint64_t *start_enable,
+                      uint64_t *end_enable, uint64_t *masked_char, uint64_t *masked_substr_id,
+                      uint64_t *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRX_H */

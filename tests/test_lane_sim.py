@@ -1,0 +1,158 @@
+"""Algorithm check without a GPU: the per-lane tile algebra the kernel runs (csrc/hrx_lane.h) and the dense
+fused tables (csrc/hrx_defs.cpp), re-enacted lane by lane on the CPU by tests/sim/lane_sim.cpp, against the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleDefs, DFA_DIR, ROOT, reference_cases
+from halo2_regex_amd import synth
+
+SIM_SRC = os.path.join(ROOT, "tests", "sim", "lane_sim.cpp")
+SIM_SO = os.path.join(ROOT, "tests", "sim", "_build", "liblane_sim.so")
+CSRC = os.path.join(ROOT, "halo2_regex_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    deps = [SIM_SRC, os.path.join(CSRC, "hrx_defs.cpp"), os.path.join(CSRC, "hrx_lane.h"), os.path.join(CSRC, "hrx_defs.hpp")]
+    if not os.path.exists(SIM_SO) or any(os.path.getmtime(SIM_SO) < os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(SIM_SO), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", SIM_SO, SIM_SRC,
+                               os.path.join(CSRC, "hrx_defs.cpp")])
+    lib = C.CDLL(SIM_SO)
+    lib.sim_new.restype = C.c_void_p
+    lib.sim_free.argtypes = [C.c_void_p]
+    lib.sim_push_allstr.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.sim_push_substr.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.sim_finalize.argtypes = [C.c_void_p]
+    lib.sim_witness_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for f in (lib.sim_fill_up, lib.sim_fill_down):
+        f.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        f.restype = C.c_uint64
+    return lib
+
+
+class SimDefs:
+    def __init__(self, lib, defs):
+        self.lib = lib
+        self.h = lib.sim_new()
+        for allstr, substrs in defs:
+            t = open(os.path.join(DFA_DIR, allstr), "rb").read() if isinstance(allstr, str) else allstr
+            assert lib.sim_push_allstr(self.h, t, len(t)) == 0
+            for s in substrs:
+                t = open(os.path.join(DFA_DIR, s), "rb").read() if isinstance(s, str) else s
+                assert lib.sim_push_substr(self.h, t, len(t)) == 0
+        assert lib.sim_finalize(self.h) == 0
+        self.D = len(defs)
+
+    def run(self, chars, lens, M):
+        chars = np.ascontiguousarray(chars, np.uint8)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        B, stride = chars.shape
+        rec = np.zeros((B, M, self.D), np.uint32)
+        msk = np.zeros((B, M), np.uint16)
+        st = np.zeros(B, np.uint64)
+        fix = np.zeros(1, np.uint64)
+        self.lib.sim_witness_batch(self.h, chars.ctypes.data, stride, lens.ctypes.data, B, M, rec.ctypes.data,
+                                   msk.ctypes.data, st.ctypes.data, fix.ctypes.data)
+        return rec, msk, st, int(fix[0])
+
+
+CFG_A = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]], ["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]]]
+CFG_1 = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]]]
+CFG_23 = [["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]], ["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
+CFG_3 = [["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
+CFG_EX = [["ex_allstr.txt", ["ex_substr_id1.txt"]]]
+
+
+def _compare(oracle, sim, cfg, chars, lens, M):
+    o = OracleDefs.from_files(oracle, cfg)
+    s = SimDefs(sim, cfg)
+    orec, omsk, ost = o.witness_batch(chars, lens, M)
+    srec, smsk, sst, fix = s.run(chars, lens, M)
+    assert np.array_equal(ost, sst)
+    ok = (ost & np.uint64(0xff)) == 0
+    assert np.array_equal(orec[ok], srec[ok])
+    assert np.array_equal(omsk[ok], smsk[ok])
+    return ost, omsk, fix
+
+
+def test_scan_primitives_match_the_sequential_recurrence(sim):
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        dens = rng.choice([2, 4, 16])
+        a = int(rng.integers(0, 2**63)) & int(rng.integers(0, 2**63)) if dens > 2 else int(rng.integers(0, 2**63))
+        b = int(rng.integers(0, 2**63))
+        setm = a & ~b & (2**64 - 1)
+        rstm = b & ~a & (2**64 - 1)
+        if dens == 16:
+            setm &= int(rng.integers(0, 2**63)); rstm &= int(rng.integers(0, 2**63))
+        for cin in (0, 1):
+            last, up = cin, 0
+            for i in range(64):          # lib.rs:631-642
+                if (setm >> i) & 1: last = 1
+                if (rstm >> i) & 1: last = 0
+                up |= last << i
+            last, dn = cin, 0
+            for i in range(63, -1, -1):  # lib.rs:699-710
+                if (setm >> i) & 1: last = 1
+                if (rstm >> i) & 1: last = 0
+                dn |= last << i
+            assert sim.sim_fill_up(setm, rstm, cin) == up
+            assert sim.sim_fill_down(setm, rstm, cin) == dn
+
+
+@pytest.mark.parametrize("case", reference_cases(), ids=[c["name"] for c in reference_cases()])
+def test_reference_cases(oracle, sim, case):
+    inp = case["input"].encode("latin-1")
+    M = case["max_chars_size"]
+    chars = np.zeros((1, (len(inp) + 15) // 16 * 16), np.uint8)
+    chars[0, :len(inp)] = np.frombuffer(inp, np.uint8)
+    _compare(oracle, sim, case["defs"], chars, np.array([len(inp)], np.uint32), M)
+
+
+@pytest.mark.parametrize("M", [1, 7, 63, 64, 65, 128, 200, 1024])
+def test_ragged_lengths_and_row_counts(oracle, sim, M):
+    chars, lens = synth.ragged(96, M, seed=M)
+    st, _, _ = _compare(oracle, sim, CFG_1, chars, lens, M)
+    assert ((st & np.uint64(0xff)) == 0).all()
+    _compare(oracle, sim, CFG_A, chars, lens, M)
+
+
+def test_reveal_mask_stress_crosses_tiles_and_needs_fixups(oracle, sim):
+    chars, lens = synth.reveal_stress(600, 700, seed=11)
+    for cfg in (CFG_1, CFG_3, CFG_A, CFG_23):
+        st, msk, fix = _compare(oracle, sim, cfg, chars, lens, 704)
+    # the stress set must actually exercise the optimistic end-mask protocol, both ways
+    _, msk, fix = _compare(oracle, sim, CFG_3, chars, lens, 704)
+    assert fix > 0 and msk.any()
+
+
+def test_invalid_transition_and_bad_length_status(oracle, sim):
+    chars, lens = synth.ragged(64, 300, seed=3)
+    rng = np.random.default_rng(1)
+    for b in range(0, 64, 3):                      # bytes outside the alphabet -> lib.rs:817
+        if lens[b]:
+            chars[b, int(rng.integers(0, lens[b]))] = 200 + b % 50
+    lens[5] = 400                                  # n > M
+    st, _, _ = _compare(oracle, sim, CFG_A, chars, lens, 304)
+    codes = st & np.uint64(0xff)
+    assert (codes == 1).any() and (codes == 3).any() and (codes == 0).any()
+    # partial DFA of the example: state 2 has no out-edges
+    inp = b"email was meant for @vitalik.!"
+    c = np.zeros((1, 32), np.uint8); c[0, :len(inp)] = np.frombuffer(inp, np.uint8)
+    st, _, _ = _compare(oracle, sim, CFG_EX, c, np.array([len(inp)], np.uint32), 128)
+    assert int(st[0]) & 0xff == 1 and int(st[0]) >> 40 == 29
+
+
+def test_flag_overlap_is_reported(oracle, sim):
+    # the same def twice: both defs raise start/end flags on the same rows -> out of contract
+    cfg = [CFG_1[0], CFG_1[0]]
+    inp = b"email was meant for @ab."
+    c = np.zeros((2, 32), np.uint8); c[0, :len(inp)] = np.frombuffer(inp, np.uint8)
+    st, _, _ = _compare(oracle, sim, cfg, c, np.array([len(inp), 0], np.uint32), 64)
+    assert int(st[0]) & 0xff == 2 and int(st[1]) & 0xff == 0

@@ -1,0 +1,194 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle (bit-exact) and against the
+reference's own known answers.  Run with -m gpu on an MI355X."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleDefs, DFA_DIR, reference_cases
+
+pytestmark = pytest.mark.gpu
+
+CFG_1 = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]]]
+CFG_A = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]], ["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]]]
+CFG_3 = [["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
+CFG_23 = [["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]], ["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
+CFG_123 = CFG_A + CFG_3
+CFG_EX = [["ex_allstr.txt", ["ex_substr_id1.txt"]]]
+
+
+@pytest.fixture(scope="module")
+def hra():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    import halo2_regex_amd as m
+    return m
+
+
+def _cfg(hra, names, M):
+    defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(os.path.join(DFA_DIR, a)),
+                          [hra.SubstrRegexDef.read_from_text(os.path.join(DFA_DIR, s)) for s in subs]) for a, subs in names]
+    return hra.RegexVerifyConfig.configure(M, defs, device=0)
+
+
+def _check_batch(hra, oracle, names, chars, lens, M):
+    cfg = _cfg(hra, names, M)
+    o = OracleDefs.from_files(oracle, names)
+    orec, omsk, ost = o.witness_batch(chars, lens, M)
+    grec, gmsk, gst = cfg.witness_batch_host(chars, lens)
+    assert np.array_equal(ost, gst)
+    ok = (ost & np.uint64(0xff)) == 0
+    assert np.array_equal(orec[ok], grec[ok])
+    assert np.array_equal(omsk[ok], gmsk[ok])
+    return ost, omsk
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own tests, through the reference-shaped single-string surface
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", reference_cases(), ids=[c["name"] for c in reference_cases()])
+def test_reference_known_answers(hra, oracle, case):
+    M = case["max_chars_size"]
+    cfg = _cfg(hra, case["defs"], M)
+    inp = case["input"].encode("latin-1")
+    result = cfg.match_substrs(inp)                                   # lib.rs:1042
+    expected_masked_chars = np.zeros(M, np.uint64)
+    expected_substr_ids = np.zeros(M, np.uint64)
+    for substr_idx, (start, chars) in enumerate(case["expected_substrs"]):   # lib.rs:1046-1051
+        for idx, ch in enumerate(chars.encode("latin-1")):
+            expected_masked_chars[start + idx] = ch
+            expected_substr_ids[start + idx] = substr_idx + 1
+    if case["masked_outputs_asserted"]:
+        assert np.array_equal(result.masked_characters, expected_masked_chars)   # lib.rs:1052-1059
+        assert np.array_equal(result.all_substr_ids, expected_substr_ids)
+    accepted = hra.decode_status(result.status)["accept"] == (1 << cfg.num_defs) - 1
+    assert accepted == case["verify_ok"]                              # MockProver::verify() outcome
+    # every column against the oracle's restatement of match_substrs
+    o = OracleDefs.from_files(oracle, case["defs"]).match_substrs(inp, M)
+    assert np.array_equal(result.all_enable_flags, o["enable"])
+    assert np.array_equal(result.all_characters, o["character"])
+    assert np.array_equal(result.states, o["state"])
+    assert np.array_equal(result.substr_ids, o["substr_id"])
+    assert np.array_equal(result.start_enables, o["start_enable"])
+    assert np.array_equal(result.end_enables, o["end_enable"])
+    assert np.array_equal(result.masked_characters, o["masked_char"])
+    assert np.array_equal(result.all_substr_ids, o["masked_substr_id"])
+
+
+@pytest.mark.parametrize("case", reference_cases()[:6], ids=[c["name"] for c in reference_cases()[:6]])
+def test_derive_functions_match_lib_rs_804_888(hra, oracle, case):
+    cfg = _cfg(hra, case["defs"], case["max_chars_size"])
+    o = OracleDefs.from_files(oracle, case["defs"])
+    inp = case["input"].encode("latin-1")
+    states = cfg.derive_states(inp)
+    assert states.shape == (cfg.num_defs, len(inp) + 1) and np.array_equal(states, o.derive_states(inp))
+    sids = cfg.derive_substr_ids(states)
+    assert np.array_equal(sids, o.derive_substr_ids(states))
+    st, en = cfg.derive_is_start_end(states, sids)
+    ost, oen = o.derive_is_start_end(states, sids)
+    assert np.array_equal(st, ost) and np.array_equal(en, oen)
+
+
+def test_invalid_transition_panics_with_the_reference_message(hra):
+    cfg = _cfg(hra, CFG_EX, 128)
+    with pytest.raises(hra.HrxError, match=r"^The transition from 2 by 33 is invalid!$") as e:   # lib.rs:817
+        cfg.derive_states(b"email was meant for @vitalik.!")
+    assert e.value.code == hra.HRX_ERR_INVALID_TRANSITION
+    with pytest.raises(hra.HrxError, match=r"The transition from 0 by 200 is invalid!"):
+        _cfg(hra, CFG_1, 64).match_substrs(bytes([200]))
+    assert _cfg(hra, CFG_1, 64).derive_states(b"").tolist() == [[0]]
+
+
+# ---------------------------------------------------------------------------------------------
+# batches against the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [1, 7, 8, 63, 64, 65, 72, 128, 200, 1024])
+def test_ragged_batches_every_row_count(hra, oracle, M):
+    from halo2_regex_amd import synth
+    chars, lens = synth.ragged(200, M, seed=M)
+    _check_batch(hra, oracle, CFG_1, chars, lens, M)
+    _check_batch(hra, oracle, CFG_A, chars, lens, M)
+
+
+@pytest.mark.parametrize("names", [CFG_1, CFG_3, CFG_A, CFG_23, CFG_123], ids=["r1", "r3", "r1r2", "r2r3", "r1r2r3"])
+def test_reveal_mask_stress(hra, oracle, names):
+    from halo2_regex_amd import synth
+    chars, lens = synth.reveal_stress(1500, 700, seed=11)
+    st, msk = _check_batch(hra, oracle, names, chars, lens, 704)
+    assert msk.any()
+    chars, lens = synth.reveal_stress(300, 2000, seed=12)
+    _check_batch(hra, oracle, names, chars, lens, 2003)               # unaligned row count
+
+
+def test_invalid_bytes_bad_lengths_and_overlap_status(hra, oracle):
+    from halo2_regex_amd import synth
+    chars, lens = synth.ragged(257, 300, seed=3)
+    rng = np.random.default_rng(1)
+    for b in range(0, 257, 3):
+        if lens[b]:
+            chars[b, int(rng.integers(0, lens[b]))] = 200 + b % 50
+    lens[5] = 400
+    st, _ = _check_batch(hra, oracle, CFG_A, chars, lens, 304)
+    codes = st & np.uint64(0xff)
+    assert (codes == 1).any() and (codes == 3).any() and (codes == 0).any()
+    inp = b"email was meant for @ab."
+    c = np.zeros((2, 32), np.uint8)
+    c[0, :len(inp)] = np.frombuffer(inp, np.uint8)
+    st, _ = _check_batch(hra, oracle, [CFG_1[0], CFG_1[0]], c, np.array([len(inp), 0], np.uint32), 64)
+    assert int(st[0]) & 0xff == 2
+
+
+def test_planted_configs_of_baseline(hra, oracle):
+    from halo2_regex_amd import synth
+    chars, lens = synth.regex1_planted(4096, 1023, seed=0, stride=1024)      # cfg 2(b) shape, small batch
+    st, msk = _check_batch(hra, oracle, CFG_1, chars, lens, 1024)
+    assert (msk != 0).any(axis=1).mean() > 0.9                               # almost every string reveals its plant
+    chars, lens = synth.regex23_planted(2048, 2047, seed=1, stride=2048)     # cfg 3 shape, small batch
+    _check_batch(hra, oracle, CFG_23, chars, lens, 2048)
+    chars, lens = synth.noise(1024, 1024, seed=0)                            # n == M
+    _check_batch(hra, oracle, CFG_1, chars, lens, 1024)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE cfg 2 at full size: device-resident path + size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_full_size_cfg2_device_resident(hra, oracle):
+    import torch
+    from halo2_regex_amd import synth
+    B, n, M = 65536, 1023, 1024
+    chars, lens = synth.regex1_planted(B, n, seed=0, stride=1024)
+    cfg = _cfg(hra, CFG_1, M)
+    dev = torch.device("cuda", 0)
+    d_chars = torch.from_numpy(chars).to(dev)
+    d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    rec, msk, st = cfg.witness_batch(d_chars, d_lens)
+    torch.cuda.synchronize()
+    rec_h = rec.cpu().numpy().view(np.uint32)
+    msk_h = msk.cpu().numpy().view(np.uint16)
+    st_h = st.cpu().numpy().view(np.uint64)
+    assert (st_h & np.uint64(0xff) == 0).all()
+    # (1) a seeded sample of strings, bit-exact against the oracle
+    o = OracleDefs.from_files(oracle, CFG_1)
+    idx = np.random.default_rng(0).choice(B, 768, replace=False)
+    orec, omsk, ost = o.witness_batch(chars[idx], lens[idx], M)
+    assert np.array_equal(orec, rec_h[idx]) and np.array_equal(omsk, msk_h[idx]) and np.array_equal(ost, st_h[idx])
+    # (2) idempotence: a second launch into fresh buffers gives the same bytes (checksum of checksums)
+    rec2, msk2, st2 = cfg.witness_batch(d_chars, d_lens)
+    torch.cuda.synchronize()
+    assert torch.equal(rec, rec2) and torch.equal(msk, msk2) and torch.equal(st, st2)
+    # (3) strings are independent: any shard of the batch reproduces its slice of the whole (the multi-GPU rule)
+    for world in (2, 8):
+        for rank in (0, world - 1):
+            b, c = hra.shard_range(B, world, rank)
+            r3, m3, s3 = cfg.witness_batch(d_chars[b:b + c].contiguous(), d_lens[b:b + c].contiguous())
+            torch.cuda.synchronize()
+            assert torch.equal(r3, rec[b:b + c]) and torch.equal(m3, msk[b:b + c]) and torch.equal(s3, st[b:b + c])
+    # (4) structural properties of every row of every string (App. A.2): padding rows, masked only where tagged
+    state = rec_h[:, :, 0] & 0xffff
+    sid = (rec_h[:, :, 0] >> 16) & 0xff
+    assert (state[:, n + 1:] == 29).all() and (sid[:, n:] == 0).all()
+    assert (state[:, 0] == 0).all()
+    assert ((msk_h != 0) <= (sid != 0)).all()
+    assert ((msk_h >> 8)[msk_h != 0] == 1).all()
+    assert ((msk_h & 0xff)[msk_h != 0] == chars[:, :M][msk_h != 0]).all()
