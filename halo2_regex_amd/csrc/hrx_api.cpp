@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -257,15 +258,16 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
     if (M == 0 || M > (1u << 24)) return fail(HRX_ERR_ARG, "max_chars_size must be in 1..2^24");
     if (B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "batch too large");
-    if ((stride & 15) || ((uintptr_t)chars & 15)) return fail(HRX_ERR_ARG, "chars must be 16-byte aligned with stride % 16 == 0");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15))
+        return fail(HRX_ERR_ARG, "chars must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
     if (((uintptr_t)records & 15) || ((uintptr_t)masked & 15) || ((uintptr_t)status & 7) || ((uintptr_t)lens & 3))
         return fail(HRX_ERR_ARG, "output buffers must be 16-byte aligned");
     WitnessArgs a{};
     a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
     a.records = records; a.masked = masked; a.status = status;
     a.table_image = ctx->d_table; a.table_bytes = (uint32_t)(ctx->s.table_image.size() * 4);
-    a.n_groups = (uint32_t)((B + 63) / 64);
     a.D = (uint32_t)ctx->s.defs.size();
+    if (const char *dbg = std::getenv("HRX_DEBUG_FLAGS")) a.debug = (uint32_t)std::atoi(dbg);
     for (uint32_t d = 0; d < a.D; ++d) a.dc[d] = ctx->s.consts[d];
     LaunchInfo li;
     if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
@@ -278,7 +280,7 @@ int hrx_witness_batch_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, stream ? (hipStream_t)stream : ctx->stream);
+    return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream);
 }
 
 static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
@@ -286,7 +288,7 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
     if (B == 0) return HRX_OK;
     if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
     const size_t D = ctx->s.defs.size();
-    const size_t dstride = (stride + 15) & ~(size_t)15;
+    const size_t dstride = stride ? (stride + 15) & ~(size_t)15 : 16;
     HIP_TRY(ctx->chars.reserve(dstride * B + 16));
     HIP_TRY(ctx->lens.reserve(4 * B));
     HIP_TRY(ctx->records.reserve(4 * B * M * D));
@@ -296,7 +298,7 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
     if (dstride != stride) HIP_TRY(hipMemsetAsync(ctx->chars.p, 0, dstride * B, st));
     if (stride) HIP_TRY(hipMemcpy2DAsync(ctx->chars.p, dstride, chars, stride, stride, B, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->lens.p, lens, 4 * B, hipMemcpyHostToDevice, st));
-    if (int rc = launch_batch(ctx, (const uint8_t *)ctx->chars.p, dstride ? dstride : 16, (const uint32_t *)ctx->lens.p, B, M,
+    if (int rc = launch_batch(ctx, (const uint8_t *)ctx->chars.p, dstride, (const uint32_t *)ctx->lens.p, B, M,
                               (uint32_t *)ctx->records.p, (uint16_t *)ctx->masked.p, (uint64_t *)ctx->status.p, st))
         return rc;
     HIP_TRY(hipMemcpyAsync(records, ctx->records.p, 4 * B * M * D, hipMemcpyDeviceToHost, st));

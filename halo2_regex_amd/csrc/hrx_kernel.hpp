@@ -19,23 +19,28 @@ struct WitnessArgs {
     uint64_t *status;
     const uint32_t *table_image;  // device copy of DefsSet::table_image
     uint32_t table_bytes;
-    uint32_t n_groups;            // ceil(B / 64)
+    uint32_t n_groups;            // ceil(B / gs), set by plan_witness_launch
+    uint32_t gs;                  // strings per wave (64, 32 or 16), set by plan_witness_launch
     uint32_t D;
+    uint32_t debug;               // HRX_DEBUG_FLAGS (profiling ablations only): 1 skip record stores, 2 skip masked stores
+    unsigned long long *stamps;   // profiling only (tools/kbench): per wave and tile 4 s_memtime stamps; NULL in the product
     DefConsts dc[3];
 };
 
 struct LaunchInfo {
-    int waves_per_wg;
+    int split;         // 1: walker/storer kernel (witness_split_kernel), 0: one-wave-does-all kernel (witness_kernel)
+    int waves_per_wg;  // split: 2 * pairs
+    int nslots;        // split: ring slots per walker/storer pair
     int grid;
     size_t lds_bytes;
 };
 
 // LDS bytes one wave stages per 64-string x 64-row tile
-constexpr size_t wave_stage_bytes(int D) { return 64 * (256 * (size_t)D + 16) + 64 * 80 + 64 * 8; }
+constexpr size_t wave_stage_bytes(int D, unsigned gs) { return ((size_t)gs + 1) * ((256 * (size_t)D + 16) + 80 + 8); }
 constexpr size_t kLdsLimit = 160 * 1024;
 
 // Picks the launch geometry for `a` on a device with `num_cus` CUs; returns false if nothing fits.
-bool plan_witness_launch(const WitnessArgs &a, int num_cus, LaunchInfo &out);
+bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out);
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 
 // states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])

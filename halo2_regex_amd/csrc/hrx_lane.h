@@ -97,34 +97,37 @@ struct TileMasks {
     uint32_t fix_start;
 };
 
-// Reveal mask of one tile (src/lib.rs:598-764 on integers).
+// Reveal mask of one tile of W rows, W <= 64 (src/lib.rs:598-764 on integers); bits >= W of the inputs are 0.
 //
 // The backward scan (end_mask) of row p depends on rows > p.  The backward event that
 // decides position q-1 is made of row q's own quantities (lib.rs:665-698):
 //     set   = EN[q] & (SID[q] != SID[q-1]),   reset = !EN[q] & ST[q] & (SID[q] != SID[q-1])
-// so all events of positions t0-1 .. t0+62 are known inside the tile; what is not
-// known is the first event at or after t0+63.  `exact` says there is none
+// so all events of positions t0-1 .. t0+W-2 are known inside the tile; what is not
+// known is the first event at or after t0+W-1.  `exact` says there is none
 // (the string or the region ends inside/before this tile: no events at rows > n, none at row M).
 // Otherwise the rows after the tile's last event are emitted optimistically with
 // end_mask = 1 (the common case: a substring that ends in the next tile) and the lane
 // remembers where they start; the first event of a later tile confirms them or asks for
 // them to be zeroed (`fix`).  Each row is fixed at most once.
+template <int W = 64>
 HRX_HD TileMasks tile_masks(const TileBits &b, MaskCarry &c, uint32_t t0, bool exact, uint64_t valid) {
+    constexpr uint64_t kAll = W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull);
     TileMasks out;
-    const uint64_t en0 = (b.en1 << 1) | (uint64_t)c.en;  // bit p = EN[t0+p]
-    c.en = (uint32_t)(b.en1 >> 63);
+    const uint64_t en0 = ((b.en1 << 1) | (uint64_t)c.en) & kAll;  // bit p = EN[t0+p]
+    c.en = (uint32_t)(b.en1 >> (W - 1)) & 1u;
     // forward: start_mask                                                     lib.rs:598-645
     const uint64_t setF = b.st & b.ch;
     const uint64_t rstF = ~b.st & en0 & b.ch;
-    const uint64_t sm = fill_up(setF, rstF, c.sm);
-    c.sm = (uint32_t)(sm >> 63);
+    const uint64_t sm = fill_up(setF, rstF, c.sm) & kAll;
+    c.sm = (uint32_t)(sm >> (W - 1)) & 1u;
     // backward: end_mask; bit j of setB/rstB is the event of position t0+j-1   lib.rs:663-714
     const uint64_t setB = en0 & b.ch;
     const uint64_t rstB = ~en0 & b.st & b.ch;
     const uint32_t cin = exact ? 0u : 1u;
-    const uint64_t F = fill_down(setB, rstB, cin);      // F[j]: first event at bit >= j is a set (cin if none)
-    const uint64_t em = (F >> 1) | ((uint64_t)cin << 63);  // end_mask[t0+p] = F[p+1]
-    out.mask = sm & em & valid;                          // lib.rs:740-745
+    // fill towards lower positions over W bits: mirror the W-bit field, fill up, mirror back
+    const uint64_t F = brev64(fill_up(brev64(setB) >> (64 - W), brev64(rstB) >> (64 - W), cin) << (64 - W));
+    const uint64_t em = (F >> 1) | ((uint64_t)cin << (W - 1));  // end_mask[t0+p] = F[p+1]
+    out.mask = sm & em & valid & kAll;                              // lib.rs:740-745
     const uint64_t any = setB | rstB;
     out.fix = 0;
     out.fix_start = 0;
@@ -140,8 +143,8 @@ HRX_HD TileMasks tile_masks(const TileBits &b, MaskCarry &c, uint32_t t0, bool e
     return out;
 }
 
-// No backward event can exist beyond this tile (rows > n carry no flags, row M does not exist).
-HRX_HD bool tile_is_exact(uint32_t t0, uint32_t n, uint32_t M) { return n <= t0 + 63u || t0 + 64u >= M; }
+// No backward event can exist beyond this W-row tile (rows > n carry no flags, row M does not exist).
+HRX_HD bool tile_is_exact(uint32_t t0, uint32_t n, uint32_t M, uint32_t W = 64) { return n <= t0 + W - 1u || t0 + W >= M; }
 
 // rows r = t0+p with r < n, as a bitvector
 HRX_HD uint64_t rows_below(uint32_t t0, uint32_t n) {

@@ -117,7 +117,7 @@ const char *hrx_last_error(void);
  *            2 two defs flag the same row (out of contract): bits 40..63 row
  *            3 n_b > M
  *            records/masked of a string whose code != 0 are unspecified.
- * All five pointers are DEVICE pointers on ctx's device; `stream` is a hipStream_t (NULL = ctx's own stream).
+ * All five pointers are DEVICE pointers on ctx's device; `stream` is a hipStream_t (NULL = the HIP null stream).
  * The call is asynchronous on that stream.
  */
 int hrx_witness_batch_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,

@@ -37,13 +37,16 @@ int sim_finalize(void *p) {
     return finalize_defs(*(DefsSet *)p, err);
 }
 
+}  // extern "C"
+
 // Same buffers as hrx_witness_batch_host.  fixups (optional) counts optimistic rows that had to be zeroed.
-void sim_witness_batch(void *p, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
-                       uint32_t *records, uint16_t *masked, uint64_t *status, uint64_t *fixups) {
+template <int W>
+static void sim_batch_w(void *p, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                        uint32_t *records, uint16_t *masked, uint64_t *status, uint64_t *fixups) {
     const DefsSet &s = *(DefsSet *)p;
     const int D = (int)s.defs.size();
     const uint32_t *T = s.table_image.data();
-    const uint32_t ntiles = (uint32_t)((M + 63) / 64);
+    const uint32_t ntiles = (uint32_t)((M + W - 1) / W);
     uint64_t nfix = 0;
     for (size_t b = 0; b < B; ++b) {
         const uint8_t *cp = chars + b * stride;
@@ -58,12 +61,12 @@ void sim_witness_batch(void *p, const uint8_t *chars, size_t stride, const uint3
         uint32_t *rec = records + b * M * D;
         uint16_t *msk = masked + b * M;
         for (uint32_t t = 0; t < ntiles; ++t) {
-            const uint32_t t0 = t * 64;
+            const uint32_t t0 = t * W;
             const int rem = (int)n - (int)t0, mrem = (int)M - 1 - (int)t0;
-            uint32_t trec[64 * 3];
-            uint8_t tch[64];
+            uint32_t trec[W * 3];
+            uint8_t tch[W];
             TileBits tb = {0, 0, 0};
-            for (int p = 0; p < 64; ++p) {
+            for (int p = 0; p < W; ++p) {
                 const uint32_t r = t0 + p;
                 const uint8_t c = (r < n) ? cp[r] : 0;  // the kernel zero-fills chunks it does not load
                 tch[p] = c;
@@ -92,26 +95,26 @@ void sim_witness_batch(void *p, const uint8_t *chars, size_t stride, const uint3
             for (int d = 0; d < D; ++d) {
                 if (!((dead >> d) & 1) && mx[d] >= s.consts[d].dead_entry) {
                     const uint32_t dead_state = s.consts[d].n_rows - 1;
-                    for (uint32_t p = 0; p < 64; ++p) {
+                    for (uint32_t p = 0; p < (uint32_t)W; ++p) {
                         const uint32_t s_p = trec[p * D + d] & 0xffff;
-                        const uint32_t s_n = p < 63 ? (trec[(p + 1) * D + d] & 0xffff) : ((e[d] >> kNextShift) - s.consts[d].row_base);
+                        const uint32_t s_n = p < (uint32_t)W - 1 ? (trec[(p + 1) * D + d] & 0xffff) : ((e[d] >> kNextShift) - s.consts[d].row_base);
                         if (s_n == dead_state && s_p != dead_state) { err_pos[d] = t0 + p; err_state[d] = s_p; err_char[d] = tch[p]; break; }
                     }
                     dead |= 1u << d;
                 }
             }
-            if (n >= t0 && n < t0 + 64) {
+            if (n >= t0 && n < t0 + W) {
                 accept = 0;
                 for (int d = 0; d < D; ++d) accept |= ((trec[(n - t0) * D + d] & 0xffff) == s.consts[d].accepted_state ? 1u : 0u) << d;
-            } else if (n == t0 + 64 && t + 1 == ntiles) {
+            } else if (n == t0 + W && t + 1 == ntiles) {
                 accept = 0;
                 for (int d = 0; d < D; ++d) accept |= (((e[d] >> kNextShift) - s.consts[d].row_base) == s.consts[d].accepted_state ? 1u : 0u) << d;
             }
-            const TileMasks tm = tile_masks(tb, mc, t0, tile_is_exact(t0, n, (uint32_t)M), rows_below(t0, n));
+            const TileMasks tm = tile_masks<W>(tb, mc, t0, tile_is_exact(t0, n, (uint32_t)M, W), rows_below(t0, n));
             if (tm.fix) {
                 for (uint32_t r = tm.fix_start; r < t0; ++r) { if (msk[r]) ++nfix; msk[r] = 0; }
             }
-            for (uint32_t p = 0; p < 64 && t0 + p < M; ++p) {
+            for (uint32_t p = 0; p < (uint32_t)W && t0 + p < M; ++p) {
                 uint32_t sid = 0;
                 for (int d = 0; d < D; ++d) { rec[(size_t)(t0 + p) * D + d] = trec[p * D + d]; sid += (trec[p * D + d] >> 16) & 0xff; }
                 msk[t0 + p] = ((tm.mask >> p) & 1) ? (uint16_t)(tch[p] | (sid << 8)) : 0;
@@ -125,6 +128,20 @@ void sim_witness_batch(void *p, const uint8_t *chars, size_t stride, const uint3
         status[b] = sw;
     }
     if (fixups) *fixups = nfix;
+}
+
+extern "C" {
+
+void sim_witness_batch(void *p, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                       uint32_t *records, uint16_t *masked, uint64_t *status, uint64_t *fixups) {
+    sim_batch_w<64>(p, chars, stride, lens, B, M, records, masked, status, fixups);
+}
+// tile width of the walker/storer kernel: 32 rows (D = 1) or 16 rows (D = 2)
+void sim_witness_batch_w(void *p, int W, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                         uint32_t *records, uint16_t *masked, uint64_t *status, uint64_t *fixups) {
+    if (W == 32) sim_batch_w<32>(p, chars, stride, lens, B, M, records, masked, status, fixups);
+    else if (W == 16) sim_batch_w<16>(p, chars, stride, lens, B, M, records, masked, status, fixups);
+    else sim_batch_w<64>(p, chars, stride, lens, B, M, records, masked, status, fixups);
 }
 
 // direct access to the scan primitives for property tests

@@ -30,6 +30,8 @@ def sim():
     lib.sim_finalize.argtypes = [C.c_void_p]
     lib.sim_witness_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sim_witness_batch_w.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     for f in (lib.sim_fill_up, lib.sim_fill_down):
         f.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
         f.restype = C.c_uint64
@@ -49,7 +51,7 @@ class SimDefs:
         assert lib.sim_finalize(self.h) == 0
         self.D = len(defs)
 
-    def run(self, chars, lens, M):
+    def run(self, chars, lens, M, W=64):
         chars = np.ascontiguousarray(chars, np.uint8)
         lens = np.ascontiguousarray(lens, np.uint32)
         B, stride = chars.shape
@@ -57,8 +59,8 @@ class SimDefs:
         msk = np.zeros((B, M), np.uint16)
         st = np.zeros(B, np.uint64)
         fix = np.zeros(1, np.uint64)
-        self.lib.sim_witness_batch(self.h, chars.ctypes.data, stride, lens.ctypes.data, B, M, rec.ctypes.data,
-                                   msk.ctypes.data, st.ctypes.data, fix.ctypes.data)
+        self.lib.sim_witness_batch_w(self.h, W, chars.ctypes.data, stride, lens.ctypes.data, B, M, rec.ctypes.data,
+                                     msk.ctypes.data, st.ctypes.data, fix.ctypes.data)
         return rec, msk, st, int(fix[0])
 
 
@@ -69,16 +71,20 @@ CFG_3 = [["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
 CFG_EX = [["ex_allstr.txt", ["ex_substr_id1.txt"]]]
 
 
-def _compare(oracle, sim, cfg, chars, lens, M):
+def _compare(oracle, sim, cfg, chars, lens, M, widths=(64, 32, 16)):
+    """every tile width the kernels use: 64 (one-wave kernel), 32 and 16 (walker/storer kernel)"""
     o = OracleDefs.from_files(oracle, cfg)
     s = SimDefs(sim, cfg)
     orec, omsk, ost = o.witness_batch(chars, lens, M)
-    srec, smsk, sst, fix = s.run(chars, lens, M)
-    assert np.array_equal(ost, sst)
     ok = (ost & np.uint64(0xff)) == 0
-    assert np.array_equal(orec[ok], srec[ok])
-    assert np.array_equal(omsk[ok], smsk[ok])
-    return ost, omsk, fix
+    fixes = []
+    for W in widths:
+        srec, smsk, sst, fix = s.run(chars, lens, M, W)
+        assert np.array_equal(ost, sst), W
+        assert np.array_equal(orec[ok], srec[ok]), W
+        assert np.array_equal(omsk[ok], smsk[ok]), W
+        fixes.append(fix)
+    return ost, omsk, fixes[0]
 
 
 def test_scan_primitives_match_the_sequential_recurrence(sim):

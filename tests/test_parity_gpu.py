@@ -121,6 +121,19 @@ def test_reveal_mask_stress(hra, oracle, names):
     _check_batch(hra, oracle, names, chars, lens, 2003)               # unaligned row count
 
 
+@pytest.mark.parametrize("flags", ["65536", "196608"], ids=["one-wave-gs64", "one-wave-gs32"])
+def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
+    """D <= 2 normally takes the walker/storer kernel; force the one-wave kernel (used for D = 3 and unaligned M)
+    through the same batches, at its regular and its small-batch group size."""
+    from halo2_regex_amd import synth
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", flags)
+    chars, lens = synth.reveal_stress(700, 700, seed=21)
+    _check_batch(hra, oracle, CFG_1, chars, lens, 704)
+    _check_batch(hra, oracle, CFG_23, chars, lens, 704)
+    chars, lens = synth.ragged(300, 200, seed=4)
+    _check_batch(hra, oracle, CFG_A, chars, lens, 200)
+
+
 def test_invalid_bytes_bad_lengths_and_overlap_status(hra, oracle):
     from halo2_regex_amd import synth
     chars, lens = synth.ragged(257, 300, seed=3)
