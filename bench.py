@@ -43,6 +43,19 @@ def cpu_baseline(names, chars, lens, M, budget_s=12.0):
                       "host has %d cores" % (nstr, reps, rows, dt, os.cpu_count())}
 
 
+def pmc_traffic(args, D):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json:
+    WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect counters
+    itself; None unless the committed passes were taken on the workload being run."""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", "r01_split_pmc.json")))
+        if args.config == "regex1" and args.batch == 65536 and args.n == 1023 and args.rows == 1024 and args.dist == "planted":
+            return p["hbm_bytes_per_launch"]["total"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,8 +151,8 @@ def main():
                        "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
                        "sharding": "by string index, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "hrx::witness_kernel<%d,true>" % D, "avg_launch_ms": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, D),
+                         "kernel": "hrx::witness_split_kernel<%d,%d>" % (D, 32 // D), "avg_launch_ms": kern_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,91 @@
+//! hrx.rs — the binding a halo2-regex maintainer would add (e.g. as `src/hrx.rs`) to route the witness path of
+//! `RegexVerifyConfig::match_substrs` through libhrx.so.  NOT compiled in this repository (the image has no
+//! Rust toolchain); it documents the drop-in call sites against include/hrx.h.  See INTEGRATION.md.
+#![allow(non_camel_case_types)]
+use std::ffi::{c_char, c_int, c_void, CStr};
+
+#[repr(C)] pub struct hrx_defs { _p: [u8; 0] }
+#[repr(C)] pub struct hrx_ctx { _p: [u8; 0] }
+
+#[link(name = "hrx")]
+extern "C" {
+    pub fn hrx_defs_create(out: *mut *mut hrx_defs) -> c_int;
+    pub fn hrx_defs_destroy(defs: *mut hrx_defs);
+    pub fn hrx_defs_push_allstr(defs: *mut hrx_defs, first: u64, accepted: u64, largest: u64, n: usize,
+                                cur: *const u64, next: *const u64, chr: *const u8, line_idx: *const u64) -> c_int;
+    pub fn hrx_defs_push_substr(defs: *mut hrx_defs, n_pairs: usize, pair_cur: *const u64, pair_next: *const u64,
+                                n_start: usize, starts: *const u64, n_end: usize, ends: *const u64) -> c_int;
+    pub fn hrx_defs_finalize(defs: *mut hrx_defs) -> c_int;
+    pub fn hrx_ctx_create(defs: *const hrx_defs, device: c_int, out: *mut *mut hrx_ctx) -> c_int;
+    pub fn hrx_ctx_destroy(ctx: *mut hrx_ctx);
+    pub fn hrx_last_error() -> *const c_char;
+    pub fn hrx_witness_batch_host(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, lens: *const u32, b: usize,
+                                  m: usize, records: *mut u32, masked: *mut u16, status: *mut u64) -> c_int;
+    pub fn hrx_witness_batch_device(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, lens: *const u32, b: usize,
+                                    m: usize, records: *mut u32, masked: *mut u16, status: *mut u64,
+                                    stream: *mut c_void) -> c_int;
+    pub fn hrx_derive_states(ctx: *mut hrx_ctx, characters: *const u8, n: usize, states: *mut u64) -> c_int;
+    pub fn hrx_derive_substr_ids(ctx: *mut hrx_ctx, states: *const u64, n: usize, substr_ids: *mut u64) -> c_int;
+    pub fn hrx_derive_is_start_end(ctx: *mut hrx_ctx, states: *const u64, substr_ids: *const u64, n: usize,
+                                   is_start: *mut u8, is_end: *mut u8) -> c_int;
+}
+
+fn last_error() -> String { unsafe { CStr::from_ptr(hrx_last_error()).to_string_lossy().into_owned() } }
+
+/// Owns the device context built from `Vec<RegexDefs>`; shared (Arc) by the clones halo2 makes of the config.
+pub struct HrxHandle { defs: *mut hrx_defs, ctx: *mut hrx_ctx }
+unsafe impl Send for HrxHandle {}
+unsafe impl Sync for HrxHandle {} // calls on one ctx are serialised inside the library
+
+impl HrxHandle {
+    /// From the structs of src/defs.rs: state_lookup entries in any order with their line indices (table.rs:108 order).
+    pub fn new(regex_defs: &[crate::defs::RegexDefs], device: i32) -> Self {
+        unsafe {
+            let mut defs = std::ptr::null_mut();
+            assert_eq!(hrx_defs_create(&mut defs), 0);
+            for rd in regex_defs {
+                let (mut cur, mut next, mut chr, mut idx) = (vec![], vec![], vec![], vec![]);
+                for ((c, s), (i, n)) in rd.allstr.state_lookup.iter() { cur.push(*s); next.push(*n); chr.push(*c); idx.push(*i as u64); }
+                assert_eq!(hrx_defs_push_allstr(defs, rd.allstr.first_state_val, rd.allstr.accepted_state_val,
+                    rd.allstr.largest_state_val, cur.len(), cur.as_ptr(), next.as_ptr(), chr.as_ptr(), idx.as_ptr()), 0, "{}", last_error());
+                for sd in rd.substrs.iter() {
+                    let (a, b): (Vec<u64>, Vec<u64>) = sd.valid_state_transitions.iter().cloned().unzip();
+                    assert_eq!(hrx_defs_push_substr(defs, a.len(), a.as_ptr(), b.as_ptr(), sd.start_states.len(),
+                        sd.start_states.as_ptr(), sd.end_states.len(), sd.end_states.as_ptr()), 0, "{}", last_error());
+                }
+            }
+            assert_eq!(hrx_defs_finalize(defs), 0, "{}", last_error());
+            let mut ctx = std::ptr::null_mut();
+            assert_eq!(hrx_ctx_create(defs, device, &mut ctx), 0, "{}", last_error());
+            HrxHandle { defs, ctx }
+        }
+    }
+
+    /// Drop-in for `RegexVerifyConfig::derive_states` (src/lib.rs:804-823), same panic text.
+    pub fn derive_states(&self, num_defs: usize, characters: &[u8]) -> Vec<Vec<u64>> {
+        let n = characters.len();
+        let mut flat = vec![0u64; num_defs * (n + 1)];
+        let rc = unsafe { hrx_derive_states(self.ctx, characters.as_ptr(), n, flat.as_mut_ptr()) };
+        if rc != 0 { panic!("{}", last_error()); } // "The transition from {} by {} is invalid!"
+        flat.chunks(n + 1).map(|c| c.to_vec()).collect()
+    }
+
+    /// The batch surface: compact witness rows for many strings (one circuit each) sharing this config.
+    /// records[b][r][d] = state | substr_id<<16 | start_enable<<24 | end_enable<<25; masked[b][r] = char | id<<8.
+    pub fn witness_batch(&self, num_defs: usize, chars: &[u8], stride: usize, lens: &[u32], max_chars_size: usize)
+        -> (Vec<u32>, Vec<u16>, Vec<u64>) {
+        let b = lens.len();
+        let (mut rec, mut msk, mut st) = (vec![0u32; b * max_chars_size * num_defs], vec![0u16; b * max_chars_size], vec![0u64; b]);
+        let rc = unsafe { hrx_witness_batch_host(self.ctx, chars.as_ptr(), stride, lens.as_ptr(), b, max_chars_size,
+                                                 rec.as_mut_ptr(), msk.as_mut_ptr(), st.as_mut_ptr()) };
+        if rc != 0 { panic!("{}", last_error()); }
+        for (i, s) in st.iter().enumerate() {
+            if s & 0xff == 1 { panic!("string {}: The transition from {} by {} is invalid!", i, (s >> 24) & 0xffff, (s >> 16) & 0xff); }
+        }
+        (rec, msk, st)
+    }
+}
+
+impl Drop for HrxHandle {
+    fn drop(&mut self) { unsafe { hrx_ctx_destroy(self.ctx); hrx_defs_destroy(self.defs); } }
+}

@@ -100,6 +100,18 @@ def test_invalid_transition_panics_with_the_reference_message(hra):
     assert _cfg(hra, CFG_1, 64).derive_states(b"").tolist() == [[0]]
 
 
+def test_cpp_host_mirror_runs_the_reference_test(hra):
+    """tests/host_cpp/test_host.cpp = test_substr_pass1 (lib.rs:1067-1092) through csrc/hrx_host.hpp"""
+    import subprocess
+    from oracle_lib import ROOT
+    exe = "/tmp/hrx_test_host_gpu"
+    csrc = os.path.join(ROOT, "halo2_regex_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host_cpp", "test_host.cpp"), "-o", exe,
+                           "-L" + csrc, "-lhrx", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.run([exe, DFA_DIR, "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and "gpu ok" in out.stdout, out.stdout + out.stderr
+
+
 # ---------------------------------------------------------------------------------------------
 # batches against the oracle
 # ---------------------------------------------------------------------------------------------
