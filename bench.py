@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--dist", choices=["planted", "noise"], default="planted")
     ap.add_argument("--config", choices=["regex1", "regex23"], default="regex1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense", action="store_true", help="power-of-two pitches (M rows per string, n rounded to 16 bytes) "
+                    "instead of hrx_recommended_pitches")
     args = ap.parse_args()
 
     import numpy as np
@@ -95,7 +97,10 @@ def main():
         gen = synth.regex23_planted if args.dist == "planted" else synth.noise
     D = len(names)
     M, n, B = args.rows, args.n, args.batch
-    stride = (max(n, 1) + 15) // 16 * 16
+    rec_pitch, msk_pitch, rec_stride = hra.recommended_pitches(M)
+    if args.dense:
+        rec_pitch, msk_pitch, rec_stride = M, M, (max(n, 1) + 15) // 16 * 16
+    stride = rec_stride
     defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(os.path.join(DFA_DIR, a)),
                           [hra.SubstrRegexDef.read_from_text(os.path.join(DFA_DIR, s)) for s in subs]) for a, subs in names]
     cfg = hra.RegexVerifyConfig.configure(M, defs, device=local_rank)
@@ -104,7 +109,7 @@ def main():
     chars, lens = gen(B, n, seed=rank, stride=stride)
     d_chars = torch.from_numpy(chars).to(dev)
     d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
-    out = cfg.alloc_outputs(B, dev)
+    out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
     rows_per_step = int(lens.sum())
 
     def barrier():
@@ -133,6 +138,7 @@ def main():
 
     # sanity: every string of the timed workload finished with status 0 and the result is reproducible
     st = out[2].cpu().numpy().view(np.uint64)
+    assert out[0].shape == (B, M, D) and out[1].shape == (B, M)
     assert ((st & np.uint64(0xff)) == 0).all(), "status != ok in the bench workload"
 
     if rank == 0:
@@ -149,6 +155,8 @@ def main():
                                       stride, n, M, "alphabet-uniform noise + planted match" if args.dist == "planted"
                                       else "alphabet-uniform noise"),
                        "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
+                       "buffers": "string-major; input stride %d B, records pitch %d rows, masked pitch %d rows "
+                                  "(hrx_recommended_pitches: not powers of two)" % (stride, rec_pitch, msk_pitch),
                        "sharding": "by string index, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, D),

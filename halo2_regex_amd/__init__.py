@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
     "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count",
-    "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_host",
+    "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
+    "hrx_recommended_pitches", "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
 ]
 
@@ -77,6 +78,8 @@ def _load():
         "hrx_ctx_destroy": (None, [vp]),
         "hrx_last_error": (C.c_char_p, []),
         "hrx_witness_batch_device": (i, [vp, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
+        "hrx_witness_batch_device_pitched": (i, [vp, vp, sz, vp, sz, sz, vp, sz, vp, sz, vp, vp]),
+        "hrx_recommended_pitches": (None, [sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "hrx_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
         "hrx_shard_range": (None, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_derive_states": (i, [vp, _u8p, sz, _u64p]),
@@ -204,6 +207,14 @@ def device_count():
     return n.value
 
 
+def recommended_pitches(M):
+    """(records pitch, masked pitch) in rows and an input stride in bytes that keep the write/read fronts off a
+    power-of-two stride (hrx_recommended_pitches)."""
+    a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    lib.hrx_recommended_pitches(M, C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
 def shard_range(B, world, rank):
     b, c = C.c_size_t(0), C.c_size_t(0)
     lib.hrx_shard_range(B, world, rank, C.byref(b), C.byref(c))
@@ -316,28 +327,33 @@ class RegexVerifyConfig:
                                           _ptr(rec, _u32p), _ptr(msk, _u16p), _ptr(st, _u64p)))
         return rec, msk, st
 
-    def alloc_outputs(self, B, device=None):
-        """Device buffers for witness_batch: records int32 (B,M,D), masked int16 (B,M), status int64 (B,)."""
+    def alloc_outputs(self, B, device=None, pitched=False):
+        """Device buffers for witness_batch: records int32 (B,M,D), masked int16 (B,M), status int64 (B,).
+        pitched=True: the same shapes as views into buffers whose per-string pitch is hrx_recommended_pitches(M)
+        (rows M.. of each string's slot are never written)."""
         dev = torch.device("cuda", self.device) if device is None else device
         M, D = self.max_chars_size, self.num_defs
-        return (torch.empty((B, M, D), dtype=torch.int32, device=dev),
-                torch.empty((B, M), dtype=torch.int16, device=dev),
-                torch.empty((B,), dtype=torch.int64, device=dev))
+        rp, mp = (recommended_pitches(M)[:2] if pitched else (M, M))
+        rec = torch.empty((B, rp, D), dtype=torch.int32, device=dev)[:, :M]
+        msk = torch.empty((B, mp), dtype=torch.int16, device=dev)[:, :M]
+        return rec, msk, torch.empty((B,), dtype=torch.int64, device=dev)
 
     def witness_batch(self, chars, lens, out=None, stream=None):
         """Device-resident batch: chars (B, stride) uint8 CUDA tensor (stride % 16 == 0), lens (B,) int32 CUDA tensor.
         Asynchronous on `stream` (default: torch's current stream).  Returns (records, masked, status) tensors whose
         bit patterns are the u32/u16/u64 layouts of include/hrx.h."""
         assert chars.is_cuda and lens.is_cuda and chars.dtype == torch.uint8 and lens.dtype == torch.int32
-        assert chars.is_contiguous() and lens.is_contiguous()
-        B, stride = chars.shape
+        assert chars.stride(1) == 1 and lens.is_contiguous()
+        B, stride = chars.shape[0], chars.stride(0)       # a (B, n) view of a wider buffer is fine
         if out is None:
             out = self.alloc_outputs(B, chars.device)
         rec, msk, st = out
+        D = self.num_defs
+        assert rec.stride(2) == 1 and rec.stride(1) == D and rec.stride(0) % D == 0 and msk.stride(1) == 1
         s = torch.cuda.current_stream(chars.device) if stream is None else stream
-        _check(lib.hrx_witness_batch_device(self._need_ctx(), chars.data_ptr(), stride, lens.data_ptr(), B,
-                                            self.max_chars_size, rec.data_ptr(), msk.data_ptr(), st.data_ptr(),
-                                            s.cuda_stream))
+        _check(lib.hrx_witness_batch_device_pitched(self._need_ctx(), chars.data_ptr(), stride, lens.data_ptr(), B,
+                                                    self.max_chars_size, rec.data_ptr(), rec.stride(0) // D,
+                                                    msk.data_ptr(), msk.stride(0), st.data_ptr(), s.cuda_stream))
         return rec, msk, st
 
 

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                     const int j = __ffsll((unsigned long long)fixm) - 1;
                     fixm &= fixm - 1;
                     const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
-                    uint16_t *mrow = a.masked + (size_t)(b0 + j) * M;
+                    uint16_t *mrow = a.masked + (size_t)(b0 + j) * a.msk_pitch;
                     for (uint32_t r = (fs & ~63u) + lane; r < t0; r += 64u)
                         if (r >= fs) mrow[r] = 0;
                 }
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                 constexpr uint32_t CPS = 16u * D, SPI = 64u / CPS;
                 const uint32_t js0 = lane / CPS, w = lane % CPS;
                 uint32_t lds_a = rec_base + js0 * RSB + w * 16u;
-                unsigned char *gp = reinterpret_cast<unsigned char *>(a.records + ((size_t)(b0 + js0) * M + t0) * D + w * 4u);
-                const size_t gstep = (size_t)SPI * M * D * 4u;
+                unsigned char *gp = reinterpret_cast<unsigned char *>(a.records + ((size_t)(b0 + js0) * a.rec_pitch + t0) * D + w * 4u);
+                const size_t gstep = (size_t)SPI * a.rec_pitch * D * 4u;
                 if (!(a.debug & 1u)) {
                     const uint32_t nit = CPS * GS / 64u;  // wave-instructions that cover the group's GS string-tiles
                     for (uint32_t it0 = 0; it0 < nit; it0 += 8u) {
@@ -375,8 +375,8 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                 }
                 // masked rows: a string-tile is 128 contiguous bytes = 8 chunks of 16 B (8 rows each)
                 const uint32_t mj0 = lane >> 3, mw = lane & 7u;
-                unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked + (size_t)(b0 + mj0) * M + t0 + mw * 8u);
-                const size_t mstep = (size_t)8u * M * 2u;
+                unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked + (size_t)(b0 + mj0) * a.msk_pitch + t0 + mw * 8u);
+                const size_t mstep = (size_t)8u * a.msk_pitch * 2u;
                 if (!(a.debug & 2u)) {
                     if (!any_mask) {
                         for (uint32_t it = 0; it < GS / 8u; ++it) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                     const uint32_t js = chunk / CPS, w = chunk % CPS;
                     if (js < GS && b0 + js < a.B && w < lim && !(a.debug & 1u)) {
                         const uint4 v = lds_u128(rec_base + js * RSB + w * 16u);
-                        uint32_t *dst = a.records + ((size_t)(b0 + js) * M + t0) * D + w * 4u;
+                        uint32_t *dst = a.records + ((size_t)(b0 + js) * a.rec_pitch + t0) * D + w * 4u;
                         *reinterpret_cast<uint4 *>(dst) = v;
                     }
                 }
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (any_mask && js < GS) v = masked_chunk<D>(js, w, rec_base, chr_base, mb_base);
                     if (js < GS && b0 + js < a.B && w < mlim && !(a.debug & 2u))
-                        *reinterpret_cast<uint4 *>(a.masked + (size_t)(b0 + js) * M + t0 + w * 8u) = v;
+                        *reinterpret_cast<uint4 *>(a.masked + (size_t)(b0 + js) * a.msk_pitch + t0 + w * 8u) = v;
                 }
             } else {
                 // generic M: one dword / one u16 per lane, still contiguous per string
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                     for (int dd = 0; dd < D; ++dd) {
                         const uint32_t i = dd * 64u + lane;
                         if (i < rows * D)
-                            a.records[((size_t)(b0 + js) * M + t0) * D + i] = lds_u32(rec_base + js * RSB + i * 4u);
+                            a.records[((size_t)(b0 + js) * a.rec_pitch + t0) * D + i] = lds_u32(rec_base + js * RSB + i * 4u);
                     }
                     if (lane < rows) {
                         uint32_t o = 0;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                                 o = smem[chr_base + js * CSB + lane] | (sid << 8);
                             }
                         }
-                        a.masked[(size_t)(b0 + js) * M + t0 + lane] = (uint16_t)o;
+                        a.masked[(size_t)(b0 + js) * a.msk_pitch + t0 + lane] = (uint16_t)o;
                     }
                 }
             }
@@ -521,6 +521,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
     const uint32_t pair_bytes = nslots * G::kSlotBytes + G::kPairFixed;
     const uint32_t ring_base = a.table_bytes + pair * pair_bytes;
     const uint32_t prod_off = ring_base + nslots * G::kSlotBytes, cons_off = prod_off + 4u;
+    const uint32_t scratch_off = a.table_bytes + pairs * pair_bytes + pair * 256u;  // 256 B per storer: LDS-DMA sink
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -583,12 +584,17 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 SwizzledChunks chunks;
 #pragma unroll
                 for (uint32_t c = 0; c < 8u; ++c) chunks.addr[c] = slot + lane * 128u + ((c ^ l7) << 4);
+                unsigned long long *stamp = a.stamps ? a.stamps + ((size_t)(blockIdx.x * pairs + pair) * ntiles + t) * 8u : nullptr;
+                if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memtime();
                 if (seq >= nslots) ring_wait(cons_off, seq - nslots + 1u);  // the storer has drained this slot
+                if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
 
                 // ---------------- walk + tag: lib.rs:804-888 ----------------
-                TileBits tb;
+                TileBits tb = {0, 0, 0};
                 const bool full = (t0 + T < min_n);
-                if (full)
+                if (a.debug & 16u) {
+                    // profiling only: no walk, the storer moves whatever the slot holds
+                } else if (full)
                     tb = walk_tile<D, true, T>(L, act, a, chunks, 0, 0, t0);
                 else
                     tb = walk_tile<D, false, T>(L, act, a, chunks, (int)n - (int)t0, (int)M - 1 - (int)t0, t0);
@@ -645,6 +651,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                             v4u32{act[i].x, act[i].y, act[i].z, act[i].w};
                 }
                 ring_post(prod_off, seq + 1u);
+                if (stamp && lane == 0) stamp[2] = __builtin_amdgcn_s_memtime();
 
                 // next tile's bytes move to the front; every kSuper tiles the pending batch takes over
                 if ((t + 1) % kSuper != 0) {
@@ -656,6 +663,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                     settle_n(act);
                     if (!(a.debug & 4u)) load_batch(pen, t0 + T + kSuper * T);
                 }
+                if (stamp && lane == 0) stamp[3] = __builtin_amdgcn_s_memtime();
             }
             // ---------------- per-string status ----------------
             if (active) {
@@ -680,7 +688,25 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
             // stores interleaved with the record stream cost more than everything else together (measured:
             // 138 us vs 65 us per launch).  So the masked rows of an even tile wait in registers (mk) and go out
             // with the odd tile's: 64 rows = one full line per string.
+            // L2 warm-up for the walker.  Behind the saturated write path an HBM read takes ~10 us, more than the walker's
+            // prefetch distance can cover, and its vmcnt is in-order, so it cannot run far-ahead loads itself.  The storer
+            // never waits on vmcnt, so every 128 rows it issues ONE LDS-DMA load (no VGPR destination; 4 bytes per lane into
+            // a scratch word nobody reads) that pulls each string's 128-byte line of kTouch batches ahead into L2.
             constexpr uint32_t kBlk = 64u;
+            constexpr uint32_t kTouchRows = 128u, kTouchAhead = 5u * 128u;
+            const uint32_t n_s = active ? min(a.lens[b], M) : M;
+            const uint32_t last_line = n_s ? ((n_s - 1u) & ~127u) : 0u;
+            const uint8_t *tptr = a.chars + (size_t)(active ? b : a.B - 1u) * a.stride;
+            auto touch = [&](uint32_t row) {
+                if (!(a.debug & 8u)) {
+                    uint32_t saved_m0;  // M0 = LDS base of the DMA; restored, the compiler does not expect it to change
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(saved_m0)
+                                 : "v"(tptr + min(row, last_line)), "s"(scratch_off)
+                                 : "memory");
+                }
+            };
+            for (uint32_t r = 2u * kTouchRows; r <= kTouchAhead; r += kTouchRows) touch(r);
             uint4 mk[8];
             const uint32_t mj0 = lane >> 3, mw = lane & 7u;  // masked block mapping: string (it*8 + mj0), rows 8*mw..8*mw+7
             for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
@@ -689,7 +715,10 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 const uint32_t sub = (t0 - blk0) / T;  // which T-row part of the 64-row block this tile is
                 const bool blk_last = (t0 + T >= blk0 + kBlk) || (t + 1 == ntiles);
                 const uint32_t slot = ring_base + (seq % nslots) * G::kSlotBytes;
+                unsigned long long *stamp = a.stamps ? a.stamps + ((size_t)(blockIdx.x * pairs + pair) * ntiles + t) * 8u : nullptr;
+                if (stamp && lane == 0) stamp[4] = __builtin_amdgcn_s_memtime();
                 ring_wait(prod_off, seq + 1u);
+                if (stamp && lane == 0) stamp[5] = __builtin_amdgcn_s_memtime();
                 const v2u32 hdr = *(__attribute__((address_space(3))) const v2u32 *)(uintptr_t)(slot + G::kSlotHdr + lane * 8u);
                 const bool any_mask = __any(hdr.x != 0);
                 if (sub == 0) {
@@ -704,7 +733,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                         fixm &= fixm - 1;
                         const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)hdr.y, j);
                         // rows already in memory: everything below this 64-row block
-                        uint16_t *mrow = a.masked + (size_t)(b0 + j) * M;
+                        uint16_t *mrow = a.masked + (size_t)(b0 + j) * a.msk_pitch;
                         for (uint32_t r = (fs & ~63u) + lane; r < blk0; r += 64u)
                             if (r >= fs) mrow[r] = 0;
                         // rows of this block still held in mk (earlier tiles of the block)
@@ -734,8 +763,8 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                         const uint32_t js = it * 8u + js0;
                         v[it] = lds_u128(slot + js * 128u + ((w ^ (js & 7u)) << 4));
                     }
-                    unsigned char *gp = reinterpret_cast<unsigned char *>(a.records + ((size_t)(b0 + js0) * M + t0) * D + w * 4u);
-                    const size_t gstep = (size_t)8u * M * D * 4u;
+                    unsigned char *gp = reinterpret_cast<unsigned char *>(a.records + ((size_t)(b0 + js0) * a.rec_pitch + t0) * D + w * 4u);
+                    const size_t gstep = (size_t)8u * a.rec_pitch * D * 4u;
                     const uint32_t lim = rows * D / 4u;
                     if (!(a.debug & 1u)) {
 #pragma unroll
@@ -774,9 +803,10 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                     }
                 }
                 ring_post(cons_off, seq + 1u);  // every LDS read of the slot has returned; the stores may still be in flight
+                if (t0 % kTouchRows == 0) touch(t0 + kTouchAhead + kTouchRows);
                 if (blk_last && !(a.debug & 2u)) {
-                    unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked + (size_t)(b0 + mj0) * M + blk0 + mw * 8u);
-                    const size_t mstep = (size_t)8u * M * 2u;
+                    unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked + (size_t)(b0 + mj0) * a.msk_pitch + blk0 + mw * 8u);
+                    const size_t mstep = (size_t)8u * a.msk_pitch * 2u;
                     const bool blk_whole = (b0 + 64u <= a.B) && (blk0 + kBlk <= M);
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
@@ -784,6 +814,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                         mp += mstep;
                     }
                 }
+                if (stamp && lane == 0) stamp[6] = __builtin_amdgcn_s_memtime();
             }
         }
     }
@@ -794,7 +825,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
     // ---- walker/storer kernel: D in {1,2}, rows in multiples of 8, ring of >= 2 slots per pair
     if ((a.D == 1 || a.D == 2) && a.M % 8u == 0 && !(a.debug & 0x10000u)) {
-        const size_t slot = 64 * 128 + 64 * 8 + 64 * (a.D == 1 ? 32 : 16), fixed = 16;
+        const size_t slot = 64 * 128 + 64 * 8 + 64 * (a.D == 1 ? 32 : 16), fixed = 16 + 256;  // + the storer's LDS-DMA sink
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;  // small batches: spread over the CUs
         for (; pairs >= 1; --pairs) {

@@ -14,6 +14,7 @@ struct WitnessArgs {
     uint64_t stride;
     const uint32_t *lens;
     uint32_t B, M;
+    uint32_t rec_pitch, msk_pitch;  // rows between consecutive strings in records / masked (>= M)
     uint32_t *records;
     uint16_t *masked;
     uint64_t *status;

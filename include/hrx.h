@@ -122,6 +122,13 @@ const char *hrx_last_error(void);
  */
 int hrx_witness_batch_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
                              size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream);
+/* Same with pitched outputs: string b's rows start at records + b*rec_pitch*D and masked + b*msk_pitch (pitches in rows,
+ * >= M, multiples of 8 when M is).  A pitch that is not a power of two keeps the chip-wide write front off a subset of the
+ * HBM channels; hrx_recommended_pitches gives values for a given M (and an input stride). */
+int hrx_witness_batch_device_pitched(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
+                                     size_t M, uint32_t *records, size_t rec_pitch, uint16_t *masked, size_t msk_pitch,
+                                     uint64_t *status, void *stream);
+void hrx_recommended_pitches(size_t M, size_t *rec_pitch, size_t *msk_pitch, size_t *chars_stride);
 /* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers; synchronous. */
 int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
                            size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);

@@ -209,6 +209,16 @@ def test_full_size_cfg2_device_resident(hra, oracle):
             r3, m3, s3 = cfg.witness_batch(d_chars[b:b + c].contiguous(), d_lens[b:b + c].contiguous())
             torch.cuda.synchronize()
             assert torch.equal(r3, rec[b:b + c]) and torch.equal(m3, msk[b:b + c]) and torch.equal(s3, st[b:b + c])
+    # (3b) pitched buffers (hrx_recommended_pitches: non-power-of-two strides) hold the same rows
+    rp, mp, cs = hra.recommended_pitches(M)
+    assert rp >= M and mp >= M and rp % 8 == 0 and mp % 64 == 0 and cs % 16 == 0 and cs >= M
+    wide = torch.zeros((B, cs), dtype=torch.uint8, device=dev)
+    wide[:, :1024] = d_chars
+    outp = cfg.alloc_outputs(B, dev, pitched=True)
+    assert outp[0].stride(0) == rp and outp[1].stride(0) == mp
+    r4, m4, s4 = cfg.witness_batch(wide, d_lens, out=outp)
+    torch.cuda.synchronize()
+    assert torch.equal(r4, rec) and torch.equal(m4, msk) and torch.equal(s4, st)
     # (4) structural properties of every row of every string (App. A.2): padding rows, masked only where tagged
     state = rec_h[:, :, 0] & 0xffff
     sid = (rec_h[:, :, 0] >> 16) & 0xff

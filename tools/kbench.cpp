@@ -27,6 +27,8 @@ int main(int argc, char **argv) {
     const int steps = argc > 6 ? atoi(argv[6]) : 50;
     const uint32_t debug = argc > 7 ? (uint32_t)strtoul(argv[7], 0, 0) : 0;
     const int want_stamps = argc > 8 ? atoi(argv[8]) : 0;
+    const size_t rec_off = argc > 9 ? atol(argv[9]) : 0, msk_off = argc > 10 ? atol(argv[10]) : 0, chr_off = argc > 11 ? atol(argv[11]) : 0;
+    const size_t rec_pad = argc > 12 ? atol(argv[12]) : 0, msk_pad = argc > 13 ? atol(argv[13]) : 0, chr_pad = argc > 14 ? atol(argv[14]) : 0;
     DefsSet s;
     RegexDefs rd;
     std::string t = slurp(argv[1]);
@@ -38,7 +40,7 @@ int main(int argc, char **argv) {
     s.defs.push_back(rd);
     std::string err;
     if (finalize_defs(s, err)) { fprintf(stderr, "%s\n", err.c_str()); return 4; }
-    const size_t stride = (n + 15) / 16 * 16;
+    const size_t stride = (n + 15) / 16 * 16 + chr_pad;
     std::vector<uint8_t> h(B * stride);
     uint64_t x = 88172645463325252ull;
     static const uint8_t alpha[98] = {9, 10, 13};
@@ -47,19 +49,22 @@ int main(int argc, char **argv) {
     for (auto &c : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; c = al[x % 98]; }
     std::vector<uint32_t> lens(B, (uint32_t)n);
     uint8_t *d_chars; uint32_t *d_lens, *d_rec, *d_tab; uint16_t *d_msk; uint64_t *d_st; unsigned long long *d_stamps = nullptr;
-    CK(hipMalloc(&d_chars, h.size())); CK(hipMalloc(&d_lens, 4 * B)); CK(hipMalloc(&d_rec, 4 * B * M)); CK(hipMalloc(&d_msk, 2 * B * M));
+    CK(hipMalloc(&d_chars, h.size() + (1 << 22))); CK(hipMalloc(&d_lens, 4 * B)); CK(hipMalloc(&d_rec, 4 * B * (M + rec_pad) + (1 << 22))); CK(hipMalloc(&d_msk, 2 * B * (M + msk_pad) + (1 << 22)));
+    d_chars += chr_off; d_rec += rec_off / 4; d_msk += msk_off / 2;
+    printf("bases: chars %p rec %p msk %p\n", (void *)d_chars, (void *)d_rec, (void *)d_msk);
     CK(hipMalloc(&d_st, 8 * B)); CK(hipMalloc(&d_tab, s.table_image.size() * 4));
     CK(hipMemcpy(d_chars, h.data(), h.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(d_lens, lens.data(), 4 * B, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_tab, s.table_image.data(), s.table_image.size() * 4, hipMemcpyHostToDevice));
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     WitnessArgs a{};
-    a.chars = d_chars; a.stride = stride; a.lens = d_lens; a.B = (uint32_t)B; a.M = (uint32_t)M; a.records = d_rec; a.masked = d_msk;
+    a.chars = d_chars; a.stride = stride; a.lens = d_lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
+    a.rec_pitch = (uint32_t)(M + rec_pad); a.msk_pitch = (uint32_t)(M + msk_pad); a.records = d_rec; a.masked = d_msk;
     a.status = d_st; a.table_image = d_tab; a.table_bytes = (uint32_t)(s.table_image.size() * 4);
     a.D = 1; a.debug = debug; a.dc[0] = s.consts[0];
     LaunchInfo li;
     if (!plan_witness_launch(a, prop.multiProcessorCount, li)) return 5;
     const size_t ntiles = (M + 63) / 64, nw = (size_t)li.grid * li.waves_per_wg;
-    if (want_stamps) { CK(hipMalloc(&d_stamps, nw * ntiles * 32)); CK(hipMemset(d_stamps, 0, nw * ntiles * 32)); }
+    if (want_stamps) { CK(hipMalloc(&d_stamps, nw * ntiles * 128)); CK(hipMemset(d_stamps, 0, nw * ntiles * 128)); }
     printf("grid %d x %d waves, gs %u, split %d, lds %zu, clock %d kHz\n", li.grid, li.waves_per_wg, a.gs, li.split, li.lds_bytes, prop.clockRate);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i) CK(launch_witness(a, li, 0));
@@ -73,22 +78,36 @@ int main(int argc, char **argv) {
     if (want_stamps) {
         a.stamps = d_stamps;
         CK(launch_witness(a, li, 0)); CK(hipDeviceSynchronize());
-        std::vector<unsigned long long> st(nw * ntiles * 4);
+        const int per = li.split ? 8 : 4;
+        const size_t units = li.split ? (size_t)li.grid * (li.waves_per_wg / 2) : nw;
+        const size_t nt = li.split ? (M + 31) / 32 : ntiles;
+        std::vector<unsigned long long> st(units * nt * per);
         CK(hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
-        unsigned long long t00 = ~0ull;
-        for (size_t w = 0; w < nw; ++w) if (st[w * ntiles * 4] && st[w * ntiles * 4] < t00) t00 = st[w * ntiles * 4];
-        for (size_t w : {(size_t)0, (size_t)1, nw / 2, nw - 1}) {
-            printf("wave %zu: start+%llu; per tile [walk, epilogue, store-issue, gap-to-next]\n", w, st[w * ntiles * 4] - t00);
-            for (size_t tt = 0; tt < ntiles; ++tt) {
-                const unsigned long long *q = &st[(w * ntiles + tt) * 4];
-                const unsigned long long nxt = tt + 1 < ntiles ? q[4] : q[3];
-                printf("  t%02zu %6llu %6llu %6llu %6llu\n", tt, q[1] - q[0], q[2] - q[1], q[3] - q[2], nxt - q[3]);
+        if (!li.split) {
+            for (size_t w : {(size_t)0, nw / 2}) {
+                printf("wave %zu: per tile [walk, epilogue, store-issue, gap-to-next]\n", w);
+                for (size_t tt = 0; tt < nt; ++tt) {
+                    const unsigned long long *q = &st[(w * nt + tt) * 4];
+                    const unsigned long long nxt = tt + 1 < nt ? q[4] : q[3];
+                    printf("  t%02zu %6llu %6llu %6llu %6llu\n", tt, q[1] - q[0], q[2] - q[1], q[3] - q[2], nxt - q[3]);
+                }
+            }
+        } else {
+            double ww = 0, wk = 0, wr = 0, sw = 0, ss = 0; size_t cnt = 0;
+            for (size_t u = 0; u < units; ++u) for (size_t tt = 0; tt < nt; ++tt) {
+                const unsigned long long *q = &st[(u * nt + tt) * 8];
+                ww += q[1] - q[0]; wk += q[2] - q[1]; wr += q[3] - q[2]; sw += q[5] - q[4]; ss += q[6] - q[5]; ++cnt;
+            }
+            printf("mean cycles per 32-row tile: walker [ring-wait %.0f, walk+masks %.0f, rotate/loads %.0f]  storer [ring-wait %.0f, move %.0f]\n",
+                   ww / cnt, wk / cnt, wr / cnt, sw / cnt, ss / cnt);
+            for (size_t u : {(size_t)0, units / 2}) {
+                printf("pair %zu: per tile walker[wait walk rot] storer[wait move]\n", u);
+                for (size_t tt = 0; tt < nt; ++tt) {
+                    const unsigned long long *q = &st[(u * nt + tt) * 8];
+                    printf("  t%02zu %6llu %6llu %6llu | %6llu %6llu\n", tt, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[5] - q[4], q[6] - q[5]);
+                }
             }
         }
-        double sw = 0, se = 0, ss = 0; size_t cnt = 0;
-        unsigned long long tend = 0;
-        for (size_t w = 0; w < nw; ++w) for (size_t tt = 0; tt < ntiles; ++tt) { const unsigned long long *q = &st[(w * ntiles + tt) * 4]; sw += q[1] - q[0]; se += q[2] - q[1]; ss += q[3] - q[2]; ++cnt; if (q[3] > tend) tend = q[3]; }
-        printf("mean cycles per tile: walk %.0f  epilogue %.0f  store %.0f ; kernel span %llu ticks (s_memtime)\n", sw / cnt, se / cnt, ss / cnt, tend - t00);
     }
     return 0;
 }
