@@ -49,7 +49,8 @@ def pmc_traffic(args, D):
     itself; None unless the committed passes were taken on the workload being run."""
     try:
         p = json.load(open(os.path.join(ROOT, "profiles", "r01_split_pmc.json")))
-        if args.config == "regex1" and args.batch == 65536 and args.n == 1023 and args.rows == 1024 and args.dist == "planted":
+        if (args.config == "regex1" and args.batch == 65536 and args.n == 1023 and args.rows == 1024 and args.dist == "planted"
+                and args.layout == p.get("layout", "string-major")):
             return p["hbm_bytes_per_launch"]["total"]
     except Exception:
         pass
@@ -67,8 +68,11 @@ def main():
     ap.add_argument("--dist", choices=["planted", "noise"], default="planted")
     ap.add_argument("--config", choices=["regex1", "regex23"], default="regex1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dense", action="store_true", help="power-of-two pitches (M rows per string, n rounded to 16 bytes) "
-                    "instead of hrx_recommended_pitches")
+    ap.add_argument("--dense", action="store_true", help="string-major: power-of-two pitches (M rows per string, n rounded to 16 "
+                    "bytes) instead of hrx_recommended_pitches")
+    ap.add_argument("--layout", choices=["position-major", "string-major"], default="position-major",
+                    help="buffer layout of include/hrx.h: HRX_LAYOUT_POSITION_MAJOR (input and outputs chunked [pos/k][string][k], "
+                    "the coalesced layout) or HRX_LAYOUT_STRING_MAJOR")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,8 +101,9 @@ def main():
         gen = synth.regex23_planted if args.dist == "planted" else synth.noise
     D = len(names)
     M, n, B = args.rows, args.n, args.batch
+    pm = args.layout == "position-major"
     rec_pitch, msk_pitch, rec_stride = hra.recommended_pitches(M)
-    if args.dense:
+    if args.dense or pm:
         rec_pitch, msk_pitch, rec_stride = M, M, (max(n, 1) + 15) // 16 * 16
     stride = rec_stride
     defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(os.path.join(DFA_DIR, a)),
@@ -109,8 +114,14 @@ def main():
     chars, lens = gen(B, n, seed=rank, stride=stride)
     d_chars = torch.from_numpy(chars).to(dev)
     d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
-    out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
     rows_per_step = int(lens.sum())
+    if pm:
+        d_chars = hra.chars_to_position_major(d_chars)       # [stride/16][B][16]: done once, outside the timed region
+        out = cfg.alloc_outputs_position_major(B, dev)
+        step = lambda: cfg.witness_batch_position_major(d_chars, d_lens, out=out, chars_pm_stride=stride)
+    else:
+        out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
+        step = lambda: cfg.witness_batch(d_chars, d_lens, out=out)
 
     def barrier():
         torch.cuda.synchronize()
@@ -119,13 +130,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        cfg.witness_batch(d_chars, d_lens, out=out)
+        step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        cfg.witness_batch(d_chars, d_lens, out=out)   # launched on torch's current stream, where the events sit
+        step()   # launched on torch's current stream, where the events sit
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -138,7 +149,6 @@ def main():
 
     # sanity: every string of the timed workload finished with status 0 and the result is reproducible
     st = out[2].cpu().numpy().view(np.uint64)
-    assert out[0].shape == (B, M, D) and out[1].shape == (B, M)
     assert ((st & np.uint64(0xff)) == 0).all(), "status != ok in the bench workload"
 
     if rank == 0:
@@ -155,12 +165,15 @@ def main():
                                       stride, n, M, "alphabet-uniform noise + planted match" if args.dist == "planted"
                                       else "alphabet-uniform noise"),
                        "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
-                       "buffers": "string-major; input stride %d B, records pitch %d rows, masked pitch %d rows "
-                                  "(hrx_recommended_pitches: not powers of two)" % (stride, rec_pitch, msk_pitch),
+                       "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR: chars [%d/16][B][16], records "
+                                   "[M/4][B][4][D], masked [M/8][B][8] (include/hrx.h)" % stride) if pm else
+                                  ("string-major; input stride %d B, records pitch %d rows, masked pitch %d rows"
+                                   % (stride, rec_pitch, msk_pitch)),
                        "sharding": "by string index, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, D),
-                         "kernel": "hrx::witness_split_kernel<%d,%d>" % (D, 32 // D), "avg_launch_ms": kern_ms,
+                         "kernel": ("hrx::witness_pm_kernel<%d>" % D) if pm else ("hrx::witness_split_kernel<%d,%d>" % (D, 32 // D)),
+                         "avg_launch_ms": kern_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
     "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
-    "hrx_recommended_pitches", "hrx_witness_batch_host",
+    "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
 ]
 
@@ -80,6 +80,8 @@ def _load():
         "hrx_witness_batch_device": (i, [vp, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_witness_batch_device_pitched": (i, [vp, vp, sz, vp, sz, sz, vp, sz, vp, sz, vp, vp]),
         "hrx_recommended_pitches": (None, [sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+        "hrx_witness_batch_device_layout": (i, [vp, i, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
+        "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
         "hrx_shard_range": (None, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_derive_states": (i, [vp, _u8p, sz, _u64p]),
@@ -215,6 +217,25 @@ def recommended_pitches(M):
     return a.value, b.value, c.value
 
 
+LAYOUT_STRING_MAJOR, LAYOUT_POSITION_MAJOR, LAYOUT_INPUT_POSITION_MAJOR = 0, 1, 2
+
+
+def chars_to_position_major(chars):
+    """(B, stride) bytes, stride % 16 == 0  ->  flat [stride/16][B][16] (HRX_LAYOUT_INPUT_POSITION_MAJOR); torch or numpy."""
+    B, stride = chars.shape
+    c = chars.reshape(B, stride // 16, 16)
+    c = c.permute(1, 0, 2).contiguous() if hasattr(c, "permute") else np.ascontiguousarray(c.transpose(1, 0, 2))
+    return c.reshape(-1)
+
+
+def position_major_to_string_major(records_pm, masked_pm, B, M, D):
+    """View-level inverse of HRX_LAYOUT_POSITION_MAJOR (include/hrx.h): records [ceil(M/4)][B][4][D] -> (B, M, D),
+    masked [ceil(M/8)][B][8] -> (B, M).  Works on torch tensors and numpy arrays alike; no values change."""
+    rec = records_pm.reshape(-1, B, 4, D).permute(1, 0, 2, 3) if hasattr(records_pm, "permute") else records_pm.reshape(-1, B, 4, D).transpose(1, 0, 2, 3)
+    msk = masked_pm.reshape(-1, B, 8).permute(1, 0, 2) if hasattr(masked_pm, "permute") else masked_pm.reshape(-1, B, 8).transpose(1, 0, 2)
+    return rec.reshape(B, -1, D)[:, :M], msk.reshape(B, -1)[:, :M]
+
+
 def shard_range(B, world, rank):
     b, c = C.c_size_t(0), C.c_size_t(0)
     lib.hrx_shard_range(B, world, rank, C.byref(b), C.byref(c))
@@ -337,6 +358,36 @@ class RegexVerifyConfig:
         rec = torch.empty((B, rp, D), dtype=torch.int32, device=dev)[:, :M]
         msk = torch.empty((B, mp), dtype=torch.int16, device=dev)[:, :M]
         return rec, msk, torch.empty((B,), dtype=torch.int64, device=dev)
+
+    def alloc_outputs_position_major(self, B, device=None):
+        """Flat device buffers for HRX_LAYOUT_POSITION_MAJOR: records int32 [ceil(M/4)*B*4*D], masked int16 [ceil(M/8)*B*8]."""
+        dev = torch.device("cuda", self.device) if device is None else device
+        nr, nm = C.c_size_t(0), C.c_size_t(0)
+        lib.hrx_position_major_sizes(B, self.max_chars_size, self.num_defs, C.byref(nr), C.byref(nm))
+        return (torch.empty((nr.value,), dtype=torch.int32, device=dev), torch.empty((nm.value,), dtype=torch.int16, device=dev),
+                torch.empty((B,), dtype=torch.int64, device=dev))
+
+    def witness_batch_position_major(self, chars, lens, out=None, stream=None, chars_pm_stride=None):
+        """Like witness_batch, outputs in HRX_LAYOUT_POSITION_MAJOR (use position_major_to_string_major to view them per
+        string).  chars: (B, stride) string-major, or — with chars_pm_stride=stride — the flat position-major buffer made by
+        chars_to_position_major."""
+        assert chars.is_cuda and lens.is_cuda and chars.dtype == torch.uint8 and lens.dtype == torch.int32
+        layout = LAYOUT_POSITION_MAJOR
+        if chars_pm_stride is None:
+            assert chars.stride(1) == 1 and lens.is_contiguous()
+            B, stride = chars.shape[0], chars.stride(0)
+        else:
+            assert chars.is_contiguous() and chars.numel() == lens.numel() * chars_pm_stride
+            B, stride = lens.numel(), int(chars_pm_stride)
+            layout |= LAYOUT_INPUT_POSITION_MAJOR
+        if out is None:
+            out = self.alloc_outputs_position_major(B, chars.device)
+        rec, msk, st = out
+        s = torch.cuda.current_stream(chars.device) if stream is None else stream
+        _check(lib.hrx_witness_batch_device_layout(self._need_ctx(), layout, chars.data_ptr(), stride,
+                                                   lens.data_ptr(), B, self.max_chars_size, rec.data_ptr(), msk.data_ptr(),
+                                                   st.data_ptr(), s.cuda_stream))
+        return rec, msk, st
 
     def witness_batch(self, chars, lens, out=None, stream=None):
         """Device-resident batch: chars (B, stride) uint8 CUDA tensor (stride % 16 == 0), lens (B,) int32 CUDA tensor.

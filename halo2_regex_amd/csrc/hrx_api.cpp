@@ -254,7 +254,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
 
 static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                         uint32_t *records, uint16_t *masked, uint64_t *status, hipStream_t st, size_t rec_pitch = 0,
-                        size_t msk_pitch = 0) {
+                        size_t msk_pitch = 0, int layout = 0) {
     if (!rec_pitch) rec_pitch = M;
     if (!msk_pitch) msk_pitch = M;
     if (B == 0) return HRX_OK;
@@ -271,6 +271,10 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         return fail(HRX_ERR_ARG, "row pitches must be multiples of 8 rows when max_chars_size is");
     WitnessArgs a{};
     a.rec_pitch = (uint32_t)rec_pitch; a.msk_pitch = (uint32_t)msk_pitch;
+    if (layout != HRX_LAYOUT_STRING_MAJOR && layout != HRX_LAYOUT_POSITION_MAJOR &&
+        layout != (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR))
+        return fail(HRX_ERR_ARG, "unknown layout");
+    a.layout = (uint32_t)layout;
     a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
     a.records = records; a.masked = masked; a.status = status;
     a.table_image = ctx->d_table; a.table_bytes = (uint32_t)(ctx->s.table_image.size() * 4);
@@ -298,6 +302,19 @@ int hrx_witness_batch_device_pitched(hrx_ctx *ctx, const uint8_t *chars, size_t 
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream, rec_pitch, msk_pitch);
+}
+
+int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
+                                    size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream, 0, 0, layout);
+}
+
+void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16) {
+    if (records_u32) *records_u32 = (M + 3) / 4 * B * 4 * D;
+    if (masked_u16) *masked_u16 = (M + 7) / 8 * B * 8;
 }
 
 void hrx_recommended_pitches(size_t M, size_t *rec_pitch, size_t *msk_pitch, size_t *chars_stride) {

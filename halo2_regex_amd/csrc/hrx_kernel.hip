@@ -94,7 +94,7 @@ __device__ __forceinline__ TileBits walk_tile(LaneRegs<D> &L, const uint4 (&cq)[
             rbuf[slot] = state | (tag << 16);
             if (slot == 3)
                 *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)chunk((p * D + d) >> 2) = v4u32{rbuf[0], rbuf[1], rbuf[2], rbuf[3]};
-            L.mx[d] = max(L.mx[d], et[d]);
+            if (!FULL) L.mx[d] = max(L.mx[d], et[d]);  // FULL tiles: the dead row is absorbing, the live entry after the tile tells
             sid += tag & 0xffu;
             stn += (tag >> 8) & 1u;
             enn += (tag >> 9) & 1u;
@@ -121,8 +121,10 @@ __device__ __forceinline__ TileBits walk_tile(LaneRegs<D> &L, const uint4 (&cq)[
                 post(p - 1, e2, e1);
                 // pin the row's results here (zero instructions): IR-level sinking would otherwise move them to the tile end
                 asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(ch[(p - 1) >> 5]), "+v"(L.sid_prev));
+                if (!FULL) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]));
+                    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -134,7 +136,10 @@ __device__ __forceinline__ TileBits walk_tile(LaneRegs<D> &L, const uint4 (&cq)[
     }
     post(T - 1, e2, e1);
 #pragma unroll
-    for (int d = 0; d < D; ++d) L.e[d] = e1[d];
+    for (int d = 0; d < D; ++d) {
+        L.e[d] = e1[d];
+        L.mx[d] = max(L.mx[d], e1[d]);
+    }
     TileBits tb;
     tb.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
     tb.en1 = (uint64_t)en1[0] | ((uint64_t)en1[1] << 32);
@@ -820,9 +825,361 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
     }
 }
 
+// =============================================================================================
+// Position-major kernel (layout 1): records [ceil(M/4)][B][4][D] u32, masked [ceil(M/8)][B][8] u16.
+//
+// With one lane per string, four consecutive rows of a lane are 16*D contiguous bytes and the 64 lanes of a wave are
+// 64 consecutive strings: every store is a full, contiguous 1-KiB (D=1) run written straight from the walker's
+// registers — no LDS transpose, no mover wave — and at any moment the whole chip writes into one compact slab of the
+// output (rows 4q..4q+3 of all strings = 1 MiB at B = 65536).  A compact write window is what the HBM write path
+// rewards: 6.5 TB/s vs 4.3-5.2 TB/s for the string-major comb (tools/fillprobe, tools/wpattern2).
+//
+// The walker's in-order vmcnt would make any wait for an input load also wait for every store issued before it, so
+// the walker issues no loads at all: a LOADER wave per walker streams the strings' bytes into an LDS ring with LDS-DMA
+// (global_load_lds_dwordx4: no VGPRs, kRing tiles in flight, counted s_waitcnt) and the walker picks its 64 bytes per
+// tile up with four ds_read_b128.
+// =============================================================================================
+constexpr uint32_t kPmTileBytes = 64u * 64u;  // 64 strings x 64 input bytes per tile
+
+template <int D, bool FULL>
+__device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, unsigned char *&rp,
+                                                 const size_t rstep, const bool do_store, int rem, int mrem, uint32_t t0,
+                                                 uint32_t (&sidq)[16], uint32_t (&acc_state)[D], const uint4 (&pend)[8],
+                                                 unsigned char *pend_mp, const size_t mstep, const bool pend_store) {
+    uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
+    uint32_t rbuf[4];
+    const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
+                             cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+    uint32_t e1[D], e2[D], raw[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) e1[d] = e2[d] = L.e[d];
+
+    auto post = [&](const int p, const uint32_t (&es)[D], const uint32_t (&et)[D]) {
+        uint32_t sid = 0, stn = 0, enn = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const uint32_t state = (es[d] >> kNextShift) - (d ? a.dc[d].row_base : 0u);
+            uint32_t tag = et[d] & kTagMask;
+            if (!FULL) {
+                if (p >= mrem) tag &= ~kTagEnd;
+                if (p == rem) acc_state[d] = state;  // the state at row n (lib.rs:437-457)
+            }
+            const int i = p * D + d;
+            rbuf[i & 3] = state | (tag << 16);
+            if ((i & 3) == 3) {  // 16 bytes of this string's quad: a 1-KiB (x D) contiguous run across the wave
+                // quads that start at or beyond row M do not exist in [ceil(M/4)][B][4][D]
+                if (do_store && (FULL || (p & ~3) <= mrem))
+                    *reinterpret_cast<uint4 *>(rp + ((i >> 2) % D) * 16) = make_uint4(rbuf[0], rbuf[1], rbuf[2], rbuf[3]);
+                if ((p & 3) == 3) rp += rstep;
+            }
+            if (!FULL) L.mx[d] = max(L.mx[d], et[d]);
+            sid += tag & 0xffu;
+            stn += (tag >> 8) & 1u;
+            enn += (tag >> 9) & 1u;
+        }
+        if (D > 1) {
+            if (stn > 1) L.ov_row = min(L.ov_row, t0 + (uint32_t)p);
+            if (enn > 1) L.ov_row = min(L.ov_row, t0 + (uint32_t)p + 1u);
+        }
+        st[p >> 5] |= (stn ? 1u : 0u) << (p & 31);
+        en1[p >> 5] |= (enn ? 1u : 0u) << (p & 31);
+        ch[p >> 5] |= (sid != L.sid_prev ? 1u : 0u) << (p & 31);
+        L.sid_prev = sid;
+        sidq[p >> 2] |= sid << (8 * (p & 3));  // the tile's substr-id sums, one byte per row (masked rows need them)
+        // the PREVIOUS tile's masked rows leave one 16-byte piece every 8 rows instead of as a burst of 8 stores at the
+        // tile boundary (the burst filled the store queue and stalled the in-order walk: 99 -> ? us)
+        if ((p & 7) == 5 && pend_store) *reinterpret_cast<uint4 *>(pend_mp + (size_t)(p >> 3) * mstep) = pend[p >> 3];
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sidq[i] = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = q * 4 + k;
+            const uint32_t c4 = ((cw[q] >> (8 * k)) & 0xffu) << 2;
+#pragma unroll
+            for (int d = 0; d < D; ++d) raw[d] = lds_u32((e1[d] & ~kTagMask) | c4);  // delta(state, byte): lib.rs:810
+            if (p > 0) {
+                post(p - 1, e2, e1);
+                asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(ch[(p - 1) >> 5]), "+v"(L.sid_prev),
+                             "+v"(sidq[(p - 1) >> 2]));
+                if (!FULL) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                e2[d] = e1[d];
+                e1[d] = (FULL || p < rem) ? raw[d] : a.dc[d].dummy_entry;  // rows >= n: lib.rs:404-418
+            }
+        }
+    }
+    post(63, e2, e1);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        L.e[d] = e1[d];
+        L.mx[d] = max(L.mx[d], e1[d]);
+    }
+    TileBits tb;
+    tb.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
+    tb.en1 = (uint64_t)en1[0] | ((uint64_t)en1[1] << 32);
+    tb.ch = (uint64_t)ch[0] | ((uint64_t)ch[1] << 32);
+    return tb;
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t pairs = blockDim.x >> 7;  // walker waves 0..pairs-1, loader waves pairs..2*pairs-1
+    const bool is_walker = wave < pairs;
+    const uint32_t pair = is_walker ? wave : wave - pairs;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+
+    const uint32_t pair_bytes = nring * kPmTileBytes + 16u;
+    const uint32_t ring_base = a.table_bytes + pair * pair_bytes;
+    const uint32_t ready_off = ring_base + nring * kPmTileBytes, freed_off = ready_off + 4u;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        if (is_walker && lane == 0) { lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0); }
+    }
+    __syncthreads();
+
+    const uint32_t M = a.M, B = a.B;
+    const uint32_t ntiles = (M + 63u) >> 6;
+    uint32_t seq = 0;
+
+    for (uint32_t g = blockIdx.x * pairs + pair; g < a.n_groups; g += gridDim.x * pairs) {
+        const uint32_t b0 = g * 64u;
+        const uint32_t b = b0 + lane;
+        const bool active = b < B;
+        const uint32_t n_raw = active ? a.lens[b] : M;
+        const bool badlen = n_raw > M;
+        const uint32_t n = badlen ? M : n_raw;
+
+        if (!is_walker) {
+            // ================================ loader ================================
+            // string-major input: string b at chars + b*stride; position-major input: 16-byte chunk i of string b at
+            // chars + (i*B + b)*16, so one DMA instruction reads 1 KiB contiguous (coalesced, compact read window)
+            const bool in_pm = (a.layout & 2u) != 0;
+            const uint32_t bl = active ? b : B - 1u;
+            const uint8_t *cptr = in_pm ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
+            const size_t cmul = in_pm ? (size_t)B : (size_t)1;  // byte offset of chunk-start row r: r * cmul
+            const uint32_t last_chunk = n ? ((n - 1u) & ~15u) : 0u;
+            for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
+                const uint32_t t0 = t << 6;
+                if (seq >= nring) ring_wait(freed_off, seq - nring + 1u);  // the walker has read this slot
+                const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
+                uint32_t saved_m0;
+                // chunk i of all 64 strings -> slot + i*1024 + lane*16 (M0 = LDS base of the DMA, restored afterwards)
+                asm volatile("s_mov_b32 %0, m0" : "=s"(saved_m0));
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint8_t *src = (a.debug & 4u) ? cptr : cptr + (size_t)min(t0 + 16u * i, last_chunk) * cmul;  // (4: profiling, one hot line)
+                    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(slot + i * 1024u) : "memory");
+                }
+                asm volatile("s_mov_b32 m0, %0" ::"s"(saved_m0));
+                // kRing = nring tiles in flight: the tile issued nring-1 iterations ago has landed once at most
+                // 4*(nring-1) younger DMAs are outstanding (vmcnt is in-order and this wave issues nothing else)
+                if (t + 1u >= nring) {
+                    if (nring == 4u) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (nring == 3u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if (nring == 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ring_post(ready_off, seq - nring + 2u);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group tail: everything has landed
+            ring_post(ready_off, seq);
+        } else {
+            // ================================ walker ================================
+            const uint32_t min_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(n));
+            LaneRegs<D> L;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                L.e[d] = a.dc[d].first_entry;  // states[d][0] = first_state_val: lib.rs:807
+                L.mx[d] = 0;
+            }
+            L.sid_prev = 0;
+            L.ov_row = 0xffffffffu;
+            MaskCarry mc = {0, 0, 0, 0};
+            uint32_t dead = 0, accept = 0;
+            uint32_t err_pos[D], err_state[D], err_char[D], acc_state[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                err_pos[d] = err_state[d] = err_char[d] = 0;
+                acc_state[d] = (uint32_t)(a.dc[d].first_entry >> kNextShift) - a.dc[d].row_base;  // n == 0
+            }
+            const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
+            unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * D;
+            const size_t rstep = (size_t)B * 16u * D;  // one quad of rows further: [M/4][B][4][D]
+            unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
+            const size_t mstep = (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
+            uint4 pend[8];                             // the previous tile's masked rows, not yet stored
+            unsigned char *pend_mp = mp;
+            bool have_pend = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pend[k] = make_uint4(0, 0, 0, 0);
+
+            for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
+                const uint32_t t0 = t << 6;
+                const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
+                ring_wait(ready_off, seq + 1u);
+                uint4 cq[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) cq[i] = lds_u128(slot + i * 1024u + lane * 16u);
+                ring_post(freed_off, seq + 1u);
+
+                uint32_t e_start[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) e_start[d] = L.e[d];
+                uint32_t sidq[16];
+                TileBits tb;
+                const bool full = (t0 + 64u < min_n);
+                const bool do_store = active && !(a.debug & 1u);
+                const bool pend_store = active && have_pend && !(a.debug & 2u);
+                if (full)
+                    tb = walk_tile_pm<D, true>(L, cq, a, rp, rstep, do_store, 0, 0, t0, sidq, acc_state, pend, pend_mp, mstep, pend_store);
+                else
+                    tb = walk_tile_pm<D, false>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state,
+                                                pend, pend_mp, mstep, pend_store);
+
+                // ---------------- undefined transition (lib.rs:817): rare slow path, re-walk the tile ----------------
+                uint32_t newly = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    if (!((dead >> d) & 1u) && L.mx[d] >= a.dc[d].dead_entry) newly |= 1u << d;
+                if (__any(newly != 0)) {
+                    const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
+                                             cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        uint32_t e = e_start[d];
+                        bool found = !((newly >> d) & 1u);
+#pragma unroll
+                        for (int p = 0; p < 64; ++p) {
+                            const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                            const uint32_t nx = lds_u32((e & ~kTagMask) | (c << 2));
+                            if (!found && nx >= a.dc[d].dead_entry && (int)p < (int)n - (int)t0) {
+                                err_pos[d] = t0 + (uint32_t)p;
+                                err_state[d] = (e >> kNextShift) - a.dc[d].row_base;
+                                err_char[d] = c;
+                                found = true;
+                            }
+                            e = nx;
+                        }
+                        if ((newly >> d) & 1u) dead |= 1u << d;
+                    }
+                }
+                // ---------------- accept state: the state at row n (lib.rs:437-457) ----------------
+                if (!full && n == t0 + 64u && t + 1 == ntiles) {  // n == M: row n does not exist, s[n] is the live state
+#pragma unroll
+                    for (int d = 0; d < D; ++d) acc_state[d] = (L.e[d] >> kNextShift) - a.dc[d].row_base;
+                }
+                // ---------------- reveal masks: lib.rs:598-764 ----------------
+                TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
+                if (!active) { tm.mask = 0; tm.fix = 0; }
+                uint64_t fixm = __ballot(tm.fix != 0);
+                if (fixm) {  // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare)
+                    while (fixm) {
+                        const int j = __ffsll((unsigned long long)fixm) - 1;
+                        fixm &= fixm - 1;
+                        const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
+                        const uint32_t bj = b0 + (uint32_t)j;
+                        for (uint32_t r = fs + lane; r < t0; r += 64u)
+                            a.masked[((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
+                    }
+                }
+                // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8]; stored during the next walk ----------------
+                {
+                    const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
+                                             cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+                    const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
+                        uint4 v = make_uint4(0, 0, 0, 0);
+                        if (mbyte) {  // lib.rs:752-761
+                            uint32_t o[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int p = k * 8 + i;
+                                const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                                const uint32_t sid = (sidq[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                                o[i] = ((mbyte >> i) & 1u) ? (c | (sid << 8)) : 0u;
+                            }
+                            v = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+                        }
+                        pend[k] = v;
+                    }
+                    pend_mp = mp;
+                    mp += 8u * mstep;
+                    have_pend = true;
+                }
+            }
+            // the last tile's masked rows (only the octets that exist: [ceil(M/8)][B][8])
+            if (active && have_pend && !(a.debug & 2u)) {
+                const uint32_t t0 = (ntiles - 1u) << 6;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (t0 + (uint32_t)k * 8u < M) *reinterpret_cast<uint4 *>(pend_mp + (size_t)k * mstep) = pend[k];
+            }
+            // ---------------- per-string status ----------------
+            if (active) {
+                accept = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) accept |= (acc_state[d] == a.dc[d].accepted_state ? 1u : 0u) << d;
+                uint64_t sw;
+                if (badlen) {
+                    sw = kStatusBadLength;
+                } else if (dead) {
+                    sw = 0;
+#pragma unroll
+                    for (int d = D - 1; d >= 0; --d)  // lowest def wins: the reference walks defs in order (lib.rs:806)
+                        if ((dead >> d) & 1u) sw = status_invalid((uint32_t)d, err_pos[d], err_state[d], err_char[d]);
+                } else if (D > 1 && L.ov_row != 0xffffffffu) {
+                    sw = status_overlap(L.ov_row);
+                } else {
+                    sw = status_ok(accept);
+                }
+                a.status[b] = sw;
+            }
+        }
+    }
+}
+
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.gs = 64;
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
+    if (a.layout & 1u) {
+        // ---- loader/walker kernel: table + per pair a ring of up to 4 input tiles (4 KiB each)
+        int pairs = 4;
+        while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        for (; pairs >= 1; --pairs) {
+            for (int ns = 4; ns >= 2; --ns) {
+                const size_t lds = a.table_bytes + (size_t)pairs * (ns * 4096 + 16);
+                if (lds > kLdsLimit) continue;
+                out.split = 2;
+                out.waves_per_wg = 2 * pairs;
+                out.nslots = ns;
+                out.lds_bytes = lds;
+                const size_t need = ((size_t)a.n_groups + pairs - 1) / pairs;
+                size_t per_cu = kLdsLimit / lds;               // LDS
+                if (per_cu * (size_t)(2 * pairs) > 8) per_cu = 8 / (size_t)(2 * pairs);  // 2 waves per SIMD (VGPRs)
+                if (per_cu < 1) per_cu = 1;
+                const size_t cap = (size_t)num_cus * per_cu;
+                out.grid = (int)(need < cap ? need : cap);
+                if (out.grid < 1) out.grid = 1;
+                return true;
+            }
+        }
+        return false;
+    }
     // ---- walker/storer kernel: D in {1,2}, rows in multiples of 8, ring of >= 2 slots per pair
     if ((a.D == 1 || a.D == 2) && a.M % 8u == 0 && !(a.debug & 0x10000u)) {
         const size_t slot = 64 * 128 + 64 * 8 + 64 * (a.D == 1 ? 32 : 16), fixed = 16 + 256;  // + the storer's LDS-DMA sink
@@ -892,7 +1249,18 @@ static hipError_t launch_t(const WitnessArgs &a, const LaunchInfo &li, hipStream
     return hipGetLastError();
 }
 
+template <int D>
+static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
+    auto k = witness_pm_kernel<D>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)li.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(li.grid), dim3(64 * li.waves_per_wg), li.lds_bytes, stream, a, (uint32_t)li.nslots);
+    return hipGetLastError();
+}
+
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
+    if (li.split == 2) return a.D == 1 ? launch_pm<1>(a, li, stream) : a.D == 2 ? launch_pm<2>(a, li, stream) : launch_pm<3>(a, li, stream);
     if (li.split) return a.D == 1 ? launch_split<1, 32>(a, li, stream) : launch_split<2, 16>(a, li, stream);
     const bool al = (a.M % 8u) == 0;
     switch (a.D) {

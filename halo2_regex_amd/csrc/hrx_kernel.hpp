@@ -14,7 +14,8 @@ struct WitnessArgs {
     uint64_t stride;
     const uint32_t *lens;
     uint32_t B, M;
-    uint32_t rec_pitch, msk_pitch;  // rows between consecutive strings in records / masked (>= M)
+    uint32_t rec_pitch, msk_pitch;  // rows between consecutive strings in records / masked (>= M), string-major layout
+    uint32_t layout;                // 0 string-major [B][pitch][D] / [B][pitch]; 1 position-major [M/4][B][4][D] / [M/8][B][8]
     uint32_t *records;
     uint16_t *masked;
     uint64_t *status;
@@ -29,7 +30,8 @@ struct WitnessArgs {
 };
 
 struct LaunchInfo {
-    int split;         // 1: walker/storer kernel (witness_split_kernel), 0: one-wave-does-all kernel (witness_kernel)
+    int split;         // 2: loader/walker kernel for the position-major layout (witness_pm_kernel),
+                       // 1: walker/storer kernel (witness_split_kernel), 0: one-wave-does-all kernel (witness_kernel)
     int waves_per_wg;  // split: 2 * pairs
     int nslots;        // split: ring slots per walker/storer pair
     int grid;

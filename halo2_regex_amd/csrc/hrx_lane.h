@@ -109,26 +109,52 @@ struct TileMasks {
 // end_mask = 1 (the common case: a substring that ends in the next tile) and the lane
 // remembers where they start; the first event of a later tile confirms them or asks for
 // them to be zeroed (`fix`).  Each row is fixed at most once.
+// word type wide enough for a W-row tile: the walker/storer kernel's 32- and 16-row tiles run the whole algebra in
+// 32-bit registers (half the VALU work of the 64-bit form)
+template <int W> struct TileWord { typedef uint64_t type; };
+template <> struct TileWord<32> { typedef uint32_t type; };
+template <> struct TileWord<16> { typedef uint32_t type; };
+
+template <class U> HRX_HD U brev_word(U x);
+template <> HRX_HD uint64_t brev_word<uint64_t>(uint64_t x) { return brev64(x); }
+template <> HRX_HD uint32_t brev_word<uint32_t>(uint32_t x) {
+#if defined(__clang__)
+    return __builtin_bitreverse32(x);
+#else
+    return (uint32_t)(brev64((uint64_t)x) >> 32);
+#endif
+}
+template <class U> HRX_HD U fill_up_word(U set, U rst, uint32_t cin) {
+    const U P = (U) ~(set | rst);
+    const U sum = (U)((U)(P | set) + set + (U)cin);
+    return (U)(set | (P & (sum ^ P)));
+}
+
 template <int W = 64>
 HRX_HD TileMasks tile_masks(const TileBits &b, MaskCarry &c, uint32_t t0, bool exact, uint64_t valid) {
-    constexpr uint64_t kAll = W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull);
+    typedef typename TileWord<W>::type U;
+    constexpr int BITS = (int)sizeof(U) * 8;
+    constexpr U kAll = W == BITS ? (U) ~(U)0 : (U)(((U)1 << (W & (BITS - 1))) - (U)1);
+    const U st = (U)b.st, en1 = (U)b.en1, ch = (U)b.ch;
     TileMasks out;
-    const uint64_t en0 = ((b.en1 << 1) | (uint64_t)c.en) & kAll;  // bit p = EN[t0+p]
-    c.en = (uint32_t)(b.en1 >> (W - 1)) & 1u;
+    const U en0 = (U)(((U)(en1 << 1) | (U)c.en) & kAll);  // bit p = EN[t0+p]
+    c.en = (uint32_t)(en1 >> (W - 1)) & 1u;
     // forward: start_mask                                                     lib.rs:598-645
-    const uint64_t setF = b.st & b.ch;
-    const uint64_t rstF = ~b.st & en0 & b.ch;
-    const uint64_t sm = fill_up(setF, rstF, c.sm) & kAll;
+    const U setF = (U)(st & ch);
+    const U rstF = (U)(~st & en0 & ch);
+    const U sm = (U)(fill_up_word<U>(setF, rstF, c.sm) & kAll);
     c.sm = (uint32_t)(sm >> (W - 1)) & 1u;
     // backward: end_mask; bit j of setB/rstB is the event of position t0+j-1   lib.rs:663-714
-    const uint64_t setB = en0 & b.ch;
-    const uint64_t rstB = ~en0 & b.st & b.ch;
+    const U setB = (U)(en0 & ch);
+    const U rstB = (U)(~en0 & st & ch);
     const uint32_t cin = exact ? 0u : 1u;
     // fill towards lower positions over W bits: mirror the W-bit field, fill up, mirror back
-    const uint64_t F = brev64(fill_up(brev64(setB) >> (64 - W), brev64(rstB) >> (64 - W), cin) << (64 - W));
-    const uint64_t em = (F >> 1) | ((uint64_t)cin << (W - 1));  // end_mask[t0+p] = F[p+1]
-    out.mask = sm & em & valid & kAll;                              // lib.rs:740-745
-    const uint64_t any = setB | rstB;
+    const U F = brev_word<U>((U)(fill_up_word<U>((U)(brev_word<U>(setB) >> (BITS - W)), (U)(brev_word<U>(rstB) >> (BITS - W)), cin)
+                                 << (BITS - W)));
+    const U em = (U)((U)(F >> 1) | (U)((U)cin << (W - 1)));  // end_mask[t0+p] = F[p+1]
+    const U mask = (U)(sm & em & (U)valid & kAll);         // lib.rs:740-745
+    out.mask = mask;
+    const U any = (U)(setB | rstB);
     out.fix = 0;
     out.fix_start = 0;
     if (c.pend && (any != 0 || exact)) {
@@ -136,9 +162,9 @@ HRX_HD TileMasks tile_masks(const TileBits &b, MaskCarry &c, uint32_t t0, bool e
         c.pend = 0;
     }
     if (!exact) {
-        const uint64_t suffix = any ? (~0ull << msb64(any)) : ~0ull;  // rows whose end_mask came from cin
-        const uint64_t opt = out.mask & suffix;
-        if (opt != 0 && !c.pend) { c.pend = 1; c.pend_start = t0 + (uint32_t)ctz64(opt); }
+        const U suffix = any ? (U)((U) ~(U)0 << msb64((uint64_t)any)) : (U) ~(U)0;  // rows whose end_mask came from cin
+        const U opt = (U)(mask & suffix);
+        if (opt != 0 && !c.pend) { c.pend = 1; c.pend_start = t0 + (uint32_t)ctz64((uint64_t)opt); }
     }
     return out;
 }

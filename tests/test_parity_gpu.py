@@ -133,6 +133,81 @@ def test_reveal_mask_stress(hra, oracle, names):
     _check_batch(hra, oracle, names, chars, lens, 2003)               # unaligned row count
 
 
+def _check_batch_pm(hra, oracle, names, chars, lens, M):
+    """the same batch through HRX_LAYOUT_POSITION_MAJOR (loader/walker kernel), de-permuted and compared bit for bit"""
+    import torch
+    cfg = _cfg(hra, names, M)
+    o = OracleDefs.from_files(oracle, names)
+    orec, omsk, ost = o.witness_batch(chars, lens, M)
+    dev = torch.device("cuda", 0)
+    B, D = len(lens), cfg.num_defs
+    stride = (chars.shape[1] + 15) // 16 * 16
+    wide = torch.zeros((B, max(stride, 16)), dtype=torch.uint8, device=dev)
+    wide[:, :chars.shape[1]] = torch.from_numpy(chars).to(dev)
+    d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    rec, msk, st = cfg.witness_batch_position_major(wide, d_lens)
+    # and with the input chunked position-major as well: the same bytes must come out
+    rec_i, msk_i, st_i = cfg.witness_batch_position_major(hra.chars_to_position_major(wide), d_lens, chars_pm_stride=wide.shape[1])
+    torch.cuda.synchronize()
+    okm = torch.from_numpy(((ost & np.uint64(0xff)) == 0)).to(dev)
+    a_r, a_m = hra.position_major_to_string_major(rec, msk, B, M, D)
+    b_r, b_m = hra.position_major_to_string_major(rec_i, msk_i, B, M, D)
+    assert torch.equal(st, st_i) and torch.equal(a_r[okm], b_r[okm]) and torch.equal(a_m[okm], b_m[okm])
+    grec, gmsk = hra.position_major_to_string_major(rec, msk, B, M, D)
+    grec = grec.cpu().numpy().view(np.uint32)
+    gmsk = gmsk.cpu().numpy().view(np.uint16)
+    gst = st.cpu().numpy().view(np.uint64)
+    assert np.array_equal(ost, gst)
+    ok = (ost & np.uint64(0xff)) == 0
+    assert np.array_equal(orec[ok], grec[ok])
+    assert np.array_equal(omsk[ok], gmsk[ok])
+
+
+@pytest.mark.parametrize("M", [1, 7, 8, 63, 64, 65, 72, 128, 200, 1024])
+def test_position_major_ragged(hra, oracle, M):
+    from halo2_regex_amd import synth
+    chars, lens = synth.ragged(200, M, seed=M)
+    _check_batch_pm(hra, oracle, CFG_1, chars, lens, M)
+    _check_batch_pm(hra, oracle, CFG_A, chars, lens, M)
+
+
+@pytest.mark.parametrize("names", [CFG_1, CFG_3, CFG_A, CFG_23, CFG_123], ids=["r1", "r3", "r1r2", "r2r3", "r1r2r3"])
+def test_position_major_reveal_stress_and_errors(hra, oracle, names):
+    from halo2_regex_amd import synth
+    chars, lens = synth.reveal_stress(1500, 700, seed=11)
+    _check_batch_pm(hra, oracle, names, chars, lens, 704)
+    chars, lens = synth.reveal_stress(300, 2000, seed=12)
+    _check_batch_pm(hra, oracle, names, chars, lens, 2003)
+    chars, lens = synth.ragged(257, 300, seed=3)
+    rng = np.random.default_rng(1)
+    for b in range(0, 257, 3):
+        if lens[b]:
+            chars[b, int(rng.integers(0, lens[b]))] = 200 + b % 50
+    lens[5] = 400
+    _check_batch_pm(hra, oracle, names, chars, lens, 304)
+
+
+def test_position_major_full_size_cfg2(hra, oracle):
+    import torch
+    from halo2_regex_amd import synth
+    B, n, M = 65536, 1023, 1024
+    chars, lens = synth.regex1_planted(B, n, seed=0, stride=1024)
+    cfg = _cfg(hra, CFG_1, M)
+    dev = torch.device("cuda", 0)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    rec, msk, st = cfg.witness_batch_position_major(d_chars, d_lens)
+    r0, m0, s0 = cfg.witness_batch(d_chars, d_lens)         # the string-major kernel on the same batch
+    torch.cuda.synchronize()
+    r1, m1 = hra.position_major_to_string_major(rec, msk, B, M, 1)
+    assert torch.equal(r1, r0) and torch.equal(m1, m0) and torch.equal(st, s0)
+    idx = np.random.default_rng(1).choice(B, 512, replace=False)
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_1).witness_batch(chars[idx], lens[idx], M)
+    assert np.array_equal(orec, r1.cpu().numpy().view(np.uint32)[idx]) and np.array_equal(omsk, m1.cpu().numpy().view(np.uint16)[idx])
+    rec2, msk2, st2 = cfg.witness_batch_position_major(d_chars, d_lens)
+    torch.cuda.synchronize()
+    assert torch.equal(rec, rec2) and torch.equal(msk, msk2) and torch.equal(st, st2)
+
+
 @pytest.mark.parametrize("flags", ["65536", "196608"], ids=["one-wave-gs64", "one-wave-gs32"])
 def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
     """D <= 2 normally takes the walker/storer kernel; force the one-wave kernel (used for D = 3 and unaligned M)

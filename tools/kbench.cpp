@@ -53,12 +53,18 @@ int main(int argc, char **argv) {
     d_chars += chr_off; d_rec += rec_off / 4; d_msk += msk_off / 2;
     printf("bases: chars %p rec %p msk %p\n", (void *)d_chars, (void *)d_rec, (void *)d_msk);
     CK(hipMalloc(&d_st, 8 * B)); CK(hipMalloc(&d_tab, s.table_image.size() * 4));
+    if ((getenv("KB_LAYOUT") ? atoi(getenv("KB_LAYOUT")) : 0) & 2) {  // position-major input: [stride/16][B][16]
+        std::vector<uint8_t> t2(h.size());
+        for (size_t bb = 0; bb < B; ++bb) for (size_t i = 0; i < stride; ++i) t2[((i / 16) * B + bb) * 16 + i % 16] = h[bb * stride + i];
+        h.swap(t2);
+    }
     CK(hipMemcpy(d_chars, h.data(), h.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(d_lens, lens.data(), 4 * B, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_tab, s.table_image.data(), s.table_image.size() * 4, hipMemcpyHostToDevice));
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     WitnessArgs a{};
     a.chars = d_chars; a.stride = stride; a.lens = d_lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
-    a.rec_pitch = (uint32_t)(M + rec_pad); a.msk_pitch = (uint32_t)(M + msk_pad); a.records = d_rec; a.masked = d_msk;
+    a.rec_pitch = (uint32_t)(M + rec_pad); a.msk_pitch = (uint32_t)(M + msk_pad);
+    a.layout = getenv("KB_LAYOUT") ? atoi(getenv("KB_LAYOUT")) : 0; a.records = d_rec; a.masked = d_msk;
     a.status = d_st; a.table_image = d_tab; a.table_bytes = (uint32_t)(s.table_image.size() * 4);
     a.D = 1; a.debug = debug; a.dc[0] = s.consts[0];
     LaunchInfo li;
