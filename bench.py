@@ -43,14 +43,32 @@ def cpu_baseline(names, chars, lens, M, budget_s=12.0):
                       "host has %d cores" % (nstr, reps, rows, dt, os.cpu_count())}
 
 
+def copy_ceiling_gbs(dev, nbytes):
+    """Measured device-copy ceiling of this box: a plain torch copy moving the same number of bytes as one
+    launch (half read, half written).  Context for roofline.frac, which stays priced against the 8 TB/s spec."""
+    import torch
+    x = torch.empty(nbytes // 2, dtype=torch.uint8, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(3):
+        y.copy_(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * x.numel() * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def pmc_traffic(args, D):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json:
     WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect counters
     itself; None unless the committed passes were taken on the workload being run."""
     try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r01_split_pmc.json")))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r01_pm_pmc.json" if args.layout == "position-major" else "r01_split_pmc.json")))
         if (args.config == "regex1" and args.batch == 65536 and args.n == 1023 and args.rows == 1024 and args.dist == "planted"
-                and args.layout == p.get("layout", "string-major")):
+                and not args.dense):
             return p["hbm_bytes_per_launch"]["total"]
     except Exception:
         pass
@@ -176,6 +194,10 @@ def main():
                          "avg_launch_ms": kern_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D)},
         }
+        if world == 1:
+            ceil = copy_ceiling_gbs(dev, algo_bytes)
+            line["roofline"]["measured_copy_ceiling"] = ceil
+            line["roofline"]["frac_of_copy_ceiling"] = achieved / ceil
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(names, chars, lens, M)
         print(json.dumps(line), flush=True)

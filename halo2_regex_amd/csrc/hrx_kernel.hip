@@ -841,6 +841,11 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
 // =============================================================================================
 constexpr uint32_t kPmTileBytes = 64u * 64u;  // 64 strings x 64 input bytes per tile
 
+__device__ __forceinline__ void store16(unsigned char *p, const uint4 &v, const bool nt) {
+    if (nt) __builtin_nontemporal_store(v4u32{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u32 *>(p));
+    else *reinterpret_cast<uint4 *>(p) = v;
+}
+
 template <int D, bool FULL>
 __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, unsigned char *&rp,
                                                  const size_t rstep, const bool do_store, int rem, int mrem, uint32_t t0,
@@ -869,7 +874,7 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
             if ((i & 3) == 3) {  // 16 bytes of this string's quad: a 1-KiB (x D) contiguous run across the wave
                 // quads that start at or beyond row M do not exist in [ceil(M/4)][B][4][D]
                 if (do_store && (FULL || (p & ~3) <= mrem))
-                    *reinterpret_cast<uint4 *>(rp + ((i >> 2) % D) * 16) = make_uint4(rbuf[0], rbuf[1], rbuf[2], rbuf[3]);
+                    store16(rp + ((i >> 2) % D) * 16, make_uint4(rbuf[0], rbuf[1], rbuf[2], rbuf[3]), (a.debug & 32u) != 0);
                 if ((p & 3) == 3) rp += rstep;
             }
             if (!FULL) L.mx[d] = max(L.mx[d], et[d]);
@@ -888,7 +893,7 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
         sidq[p >> 2] |= sid << (8 * (p & 3));  // the tile's substr-id sums, one byte per row (masked rows need them)
         // the PREVIOUS tile's masked rows leave one 16-byte piece every 8 rows instead of as a burst of 8 stores at the
         // tile boundary (the burst filled the store queue and stalled the in-order walk: 99 -> ? us)
-        if ((p & 7) == 5 && pend_store) *reinterpret_cast<uint4 *>(pend_mp + (size_t)(p >> 3) * mstep) = pend[p >> 3];
+        if ((p & 7) == 5 && pend_store) store16(pend_mp + (size_t)(p >> 3) * mstep, pend[p >> 3], (a.debug & 64u) != 0);
     };
 #pragma unroll
     for (int i = 0; i < 16; ++i) sidq[i] = 0;
@@ -965,37 +970,76 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         if (!is_walker) {
             // ================================ loader ================================
             // string-major input: string b at chars + b*stride; position-major input: 16-byte chunk i of string b at
-            // chars + (i*B + b)*16, so one DMA instruction reads 1 KiB contiguous (coalesced, compact read window)
+            // chars + (i*B + b)*16, so one load instruction reads 1 KiB contiguous (coalesced, compact read window).
+            //
+            // Reads that trickle in while the walkers stream their output cost far more than their share of the bytes
+            // (64 MB of reads mixed into 384 MB of writes: +21 us of 93; HBM read/write turnarounds).  So the loader asks
+            // for a whole super-batch of 16 tiles (1024 rows) of its 64 strings in ONE burst: tiles 0-3 by LDS-DMA straight
+            // into the ring, tiles 4-15 into its own registers (192 VGPRs the kernel owns anyway), and later only moves
+            // registers to the ring as the walker frees slots.  At M <= 1024 every HBM read of the launch is issued in
+            // its first microseconds.
             const bool in_pm = (a.layout & 2u) != 0;
             const uint32_t bl = active ? b : B - 1u;
             const uint8_t *cptr = in_pm ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
             const size_t cmul = in_pm ? (size_t)B : (size_t)1;  // byte offset of chunk-start row r: r * cmul
             const uint32_t last_chunk = n ? ((n - 1u) & ~15u) : 0u;
-            for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
-                const uint32_t t0 = t << 6;
-                if (seq >= nring) ring_wait(freed_off, seq - nring + 1u);  // the walker has read this slot
-                const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
+            auto src_of = [&](uint32_t row) { return (a.debug & 4u) ? cptr : cptr + (size_t)min(row, last_chunk) * cmul; };
+            for (uint32_t sb = 0; sb < ntiles; sb += 16u) {
+                const uint32_t nt = min(16u, ntiles - sb);  // tiles in this super-batch (wave-uniform)
+                const uint32_t seq0 = seq;
+                uint4 buf[48];
+                // ---- issue everything: DMA for the first nring (<= 4) tiles, register loads for the rest
                 uint32_t saved_m0;
-                // chunk i of all 64 strings -> slot + i*1024 + lane*16 (M0 = LDS base of the DMA, restored afterwards)
                 asm volatile("s_mov_b32 %0, m0" : "=s"(saved_m0));
 #pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
-                    const uint8_t *src = (a.debug & 4u) ? cptr : cptr + (size_t)min(t0 + 16u * i, last_chunk) * cmul;  // (4: profiling, one hot line)
-                    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(slot + i * 1024u) : "memory");
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    if (k < nt && k < nring) {
+                        if (seq0 + k >= nring) ring_wait(freed_off, seq0 + k - nring + 1u);
+                        const uint32_t slot = ring_base + ((seq0 + k) % nring) * kPmTileBytes;
+#pragma unroll
+                        for (uint32_t i = 0; i < 4u; ++i)
+                            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_of((sb + k) * 64u + 16u * i)),
+                                         "s"(slot + i * 1024u)
+                                         : "memory");
+                    }
                 }
                 asm volatile("s_mov_b32 m0, %0" ::"s"(saved_m0));
-                // kRing = nring tiles in flight: the tile issued nring-1 iterations ago has landed once at most
-                // 4*(nring-1) younger DMAs are outstanding (vmcnt is in-order and this wave issues nothing else)
-                if (t + 1u >= nring) {
-                    if (nring == 4u) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (nring == 3u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else if (nring == 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    ring_post(ready_off, seq - nring + 2u);
+                const uint32_t ndma = min(nt, nring);  // tiles that went by DMA
+#pragma unroll
+                for (uint32_t k = 0; k < 12u; ++k) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i)
+                        buf[k * 4u + i] = *reinterpret_cast<const uint4 *>(src_of((sb + ndma + k) * 64u + 16u * i));
                 }
+                if (a.debug & 128u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment: reads strictly before writes
+                // ---- DMA tiles: the 4*ndma DMAs are the oldest outstanding operations, 48 register loads are younger
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    if (k < ndma) {
+                        if (ndma - 1u - k == 3u) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+                        else if (ndma - 1u - k == 2u) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+                        else if (ndma - 1u - k == 1u) asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+                        ring_post(ready_off, seq0 + k + 1u);
+                    }
+                }
+                // ---- register tiles: wait for a free slot, copy 4 KiB into it, publish
+#pragma unroll
+                for (uint32_t k = 0; k < 12u; ++k) {
+                    if (ndma + k < nt) {
+                        const uint32_t sq = seq0 + ndma + k;
+                        if (sq >= nring) ring_wait(freed_off, sq - nring + 1u);
+                        const uint32_t slot = ring_base + (sq % nring) * kPmTileBytes;
+#pragma unroll
+                        for (uint32_t i = 0; i < 4u; ++i)
+                            *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + i * 1024u + lane * 16u) =
+                                v4u32{buf[k * 4u + i].x, buf[k * 4u + i].y, buf[k * 4u + i].z, buf[k * 4u + i].w};
+                        ring_post(ready_off, sq + 1u);
+                    }
+                }
+                seq = seq0 + nt;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this super-batch may still be in flight
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group tail: everything has landed
-            ring_post(ready_off, seq);
         } else {
             // ================================ walker ================================
             const uint32_t min_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(n));

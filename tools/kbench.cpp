@@ -58,6 +58,11 @@ int main(int argc, char **argv) {
         for (size_t bb = 0; bb < B; ++bb) for (size_t i = 0; i < stride; ++i) t2[((i / 16) * B + bb) * 16 + i % 16] = h[bb * stride + i];
         h.swap(t2);
     }
+    if ((getenv("KB_LAYOUT") ? atoi(getenv("KB_LAYOUT")) : 0) & 4) {  // group-major input: [B/64][stride/16][64][16]
+        std::vector<uint8_t> t2(h.size());
+        for (size_t bb = 0; bb < B; ++bb) for (size_t i = 0; i < stride; ++i) t2[(((bb / 64) * (stride / 16) + i / 16) * 64 + bb % 64) * 16 + i % 16] = h[bb * stride + i];
+        h.swap(t2);
+    }
     CK(hipMemcpy(d_chars, h.data(), h.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(d_lens, lens.data(), 4 * B, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_tab, s.table_image.data(), s.table_image.size() * 4, hipMemcpyHostToDevice));
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
