@@ -125,6 +125,7 @@ __device__ __forceinline__ TileBits walk_tile(LaneRegs<D> &L, const uint4 (&cq)[
 #pragma unroll
                     for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]));
                 }
+                if (D > 1) asm volatile("" : "+v"(L.ov_row));  // or the 64 per-row flag counts stay live until the tile end
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -893,7 +894,7 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
         sidq[p >> 2] |= sid << (8 * (p & 3));  // the tile's substr-id sums, one byte per row (masked rows need them)
         // the PREVIOUS tile's masked rows leave one 16-byte piece every 8 rows instead of as a burst of 8 stores at the
         // tile boundary (the burst filled the store queue and stalled the in-order walk: 99 -> ? us)
-        if ((p & 7) == 5 && pend_store) store16(pend_mp + (size_t)(p >> 3) * mstep, pend[p >> 3], (a.debug & 64u) != 0);
+        if (D == 1 && (p & 7) == 5 && pend_store) store16(pend_mp + (size_t)(p >> 3) * mstep, pend[p >> 3], (a.debug & 64u) != 0);
     };
 #pragma unroll
     for (int i = 0; i < 16; ++i) sidq[i] = 0;
@@ -913,6 +914,7 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
 #pragma unroll
                     for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]));
                 }
+                if (D > 1) asm volatile("" : "+v"(L.ov_row));  // or the 64 per-row flag counts stay live until the tile end
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -944,9 +946,10 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     const uint32_t pair = is_walker ? wave : wave - pairs;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
-    const uint32_t pair_bytes = nring * kPmTileBytes + 16u;
+    const uint32_t pair_bytes = nring * kPmTileBytes + kPmTileBytes + 16u;  // ring + the walker's 4-KiB scratch + counters
     const uint32_t ring_base = a.table_bytes + pair * pair_bytes;
-    const uint32_t ready_off = ring_base + nring * kPmTileBytes, freed_off = ready_off + 4u;
+    const uint32_t scratch_off = ring_base + nring * kPmTileBytes;
+    const uint32_t ready_off = scratch_off + kPmTileBytes, freed_off = ready_off + 4u;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -958,8 +961,69 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
     uint32_t seq = 0;
+    const uint32_t g_first = blockIdx.x * pairs + pair, g_stride = gridDim.x * pairs;
 
-    for (uint32_t g = blockIdx.x * pairs + pair; g < a.n_groups; g += gridDim.x * pairs) {
+    if (!is_walker) {
+        // ================================ loader ================================
+        // string-major input: string b at chars + b*stride; position-major input: 16-byte chunk i of string b at
+        // chars + (i*B + b)*16, so one load instruction reads 1 KiB contiguous (coalesced, compact read window).
+        //
+        // The loader runs RT tiles (RT*4 KiB of its pair's input, 16 B per lane per load) ahead of the walker, in its own
+        // registers (192 VGPRs at D = 1 that the kernel owns anyway), over the flattened (group, tile) sequence of the
+        // pair: at M <= 1024 practically the whole input of a group is requested in one burst at the start, and the next
+        // group's bytes are on their way long before the walker gets there.  It issues nothing but these loads, so the
+        // counted s_waitcnt vmcnt(4*(RT-1)) for the oldest tile is exact.  Bytes at or beyond a string's length are
+        // read (inside the string's own stride) but never trusted.
+        constexpr uint32_t RT = D == 1 ? 12u : 8u;
+        const bool in_pm = (a.layout & 2u) != 0;
+        const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
+        const uint32_t total = my_groups * ntiles;
+        const uint32_t row_cap = (uint32_t)a.stride - 16u;  // last 16-byte chunk that exists for every string
+        const size_t cmul = in_pm ? (size_t)B : (size_t)1;  // byte offset of chunk-start row r: r * cmul
+        const size_t cmul_eff = (a.debug & 4u) ? (size_t)0 : cmul;  // (4: profiling only, every tile re-reads the hot first lines)
+        uint4 buf[RT * 4u];
+        auto issue = [&](const uint32_t q, const uint32_t k) {  // tile q of the pair's sequence -> register tile k
+            const uint32_t g = g_first + (q / ntiles) * g_stride, t = q % ntiles;
+            const uint32_t bl = min(g * 64u + lane, B - 1u);
+            const uint8_t *cptr = in_pm ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                const size_t off = (size_t)min(t * 64u + 16u * i, row_cap) * cmul_eff;
+                buf[k * 4u + i] = *reinterpret_cast<const uint4 *>(cptr + off);
+            }
+        };
+#pragma unroll
+        for (uint32_t k = 0; k < RT; ++k)
+            if (k < total) issue(k, k);
+        for (uint32_t s0 = 0; s0 < total; s0 += RT) {
+#pragma unroll
+            for (uint32_t k = 0; k < RT; ++k) {
+                const uint32_t sq = s0 + k;
+                if (sq < total) {
+                    if (sq >= nring) ring_wait(freed_off, sq - nring + 1u);  // the walker has read this slot
+                    const uint32_t slot = ring_base + (sq % nring) * kPmTileBytes;
+                    // tile sq was requested RT tiles ago; RT-1 younger tiles (4 loads each) may still be in flight
+                    if (sq + RT <= total) {
+                        if (RT == 12u) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail of the sequence: nothing younger is being issued
+                    }
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        uint4 v = buf[k * 4u + i];
+                        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));  // after the counted wait, not before
+                        *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
+                    }
+                    ring_post(ready_off, sq + 1u);
+                    if (sq + RT < total) issue(sq + RT, k);
+                }
+            }
+        }
+        return;
+    }
+
+    for (uint32_t g = g_first; g < a.n_groups; g += g_stride) {
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
         const bool active = b < B;
@@ -967,80 +1031,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         const bool badlen = n_raw > M;
         const uint32_t n = badlen ? M : n_raw;
 
-        if (!is_walker) {
-            // ================================ loader ================================
-            // string-major input: string b at chars + b*stride; position-major input: 16-byte chunk i of string b at
-            // chars + (i*B + b)*16, so one load instruction reads 1 KiB contiguous (coalesced, compact read window).
-            //
-            // Reads that trickle in while the walkers stream their output cost far more than their share of the bytes
-            // (64 MB of reads mixed into 384 MB of writes: +21 us of 93; HBM read/write turnarounds).  So the loader asks
-            // for a whole super-batch of 16 tiles (1024 rows) of its 64 strings in ONE burst: tiles 0-3 by LDS-DMA straight
-            // into the ring, tiles 4-15 into its own registers (192 VGPRs the kernel owns anyway), and later only moves
-            // registers to the ring as the walker frees slots.  At M <= 1024 every HBM read of the launch is issued in
-            // its first microseconds.
-            const bool in_pm = (a.layout & 2u) != 0;
-            const uint32_t bl = active ? b : B - 1u;
-            const uint8_t *cptr = in_pm ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
-            const size_t cmul = in_pm ? (size_t)B : (size_t)1;  // byte offset of chunk-start row r: r * cmul
-            const uint32_t last_chunk = n ? ((n - 1u) & ~15u) : 0u;
-            auto src_of = [&](uint32_t row) { return (a.debug & 4u) ? cptr : cptr + (size_t)min(row, last_chunk) * cmul; };
-            for (uint32_t sb = 0; sb < ntiles; sb += 16u) {
-                const uint32_t nt = min(16u, ntiles - sb);  // tiles in this super-batch (wave-uniform)
-                const uint32_t seq0 = seq;
-                uint4 buf[48];
-                // ---- issue everything: DMA for the first nring (<= 4) tiles, register loads for the rest
-                uint32_t saved_m0;
-                asm volatile("s_mov_b32 %0, m0" : "=s"(saved_m0));
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    if (k < nt && k < nring) {
-                        if (seq0 + k >= nring) ring_wait(freed_off, seq0 + k - nring + 1u);
-                        const uint32_t slot = ring_base + ((seq0 + k) % nring) * kPmTileBytes;
-#pragma unroll
-                        for (uint32_t i = 0; i < 4u; ++i)
-                            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_of((sb + k) * 64u + 16u * i)),
-                                         "s"(slot + i * 1024u)
-                                         : "memory");
-                    }
-                }
-                asm volatile("s_mov_b32 m0, %0" ::"s"(saved_m0));
-                const uint32_t ndma = min(nt, nring);  // tiles that went by DMA
-#pragma unroll
-                for (uint32_t k = 0; k < 12u; ++k) {
-#pragma unroll
-                    for (uint32_t i = 0; i < 4u; ++i)
-                        buf[k * 4u + i] = *reinterpret_cast<const uint4 *>(src_of((sb + ndma + k) * 64u + 16u * i));
-                }
-                if (a.debug & 128u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment: reads strictly before writes
-                // ---- DMA tiles: the 4*ndma DMAs are the oldest outstanding operations, 48 register loads are younger
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    if (k < ndma) {
-                        if (ndma - 1u - k == 3u) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
-                        else if (ndma - 1u - k == 2u) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-                        else if (ndma - 1u - k == 1u) asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-                        ring_post(ready_off, seq0 + k + 1u);
-                    }
-                }
-                // ---- register tiles: wait for a free slot, copy 4 KiB into it, publish
-#pragma unroll
-                for (uint32_t k = 0; k < 12u; ++k) {
-                    if (ndma + k < nt) {
-                        const uint32_t sq = seq0 + ndma + k;
-                        if (sq >= nring) ring_wait(freed_off, sq - nring + 1u);
-                        const uint32_t slot = ring_base + (sq % nring) * kPmTileBytes;
-#pragma unroll
-                        for (uint32_t i = 0; i < 4u; ++i)
-                            *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + i * 1024u + lane * 16u) =
-                                v4u32{buf[k * 4u + i].x, buf[k * 4u + i].y, buf[k * 4u + i].z, buf[k * 4u + i].w};
-                        ring_post(ready_off, sq + 1u);
-                    }
-                }
-                seq = seq0 + nt;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this super-batch may still be in flight
-            }
-        } else {
+        {
             // ================================ walker ================================
             const uint32_t min_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(n));
             LaneRegs<D> L;
@@ -1099,25 +1090,29 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 for (int d = 0; d < D; ++d)
                     if (!((dead >> d) & 1u) && L.mx[d] >= a.dc[d].dead_entry) newly |= 1u << d;
                 if (__any(newly != 0)) {
-                    const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
-                                             cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+                    // the tile's bytes go to this walker's LDS scratch so that the re-walk can index them at run time
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i)
+                        *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(scratch_off + lane * 64u + i * 16u) =
+                            v4u32{cq[i].x, cq[i].y, cq[i].z, cq[i].w};
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
-                        uint32_t e = e_start[d];
-                        bool found = !((newly >> d) & 1u);
-#pragma unroll
-                        for (int p = 0; p < 64; ++p) {
-                            const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
-                            const uint32_t nx = lds_u32((e & ~kTagMask) | (c << 2));
-                            if (!found && nx >= a.dc[d].dead_entry && (int)p < (int)n - (int)t0) {
-                                err_pos[d] = t0 + (uint32_t)p;
-                                err_state[d] = (e >> kNextShift) - a.dc[d].row_base;
-                                err_char[d] = c;
-                                found = true;
+                        if ((newly >> d) & 1u) {
+                            uint32_t e = e_start[d];
+                            const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
+                            for (uint32_t p = 0; p < live_rows; ++p) {
+                                const uint32_t c = smem[scratch_off + lane * 64u + p];
+                                const uint32_t nx = lds_u32((e & ~kTagMask) | (c << 2));
+                                if (nx >= a.dc[d].dead_entry) {
+                                    err_pos[d] = t0 + p;
+                                    err_state[d] = (e >> kNextShift) - a.dc[d].row_base;
+                                    err_char[d] = c;
+                                    break;
+                                }
+                                e = nx;
                             }
-                            e = nx;
+                            dead |= 1u << d;
                         }
-                        if ((newly >> d) & 1u) dead |= 1u << d;
                     }
                 }
                 // ---------------- accept state: the state at row n (lib.rs:437-457) ----------------
@@ -1159,11 +1154,13 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                             }
                             v = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
                         }
-                        pend[k] = v;
+                        if (D == 1) pend[k] = v;  // leaves during the next tile's walk
+                        else if (active && t0 + (uint32_t)k * 8u < M && !(a.debug & 2u))
+                            store16(mp + (size_t)k * mstep, v, false);  // D >= 2: the walk needs the registers; store now
                     }
                     pend_mp = mp;
                     mp += 8u * mstep;
-                    have_pend = true;
+                    have_pend = (D == 1);
                 }
             }
             // the last tile's masked rows (only the octets that exist: [ceil(M/8)][B][8])
@@ -1206,7 +1203,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
         for (; pairs >= 1; --pairs) {
             for (int ns = 4; ns >= 2; --ns) {
-                const size_t lds = a.table_bytes + (size_t)pairs * (ns * 4096 + 16);
+                const size_t lds = a.table_bytes + (size_t)pairs * (ns * 4096 + 4096 + 16);
                 if (lds > kLdsLimit) continue;
                 out.split = 2;
                 out.waves_per_wg = 2 * pairs;
