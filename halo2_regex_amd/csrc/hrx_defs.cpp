@@ -138,7 +138,7 @@ int finalize_defs(DefsSet &s, std::string &err) {
     }
     if (max_sid_sum > 255) { err = "substring ids do not fit the u8 masked_substr_id"; return HRX_ERR_BOUNDS; }
     if (total_rows * 1024 > kMaxTableBytes) {
-        err = "fused (state,char) tables need " + std::to_string(total_rows) + " KiB of LDS; limit is " +
+        err = "fused (state,char) tables need " + std::to_string(total_rows) + " KiB; limit is " +
               std::to_string(kMaxTableBytes / 1024) + " KiB";
         return HRX_ERR_BOUNDS;
     }

@@ -74,6 +74,6 @@ size_t table_transition_rows(const DefsSet &s, size_t d, uint64_t *rows4, size_t
 size_t table_endpoint_rows(const DefsSet &s, size_t d, uint64_t *rows3, size_t cap_rows);
 
 // LDS budget for the table image (the rest of the 160 KiB holds the per-wave staging)
-constexpr size_t kMaxTableBytes = 96 * 1024;
+constexpr size_t kMaxTableBytes = 2048 * 1024;  // 2048 table rows; beyond the LDS budget the kernels read the table from global memory
 
 }  // namespace hrx

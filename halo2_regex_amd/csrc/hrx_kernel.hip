@@ -33,6 +33,14 @@ __device__ __forceinline__ uint4 lds_u128(uint32_t off) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// delta lookup.  GTAB: the fused table did not fit the LDS budget and is read from global memory (it stays L2/MALL
+// resident: every wave hammers the same few hundred KiB); same entry format, same byte offsets, ~10x the latency.
+template <bool GTAB>
+__device__ __forceinline__ uint32_t table_at(const WitnessArgs &a, uint32_t off) {
+    if (GTAB) return a.table_image[off >> 2];
+    return lds_u32(off);
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, s, 64));
@@ -68,7 +76,7 @@ struct SwizzledChunks {
     __device__ __forceinline__ uint32_t operator()(int c) const { return addr[c]; }
 };
 
-template <int D, bool FULL, int T = 64, class Chunks = LinearChunks, int NQ = T / 16>
+template <int D, bool FULL, int T = 64, class Chunks = LinearChunks, int NQ = T / 16, bool GTAB = false>
 __device__ __forceinline__ TileBits walk_tile(LaneRegs<D> &L, const uint4 (&cq)[NQ], const WitnessArgs &a,
                                               const Chunks &chunk, int rem, int mrem, uint32_t t0) {
     uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
@@ -116,7 +124,7 @@ __device__ __forceinline__ TileBits walk_tile(LaneRegs<D> &L, const uint4 (&cq)[
             const int p = q * 4 + k;
             const uint32_t c4 = ((cw[q] >> (8 * k)) & 0xffu) << 2;
 #pragma unroll
-            for (int d = 0; d < D; ++d) raw[d] = lds_u32((e1[d] & ~kTagMask) | c4);  // delta(state, byte): lib.rs:810
+            for (int d = 0; d < D; ++d) raw[d] = table_at<GTAB>(a, (e1[d] & ~kTagMask) | c4);  // delta(state, byte): lib.rs:810
             if (p > 0) {
                 post(p - 1, e2, e1);
                 // pin the row's results here (zero instructions): IR-level sinking would otherwise move them to the tile end
@@ -187,7 +195,7 @@ __device__ __forceinline__ uint4 masked_chunk(uint32_t js, uint32_t w, uint32_t 
 
 // D: number of RegexDefs.  ALIGNED: M % 8 == 0, so every string-tile of records and masked rows starts on a
 // 16-byte boundary and the store phase moves 16 B per lane.
-template <int D, bool ALIGNED>
+template <int D, bool ALIGNED, bool GTAB>
 __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform by construction
@@ -198,9 +206,11 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        if (!GTAB)
+            for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
+    const uint32_t lds_tab = GTAB ? 0u : a.table_bytes;  // LDS bytes the table occupies
 
     constexpr uint32_t RSB = 256u * D + 16u;  // bytes per staged string-tile of records (+16 B: bank spread)
     constexpr uint32_t CSB = 80u;             // bytes per staged string-tile of chars
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
     // GS = 32 when the batch is too small to give every SIMD two waves of 64: with a single wave per SIMD nothing
     // can walk while that wave sits in its store burst behind HBM back-pressure.
     const uint32_t GS = a.gs;
-    const uint32_t rec_base = a.table_bytes + wave * (uint32_t)wave_stage_bytes(D, GS);
+    const uint32_t rec_base = lds_tab + wave * (uint32_t)wave_stage_bytes(D, GS);
     const uint32_t chr_base = rec_base + (GS + 1u) * RSB;  // row GS of each area: scratch for the idle lanes
     const uint32_t mb_base = chr_base + (GS + 1u) * CSB;
     const uint32_t sl = lane < GS ? lane : GS;             // this lane's staging row
@@ -261,9 +271,9 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
             TileBits tb;
             const bool full = (t0 + 64u < min_n);
             if (full)
-                tb = walk_tile<D, true>(L, cq, a, LinearChunks{my_rec}, 0, 0, t0);
+                tb = walk_tile<D, true, 64, LinearChunks, 4, GTAB>(L, cq, a, LinearChunks{my_rec}, 0, 0, t0);
             else
-                tb = walk_tile<D, false>(L, cq, a, LinearChunks{my_rec}, (int)n - (int)t0, (int)M - 1 - (int)t0, t0);
+                tb = walk_tile<D, false, 64, LinearChunks, 4, GTAB>(L, cq, a, LinearChunks{my_rec}, (int)n - (int)t0, (int)M - 1 - (int)t0, t0);
 
             if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
             bool chars_staged = false;
@@ -847,7 +857,7 @@ __device__ __forceinline__ void store16(unsigned char *p, const uint4 &v, const 
     else *reinterpret_cast<uint4 *>(p) = v;
 }
 
-template <int D, bool FULL>
+template <int D, bool FULL, bool GTAB>
 __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, unsigned char *&rp,
                                                  const size_t rstep, const bool do_store, int rem, int mrem, uint32_t t0,
                                                  uint32_t (&sidq)[16], uint32_t (&acc_state)[D], const uint4 (&pend)[8],
@@ -905,7 +915,7 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
             const int p = q * 4 + k;
             const uint32_t c4 = ((cw[q] >> (8 * k)) & 0xffu) << 2;
 #pragma unroll
-            for (int d = 0; d < D; ++d) raw[d] = lds_u32((e1[d] & ~kTagMask) | c4);  // delta(state, byte): lib.rs:810
+            for (int d = 0; d < D; ++d) raw[d] = table_at<GTAB>(a, (e1[d] & ~kTagMask) | c4);  // delta(state, byte): lib.rs:810
             if (p > 0) {
                 post(p - 1, e2, e1);
                 asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(ch[(p - 1) >> 5]), "+v"(L.sid_prev),
@@ -937,7 +947,7 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
     return tb;
 }
 
-template <int D>
+template <int D, bool GTAB>
 __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -947,13 +957,14 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
     const uint32_t pair_bytes = nring * kPmTileBytes + kPmTileBytes + 16u;  // ring + the walker's 4-KiB scratch + counters
-    const uint32_t ring_base = a.table_bytes + pair * pair_bytes;
+    const uint32_t ring_base = (GTAB ? 0u : a.table_bytes) + pair * pair_bytes;
     const uint32_t scratch_off = ring_base + nring * kPmTileBytes;
     const uint32_t ready_off = scratch_off + kPmTileBytes, freed_off = ready_off + 4u;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        if (!GTAB)
+            for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
         if (is_walker && lane == 0) { lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0); }
     }
     __syncthreads();
@@ -1079,9 +1090,9 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 const bool do_store = active && !(a.debug & 1u);
                 const bool pend_store = active && have_pend && !(a.debug & 2u);
                 if (full)
-                    tb = walk_tile_pm<D, true>(L, cq, a, rp, rstep, do_store, 0, 0, t0, sidq, acc_state, pend, pend_mp, mstep, pend_store);
+                    tb = walk_tile_pm<D, true, GTAB>(L, cq, a, rp, rstep, do_store, 0, 0, t0, sidq, acc_state, pend, pend_mp, mstep, pend_store);
                 else
-                    tb = walk_tile_pm<D, false>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state,
+                    tb = walk_tile_pm<D, false, GTAB>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state,
                                                 pend, pend_mp, mstep, pend_store);
 
                 // ---------------- undefined transition (lib.rs:817): rare slow path, re-walk the tile ----------------
@@ -1102,7 +1113,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                             const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
                             for (uint32_t p = 0; p < live_rows; ++p) {
                                 const uint32_t c = smem[scratch_off + lane * 64u + p];
-                                const uint32_t nx = lds_u32((e & ~kTagMask) | (c << 2));
+                                const uint32_t nx = table_at<GTAB>(a, (e & ~kTagMask) | (c << 2));
                                 if (nx >= a.dc[d].dead_entry) {
                                     err_pos[d] = t0 + p;
                                     err_state[d] = (e >> kNextShift) - a.dc[d].row_base;
@@ -1197,6 +1208,13 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.gs = 64;
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
+    out.gtab = 0;
+    // DFAs whose fused table leaves no room for the per-wave LDS areas are walked out of global memory (L2-resident)
+    const size_t min_stage = (a.layout & 1u) ? (2 * 4096 + 4096 + 16) : wave_stage_bytes((int)a.D, 16);
+    if (a.table_bytes + min_stage > kLdsLimit || (a.debug & 0x40000u)) out.gtab = 1;
+    const uint32_t table_bytes_saved = a.table_bytes;
+    struct Restore { WitnessArgs &a; uint32_t v; ~Restore() { a.table_bytes = v; } } restore{a, table_bytes_saved};
+    if (out.gtab) a.table_bytes = 0;  // for the LDS budgeting below only; restored on return
     if (a.layout & 1u) {
         // ---- loader/walker kernel: table + per pair a ring of up to 4 input tiles (4 KiB each)
         int pairs = 4;
@@ -1222,7 +1240,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
         return false;
     }
     // ---- walker/storer kernel: D in {1,2}, rows in multiples of 8, ring of >= 2 slots per pair
-    if ((a.D == 1 || a.D == 2) && a.M % 8u == 0 && !(a.debug & 0x10000u)) {
+    if ((a.D == 1 || a.D == 2) && a.M % 8u == 0 && !(a.debug & 0x10000u) && !out.gtab) {
         const size_t slot = 64 * 128 + 64 * 8 + 64 * (a.D == 1 ? 32 : 16), fixed = 16 + 256;  // + the storer's LDS-DMA sink
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;  // small batches: spread over the CUs
@@ -1280,9 +1298,9 @@ static hipError_t launch_split(const WitnessArgs &a, const LaunchInfo &li, hipSt
     return hipGetLastError();
 }
 
-template <int D, bool ALIGNED>
+template <int D, bool ALIGNED, bool GTAB>
 static hipError_t launch_t(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto k = witness_kernel<D, ALIGNED>;
+    auto k = witness_kernel<D, ALIGNED, GTAB>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)li.lds_bytes);
     if (e != hipSuccess) return e;
@@ -1290,9 +1308,9 @@ static hipError_t launch_t(const WitnessArgs &a, const LaunchInfo &li, hipStream
     return hipGetLastError();
 }
 
-template <int D>
+template <int D, bool GTAB>
 static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto k = witness_pm_kernel<D>;
+    auto k = witness_pm_kernel<D, GTAB>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)li.lds_bytes);
     if (e != hipSuccess) return e;
@@ -1301,13 +1319,24 @@ static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStrea
 }
 
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    if (li.split == 2) return a.D == 1 ? launch_pm<1>(a, li, stream) : a.D == 2 ? launch_pm<2>(a, li, stream) : launch_pm<3>(a, li, stream);
+    if (li.split == 2) {
+        if (li.gtab) return a.D == 1 ? launch_pm<1, true>(a, li, stream) : a.D == 2 ? launch_pm<2, true>(a, li, stream) : launch_pm<3, true>(a, li, stream);
+        return a.D == 1 ? launch_pm<1, false>(a, li, stream) : a.D == 2 ? launch_pm<2, false>(a, li, stream) : launch_pm<3, false>(a, li, stream);
+    }
     if (li.split) return a.D == 1 ? launch_split<1, 32>(a, li, stream) : launch_split<2, 16>(a, li, stream);
     const bool al = (a.M % 8u) == 0;
+    if (li.gtab) {
+        switch (a.D) {
+            case 1: return al ? launch_t<1, true, true>(a, li, stream) : launch_t<1, false, true>(a, li, stream);
+            case 2: return al ? launch_t<2, true, true>(a, li, stream) : launch_t<2, false, true>(a, li, stream);
+            case 3: return al ? launch_t<3, true, true>(a, li, stream) : launch_t<3, false, true>(a, li, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (a.D) {
-        case 1: return al ? launch_t<1, true>(a, li, stream) : launch_t<1, false>(a, li, stream);
-        case 2: return al ? launch_t<2, true>(a, li, stream) : launch_t<2, false>(a, li, stream);
-        case 3: return al ? launch_t<3, true>(a, li, stream) : launch_t<3, false>(a, li, stream);
+        case 1: return al ? launch_t<1, true, false>(a, li, stream) : launch_t<1, false, false>(a, li, stream);
+        case 2: return al ? launch_t<2, true, false>(a, li, stream) : launch_t<2, false, false>(a, li, stream);
+        case 3: return al ? launch_t<3, true, false>(a, li, stream) : launch_t<3, false, false>(a, li, stream);
         default: return hipErrorInvalidValue;
     }
 }

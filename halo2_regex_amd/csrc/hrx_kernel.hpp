@@ -34,6 +34,7 @@ struct LaunchInfo {
                        // 1: walker/storer kernel (witness_split_kernel), 0: one-wave-does-all kernel (witness_kernel)
     int waves_per_wg;  // split: 2 * pairs
     int nslots;        // split: ring slots per walker/storer pair
+    int gtab;          // 1: fused table read from global memory (too large for LDS)
     int grid;
     size_t lds_bytes;
 };

@@ -106,3 +106,24 @@ def reveal_stress(B, n, seed=7):
         chars[b, :len(out)] = np.frombuffer(out, np.uint8)
         lens[b] = len(out)
     return chars, lens
+
+
+def random_dfa(n_states, seed=2, alphabet=ALPHABET98, n_substr_pairs=40, total=True):
+    """A synthetic total (or, with total=False, 90%-dense) DFA over `alphabet` in the reference's text format
+    (src/defs.rs:60-68) plus one substring definition (defs.rs:165-177) drawn from its transitions.
+    Returns (allstr_text, substr_text)."""
+    rng = _rng(seed, 9)
+    nxt = rng.integers(0, n_states, size=(n_states, len(alphabet)))
+    lines = ["0", str(int(rng.integers(0, n_states))), str(n_states - 1)]
+    pairs = set()
+    for s in range(n_states):
+        for k, ch in enumerate(alphabet):
+            if total or rng.random() < 0.9 or s == 0:
+                lines.append("%d %d %d" % (s, int(nxt[s, k]), int(ch)))
+                pairs.add((s, int(nxt[s, k])))
+    pairs = sorted(pairs)
+    pick = [pairs[i] for i in rng.choice(len(pairs), size=min(n_substr_pairs, len(pairs)), replace=False)]
+    starts = sorted({a for a, _ in pick[: max(1, len(pick) // 4)]})
+    ends = sorted({b for _, b in pick[len(pick) // 2:]})
+    sub = ["16", "0", "1023", " ".join(map(str, starts)) + " ", " ".join(map(str, ends)) + " "] + ["%d %d" % p for p in sorted(pick)]
+    return "\n".join(lines) + "\n", "\n".join(sub) + "\n"

@@ -84,9 +84,12 @@ def test_bounds_are_rejected_loudly():
         RegexVerifyConfig.configure(8, [RegexDefs(AllstrRegexDef("0\n1\n1\n0 5 97\n"), [])], device=None)
     assert e.value.code == hra.HRX_ERR_BOUNDS
     big = "0\n1\n200\n" + "".join("%d %d 97\n" % (s, s) for s in range(201))
-    with pytest.raises(hra.HrxError) as e:   # 203 KiB of fused table does not fit LDS
-        RegexVerifyConfig.configure(8, [RegexDefs(AllstrRegexDef(big), [])], device=None)
-    assert e.value.code == hra.HRX_ERR_BOUNDS and "LDS" in str(e.value)
+    cfg = RegexVerifyConfig.configure(8, [RegexDefs(AllstrRegexDef(big), [])], device=None)   # > LDS: global-table kernels
+    assert cfg.table_bytes() == 203 * 1024
+    huge = "0\n1\n3000\n0 1 97\n"
+    with pytest.raises(hra.HrxError) as e:   # 3003 table rows: beyond the supported table size
+        RegexVerifyConfig.configure(8, [RegexDefs(AllstrRegexDef(huge), [])], device=None)
+    assert e.value.code == hra.HRX_ERR_BOUNDS
     with pytest.raises(hra.HrxError):
         RegexVerifyConfig.configure(8, [], device=None)
 

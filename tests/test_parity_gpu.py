@@ -208,6 +208,42 @@ def test_position_major_full_size_cfg2(hra, oracle):
     assert torch.equal(rec, rec2) and torch.equal(msk, msk2) and torch.equal(st, st2)
 
 
+def test_large_dfa_walks_out_of_global_memory(hra, oracle):
+    """300- and 500-state DFAs (300/500 KiB of fused table) do not fit LDS: both layouts fall back to the global-table
+    kernels; bit-exact against the oracle, including a partial DFA with undefined transitions."""
+    from halo2_regex_amd import synth
+    for nstates, total, seed in ((300, True, 2), (500, False, 3)):
+        allstr, sub = synth.random_dfa(nstates, seed=seed, total=total)
+        defs = [hra.RegexDefs(hra.AllstrRegexDef(allstr), [hra.SubstrRegexDef(sub)])]
+        cfg = hra.RegexVerifyConfig.configure(264, defs, device=0)
+        o = OracleDefs(oracle, [(allstr, [sub])])
+        chars, lens = synth.ragged(300, 264, seed=nstates, planted=False)
+        orec, omsk, ost = o.witness_batch(chars, lens, 264)
+        grec, gmsk, gst = cfg.witness_batch_host(chars, lens)
+        assert np.array_equal(ost, gst)
+        ok = (ost & np.uint64(0xff)) == 0
+        assert ok.any() and np.array_equal(orec[ok], grec[ok]) and np.array_equal(omsk[ok], gmsk[ok])
+        if not total:
+            assert (~ok).any()
+        import torch
+        dev = torch.device("cuda", 0)
+        wide = torch.zeros((300, chars.shape[1]), dtype=torch.uint8, device=dev)
+        wide[:] = torch.from_numpy(chars).to(dev)
+        rec, msk, st = cfg.witness_batch_position_major(wide, torch.from_numpy(lens.astype(np.int32)).to(dev))
+        torch.cuda.synchronize()
+        r1, m1 = hra.position_major_to_string_major(rec, msk, 300, 264, 1)
+        assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+        assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
+
+
+def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
+    from halo2_regex_amd import synth
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", str(0x40000))
+    chars, lens = synth.reveal_stress(500, 700, seed=31)
+    _check_batch(hra, oracle, CFG_A, chars, lens, 704)
+    _check_batch_pm(hra, oracle, CFG_123, chars, lens, 704)
+
+
 @pytest.mark.parametrize("flags", ["65536", "196608"], ids=["one-wave-gs64", "one-wave-gs32"])
 def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
     """D <= 2 normally takes the walker/storer kernel; force the one-wave kernel (used for D = 3 and unaligned M)
