@@ -236,6 +236,60 @@ def test_large_dfa_walks_out_of_global_memory(hra, oracle):
         assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
 
 
+def _sample_check(hra, oracle_defs, cfg, chars, lens, M, D, nsample, seed, position_major=True):
+    """device-resident run of the whole batch; a seeded sample of strings bit-exact against the oracle; idempotence"""
+    import torch
+    dev = torch.device("cuda", 0)
+    B = len(lens)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    if position_major:
+        rec, msk, st = cfg.witness_batch_position_major(d_chars, d_lens)
+        rec2, msk2, st2 = cfg.witness_batch_position_major(d_chars, d_lens)
+        torch.cuda.synchronize()
+        assert torch.equal(rec, rec2) and torch.equal(msk, msk2) and torch.equal(st, st2)
+        rec, msk = hra.position_major_to_string_major(rec, msk, B, M, D)
+    else:
+        rec, msk, st = cfg.witness_batch(d_chars, d_lens)
+        torch.cuda.synchronize()
+    idx = np.sort(np.random.default_rng(seed).choice(B, nsample, replace=False))
+    tidx = torch.from_numpy(idx).to(dev)
+    orec, omsk, ost = oracle_defs.witness_batch(chars[idx], lens[idx], M)
+    assert np.array_equal(ost, st[tidx].cpu().numpy().view(np.uint64))
+    ok = (ost & np.uint64(0xff)) == 0
+    assert np.array_equal(orec[ok], rec[tidx].cpu().numpy().view(np.uint32)[ok])
+    assert np.array_equal(omsk[ok], msk[tidx].cpu().numpy().view(np.uint16)[ok])
+    return st.cpu().numpy().view(np.uint64)
+
+
+def test_cfg3_shape_two_defs_2048_byte_strings(hra, oracle):
+    """BASELINE configs[2] shape (regex2 + regex3 with substr extraction, 2048-byte strings) at B = 32768, both layouts."""
+    from halo2_regex_amd import synth
+    B, n, M = 32768, 2047, 2048
+    chars, lens = synth.regex23_planted(B, n, seed=1, stride=2048)
+    lens[:64] = np.random.default_rng(0).integers(0, n + 1, 64)       # some ragged strings as well
+    o = OracleDefs.from_files(oracle, CFG_23)
+    cfg = _cfg(hra, CFG_23, M)
+    st = _sample_check(hra, o, cfg, chars, lens, M, 2, 256, 3, position_major=True)
+    assert (st & np.uint64(0xff) == 0).all()
+    _sample_check(hra, o, cfg, chars, lens, M, 2, 256, 4, position_major=False)
+
+
+def test_cfg5_shape_256_state_dense_dfa_4096_byte_strings(hra, oracle):
+    """BASELINE configs[4] shape: synthetic total DFA, 256 states x 256 symbols (258 KiB of fused table: global-table
+    kernels), 4096-byte inputs over all byte values."""
+    from halo2_regex_amd import synth
+    allstr, sub = synth.random_dfa(256, seed=2, alphabet=np.arange(256, dtype=np.uint8), n_substr_pairs=200)
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(allstr), [hra.SubstrRegexDef(sub)])]
+    B, n, M = 4096, 4095, 4096
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    assert cfg.table_bytes() == 258 * 1024
+    chars, lens = synth.noise(B, n, seed=2, alphabet=np.arange(256, dtype=np.uint8), stride=4096)
+    o = OracleDefs(oracle, [(allstr, [sub])])
+    st = _sample_check(hra, o, cfg, chars, lens, M, 1, 96, 5, position_major=True)
+    assert (st & np.uint64(0xff) == 0).all()
+    _sample_check(hra, o, cfg, chars, lens, M, 1, 96, 6, position_major=False)
+
+
 def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
     from halo2_regex_amd import synth
     monkeypatch.setenv("HRX_DEBUG_FLAGS", str(0x40000))
