@@ -22,25 +22,47 @@ BYTES_PER_ROW = lambda D: 1 + 4 * D + 2   # 1 B char read, 4 B re
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(names, chars, lens, M, budget_s=12.0):
+def cpu_baseline(names, chars, lens, M, budget_s=8.0):
     """The oracle (oracle/hrx_oracle.c, the reference-faithful C port) timed single-threaded on a bounded sample of
-    the same workload.  Checker/baseline only — never on the product path."""
+    the same workload — the reference itself is single-threaded — plus, as extra context, the same port
+    over all host cores and the oracle's dense-table "best CPU" variant.  Checker/baseline only — never on the
+    product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     from oracle_lib import OracleDefs, load_oracle
-    o = OracleDefs.from_files(load_oracle(), names)
+    o = OracleDefs(load_oracle(), names)
     nstr = min(len(chars), 16384)
-    t0 = time.perf_counter()
-    o.witness_batch(chars[:nstr], lens[:nstr], M)
-    dt1 = max(time.perf_counter() - t0, 1e-6)
-    reps = max(1, int(budget_s / dt1))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        o.witness_batch(chars[:nstr], lens[:nstr], M)
-    dt = time.perf_counter() - t0
-    rows = int(lens[:nstr].sum()) * reps
-    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": "first %d strings of the same batch x %d passes (%d rows), oracle/hrx_oracle.c -O3, 1 thread, %.1f s; "
-                      "host has %d cores" % (nstr, reps, rows, dt, os.cpu_count())}
+    cores = os.cpu_count() or 1
+    ndefs = len(names)
+    out = np.zeros((nstr, M, ndefs), np.uint32), np.zeros((nstr, M), np.uint16), np.zeros(nstr, np.uint64)
+    rows1 = int(lens[:nstr].sum())
+
+    def timed(budget, **kw):
+        t0 = time.perf_counter()
+        o.witness_batch(chars[:nstr], lens[:nstr], M, out=out, **kw)
+        dt1 = max(time.perf_counter() - t0, 1e-6)
+        reps = max(1, int(budget / dt1))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o.witness_batch(chars[:nstr], lens[:nstr], M, out=out, **kw)
+        dt = time.perf_counter() - t0
+        return rows1 * reps / dt, reps, dt
+
+    v, reps, dt = timed(budget_s)
+    res = {"value": v, "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": "first %d strings of the same batch x %d passes (%d rows), oracle/hrx_oracle.c -O3, 1 thread, %.1f s; "
+                     "host has %d cores" % (nstr, reps, rows1 * reps, dt, cores)}
+    v, reps, dt = timed(3.0, threads=cores)
+    res["all_cores"] = {"value": v, "unit": "rows/s", "cores": cores, "kind": "port",
+                        "sample": "same sample x %d passes, one string per task" % reps}
+    v, reps, dt = timed(2.0, dense=True)
+    res["dense_table"] = {"value": v, "unit": "rows/s", "cores": 1,
+                          "kind": "dense-table CPU variant of the oracle (not the reference's data structures)",
+                          "sample": "same sample x %d passes" % reps}
+    v, reps, dt = timed(2.0, dense=True, threads=cores)
+    res["dense_table_all_cores"] = {"value": v, "unit": "rows/s", "cores": cores, "kind": "dense-table CPU variant of the oracle",
+                                    "sample": "same sample x %d passes" % reps}
+    return res
 
 
 def copy_ceiling_gbs(dev, nbytes):
@@ -84,7 +106,9 @@ def main():
     ap.add_argument("--len", type=int, default=1023, dest="n", help="bytes per string (n); rows M = --rows")
     ap.add_argument("--rows", type=int, default=1024, help="max_chars_size M (witness rows per string)")
     ap.add_argument("--dist", choices=["planted", "noise"], default="planted")
-    ap.add_argument("--config", choices=["regex1", "regex23"], default="regex1")
+    ap.add_argument("--config", choices=["regex1", "regex23", "regex123", "dfa256"], default="regex1",
+                    help="regex1: BASELINE configs[1] (the metric's workload); regex23: configs[2] shape (D=2); regex123: D=3 with the "
+                    "reference's three DFAs; dfa256: configs[4] shape (synthetic total 256-state DFA over all 256 byte values)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense", action="store_true", help="string-major: power-of-two pitches (M rows per string, n rounded to 16 "
                     "bytes) instead of hrx_recommended_pitches")
@@ -112,12 +136,23 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    rd = lambda f: open(os.path.join(DFA_DIR, f), "rb").read()
+    pair = lambda k: (rd("regex%d_test_lookup.txt" % k), [rd("substr%d_test_lookup.txt" % k)])
+    alphabet = "98-byte alphabet"
     if args.config == "regex1":
-        names = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]]]
+        names, label = [pair(1)], "regex1_test+substr1"
         gen = synth.regex1_planted if args.dist == "planted" else synth.noise
-    else:
-        names = [["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]], ["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
+    elif args.config == "regex23":
+        names, label = [pair(2), pair(3)], "regex2+regex3 with substrs"
         gen = synth.regex23_planted if args.dist == "planted" else synth.noise
+    elif args.config == "regex123":
+        names, label = [pair(1), pair(2), pair(3)], "regex1+regex2+regex3 with substrs"
+        gen = synth.noise
+    else:
+        allb = np.arange(256, dtype=np.uint8)
+        a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=200)
+        names, label, alphabet = [(a_txt.encode(), [sub_txt.encode()])], "synthetic total DFA 256 states x 256 symbols (seed 2)", "all 256 byte values"
+        gen = lambda B, n, seed=0, stride=None: synth.noise(B, n, seed=seed, alphabet=allb, stride=stride)
     D = len(names)
     M, n, B = args.rows, args.n, args.batch
     pm = args.layout == "position-major"
@@ -125,8 +160,7 @@ def main():
     if args.dense or pm:
         rec_pitch, msk_pitch, rec_stride = M, M, (max(n, 1) + 15) // 16 * 16
     stride = rec_stride
-    defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(os.path.join(DFA_DIR, a)),
-                          [hra.SubstrRegexDef.read_from_text(os.path.join(DFA_DIR, s)) for s in subs]) for a, subs in names]
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in names]
     cfg = hra.RegexVerifyConfig.configure(M, defs, device=local_rank)
 
     # this rank's shard of the (world * B)-string job: independent strings, seeded per rank
@@ -180,9 +214,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s DFA (D=%d), %d x %d-byte strings per GPU (n=%d chars, M=%d witness rows), %s"
-                                   % ("regex1_test+substr1" if args.config == "regex1" else "regex2+regex3 with substrs", D, B,
-                                      stride, n, M, "alphabet-uniform noise + planted match" if args.dist == "planted"
-                                      else "alphabet-uniform noise"),
+                                   % (label, D, B, stride, n, M, "uniform noise over the %s%s" % (
+                                       alphabet, " + planted match" if gen in (synth.regex1_planted, synth.regex23_planted) else "")),
                        "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
                        "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR: chars [%d/16][B][16], records "
                                    "[M/4][B][4][D], masked [M/8][B][8] (include/hrx.h)" % stride) if pm else

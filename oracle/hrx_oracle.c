@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <pthread.h>
 
 /* ------------------------------------------------------------------ */
 /* containers                                                          */
@@ -505,6 +506,139 @@ void orc_witness_batch(const orc *o, const uint8_t *chars, size_t stride, const 
     for (size_t b = 0; b < B; b++)
         status[b] = orc_witness_one(o, chars + b * stride, lens[b], M, records + b * M * D, masked + b * M, scratch);
     free(scratch);
+}
+
+/* The same batch spread over `threads` host threads, one string per task (SURVEY §8d "all host cores" baseline). */
+typedef struct { const orc *o; const uint8_t *chars; size_t stride; const uint32_t *lens; size_t B, M, lo, hi;
+                 uint32_t *records; uint16_t *masked; uint64_t *status; } mt_job;
+static void *mt_worker(void *p) {
+    mt_job *j = p;
+    const size_t D = j->o->n_defs;
+    uint64_t *scratch = malloc(sizeof(uint64_t) * (4 * D + 2) * (j->M ? j->M : 1));
+    for (size_t b = j->lo; b < j->hi; b++)
+        j->status[b] = orc_witness_one(j->o, j->chars + b * j->stride, j->lens[b], j->M, j->records + b * j->M * D,
+                                       j->masked + b * j->M, scratch);
+    free(scratch);
+    return NULL;
+}
+void orc_witness_batch_mt(const orc *o, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                          uint32_t *records, uint16_t *masked, uint64_t *status, size_t threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t tid[256]; mt_job job[256];
+    for (size_t t = 0; t < threads; t++) {
+        job[t] = (mt_job){o, chars, stride, lens, B, M, B * t / threads, B * (t + 1) / threads, records, masked, status};
+        pthread_create(&tid[t], NULL, mt_worker, &job[t]);
+    }
+    for (size_t t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+}
+
+/* ------------------------------------------------------------------ */
+/* "best CPU" variant: dense fused table, no hashing       */
+/* ------------------------------------------------------------------ */
+/* Not a restatement of the reference's data structures: one u32 per (state, byte) holding everything lib.rs:804-888
+ * derives from that pair — next | substr_id<<16 | is_start<<24 | is_end<<25 | valid<<31 — filled by asking the
+ * reference-shaped containers above, then one table read per (row, def).  tests/test_oracle_golden.py checks it
+ * equal to orc_witness_batch; bench.py times it as the strongest CPU line next to the port. */
+typedef struct { uint32_t *tab[8]; uint64_t first[8], accepted[8], dummy[8]; size_t n_defs; } orc_dense;
+
+void orc_dense_free(orc_dense *t) { if (!t) return; for (size_t d = 0; d < t->n_defs; d++) free(t->tab[d]); free(t); }
+
+orc_dense *orc_dense_new(const orc *o) {
+    if (o->n_defs > 8) return NULL;
+    orc_dense *t = calloc(1, sizeof(orc_dense));
+    t->n_defs = o->n_defs;
+    uint64_t off = 1;
+    for (size_t d = 0; d < o->n_defs; d++) {
+        const regex_defs *defs = &o->defs[d];
+        const size_t S = (size_t)defs->largest_state_val + 1;
+        t->first[d] = defs->first_state_val; t->accepted[d] = defs->accepted_state_val; t->dummy[d] = S;
+        t->tab[d] = calloc(S * 256, sizeof(uint32_t));
+        for (size_t s = 0; s < S; s++)
+            for (unsigned c = 0; c < 256; c++) {
+                const lookup_slot *e = map_find(&defs->state_lookup, (uint8_t)c, s);
+                if (!e) continue;
+                uint32_t v = 0x80000000u | (uint32_t)(e->next & 0xffff);
+                for (size_t j = 0; j < defs->n_substrs; j++)
+                    if (set_contains(&defs->substrs[j].valid_state_transitions, s, e->next)) {
+                        v |= (uint32_t)((off + j) & 0xff) << 16;
+                        if (vec_contains(&defs->substrs[j].start_states, s)) v |= 1u << 24;
+                        if (vec_contains(&defs->substrs[j].end_states, e->next)) v |= 1u << 25;
+                        break;
+                    }
+                t->tab[d][s * 256 + c] = v;
+            }
+        off += defs->n_substrs;
+    }
+    return t;
+}
+
+static uint64_t dense_one(const orc_dense *t, const uint8_t *chars, size_t n, size_t M, uint32_t *records, uint16_t *masked,
+                          uint8_t *sum /* 3*(M+1): SID, ST, EN */) {
+    const size_t D = t->n_defs;
+    if (n > M) return 3ull;
+    uint8_t *SID = sum, *ST = SID + M + 1, *EN = ST + M + 1;
+    memset(sum, 0, 3 * (M + 1));
+    uint64_t accept = 0;
+    for (size_t d = 0; d < D; d++) {
+        const uint32_t *tab = t->tab[d];
+        uint32_t s = (uint32_t)t->first[d];
+        size_t r = 0;
+        for (; r < n; r++) {
+            uint32_t e = tab[(size_t)s * 256 + chars[r]];
+            if (!(e & 0x80000000u))
+                return 1ull | (uint64_t)d << 8 | (uint64_t)chars[r] << 16 | (uint64_t)(s & 0xffff) << 24 | (uint64_t)(r & 0xffffff) << 40;
+            records[r * D + d] = s | (e & 0x01ff0000u);                     /* state, sid, start_enable */
+            SID[r] += (uint8_t)(e >> 16); ST[r] += (uint8_t)(e >> 24 & 1);
+            if (r + 1 < M) {                                                /* lib.rs:501-519 stops at M-2: row M-1 never set */
+                records[r * D + d] |= e & 0x02000000u;                      /* end_enable[r] = is_end[r+1] */
+                EN[r + 1] += (uint8_t)(e >> 25 & 1);
+            }
+            s = e & 0xffff;
+        }
+        if (s == t->accepted[d]) accept |= 1ull << d;
+        if (r < M) records[r++ * D + d] = s;
+        for (; r < M; r++) records[r * D + d] = (uint32_t)t->dummy[d];
+    }
+    for (size_t r = 0; r <= M; r++)
+        if (ST[r] > 1 || EN[r] > 1) return 2ull | (uint64_t)(r & 0xffffff) << 40;
+    uint8_t m = 0;
+    for (size_t r = 0; r < M; r++) {                                        /* forward start_mask, lib.rs:598-645 */
+        int chg = (r ? SID[r - 1] : 0) != SID[r];
+        if (chg && ST[r]) m = 1; else if (chg && EN[r]) m = 0;
+        masked[r] = m;
+    }
+    m = 0;
+    for (size_t r = M; r-- > 0;) {                                          /* backward end_mask, lib.rs:663-714 */
+        int chg = (r + 1 < M ? SID[r + 1] : 0) != SID[r];
+        if (chg && EN[r + 1]) m = 1; else if (chg && ST[r + 1]) m = 0;
+        masked[r] = (masked[r] & m) ? (uint16_t)((r < n ? chars[r] : 0) | SID[r] << 8) : 0;
+    }
+    return accept << 8;
+}
+
+typedef struct { const orc_dense *t; const uint8_t *chars; size_t stride; const uint32_t *lens; size_t M, lo, hi;
+                 uint32_t *records; uint16_t *masked; uint64_t *status; } dense_job;
+static void *dense_worker(void *p) {
+    dense_job *j = p;
+    const size_t D = j->t->n_defs;
+    uint8_t *sum = malloc(3 * (j->M + 1));
+    for (size_t b = j->lo; b < j->hi; b++)
+        j->status[b] = dense_one(j->t, j->chars + b * j->stride, j->lens[b], j->M, j->records + b * j->M * D, j->masked + b * j->M, sum);
+    free(sum);
+    return NULL;
+}
+void orc_dense_witness_batch(const orc_dense *t, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                             uint32_t *records, uint16_t *masked, uint64_t *status, size_t threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t tid[256]; dense_job job[256];
+    for (size_t i = 0; i < threads; i++) {
+        job[i] = (dense_job){t, chars, stride, lens, M, B * i / threads, B * (i + 1) / threads, records, masked, status};
+        if (threads == 1) { dense_worker(&job[0]); return; }
+        pthread_create(&tid[i], NULL, dense_worker, &job[i]);
+    }
+    for (size_t i = 0; i < threads; i++) pthread_join(tid[i], NULL);
 }
 
 /* ------------------------------------------------------------------ */

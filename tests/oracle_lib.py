@@ -49,6 +49,11 @@ def load_oracle():
     lib.orc_match_substrs.argtypes = [C.c_void_p, _u8p, C.c_size_t, C.c_size_t] + [_u64p] * 9
     lib.orc_witness_batch.argtypes = [C.c_void_p, _u8p, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), _u64p]
+    lib.orc_witness_batch_mt.argtypes = lib.orc_witness_batch.argtypes + [C.c_size_t]
+    lib.orc_dense_new.argtypes = [C.c_void_p]
+    lib.orc_dense_new.restype = C.c_void_p
+    lib.orc_dense_free.argtypes = [C.c_void_p]
+    lib.orc_dense_witness_batch.argtypes = lib.orc_witness_batch.argtypes + [C.c_size_t]
     lib.orc_table_transition_rows.argtypes = [C.c_void_p, C.c_size_t, _u64p, C.c_size_t]
     lib.orc_table_transition_rows.restype = C.c_size_t
     lib.orc_table_endpoint_rows.argtypes = [C.c_void_p, C.c_size_t, _u64p, C.c_size_t]
@@ -76,6 +81,8 @@ class OracleDefs:
 
     def __del__(self):
         try:
+            if getattr(self, "_dense", None):
+                self.lib.orc_dense_free(self._dense)
             self.lib.orc_free(self.h)
         except Exception:
             pass
@@ -134,16 +141,25 @@ class OracleDefs:
         return out
 
     # --- compact batch ------------------------------------
-    def witness_batch(self, chars2d, lens, M):
-        """chars2d: (B, stride) uint8; lens: (B,) uint32 -> records (B,M,D) u32, masked (B,M) u16, status (B,) u64"""
+    def witness_batch(self, chars2d, lens, M, threads=1, dense=False, out=None):
+        """chars2d: (B, stride) uint8; lens: (B,) uint32 -> records (B,M,D) u32, masked (B,M) u16, status (B,) u64.
+        threads > 1: one string per task over host threads; dense=True: the dense-table "best CPU" variant."""
         chars2d = np.ascontiguousarray(chars2d, dtype=np.uint8)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         B, stride = chars2d.shape
-        rec = np.zeros((B, M, self.D), np.uint32)
-        msk = np.zeros((B, M), np.uint16)
-        status = np.zeros(B, np.uint64)
-        self.lib.orc_witness_batch(self.h, _p(chars2d, _u8p), stride, _p(lens, C.POINTER(C.c_uint32)), B, M,
-                                   _p(rec, C.POINTER(C.c_uint32)), _p(msk, C.POINTER(C.c_uint16)), _p(status, _u64p))
+        if out is None:
+            out = np.zeros((B, M, self.D), np.uint32), np.zeros((B, M), np.uint16), np.zeros(B, np.uint64)
+        rec, msk, status = out
+        args = (_p(chars2d, _u8p), stride, _p(lens, C.POINTER(C.c_uint32)), B, M,
+                _p(rec, C.POINTER(C.c_uint32)), _p(msk, C.POINTER(C.c_uint16)), _p(status, _u64p))
+        if dense:
+            if getattr(self, "_dense", None) is None:
+                self._dense = self.lib.orc_dense_new(self.h)
+            self.lib.orc_dense_witness_batch(self._dense, *args, threads)
+        elif threads > 1:
+            self.lib.orc_witness_batch_mt(self.h, *args, threads)
+        else:
+            self.lib.orc_witness_batch(self.h, *args)
         return rec, msk, status
 
     # --- src/table.rs:61-198 ------------------------------------------------

@@ -135,3 +135,25 @@ def test_table_rows_match_table_rs(oracle):
     assert [list(map(int, r)) for r in ep] == [[0, 29, 29], [1, 21, 29]] + [[1, 29, e] for e in (22, 23, 25, 26, 27, 28)]
     ep = A.table_endpoint_rows(1)
     assert [list(map(int, r)) for r in ep] == [[0, 13, 13], [2, 10, 13], [2, 13, 11]]
+
+
+def test_threaded_and_dense_cpu_variants_equal_the_port(oracle):
+    """bench.py's extra CPU lines (all host cores; dense-table "best CPU") produce the port's bytes."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from halo2_regex_amd import synth
+    cases = [([["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]]], synth.ragged(300, 200, seed=4), 200),
+             ([["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]]], synth.reveal_stress(200, 256, seed=9), 256),
+             ([["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]], ["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]],
+              synth.regex23_planted(200, 511, seed=1), 512),
+             ([["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]], ["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]],
+              synth.ragged(200, 128, seed=8), 128)]
+    for names, (chars, lens), M in cases:
+        o = OracleDefs.from_files(oracle, names)
+        rec, msk, st = o.witness_batch(chars, lens, M)
+        ok = (st & np.uint64(0xff)) == 0
+        assert ok.any()
+        for kw in (dict(threads=4), dict(dense=True), dict(dense=True, threads=3)):
+            r2, m2, s2 = o.witness_batch(chars, lens, M, **kw)
+            assert np.array_equal(st, s2), kw
+            assert np.array_equal(rec[ok], r2[ok]) and np.array_equal(msk[ok], m2[ok]), kw
