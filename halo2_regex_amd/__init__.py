@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
+    "hrx_regex_to_allstr_text", "hrx_regex_to_dfa_json",
 ]
 
 _u64p = C.POINTER(C.c_uint64)
@@ -88,6 +89,8 @@ def _load():
         "hrx_derive_substr_ids": (i, [vp, _u64p, sz, _u64p]),
         "hrx_derive_is_start_end": (i, [vp, _u64p, _u64p, sz, _u8p, _u8p]),
         "hrx_match_substrs": (i, [vp, _u8p, sz, sz] + [_u64p] * 9),
+        "hrx_regex_to_allstr_text": (i, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]),
+        "hrx_regex_to_dfa_json": (i, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -110,6 +113,67 @@ def _np(a, dt):
 
 def _ptr(a, t):
     return a.ctypes.data_as(t)
+
+
+# ---------------------------------------------------------------------------------------------
+# definition generation — src/vrm/mod.rs, src/vrm/js_caller.rs, src/vrm/regex.js (host only)
+# ---------------------------------------------------------------------------------------------
+def _two_call(fn, regex):
+    data = regex.encode("utf-8") if isinstance(regex, str) else bytes(regex)
+    need = C.c_size_t(0)
+    _check(fn(data, len(data), None, 0, C.byref(need)))
+    buf = C.create_string_buffer(max(need.value, 1))
+    _check(fn(data, len(data), buf, need.value, C.byref(need)))
+    return buf.raw[:need.value]
+
+
+def get_dfa_json_value(regex):
+    """get_dfa_json_value (src/vrm/js_caller.rs:43-48): the minimal DFA of `regex` as the parsed JSON value
+    regexToDfa returns — computed natively, no JS engine."""
+    import json
+    return json.loads(_two_call(lib.hrx_regex_to_dfa_json, regex).decode("utf-8"))
+
+
+def regex_to_dfa_json_text(regex):
+    return _two_call(lib.hrx_regex_to_dfa_json, regex).decode("utf-8")
+
+
+def regex_to_allstr_text(regex):
+    """regexToDfa + dfa_to_regex_def_text (src/vrm/js_caller.rs:127-157): the AllstrRegexDef text of `regex`."""
+    return _two_call(lib.hrx_regex_to_allstr_text, regex).decode("ascii")
+
+
+class RegexPartConfig:
+    """RegexPartConfig (src/vrm/mod.rs:39-49)."""
+
+    def __init__(self, is_public, regex_def, max_size, solidity=None):
+        self.is_public, self.regex_def, self.max_size, self.solidity = bool(is_public), regex_def, int(max_size), solidity
+
+
+class DecomposedRegexConfig:
+    """DecomposedRegexConfig (src/vrm/mod.rs:31-37).  gen_allstr_text / gen_allstr_file cover the AllstrRegexDef half
+    of gen_regex_files (mod.rs:62-95); the SubstrRegexDef half (mod.rs:309-600, fancy-regex path matching) is not
+    built — SURVEY §8 f2."""
+
+    def __init__(self, max_byte_size, parts):
+        self.max_byte_size, self.parts = int(max_byte_size), list(parts)
+
+    @classmethod
+    def from_json(cls, text):
+        import json
+        v = json.loads(text)
+        return cls(v["max_byte_size"], [RegexPartConfig(p["is_public"], p["regex_def"], p["max_size"], p.get("solidity"))
+                                       for p in v["parts"]])
+
+    def all_regex(self):
+        return "".join(p.regex_def for p in self.parts)   # mod.rs:87-91
+
+    def gen_allstr_text(self):
+        return regex_to_allstr_text(self.all_regex())
+
+    def gen_allstr_file(self, allstr_file_path):
+        with open(allstr_file_path, "w") as f:
+            f.write(self.gen_allstr_text())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -500,3 +500,20 @@ int hrx_match_substrs(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- definition generation (hrx_compile.cpp)
+static int regex_compile_entry(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed, bool json) {
+    if ((!regex && regex_len) || (!out && cap) || !needed) return fail(HRX_ERR_ARG, "null argument");
+    std::string res, err;
+    bool ok = json ? hrx::compile_regex(regex, regex_len, &res, nullptr, err) : hrx::compile_regex(regex, regex_len, nullptr, &res, err);
+    if (!ok) return fail(HRX_ERR_PARSE, err);
+    *needed = res.size();
+    if (out) memcpy(out, res.data(), std::min(cap, res.size()));
+    return HRX_OK;
+}
+extern "C" int hrx_regex_to_allstr_text(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed) {
+    return regex_compile_entry(regex, regex_len, out, cap, needed, false);
+}
+extern "C" int hrx_regex_to_dfa_json(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed) {
+    return regex_compile_entry(regex, regex_len, out, cap, needed, true);
+}

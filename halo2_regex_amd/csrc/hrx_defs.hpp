@@ -73,6 +73,9 @@ int finalize_defs(DefsSet &s, std::string &err);
 size_t table_transition_rows(const DefsSet &s, size_t d, uint64_t *rows4, size_t cap_rows);
 size_t table_endpoint_rows(const DefsSet &s, size_t d, uint64_t *rows3, size_t cap_rows);
 
+// hrx_compile.cpp: regex -> minimal DFA in the reference's numbering; either output may be null
+bool compile_regex(const char *regex, size_t len, std::string *json_out, std::string *text_out, std::string &err);
+
 // LDS budget for the table image (the rest of the 160 KiB holds the per-wave staging)
 constexpr size_t kMaxTableBytes = 2048 * 1024;  // 2048 table rows; beyond the LDS budget the kernels read the table from global memory
 

@@ -171,6 +171,21 @@ int hrx_match_substrs(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t 
                       uint64_t *end_enable, uint64_t *masked_char, uint64_t *masked_substr_id,
                       uint64_t *status);
 
+/* ------------------------------------------------------------------ */
+/* Definition generation: regex -> minimal DFA (host only, no GPU)     */
+/* ------------------------------------------------------------------ */
+
+/* The table step in front of the witness path, without V8: what DecomposedRegexConfig::gen_regex_files
+ * (src/vrm/mod.rs:62-95) obtains from get_dfa_json_value -> regexToDfa (src/vrm/js_caller.rs:43-48,
+ * src/vrm/regex.js:40-92) and dfa_to_regex_def_text (src/vrm/js_caller.rs:127-157).  `regex` is the concatenation of
+ * the parts' regex_def, UTF-8, in the dialect of regex.js:236-367.  Byte-identical to the reference's output
+ * (state numbering included).  Two-call pattern: *needed receives the byte length of the result; min(needed, cap)
+ * bytes are written to out (no terminator); out may be NULL with cap 0.  A malformed pattern returns HRX_ERR_PARSE
+ * with the parser's message ("Error: empty input at 2." ...) in hrx_last_error(). */
+int hrx_regex_to_allstr_text(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed);
+/* The intermediate value itself: the JSON text regexToDfa returns ([{"type":..,"edges":{key:target}}, ...]). */
+int hrx_regex_to_dfa_json(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed);
+
 #ifdef __cplusplus
 }
 #endif
