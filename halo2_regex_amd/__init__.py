@@ -32,13 +32,18 @@ ABI_SYMBOLS = [
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
-    "hrx_regex_to_allstr_text", "hrx_regex_to_dfa_json",
+    "hrx_regex_to_allstr_text", "hrx_regex_to_dfa_json", "hrx_gen_regex_files", "hrx_regex_files_num_substrs",
+    "hrx_regex_files_allstr", "hrx_regex_files_substr", "hrx_regex_files_destroy", "hrx_format_regex_str", "hrx_regex_find",
 ]
 
 _u64p = C.POINTER(C.c_uint64)
 _u32p = C.POINTER(C.c_uint32)
 _u16p = C.POINTER(C.c_uint16)
 _u8p = C.POINTER(C.c_uint8)
+
+
+class _RegexPartC(C.Structure):      # hrx_regex_part of include/hrx.h
+    _fields_ = [("regex_def", C.c_char_p), ("regex_len", C.c_size_t), ("is_public", C.c_int), ("max_size", C.c_size_t)]
 
 
 class HrxError(RuntimeError):
@@ -91,6 +96,13 @@ def _load():
         "hrx_match_substrs": (i, [vp, _u8p, sz, sz] + [_u64p] * 9),
         "hrx_regex_to_allstr_text": (i, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]),
         "hrx_regex_to_dfa_json": (i, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]),
+        "hrx_gen_regex_files": (i, [C.POINTER(_RegexPartC), sz, sz, C.POINTER(vp)]),
+        "hrx_regex_files_num_substrs": (sz, [vp]),
+        "hrx_regex_files_allstr": (vp, [vp, C.POINTER(sz)]),
+        "hrx_regex_files_substr": (vp, [vp, sz, C.POINTER(sz)]),
+        "hrx_regex_files_destroy": (None, [vp]),
+        "hrx_format_regex_str": (i, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]),
+        "hrx_regex_find": (i, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(i), C.POINTER(sz), C.POINTER(sz)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -143,6 +155,21 @@ def regex_to_allstr_text(regex):
     return _two_call(lib.hrx_regex_to_allstr_text, regex).decode("ascii")
 
 
+def format_regex_str(regex):
+    """format_regex_str (src/vrm/js_caller.rs:36-41): formatRegexPrintable of src/vrm/regex.js:24-39."""
+    return _two_call(lib.hrx_format_regex_str, regex).decode("utf-8")
+
+
+def regex_find(pattern, text):
+    """The leftmost-first search gen_regex_files runs for every part on every DFA path (mod.rs:553-583);
+    returns (start, end) or None."""
+    p = pattern.encode("utf-8") if isinstance(pattern, str) else bytes(pattern)
+    t = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    found, s0, e0 = C.c_int(0), C.c_size_t(0), C.c_size_t(0)
+    _check(lib.hrx_regex_find(p, len(p), t, len(t), C.byref(found), C.byref(s0), C.byref(e0)))
+    return (s0.value, e0.value) if found.value else None
+
+
 class RegexPartConfig:
     """RegexPartConfig (src/vrm/mod.rs:39-49)."""
 
@@ -151,9 +178,8 @@ class RegexPartConfig:
 
 
 class DecomposedRegexConfig:
-    """DecomposedRegexConfig (src/vrm/mod.rs:31-37).  gen_allstr_text / gen_allstr_file cover the AllstrRegexDef half
-    of gen_regex_files (mod.rs:62-95); the SubstrRegexDef half (mod.rs:309-600, fancy-regex path matching) is not
-    built — SURVEY §8 f2."""
+    """DecomposedRegexConfig (src/vrm/mod.rs:31-37): gen_regex_files (mod.rs:62-307) computed natively — the
+    AllstrRegexDef text of the concatenated parts and one SubstrRegexDef text per public part."""
 
     def __init__(self, max_byte_size, parts):
         self.max_byte_size, self.parts = int(max_byte_size), list(parts)
@@ -174,6 +200,37 @@ class DecomposedRegexConfig:
     def gen_allstr_file(self, allstr_file_path):
         with open(allstr_file_path, "w") as f:
             f.write(self.gen_allstr_text())
+
+    def gen_regex_texts(self):
+        """-> (allstr_text, [substr_text per public part])"""
+        keep = [p.regex_def.encode("utf-8") for p in self.parts]
+        arr = (_RegexPartC * max(len(keep), 1))()
+        for k, (p, b) in enumerate(zip(self.parts, keep)):
+            arr[k] = _RegexPartC(b, len(b), int(p.is_public), p.max_size)
+        h = C.c_void_p()
+        _check(lib.hrx_gen_regex_files(arr, len(keep), self.max_byte_size, C.byref(h)))
+        try:
+            n = C.c_size_t(0)
+            ptr = lib.hrx_regex_files_allstr(h, C.byref(n))
+            allstr = C.string_at(ptr, n.value).decode("ascii")
+            subs = []
+            for k in range(lib.hrx_regex_files_num_substrs(h)):
+                ptr = lib.hrx_regex_files_substr(h, k, C.byref(n))
+                subs.append(C.string_at(ptr, n.value).decode("ascii"))
+        finally:
+            lib.hrx_regex_files_destroy(h)
+        return allstr, subs
+
+    def gen_regex_files(self, allstr_file_path, substr_file_pathes):
+        """gen_regex_files (mod.rs:62-307): writes the AllstrRegexDef file and one SubstrRegexDef file per public part."""
+        allstr, subs = self.gen_regex_texts()
+        if len(substr_file_pathes) < len(subs):
+            raise ValueError("%d public parts but %d substr paths" % (len(subs), len(substr_file_pathes)))
+        with open(allstr_file_path, "w") as f:
+            f.write(allstr)
+        for path, text in zip(substr_file_pathes, subs):
+            with open(path, "w") as f:
+                f.write(text)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -493,7 +493,8 @@ static bool allstr_text(const rx::MinDfa &m, std::string &out, std::string &err)
     return true;
 }
 
-bool compile_regex(const char *regex, size_t len, std::string *json_out, std::string *text_out, std::string &err) {
+bool compile_regex(const char *regex, size_t len, std::string *json_out, std::string *text_out, std::string &err,
+                   CompiledDfa *dfa_out) {
     std::vector<uint16_t> units;
     if (!rx::utf8_to_units(regex, len, units, err)) return false;
     std::vector<rx::Tok> toks;
@@ -517,6 +518,17 @@ bool compile_regex(const char *regex, size_t len, std::string *json_out, std::st
     rx::MinDfa m = rx::minimise(dfa);
     if (json_out) *json_out = dfa_json(m);
     if (text_out && !allstr_text(m, *text_out, err)) return false;
+    if (dfa_out) {                     // the parsed JSON value as the Rust side sees it: edges in BTreeMap (byte) order
+        dfa_out->nodes.clear();
+        for (auto &n : m.nodes) {
+            CompiledDfa::Node o; o.accept = n.accept;
+            std::vector<size_t> order(n.edges.size());
+            for (size_t k = 0; k < order.size(); k++) order[k] = k;
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return n.edges[a].first < n.edges[b].first; });
+            for (size_t k : order) o.edges.push_back({n.edges[k].first, n.edges[k].second, n.key_syms[k]});
+            dfa_out->nodes.push_back(std::move(o));
+        }
+    }
     return true;
 }
 

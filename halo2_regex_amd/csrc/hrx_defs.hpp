@@ -74,7 +74,21 @@ size_t table_transition_rows(const DefsSet &s, size_t d, uint64_t *rows4, size_t
 size_t table_endpoint_rows(const DefsSet &s, size_t d, uint64_t *rows3, size_t cap_rows);
 
 // hrx_compile.cpp: regex -> minimal DFA in the reference's numbering; either output may be null
-bool compile_regex(const char *regex, size_t len, std::string *json_out, std::string *text_out, std::string &err);
+struct CompiledDfa {               // Vec<serde_json::Value> of get_dfa_json_value, edges in map (byte) order of the key text
+    struct Edge { std::string key; int to; std::vector<uint16_t> syms; };
+    struct Node { bool accept; std::vector<Edge> edges; };
+    std::vector<Node> nodes;
+};
+bool compile_regex(const char *regex, size_t len, std::string *json_out, std::string *text_out, std::string &err,
+                   CompiledDfa *dfa_out = nullptr);
+
+// hrx_substr.cpp: DecomposedRegexConfig::gen_regex_files (src/vrm/mod.rs:62-307): allstr text + one substr text per public part
+struct RegexPart { std::string regex_def; bool is_public; size_t max_size; };
+struct RegexFiles { std::string allstr; std::vector<std::string> substrs; };
+bool gen_regex_files(const std::vector<RegexPart> &parts, size_t max_byte_size, RegexFiles &out, std::string &err);
+std::string format_regex_printable(const std::string &s);                      // formatRegexPrintable, src/vrm/regex.js:24-39
+// leftmost-first search (regex crate semantics, which fancy-regex delegates to); false if no match; err set on syntax it does not cover
+bool regex_find(const std::string &pattern, const std::string &text, size_t &start, size_t &end, bool &found, std::string &err);
 
 // LDS budget for the table image (the rest of the 160 KiB holds the per-wave staging)
 constexpr size_t kMaxTableBytes = 2048 * 1024;  // 2048 table rows; beyond the LDS budget the kernels read the table from global memory

@@ -186,6 +186,31 @@ int hrx_regex_to_allstr_text(const char *regex, size_t regex_len, char *out, siz
 /* The intermediate value itself: the JSON text regexToDfa returns ([{"type":..,"edges":{key:target}}, ...]). */
 int hrx_regex_to_dfa_json(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed);
 
+/* DecomposedRegexConfig::gen_regex_files (src/vrm/mod.rs:62-307) as a whole: the AllstrRegexDef text of the
+ * concatenated parts and one SubstrRegexDef text per public part (extract_substr_ids, mod.rs:309-538;
+ * get_substr_defs_from_path, mod.rs:540-600; text format mod.rs:268-304).  The part regexes are searched in the
+ * DFA's paths with leftmost-first semantics (what fancy-regex 0.11 / the regex crate do for these patterns);
+ * pattern syntax outside the subset formatRegexPrintable emits from the DFA dialect -> HRX_ERR_PARSE. */
+typedef struct hrx_regex_part {
+    const char *regex_def; /* UTF-8, not terminated */
+    size_t regex_len;
+    int is_public;
+    size_t max_size;
+} hrx_regex_part;
+typedef struct hrx_regex_files hrx_regex_files;
+int hrx_gen_regex_files(const hrx_regex_part *parts, size_t n_parts, size_t max_byte_size, hrx_regex_files **out);
+size_t hrx_regex_files_num_substrs(const hrx_regex_files *files);
+/* pointers stay valid until hrx_regex_files_destroy; texts are not terminated, *len receives the byte length */
+const char *hrx_regex_files_allstr(const hrx_regex_files *files, size_t *len);
+const char *hrx_regex_files_substr(const hrx_regex_files *files, size_t idx, size_t *len);
+void hrx_regex_files_destroy(hrx_regex_files *files);
+/* format_regex_str (src/vrm/js_caller.rs:36-41 -> formatRegexPrintable, src/vrm/regex.js:24-39); two-call pattern */
+int hrx_format_regex_str(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed);
+/* The search gen_regex_files runs per part and path: leftmost-first match of `pattern` in `text`.
+ * *found = 0/1; [*start, *end) the match. */
+int hrx_regex_find(const char *pattern, size_t pattern_len, const char *text, size_t text_len, int *found, size_t *start,
+                   size_t *end);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""SubstrRegexDef generation (src/vrm/mod.rs:62-600) — host-only code, no GPU.
+
+Pins: the reference's committed substr{1,2,3}_test_lookup.txt (byte-identical) and examples/ex_substr_id1.txt (same
+content; that file predates the sorted writer), formatRegexPrintable vectors produced by running the reference's JS
+(tests/golden/compiler/gen_format_golden.js), and — for the leftmost-first matcher that stands in for fancy-regex /
+the regex crate — CPython's `re` on the same syntax subset."""
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import halo2_regex_amd as hra
+from oracle_lib import OracleDefs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DFA_DIR = os.path.join(HERE, "golden", "dfa")
+
+
+def _cfg(name):
+    return hra.DecomposedRegexConfig.from_json(open(os.path.join(DFA_DIR, name + ".json")).read())
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_reference_substr_files_are_reproduced(k, tmp_path):
+    cfg = _cfg("regex%d_test" % k)
+    a, subs = tmp_path / "allstr.txt", [tmp_path / "substr.txt"]
+    cfg.gen_regex_files(a, subs)
+    assert a.read_text() == open(os.path.join(DFA_DIR, "regex%d_test_lookup.txt" % k)).read()
+    assert subs[0].read_text() == open(os.path.join(DFA_DIR, "substr%d_test_lookup.txt" % k)).read()
+
+
+def test_example_substr_file_same_content():
+    _, subs = _cfg("ex_regex").gen_regex_texts()
+    ref = open(os.path.join(DFA_DIR, "ex_substr_id1.txt")).read().split("\n")
+    got = subs[0].split("\n")
+    assert got[:5] == ref[:5] and sorted(got[5:]) == sorted(ref[5:])
+
+
+def test_format_regex_str_matches_the_js():
+    cases = json.load(open(os.path.join(HERE, "golden", "compiler", "format_cases.json")))
+    assert len(cases) > 100
+    for c in cases:
+        assert hra.format_regex_str(c["regex_def"]) == c["formatted"], c["regex_def"]
+
+
+def _rand_pattern(rng, depth):
+    r = rng.random()
+    if depth <= 0 or r < 0.35:
+        return rng.choice(["a", "b", "c", "1", ".", "\\.", "\\d", "[ab]", "[^a]", "[a-c1]", "\\n", "x", " ", "\\/", "\\x61", "\\x62", "\\|"])
+    if r < 0.6:
+        return "".join(_rand_pattern(rng, depth - 1) for _ in range(rng.randint(2, 3)))
+    if r < 0.8:
+        alts = [_rand_pattern(rng, depth - 1) for _ in range(rng.randint(2, 3))]
+        if rng.random() < 0.15:
+            alts.append("")
+        return "(" + "|".join(alts) + ")"
+    q = rng.choice(["*", "+", "?", "{2}", "{1,3}", "{2,}", "*?", "+?", "??"])
+    body = _rand_pattern(rng, depth - 1)
+    # Loops whose body can match the empty string are left out: there backtracking engines (CPython) and automaton
+    # engines (the regex crate, this one) are known to pick different iterations; no part regex in the reference's
+    # fixtures has one.
+    if q not in ("?", "??") and re.fullmatch(body.encode(), b"") is not None:
+        return "(" + body + ")"
+    return "(" + body + ")" + q
+
+
+def test_leftmost_first_search_agrees_with_cpython_re():
+    rng = random.Random(77)
+    n = 0
+    for _ in range(3000):
+        pat = _rand_pattern(rng, rng.randint(1, 4))
+        try:
+            cre = re.compile(pat.encode())
+        except re.error:
+            continue
+        for _ in range(4):
+            text = "".join(rng.choice("abc1x. \n/|") for _ in range(rng.randint(0, 12)))
+            m = cre.search(text.encode())
+            got = hra.regex_find(pat, text)
+            assert got == (m.span() if m else None), (pat, text)
+            n += 1
+    assert n > 8000
+
+
+def test_escapes_the_formatter_emits():
+    assert hra.regex_find("\\u000b\\f\\r\\n\\t", "a\x0b\x0c\r\n\t") == (1, 6)
+    assert hra.regex_find("\\u0062+", "abbc") == (1, 3)
+    assert hra.regex_find("a{", "xa{") == (1, 3) and hra.regex_find("{}", "{}") == (0, 2)      # not a counted repeat: literal
+    assert hra.regex_find("\\\"q\\\"", 'say "q"') == (4, 7)
+
+
+def test_unsupported_syntax_is_rejected_not_guessed():
+    for pat in ("(?=a)b", "a\\b", "(?i)a", "^a", "a$", "*a", "[[:alpha:]]"):
+        with pytest.raises(hra.HrxError):
+            hra.regex_find(pat, "a")
+
+
+def test_generated_definitions_reveal_the_public_parts(oracle):
+    """End to end on a NEW decomposed regex (two public parts): generate both definition texts natively, load them,
+    and check with the oracle's match_substrs that exactly the public substrings are revealed with ids 1 and 2."""
+    az = "(" + "|".join("abcdefghijklmnopqrstuvwxyz") + ")+"
+    dg = "(" + "|".join("0123456789") + ")+"
+    cfg = hra.DecomposedRegexConfig(64, [hra.RegexPartConfig(False, "to:", 3), hra.RegexPartConfig(True, az, 8),
+                                         hra.RegexPartConfig(False, " amount=", 8), hra.RegexPartConfig(True, dg, 6),
+                                         hra.RegexPartConfig(False, ";", 1)])
+    allstr, subs = cfg.gen_regex_texts()
+    assert len(subs) == 2
+    o = OracleDefs(oracle, [(allstr, subs)])
+    for name, amount in (("bob", "42"), ("alice", "7"), ("z", "123456")):
+        s = ("to:%s amount=%s;" % (name, amount)).encode()
+        out = o.match_substrs(s, 64)
+        assert out["rc"] == 0 and out["info"][4] == 1           # accepted
+        mc, ms = out["masked_char"], out["masked_substr_id"]
+        assert bytes(int(c) for c in mc[3:3 + len(name)]) == name.encode() and set(ms[3:3 + len(name)]) == {1}
+        p = 3 + len(name) + 8
+        assert bytes(int(c) for c in mc[p:p + len(amount)]) == amount.encode() and set(ms[p:p + len(amount)]) == {2}
+        keep = np.zeros(64, bool)
+        keep[3:3 + len(name)] = True
+        keep[p:p + len(amount)] = True
+        assert not mc[~keep].any() and not ms[~keep].any()
