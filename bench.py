@@ -106,9 +106,9 @@ def main():
     ap.add_argument("--len", type=int, default=1023, dest="n", help="bytes per string (n); rows M = --rows")
     ap.add_argument("--rows", type=int, default=1024, help="max_chars_size M (witness rows per string)")
     ap.add_argument("--dist", choices=["planted", "noise"], default="planted")
-    ap.add_argument("--config", choices=["regex1", "regex23", "regex123", "dfa256"], default="regex1",
+    ap.add_argument("--config", choices=["regex1", "regex23", "regex123", "headers3", "dfa256"], default="regex1",
                     help="regex1: BASELINE configs[1] (the metric's workload); regex23: configs[2] shape (D=2); regex123: D=3 with the "
-                    "reference's three DFAs; dfa256: configs[4] shape (synthetic total 256-state DFA over all 256 byte values)")
+                    "reference's three DFAs; headers3: configs[3] shape (D=3 from/to/subject header definitions, 5 substrs); dfa256: configs[4] shape (synthetic total 256-state DFA over all 256 byte values)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense", action="store_true", help="string-major: power-of-two pitches (M rows per string, n rounded to 16 "
                     "bytes) instead of hrx_recommended_pitches")
@@ -148,6 +148,10 @@ def main():
     elif args.config == "regex123":
         names, label = [pair(1), pair(2), pair(3)], "regex1+regex2+regex3 with substrs"
         gen = synth.noise
+    elif args.config == "headers3":
+        hdr = lambda n, ns: (rd(n + "_lookup.txt"), [rd("%s_substr%d.txt" % (n, k)) for k in range(ns)])
+        names, label = [hdr("header_from", 1), hdr("header_to", 1), hdr("header_subject", 3)], "from/to/subject header definitions (5 substrs)"
+        gen = synth.headers_planted if args.dist == "planted" else synth.noise
     else:
         allb = np.arange(256, dtype=np.uint8)
         a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=200)
@@ -215,7 +219,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s DFA (D=%d), %d x %d-byte strings per GPU (n=%d chars, M=%d witness rows), %s"
                                    % (label, D, B, stride, n, M, "uniform noise over the %s%s" % (
-                                       alphabet, " + planted match" if gen in (synth.regex1_planted, synth.regex23_planted) else "")),
+                                       alphabet, " + planted match" if gen in (synth.regex1_planted, synth.regex23_planted, synth.headers_planted) else "")),
                        "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
                        "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR: chars [%d/16][B][16], records "
                                    "[M/4][B][4][D], masked [M/8][B][8] (include/hrx.h)" % stride) if pm else

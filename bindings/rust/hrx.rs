@@ -28,6 +28,38 @@ extern "C" {
     pub fn hrx_derive_substr_ids(ctx: *mut hrx_ctx, states: *const u64, n: usize, substr_ids: *mut u64) -> c_int;
     pub fn hrx_derive_is_start_end(ctx: *mut hrx_ctx, states: *const u64, substr_ids: *const u64, n: usize,
                                    is_start: *mut u8, is_end: *mut u8) -> c_int;
+    // definition generation (replaces the js_sandbox / fancy-regex path of src/vrm)
+    pub fn hrx_gen_regex_files(parts: *const hrx_regex_part, n_parts: usize, max_byte_size: usize,
+                               out: *mut *mut hrx_regex_files) -> c_int;
+    pub fn hrx_regex_files_num_substrs(files: *const hrx_regex_files) -> usize;
+    pub fn hrx_regex_files_allstr(files: *const hrx_regex_files, len: *mut usize) -> *const c_char;
+    pub fn hrx_regex_files_substr(files: *const hrx_regex_files, idx: usize, len: *mut usize) -> *const c_char;
+    pub fn hrx_regex_files_destroy(files: *mut hrx_regex_files);
+}
+
+#[repr(C)] pub struct hrx_regex_part { regex_def: *const c_char, regex_len: usize, is_public: c_int, max_size: usize }
+#[repr(C)] pub struct hrx_regex_files { _private: [u8; 0] }
+
+/// Drop-in body for `DecomposedRegexConfig::gen_regex_files` (src/vrm/mod.rs:62-307): same files, no V8.
+pub fn gen_regex_files(cfg: &crate::vrm::DecomposedRegexConfig, allstr_file_path: &std::path::PathBuf,
+                       substr_file_pathes: &[std::path::PathBuf]) -> Result<(), crate::vrm::VrmError> {
+    let parts: Vec<hrx_regex_part> = cfg.parts.iter().map(|p| hrx_regex_part {
+        regex_def: p.regex_def.as_ptr() as *const c_char, regex_len: p.regex_def.len(),
+        is_public: p.is_public as c_int, max_size: p.max_size }).collect();
+    unsafe {
+        let mut files = std::ptr::null_mut();
+        if hrx_gen_regex_files(parts.as_ptr(), parts.len(), cfg.max_byte_size, &mut files) != 0 { panic!("{}", last_error()); }
+        let text = |p: *const c_char, n: usize| std::slice::from_raw_parts(p as *const u8, n).to_vec();
+        let mut n = 0usize;
+        let p = hrx_regex_files_allstr(files, &mut n);
+        std::fs::write(allstr_file_path, text(p, n))?;
+        for idx in 0..hrx_regex_files_num_substrs(files) {
+            let p = hrx_regex_files_substr(files, idx, &mut n);
+            std::fs::write(&substr_file_pathes[idx], text(p, n))?;
+        }
+        hrx_regex_files_destroy(files);
+    }
+    Ok(())
 }
 
 fn last_error() -> String { unsafe { CStr::from_ptr(hrx_last_error()).to_string_lossy().into_owned() } }

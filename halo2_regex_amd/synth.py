@@ -61,6 +61,22 @@ def regex23_planted(B, n, seed=1, stride=None):
     return chars, lens
 
 
+def headers_planted(B, n, seed=3, stride=None):
+    """cfg 4: noise with one e-mail-header block planted per string — a `from:`, a `to:` and a `subject:Send <amount>
+    <TOKEN> to <address>` line — for the D=3 stand-in definitions tests/golden/dfa/header_{from,to,subject}.json
+    (1 / 1 / 3 public parts; compiled by this repo's regex compiler, BASELINE.md §4 cfg 4)."""
+    chars, lens = noise(B, n, seed, stride=stride)
+    rng = _rng(seed, 1)
+    up = lambda r, lo, hi: _word(r, lo, hi).upper()
+
+    def block(r):
+        addr = lambda: _word(r, 1, 6) + b"@" + _word(r, 1, 5) + b"." + _word(r, 2, 3)
+        amount = str(int(r.integers(1, 100000))).encode() + (b"." + str(int(r.integers(0, 100))).encode() if r.integers(0, 2) else b"")
+        return (b"\r\nfrom:" + _word(r, 1, 6) + b" <" + addr() + b">\r\nto:" + addr() + b"\r\nsubject:Send " + amount + b" "
+                + up(r, 2, 4) + b" to " + addr() + b"\r\n")
+    return _plant(chars, lens, rng, block), lens
+
+
 def ragged(B, n_max, seed=5, alphabet=ALPHABET98, planted=True):
     """Variable lengths 0..n_max (including empty and full strings), regex1-style plants."""
     rng = _rng(seed, 2)

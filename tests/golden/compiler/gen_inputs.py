@@ -52,6 +52,6 @@ for _ in range(100):
     words = ["".join(rng.choice(DIG) for _ in range(rng.randint(1, 5))) for _ in range(rng.randint(2, 7))]
     tail = rng.choice(["", "*", "+", "?"])
     rand.append("(" + "|".join(words) + ")" + tail + rng.choice(["", "x", "(0|1)*", "9+"]))
-json.dump({"small": hand + rand, "big": ["regex1_test", "regex2_test", "regex3_test", "ex_regex"]}, open("inputs.json", "w"), indent=0,
+json.dump({"small": hand + rand, "big": ["regex1_test", "regex2_test", "regex3_test", "ex_regex", "header_from", "header_to", "header_subject"]}, open("inputs.json", "w"), indent=0,
           ensure_ascii=True)
 print(len(hand), len(rand))

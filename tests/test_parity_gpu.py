@@ -290,6 +290,22 @@ def test_cfg5_shape_256_state_dense_dfa_4096_byte_strings(hra, oracle):
     _sample_check(hra, o, cfg, chars, lens, M, 1, 96, 6, position_major=False)
 
 
+def test_cfg4_shape_three_header_defs_five_substrs(hra, oracle):
+    """BASELINE configs[3] shape: D=3 header-style definitions (from / to / subject; substr ids 1..5) compiled by this
+    repo's own regex compiler; 2048-row strings in both layouts and 32768-byte strings, sampled against the oracle."""
+    from halo2_regex_amd import synth
+    from test_substr_gen import header_def_texts
+    texts = header_def_texts()
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in texts]
+    o = OracleDefs(oracle, texts)
+    for B, n, M, ns in ((4096, 2047, 2048, 128), (256, 32767, 32768, 12)):
+        cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+        chars, lens = synth.headers_planted(B, n, seed=3, stride=M)
+        st = _sample_check(hra, o, cfg, chars, lens, M, 3, ns, 11, position_major=True)
+        assert ((st & np.uint64(0xff)) == 0).all() and (st == np.uint64(0x700)).mean() > 0.99    # a block planted at offset 0 is not accepted
+        _sample_check(hra, o, cfg, chars, lens, M, 3, ns, 12, position_major=False)
+
+
 def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
     from halo2_regex_amd import synth
     monkeypatch.setenv("HRX_DEBUG_FLAGS", str(0x40000))

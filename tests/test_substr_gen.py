@@ -121,3 +121,36 @@ def test_generated_definitions_reveal_the_public_parts(oracle):
         keep[3:3 + len(name)] = True
         keep[p:p + len(amount)] = True
         assert not mc[~keep].any() and not ms[~keep].any()
+
+
+HEADER_DEFS = [("header_from", 1), ("header_to", 1), ("header_subject", 3)]
+
+
+def header_def_texts():
+    rd = lambda f: open(os.path.join(DFA_DIR, f), "rb").read()
+    return [(rd(n + "_lookup.txt"), [rd("%s_substr%d.txt" % (n, k)) for k in range(ns)]) for n, ns in HEADER_DEFS]
+
+
+def test_cfg4_header_definitions_regenerate_and_reveal(oracle):
+    """BASELINE cfg 4's D=3 stand-ins (from / to / subject, 1 / 1 / 3 public parts): the committed definition files are
+    what this repo's compiler produces from the committed JSONs (the allstr halves are also pinned to the reference's
+    JS by test_compiler.py), and on synth.headers_planted every string is accepted by all three with ids 1..5 revealed."""
+    from halo2_regex_amd import synth
+    for (name, ns), (allstr, subs) in zip(HEADER_DEFS, header_def_texts()):
+        a, s = _cfg(name).gen_regex_texts()
+        assert a.encode() == allstr and [x.encode() for x in s] == subs and len(s) == ns
+    o = OracleDefs(oracle, header_def_texts())
+    chars, lens = synth.headers_planted(48, 700, seed=3)
+    rec, msk, st = o.witness_batch(chars, lens, 704)
+    assert (st == 0x700).all()
+    for b in range(48):
+        s = bytes(chars[b, :700])
+        ids = (msk[b] >> 8).astype(int)
+        revealed = {k: bytes((msk[b][ids == k] & 0xff).astype(np.uint8)) for k in range(1, 6)}
+        frm = s[s.index(b"\r\nfrom:"):]
+        assert revealed[1] == frm[frm.index(b"<") + 1:frm.index(b">")]
+        to = frm[frm.index(b"\r\nto:") + 5:]
+        assert revealed[2] == to[:to.index(b"\r\n")]
+        subj = to[to.index(b"subject:Send ") + 13:]
+        amount, token, _, addr = subj[:subj.index(b"\r\n")].split(b" ")
+        assert (revealed[3], revealed[4], revealed[5]) == (amount, token, addr)
