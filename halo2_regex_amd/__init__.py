@@ -350,9 +350,10 @@ def chars_to_position_major(chars):
 
 
 def position_major_to_string_major(records_pm, masked_pm, B, M, D):
-    """View-level inverse of HRX_LAYOUT_POSITION_MAJOR (include/hrx.h): records [ceil(M/4)][B][4][D] -> (B, M, D),
+    """View-level inverse of HRX_LAYOUT_POSITION_MAJOR (include/hrx.h): records [ceil(M/4)][D][B][4] -> (B, M, D),
     masked [ceil(M/8)][B][8] -> (B, M).  Works on torch tensors and numpy arrays alike; no values change."""
-    rec = records_pm.reshape(-1, B, 4, D).permute(1, 0, 2, 3) if hasattr(records_pm, "permute") else records_pm.reshape(-1, B, 4, D).transpose(1, 0, 2, 3)
+    r = records_pm.reshape(-1, D, B, 4)
+    rec = r.permute(2, 0, 3, 1) if hasattr(r, "permute") else r.transpose(2, 0, 3, 1)      # (B, M/4, 4, D)
     msk = masked_pm.reshape(-1, B, 8).permute(1, 0, 2) if hasattr(masked_pm, "permute") else masked_pm.reshape(-1, B, 8).transpose(1, 0, 2)
     return rec.reshape(B, -1, D)[:, :M], msk.reshape(B, -1)[:, :M]
 

@@ -56,6 +56,7 @@ struct hrx_ctx {
     int num_cus = 0;
     hipStream_t stream = nullptr;
     uint32_t *d_table = nullptr;
+    uint64_t *d_wide = nullptr;
     std::vector<uint16_t *> d_pair;
     std::vector<uint8_t *> d_member;
     std::mutex mu;
@@ -214,6 +215,10 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_table, c->s.table_image.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(c->d_table, c->s.table_image.data(), c->s.table_image.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !c->s.wide_image.empty()) {
+        e = hipMalloc((void **)&c->d_wide, c->s.wide_image.size() * 8);
+        if (e == hipSuccess) e = hipMemcpy(c->d_wide, c->s.wide_image.data(), c->s.wide_image.size() * 8, hipMemcpyHostToDevice);
+    }
     for (size_t d = 0; e == hipSuccess && d < c->s.pair_tags.size(); ++d) {
         uint16_t *p = nullptr;
         e = hipMalloc((void **)&p, c->s.pair_tags[d].size() * 2);
@@ -243,6 +248,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_wide) (void)hipFree(c->d_wide);
     for (uint16_t *p : c->d_pair) (void)hipFree(p);
     for (uint8_t *p : c->d_member) (void)hipFree(p);
     c->chars.release(); c->lens.release(); c->records.release(); c->masked.release();
@@ -278,6 +284,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
     a.records = records; a.masked = masked; a.status = status;
     a.table_image = ctx->d_table; a.table_bytes = (uint32_t)(ctx->s.table_image.size() * 4);
+    a.wide_image = ctx->d_wide;
     a.D = (uint32_t)ctx->s.defs.size();
     if (const char *dbg = std::getenv("HRX_DEBUG_FLAGS")) a.debug = (uint32_t)std::atoi(dbg);
     for (uint32_t d = 0; d < a.D; ++d) a.dc[d] = ctx->s.consts[d];

@@ -171,6 +171,32 @@ int finalize_defs(DefsSet &s, std::string &err) {
         }
         s.endpoint_member.push_back(std::move(mem));
     }
+    // WIDE image for the position-major kernel
+    s.wide_image.clear();
+    bool ascii = total_rows <= 255;
+    for (const RegexDefs &rd : s.defs)
+        for (const auto &kv : rd.allstr.state_lookup) if (kv.first.first >= 128) ascii = false;
+    if (ascii) {
+        s.wide_image.assign(total_rows * 128, 0);
+        for (size_t d = 0; d < s.defs.size(); ++d) {
+            const RegexDefs &rd = s.defs[d];
+            const DefConsts &c = s.consts[d];
+            const uint64_t L = rd.allstr.largest_state_val;
+            uint64_t *W = s.wide_image.data() + (size_t)c.row_base * 128;
+            const uint64_t dead_lo = (uint64_t)(c.row_base + L + 2) << kWideRowShift, dummy_lo = (uint64_t)(c.row_base + L + 1) << kWideRowShift;
+            for (uint64_t st = 0; st <= L + 2; ++st)
+                for (int ch = 0; ch < 128; ++ch)
+                    W[st * 128 + ch] = st == L + 1 ? (dummy_lo | (L + 1) << 32) : (dead_lo | std::min<uint64_t>(st, L + 1) << 32);
+            for (const auto &kv : rd.allstr.state_lookup) {
+                const uint64_t ch = kv.first.first, cur = kv.first.second, next = kv.second.next;
+                const uint64_t tag = pair_tag(rd, c.substr_id_offset, cur, next);
+                const uint64_t sid = tag & 0xff, is_start = (tag >> 8) & 1, is_end = (tag >> 9) & 1;
+                const uint64_t lo = (uint64_t)(c.row_base + next) << kWideRowShift | sid << kWideSidShift | is_start << kWideStartShift |
+                                    is_end << kWideEndShift;
+                W[cur * 128 + ch] = lo | (cur | tag << 16) << 32;
+            }
+        }
+    }
     s.finalized = true;
     return HRX_OK;
 }

@@ -57,6 +57,9 @@ struct DefsSet {
     bool finalized = false;
     // dense image: for def d, n_rows x 256 u32 entries at table_base (see hrx_lane.h for the entry format)
     std::vector<uint32_t> table_image;
+    // WIDE image (hrx_lane.h): n_rows x 128 u64 entries per def, same row numbering; empty unless every transition
+    // symbol is < 128 and the rows fit an 8-bit row number
+    std::vector<uint64_t> wide_image;
     std::vector<DefConsts> consts;
     // (cur,next) -> {sid, is_start(cur), is_end(next)} per def, for the states-in entry points (lib.rs:825-888)
     std::vector<std::vector<uint16_t>> pair_tags;  // [(largest+1)^2], entry = tag bits as in the fused table

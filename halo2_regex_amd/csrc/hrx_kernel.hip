@@ -837,7 +837,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
 }
 
 // =============================================================================================
-// Position-major kernel (layout 1): records [ceil(M/4)][B][4][D] u32, masked [ceil(M/8)][B][8] u16.
+// Position-major kernel (layout 1): records [ceil(M/4)][D][B][4] u32, masked [ceil(M/8)][B][8] u16.
 //
 // With one lane per string, four consecutive rows of a lane are 16*D contiguous bytes and the 64 lanes of a wave are
 // 64 consecutive strings: every store is a full, contiguous 1-KiB (D=1) run written straight from the walker's
@@ -863,7 +863,8 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
                                                  uint32_t (&sidq)[16], uint32_t (&acc_state)[D], const uint4 (&pend)[8],
                                                  unsigned char *pend_mp, const size_t mstep, const bool pend_store) {
     uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
-    uint32_t rbuf[4];
+    uint32_t rbuf[D][4];
+    const size_t plane = (a.debug & 0x100000u) ? (size_t)16u : (size_t)a.B * 16u;   // [ceil(M/4)][D][B][4]: one def's quads of all strings (0x100000, profiling: [M/4][B][D][4])
     const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                              cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
     uint32_t e1[D], e2[D], raw[D];
@@ -880,13 +881,12 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
                 if (p >= mrem) tag &= ~kTagEnd;
                 if (p == rem) acc_state[d] = state;  // the state at row n (lib.rs:437-457)
             }
-            const int i = p * D + d;
-            rbuf[i & 3] = state | (tag << 16);
-            if ((i & 3) == 3) {  // 16 bytes of this string's quad: a 1-KiB (x D) contiguous run across the wave
-                // quads that start at or beyond row M do not exist in [ceil(M/4)][B][4][D]
+            rbuf[d][p & 3] = state | (tag << 16);
+            if ((p & 3) == 3) {  // four rows of def d of this string: 16 bytes, a 1-KiB contiguous run across the wave
+                // quads that start at or beyond row M do not exist in [ceil(M/4)][D][B][4]
                 if (do_store && (FULL || (p & ~3) <= mrem))
-                    store16(rp + ((i >> 2) % D) * 16, make_uint4(rbuf[0], rbuf[1], rbuf[2], rbuf[3]), (a.debug & 32u) != 0);
-                if ((p & 3) == 3) rp += rstep;
+                    store16(rp + (size_t)d * plane, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]), (a.debug & 32u) != 0);
+                if (d == D - 1) rp += rstep;
             }
             if (!FULL) L.mx[d] = max(L.mx[d], et[d]);
             sid += tag & 0xffu;
@@ -947,7 +947,120 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
     return tb;
 }
 
-template <int D, bool GTAB>
+// ---------------------------------------------------------------------------------------------
+// WIDE-table walk (hrx_lane.h): one ds_read_b64 per row and def returns the chain word AND the finished record, so a
+// row costs, beyond the lookups,  v_add3 (per-row sums of substr ids and flag counts over the defs, straight from the
+// chain words) + v_bfe (substr id) + 2 shifts + 2 v_alignbit (start / end bit into the tile bitvectors) +
+// v_cmp/v_addc (id-changed bit) + 1 v_lshl_or (the id byte kept for the masked rows)  —  ~14 VALU at D = 3 against
+// ~65 for the narrow entry format, which made the D = 3 walk issue-bound (a wave64 VALU op occupies its SIMD for
+// 4 cycles).  Two defs flagging the same row only set tile_ov != 0 here; the exact row is found by the tile re-walk.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) const v2u32 lds_cv2u32;
+__device__ __forceinline__ uint2 lds_u64(uint32_t off) {
+    const v2u32 v = *(lds_cv2u32 *)(uintptr_t)off;
+    return make_uint2(v.x, v.y);
+}
+
+template <int D, bool FULL>
+__device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, unsigned char *&rp,
+                                                      const size_t rstep, const bool do_store, int rem, int mrem, uint32_t &tile_ov,
+                                                      uint32_t (&sidq)[16], uint32_t (&acc_state)[D], const uint4 (&pend)[8],
+                                                      unsigned char *pend_mp, const size_t mstep, const bool pend_store) {
+    uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
+    uint32_t rbuf[D][4];
+    const size_t plane = (a.debug & 0x100000u) ? (size_t)16u : (size_t)a.B * 16u;   // [ceil(M/4)][D][B][4]: one def's quads of all strings (0x100000, profiling: [M/4][B][D][4])
+    uint32_t ov = 0;
+    // bytes >= 128 have no column: they are masked here and the tile is re-walked by the caller
+    const uint32_t cw[16] = {cq[0].x & 0x7f7f7f7fu, cq[0].y & 0x7f7f7f7fu, cq[0].z & 0x7f7f7f7fu, cq[0].w & 0x7f7f7f7fu,
+                             cq[1].x & 0x7f7f7f7fu, cq[1].y & 0x7f7f7f7fu, cq[1].z & 0x7f7f7f7fu, cq[1].w & 0x7f7f7f7fu,
+                             cq[2].x & 0x7f7f7f7fu, cq[2].y & 0x7f7f7f7fu, cq[2].z & 0x7f7f7f7fu, cq[2].w & 0x7f7f7f7fu,
+                             cq[3].x & 0x7f7f7f7fu, cq[3].y & 0x7f7f7f7fu, cq[3].z & 0x7f7f7f7fu, cq[3].w & 0x7f7f7f7fu};
+    uint32_t lo[D], plo[D], phi[D];   // lo: chain word after the newest row; plo/phi: chain word and record of the row being posted
+#pragma unroll
+    for (int d = 0; d < D; ++d) { lo[d] = plo[d] = L.e[d]; phi[d] = 0; }
+
+    auto post = [&](const int p) {    // row p: chain words plo[], records phi[]
+        uint32_t T;
+        if (D == 1) T = plo[0];
+        else if (D == 2) T = plo[0] + plo[1];
+        else T = plo[0] + plo[1] + plo[D - 1];
+        if (!FULL) {
+            if (p >= mrem) T &= ~(3u << kWideEndShift);   // end_enable of row M-1 is never assigned (lib.rs:501)
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            uint32_t rec = phi[d];
+            if (!FULL) {
+                if (p >= mrem) rec &= ~(1u << 25);
+            }
+            rbuf[d][p & 3] = rec;
+            if ((p & 3) == 3) {  // four rows of def d of this string: 16 bytes, a 1-KiB contiguous run across the wave
+                if (do_store && (FULL || (p & ~3) <= mrem))
+                    store16(rp + (size_t)d * plane, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]), (a.debug & 32u) != 0);
+                if (d == D - 1) rp += rstep;
+            }
+        }
+        const uint32_t sid = (T >> kWideSidShift) & 0xffu;
+        const uint32_t F = T >> kWideStartShift;          // bits 0..1 start count, 2..3 end count
+        if (D > 1) ov |= F & 0xau;                        // a count of 2 or 3: two defs flag the same row
+        st[p >> 5] = __builtin_amdgcn_alignbit(F, st[p >> 5], 1);
+        en1[p >> 5] = __builtin_amdgcn_alignbit(T >> kWideEndShift, en1[p >> 5], 1);
+        // ch = (ch << 1) | (sid != sid_prev): bits arrive in reverse row order, undone once per word below
+        asm volatile("v_cmp_ne_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ch[p >> 5]) : "v"(sid), "v"(L.sid_prev) : "vcc");
+        L.sid_prev = sid;
+        sidq[p >> 2] |= sid << (8 * (p & 3));
+        if (D == 1 && (p & 7) == 5 && pend_store) store16(pend_mp + (size_t)(p >> 3) * mstep, pend[p >> 3], (a.debug & 64u) != 0);
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sidq[i] = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = q * 4 + k;
+            const uint32_t c8 = ((cw[q] >> (8 * k)) & 0xffu) << 3;
+            uint2 raw[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) raw[d] = lds_u64((lo[d] & kWideRowMask) | c8);   // delta(state, byte): lib.rs:810
+            if (p > 0) {
+                post(p - 1);
+                asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(L.sid_prev), "+v"(sidq[(p - 1) >> 2]));
+                if (D > 1) asm volatile("" : "+v"(ov));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const uint32_t prev = lo[d];             // chain word after row p-1: its row field is the state at row p
+                if (FULL) {
+                    lo[d] = raw[d].x;
+                    phi[d] = raw[d].y;
+                } else {
+                    const bool live = p < rem;
+                    const uint32_t state_here = ((prev >> kWideRowShift) & 0xffu) - a.dc[d].row_base;
+                    if (p == rem) acc_state[d] = state_here;                       // the state at row n (lib.rs:437-457)
+                    lo[d] = live ? raw[d].x : a.dc[d].dummy_entry;                 // rows >= n: lib.rs:404-418
+                    phi[d] = live ? raw[d].y : (p == rem ? state_here : (a.dc[d].dummy_entry >> kWideRowShift) - a.dc[d].row_base);
+                    L.mx[d] = live ? raw[d].x : L.mx[d];                           // last real chain word (dead-row check)
+                }
+                plo[d] = lo[d];
+            }
+        }
+    }
+    post(63);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        L.e[d] = lo[d];
+        if (FULL) L.mx[d] = lo[d];
+    }
+    tile_ov = ov;
+    TileBits tb;
+    tb.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
+    tb.en1 = (uint64_t)en1[0] | ((uint64_t)en1[1] << 32);
+    tb.ch = (uint64_t)__builtin_bitreverse32(ch[0]) | ((uint64_t)__builtin_bitreverse32(ch[1]) << 32);
+    return tb;
+}
+
+template <int D, bool GTAB, bool WIDE>
 __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -961,7 +1074,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     const uint32_t scratch_off = ring_base + nring * kPmTileBytes;
     const uint32_t ready_off = scratch_off + kPmTileBytes, freed_off = ready_off + 4u;
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
+        const uint4 *src = WIDE ? reinterpret_cast<const uint4 *>(a.wide_image) : reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         if (!GTAB)
             for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
@@ -1062,8 +1175,8 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 acc_state[d] = (uint32_t)(a.dc[d].first_entry >> kNextShift) - a.dc[d].row_base;  // n == 0
             }
             const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
-            unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * D;
-            const size_t rstep = (size_t)B * 16u * D;  // one quad of rows further: [M/4][B][4][D]
+            unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * ((a.debug & 0x100000u) ? D : 1);
+            const size_t rstep = (size_t)B * 16u * D;  // one quad of rows further: [M/4][D][B][4]
             unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
             const size_t mstep = (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
             uint4 pend[8];                             // the previous tile's masked rows, not yet stored
@@ -1089,7 +1202,27 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 const bool full = (t0 + 64u < min_n);
                 const bool do_store = active && !(a.debug & 1u);
                 const bool pend_store = active && have_pend && !(a.debug & 2u);
-                if (full)
+                uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
+                if (WIDE) {
+                    const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
+                                              cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+                    if (full) {
+                        tb = walk_tile_pm_wide<D, true>(L, cq, a, rp, rstep, do_store, 0, 0, tile_ov, sidq, acc_state, pend, pend_mp, mstep, pend_store);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) hb |= cwl[q];
+                        hb &= 0x80808080u;
+                    } else {
+                        tb = walk_tile_pm_wide<D, false>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, tile_ov, sidq,
+                                                         acc_state, pend, pend_mp, mstep, pend_store);
+                        const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {   // bytes at or beyond the string's length are not trusted
+                            const uint32_t nb = live_rows > 4u * q ? min(live_rows - 4u * q, 4u) : 0u;
+                            hb |= cwl[q] & (nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u));
+                        }
+                        hb &= 0x80808080u;
+                    }
+                } else if (full)
                     tb = walk_tile_pm<D, true, GTAB>(L, cq, a, rp, rstep, do_store, 0, 0, t0, sidq, acc_state, pend, pend_mp, mstep, pend_store);
                 else
                     tb = walk_tile_pm<D, false, GTAB>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state,
@@ -1098,8 +1231,12 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 // ---------------- undefined transition (lib.rs:817): rare slow path, re-walk the tile ----------------
                 uint32_t newly = 0;
 #pragma unroll
-                for (int d = 0; d < D; ++d)
-                    if (!((dead >> d) & 1u) && L.mx[d] >= a.dc[d].dead_entry) newly |= 1u << d;
+                for (int d = 0; d < D; ++d) {
+                    // WIDE: the dead row absorbs, so the last real chain word tells; a byte >= 128 has no column and was
+                    // walked through its masked alias, so such a tile is re-walked as well
+                    const bool hit = WIDE ? ((L.mx[d] & kWideRowMask) == a.dc[d].dead_entry || hb != 0) : L.mx[d] >= a.dc[d].dead_entry;
+                    if (!((dead >> d) & 1u) && hit) newly |= 1u << d;
+                }
                 if (__any(newly != 0)) {
                     // the tile's bytes go to this walker's LDS scratch so that the re-walk can index them at run time
 #pragma unroll
@@ -1111,25 +1248,62 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                         if ((newly >> d) & 1u) {
                             uint32_t e = e_start[d];
                             const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
+                            bool found = false;
                             for (uint32_t p = 0; p < live_rows; ++p) {
                                 const uint32_t c = smem[scratch_off + lane * 64u + p];
-                                const uint32_t nx = table_at<GTAB>(a, (e & ~kTagMask) | (c << 2));
-                                if (nx >= a.dc[d].dead_entry) {
+                                uint32_t nx;
+                                bool bad;
+                                if (WIDE) {
+                                    nx = c < 128u ? lds_u32((e & kWideRowMask) | (c << 3)) : a.dc[d].dead_entry;
+                                    bad = (nx & kWideRowMask) == a.dc[d].dead_entry;
+                                } else {
+                                    nx = table_at<GTAB>(a, (e & ~kTagMask) | (c << 2));
+                                    bad = nx >= a.dc[d].dead_entry;
+                                }
+                                if (bad) {
                                     err_pos[d] = t0 + p;
-                                    err_state[d] = (e >> kNextShift) - a.dc[d].row_base;
+                                    err_state[d] = (WIDE ? ((e >> kWideRowShift) & 0xffu) : (e >> kNextShift)) - a.dc[d].row_base;
                                     err_char[d] = c;
+                                    found = true;
                                     break;
                                 }
                                 e = nx;
                             }
-                            dead |= 1u << d;
+                            if (found || !WIDE) dead |= 1u << d;
+                        }
+                    }
+                }
+                // ---------------- WIDE: two defs flagged the same row somewhere in this tile: find the row (rare) ----------------
+                if (WIDE && D > 1 && __any(tile_ov != 0 && L.ov_row == 0xffffffffu)) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i)
+                        *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(scratch_off + lane * 64u + i * 16u) =
+                            v4u32{cq[i].x, cq[i].y, cq[i].z, cq[i].w};
+                    if (tile_ov != 0 && L.ov_row == 0xffffffffu) {
+                        uint32_t e[D];
+#pragma unroll
+                        for (int d = 0; d < D; ++d) e[d] = e_start[d];
+                        const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
+                        for (uint32_t p = 0; p < live_rows && L.ov_row == 0xffffffffu; ++p) {
+                            const uint32_t c = smem[scratch_off + lane * 64u + p] & 0x7fu;
+                            uint32_t T = 0;
+#pragma unroll
+                            for (int d = 0; d < D; ++d) {
+                                e[d] = lds_u32((e[d] & kWideRowMask) | (c << 3));
+                                T += e[d];
+                            }
+                            if (t0 + p + 1u >= M) T &= ~(3u << kWideEndShift);
+                            const uint32_t F = T >> kWideStartShift;
+                            if (F & 2u) L.ov_row = t0 + p;                       // two is_start flags on row p
+                            else if (F & 8u) L.ov_row = t0 + p + 1u;             // two is_end flags on row p+1
                         }
                     }
                 }
                 // ---------------- accept state: the state at row n (lib.rs:437-457) ----------------
                 if (!full && n == t0 + 64u && t + 1 == ntiles) {  // n == M: row n does not exist, s[n] is the live state
 #pragma unroll
-                    for (int d = 0; d < D; ++d) acc_state[d] = (L.e[d] >> kNextShift) - a.dc[d].row_base;
+                    for (int d = 0; d < D; ++d)
+                        acc_state[d] = (WIDE ? ((L.e[d] >> kWideRowShift) & 0xffu) : (L.e[d] >> kNextShift)) - a.dc[d].row_base;
                 }
                 // ---------------- reveal masks: lib.rs:598-764 ----------------
                 TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
@@ -1209,6 +1383,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.gs = 64;
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
     out.gtab = 0;
+    out.wide = 0;
     // DFAs whose fused table leaves no room for the per-wave LDS areas are walked out of global memory (L2-resident)
     const size_t min_stage = (a.layout & 1u) ? (2 * 4096 + 4096 + 16) : wave_stage_bytes((int)a.D, 16);
     if (a.table_bytes + min_stage > kLdsLimit || (a.debug & 0x40000u)) out.gtab = 1;
@@ -1224,6 +1399,13 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
                 const size_t lds = a.table_bytes + (size_t)pairs * (ns * 4096 + 4096 + 16);
                 if (lds > kLdsLimit) continue;
                 out.split = 2;
+                // WIDE table: ~3x fewer VALU ops per row at D = 3, which shortens a string's serial walk — it wins while
+                // every group has a walker slot to itself (the launch then lasts one string's walk: 4.39 vs 5.09 ms at
+                // 32768 x 32768 B, D = 3) and loses 5-10 % once the slots are oversubscribed and the launch is bound by
+                // the store path (profiles/r01_config_sweep).  D = 1 gains nothing: its walk is LDS-latency-bound.
+                // debug 0x80000 forces the narrow table, 0x200000 the wide one.
+                out.wide = (a.wide_image && !out.gtab && !(a.debug & 0x80000u) &&
+                            ((a.D >= 2 && (size_t)a.n_groups <= (size_t)num_cus * 4) || (a.debug & 0x200000u))) ? 1 : 0;
                 out.waves_per_wg = 2 * pairs;
                 out.nslots = ns;
                 out.lds_bytes = lds;
@@ -1308,9 +1490,9 @@ static hipError_t launch_t(const WitnessArgs &a, const LaunchInfo &li, hipStream
     return hipGetLastError();
 }
 
-template <int D, bool GTAB>
+template <int D, bool GTAB, bool WIDE = false>
 static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto k = witness_pm_kernel<D, GTAB>;
+    auto k = witness_pm_kernel<D, GTAB, WIDE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)li.lds_bytes);
     if (e != hipSuccess) return e;
@@ -1320,6 +1502,7 @@ static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStrea
 
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
     if (li.split == 2) {
+        if (li.wide) return a.D == 1 ? launch_pm<1, false, true>(a, li, stream) : a.D == 2 ? launch_pm<2, false, true>(a, li, stream) : launch_pm<3, false, true>(a, li, stream);
         if (li.gtab) return a.D == 1 ? launch_pm<1, true>(a, li, stream) : a.D == 2 ? launch_pm<2, true>(a, li, stream) : launch_pm<3, true>(a, li, stream);
         return a.D == 1 ? launch_pm<1, false>(a, li, stream) : a.D == 2 ? launch_pm<2, false>(a, li, stream) : launch_pm<3, false>(a, li, stream);
     }

@@ -15,12 +15,13 @@ struct WitnessArgs {
     const uint32_t *lens;
     uint32_t B, M;
     uint32_t rec_pitch, msk_pitch;  // rows between consecutive strings in records / masked (>= M), string-major layout
-    uint32_t layout;                // 0 string-major [B][pitch][D] / [B][pitch]; 1 position-major [M/4][B][4][D] / [M/8][B][8]
+    uint32_t layout;                // 0 string-major [B][pitch][D] / [B][pitch]; 1 position-major [M/4][D][B][4] / [M/8][B][8]
     uint32_t *records;
     uint16_t *masked;
     uint64_t *status;
     const uint32_t *table_image;  // device copy of DefsSet::table_image
     uint32_t table_bytes;
+    const uint64_t *wide_image;   // device copy of DefsSet::wide_image (same byte size as table_image), or NULL
     uint32_t n_groups;            // ceil(B / gs), set by plan_witness_launch
     uint32_t gs;                  // strings per wave (64, 32 or 16), set by plan_witness_launch
     uint32_t D;
@@ -35,6 +36,7 @@ struct LaunchInfo {
     int waves_per_wg;  // split: 2 * pairs
     int nslots;        // split: ring slots per walker/storer pair
     int gtab;          // 1: fused table read from global memory (too large for LDS)
+    int wide;          // 1: position-major kernel on the WIDE table (hrx_lane.h)
     int grid;
     size_t lds_bytes;
 };

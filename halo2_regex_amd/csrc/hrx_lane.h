@@ -35,6 +35,16 @@ constexpr int kNextShift = 10;
 constexpr uint32_t kTagStart = 1u << 8;
 constexpr uint32_t kTagEnd = 1u << 9;
 
+// WIDE table (position-major kernel, DFAs whose symbols are all < 128): 8-byte entries, 128 columns, the same 1 KiB
+// per state row.  lo word = the walk's chain word, hi word = the finished compact record of the row.
+//   lo: bits 3..9 zero (column), 10..17 absolute table row of the NEXT state (the LDS byte address of that row),
+//       18..19 zero (carry guard), 20..27 substr_id, 28..29 is_start (a 2-bit counter field), 30..31 is_end (ditto):
+//       the per-row sums over the defs are ONE v_add3_u32 of the lo words, no masking.
+//   hi: state | substr_id << 16 | is_start << 24 | is_end << 25  (SURVEY App. A.4 record).
+constexpr int kWideRowShift = 10;
+constexpr uint32_t kWideRowMask = 0xffu << kWideRowShift;
+constexpr int kWideSidShift = 20, kWideStartShift = 28, kWideEndShift = 30;
+
 // compact witness record (u32): state | substr_id << 16 | start_enable << 24 | end_enable << 25
 constexpr uint32_t kRecEndBit = 1u << 25;
 

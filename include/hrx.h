@@ -131,11 +131,12 @@ int hrx_witness_batch_device_pitched(hrx_ctx *ctx, const uint8_t *chars, size_t 
 void hrx_recommended_pitches(size_t M, size_t *rec_pitch, size_t *msk_pitch, size_t *chars_stride);
 /* Output layouts of the device entry point below.
  *   HRX_LAYOUT_STRING_MAJOR   records [B][M][D], masked [B][M]                       (hrx_witness_batch_device)
- *   HRX_LAYOUT_POSITION_MAJOR records [ceil(M/4)][B][4][D], masked [ceil(M/8)][B][8]:
- *       record of (string b, row r, def d) at ((r/4*B + b)*4 + r%4)*D + d;  masked of (b, r) at (r/8*B + b)*8 + r%8.
- *       Four rows of one string are 16*D contiguous bytes and consecutive strings are adjacent, so with one GPU lane
- *       per string every store is a full contiguous line run and the whole device writes into one compact slab at a
- *       time — the layout the HBM write path rewards; rows >= M of the last quad/octet are unspecified.
+ *   HRX_LAYOUT_POSITION_MAJOR records [ceil(M/4)][D][B][4], masked [ceil(M/8)][B][8]:
+ *       record of (string b, row r, def d) at ((r/4*D + d)*B + b)*4 + r%4;  masked of (b, r) at (r/8*B + b)*8 + r%8.
+ *       Four rows of one string and def are 16 contiguous bytes and consecutive strings are adjacent, so with one GPU
+ *       lane per string every store instruction writes one contiguous 1-KiB run of full lines, and the whole device
+ *       writes into one compact slab at a time — the layout the HBM write path rewards; rows >= M of
+ *       the last quad/octet are unspecified.
  *       Buffer sizes: hrx_position_major_sizes.  The values are identical to the string-major ones.
  *   HRX_LAYOUT_INPUT_POSITION_MAJOR (or-ed with HRX_LAYOUT_POSITION_MAJOR): the input is chunked the same way,
  *       chars [stride/16][B][16]: byte i of string b at ((i/16)*B + b)*16 + i%16 — what a caller that assembles the

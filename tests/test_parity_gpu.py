@@ -314,6 +314,25 @@ def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
     _check_batch_pm(hra, oracle, CFG_123, chars, lens, 704)
 
 
+@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000)], ids=["narrow-table", "wide-table"])
+def test_position_major_kernel_on_both_table_formats(hra, oracle, flags, monkeypatch):
+    """The position-major kernel picks the WIDE table (8-byte entries: chain word + finished record) for D >= 2 while
+    every group has a walker slot; force each format through the same batches, D = 1..3, including strings with
+    undefined transitions, bytes >= 128 (no column in the WIDE table) and two defs flagging the same row."""
+    from halo2_regex_amd import synth
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", flags)
+    chars, lens = synth.reveal_stress(700, 700, seed=21)
+    chars[5, 100] = 200                      # a byte the DFAs have no column for
+    chars[6, 699] = 255
+    chars[7, 650] = 128
+    lens[7] = 600                            # ... beyond the string's length: must not matter
+    for cfg in (CFG_1, CFG_23, CFG_123, CFG_A):
+        _check_batch_pm(hra, oracle, cfg, chars, lens, 704)
+    chars, lens = synth.ragged(300, 200, seed=4)
+    _check_batch_pm(hra, oracle, CFG_123, chars, lens, 200)
+    _check_batch_pm(hra, oracle, [CFG_1[0], CFG_1[0]], chars, lens, 200)     # the same def twice: every flag overlaps
+
+
 @pytest.mark.parametrize("flags", ["65536", "196608"], ids=["one-wave-gs64", "one-wave-gs32"])
 def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
     """D <= 2 normally takes the walker/storer kernel; force the one-wave kernel (used for D = 3 and unaligned M)
