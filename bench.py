@@ -228,7 +228,10 @@ def main():
                        "sharding": "by string index, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, D),
-                         "kernel": ("hrx::witness_pm_kernel<%d>" % D) if pm else ("hrx::witness_split_kernel<%d,%d>" % (D, 32 // D)),
+                         "kernel": ("hrx::witness_pm_kernel<%d, %s, %s>" % (D, "true" if cfg.table_bytes() + 12304 > 160 * 1024 else "false",
+                                                                                 "true" if D >= 2 and (B + 63) // 64 <= 1024 and args.config != "dfa256" else "false"))
+                                   if pm else ("hrx::witness_split_kernel<%d, %d>" % (D, 32 // D) if D <= 2 and args.config != "dfa256"
+                                               else "hrx::witness_kernel<%d, ...>" % D),
                          "avg_launch_ms": kern_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D)},
         }

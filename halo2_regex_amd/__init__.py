@@ -292,7 +292,7 @@ class _DefsHandle:
             raise
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:   # (module globals are gone at interpreter shutdown)
             lib.hrx_defs_destroy(self.h)
             self.h = None
 
@@ -390,7 +390,7 @@ class RegexVerifyConfig:
         return cls(max_chars_size, regex_defs, device)
 
     def __del__(self):
-        if getattr(self, "_ctx", None):
+        if getattr(self, "_ctx", None) and lib is not None:
             lib.hrx_ctx_destroy(self._ctx)
             self._ctx = None
 
