@@ -110,6 +110,7 @@ def main():
                     help="regex1: BASELINE configs[1] (the metric's workload); regex23: configs[2] shape (D=2); regex123: D=3 with the "
                     "reference's three DFAs; headers3: configs[3] shape (D=3 from/to/subject header definitions, 5 substrs); dfa256: configs[4] shape (synthetic total 256-state DFA over all 256 byte values)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch the timed steps one by one instead of replaying a HIP graph of them")
     ap.add_argument("--dense", action="store_true", help="string-major: power-of-two pitches (M rows per string, n rounded to 16 "
                     "bytes) instead of hrx_recommended_pitches")
     ap.add_argument("--layout", choices=["position-major", "string-major"], default="position-major",
@@ -186,14 +187,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the kernel and geometry the planner picks for this shape on this device (what rocprofv3 will list)
+    desc = cfg.describe_launch(B, layout=3 if pm else 0, num_cus=torch.cuda.get_device_properties(dev).multi_processor_count)
+
     for _ in range(args.warmup):
         step()
+    barrier()
+    # The K timed steps are K kernel launches.  They are recorded once into a HIP graph (stream capture of the very same
+    # step() calls) and the graph is replayed inside the timed region, so that a slow host thread cannot turn the
+    # measurement into a launch-rate test (one launch is ~90 us of device time); --eager launches them one by one.
+    run_steps, launch_mode = None, "eager"
+    if not args.eager:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(args.steps):
+                        step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g.replay()                                     # one untimed replay: graph upload
+            torch.cuda.synchronize()
+            run_steps, launch_mode = g.replay, "hipGraph of %d kernel nodes" % args.steps
+        except Exception as e:                              # capture unsupported: fall back to plain launches
+            sys.stderr.write("graph capture failed (%s): eager launches\n" % e)
+            torch.cuda.synchronize()
+    if run_steps is None:
+        def run_steps():
+            for _ in range(args.steps):
+                step()   # launched on torch's current stream, where the events sit
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        step()   # launched on torch's current stream, where the events sit
+    run_steps()
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -225,13 +253,10 @@ def main():
                                    "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h)" % stride) if pm else
                                   ("string-major; input stride %d B, records pitch %d rows, masked pitch %d rows"
                                    % (stride, rec_pitch, msk_pitch)),
-                       "sharding": "by string index, no collective"},
+                       "sharding": "by string index, no collective", "launch_mode": launch_mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, D),
-                         "kernel": ("hrx::witness_pm_kernel<%d, %s, %s>" % (D, "true" if cfg.table_bytes() + 12304 > 160 * 1024 else "false",
-                                                                                 "true" if D >= 2 and (B + 63) // 64 <= 1024 and args.config != "dfa256" else "false"))
-                                   if pm else ("hrx::witness_split_kernel<%d, %d>" % (D, 32 // D) if D <= 2 and args.config != "dfa256"
-                                               else "hrx::witness_kernel<%d, ...>" % D),
+                         "kernel": desc.split(" grid=")[0], "launch": "grid=" + desc.split(" grid=")[1],
                          "avg_launch_ms": kern_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D)},
         }

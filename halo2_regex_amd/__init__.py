@@ -30,7 +30,8 @@ ABI_SYMBOLS = [
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
     "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
-    "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_witness_batch_host",
+    "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
+    "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
     "hrx_regex_to_allstr_text", "hrx_regex_to_dfa_json", "hrx_gen_regex_files", "hrx_regex_files_num_substrs",
     "hrx_regex_files_allstr", "hrx_regex_files_substr", "hrx_regex_files_destroy", "hrx_format_regex_str", "hrx_regex_find",
@@ -88,6 +89,7 @@ def _load():
         "hrx_recommended_pitches": (None, [sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "hrx_witness_batch_device_layout": (i, [vp, i, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "hrx_describe_launch": (i, [vp, i, sz, sz, i, C.c_char_p, sz]),
         "hrx_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
         "hrx_shard_range": (None, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_derive_states": (i, [vp, _u8p, sz, _u64p]),
@@ -412,6 +414,13 @@ class RegexVerifyConfig:
 
     def table_bytes(self):
         return lib.hrx_defs_table_bytes(self._defs.h)
+
+    def describe_launch(self, B, layout=0, num_cus=256):
+        """Kernel name and launch geometry the planner picks for B strings in `layout` (include/hrx.h: 0 string-major, 1 position-major
+        outputs, 3 position-major input and outputs); host-only; MI355X has 256 CUs."""
+        buf = C.create_string_buffer(256)
+        _check(lib.hrx_describe_launch(self._defs.h, layout, B, self.max_chars_size, num_cus, buf, 256))
+        return buf.value.decode()
 
     # -- the three derive_* of lib.rs:804-888 -----------------------------------------------------
     def derive_states(self, characters):

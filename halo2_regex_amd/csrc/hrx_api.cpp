@@ -57,6 +57,7 @@ struct hrx_ctx {
     hipStream_t stream = nullptr;
     uint32_t *d_table = nullptr;
     uint64_t *d_wide = nullptr;
+    uint16_t *d_half = nullptr;
     std::vector<uint16_t *> d_pair;
     std::vector<uint8_t *> d_member;
     std::mutex mu;
@@ -219,6 +220,10 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
         e = hipMalloc((void **)&c->d_wide, c->s.wide_image.size() * 8);
         if (e == hipSuccess) e = hipMemcpy(c->d_wide, c->s.wide_image.data(), c->s.wide_image.size() * 8, hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && !c->s.half_image.empty()) {
+        e = hipMalloc((void **)&c->d_half, c->s.half_image.size() * 2);
+        if (e == hipSuccess) e = hipMemcpy(c->d_half, c->s.half_image.data(), c->s.half_image.size() * 2, hipMemcpyHostToDevice);
+    }
     for (size_t d = 0; e == hipSuccess && d < c->s.pair_tags.size(); ++d) {
         uint16_t *p = nullptr;
         e = hipMalloc((void **)&p, c->s.pair_tags[d].size() * 2);
@@ -249,6 +254,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_wide) (void)hipFree(c->d_wide);
+    if (c->d_half) (void)hipFree(c->d_half);
     for (uint16_t *p : c->d_pair) (void)hipFree(p);
     for (uint8_t *p : c->d_member) (void)hipFree(p);
     c->chars.release(); c->lens.release(); c->records.release(); c->masked.release();
@@ -285,6 +291,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     a.records = records; a.masked = masked; a.status = status;
     a.table_image = ctx->d_table; a.table_bytes = (uint32_t)(ctx->s.table_image.size() * 4);
     a.wide_image = ctx->d_wide;
+    a.half_image = ctx->d_half; a.half_bytes = (uint32_t)(ctx->s.half_image.size() * 2);
     a.D = (uint32_t)ctx->s.defs.size();
     if (const char *dbg = std::getenv("HRX_DEBUG_FLAGS")) a.debug = (uint32_t)std::atoi(dbg);
     for (uint32_t d = 0; d < a.D; ++d) a.dc[d] = ctx->s.consts[d];
@@ -317,6 +324,31 @@ int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *cha
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream, 0, 0, layout);
+}
+
+int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap) {
+    if (!defs || !out || !cap) return fail(HRX_ERR_ARG, "NULL argument");
+    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
+    if (num_cus < 1) return fail(HRX_ERR_ARG, "num_cus must be >= 1");
+    const DefsSet &s = defs->s;
+    WitnessArgs a{};
+    a.layout = (uint32_t)layout; a.B = (uint32_t)B; a.M = (uint32_t)M;
+    // the planner only looks at which images exist and how large they are
+    a.table_image = s.table_image.data(); a.table_bytes = (uint32_t)(s.table_image.size() * 4);
+    a.wide_image = s.wide_image.empty() ? nullptr : s.wide_image.data();
+    a.half_image = s.half_image.empty() ? nullptr : s.half_image.data();
+    a.half_bytes = (uint32_t)(s.half_image.size() * 2);
+    a.D = (uint32_t)s.defs.size();
+    if (const char *dbg = std::getenv("HRX_DEBUG_FLAGS")) a.debug = (uint32_t)std::atoi(dbg);
+    LaunchInfo li;
+    if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+    char name[128];
+    const char *tf[2] = {"false", "true"};
+    if (li.split == 2) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, %s, %s, %s>", a.D, tf[li.gtab], tf[li.wide], tf[li.half]);
+    else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u>", a.D, 32u / a.D);
+    else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
+    std::snprintf(out, cap, "%s grid=%d waves=%d ring=%d lds=%zu", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+    return HRX_OK;
 }
 
 void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16) {

@@ -110,7 +110,7 @@ int finalize_defs(DefsSet &s, std::string &err) {
     s.consts.clear();
     s.pair_tags.clear();
     s.endpoint_member.clear();
-    size_t total_rows = 0;
+    size_t total_rows = 0, half_rows = 0;
     uint64_t off = 1;          // substr_id_offset, lib.rs:780,827,854
     uint64_t max_sid_sum = 0;  // largest value Σ_d substr_id_d can take (masked_substr_id is a u8)
     for (size_t d = 0; d < s.defs.size(); ++d) {
@@ -131,6 +131,10 @@ int finalize_defs(DefsSet &s, std::string &err) {
         c.dead_entry = (uint32_t)(total_rows + L + 2) << kNextShift;
         c.accepted_state = (uint32_t)rd.allstr.accepted_state_val;
         c.substr_id_offset = (uint32_t)off;
+        c.half_row_base = (uint32_t)half_rows;
+        c.first_state = (uint32_t)rd.allstr.first_state_val;
+        c.dummy_state = (uint32_t)L + 1;
+        half_rows += L + 1;
         s.consts.push_back(c);
         total_rows += c.n_rows;
         if (!rd.substrs.empty()) max_sid_sum += off + rd.substrs.size() - 1;
@@ -194,6 +198,21 @@ int finalize_defs(DefsSet &s, std::string &err) {
                 const uint64_t lo = (uint64_t)(c.row_base + next) << kWideRowShift | sid << kWideSidShift | is_start << kWideStartShift |
                                     is_end << kWideEndShift;
                 W[cur * 128 + ch] = lo | (cur | tag << 16) << 32;
+            }
+        }
+    }
+    // HALF image for the position-major kernel: 2-byte entries, real states only
+    s.half_image.clear();
+    if (half_rows <= 256 && off - 1 <= kHalfMaxSid) {
+        s.half_image.assign(half_image_bytes((uint32_t)half_rows) / 2, (uint16_t)kHalfDead);
+        for (size_t d = 0; d < s.defs.size(); ++d) {
+            const RegexDefs &rd = s.defs[d];
+            const DefConsts &c = s.consts[d];
+            for (const auto &kv : rd.allstr.state_lookup) {
+                const uint32_t ch = (uint32_t)kv.first.first, cur = (uint32_t)kv.first.second, next = (uint32_t)kv.second.next;
+                const uint32_t tag = pair_tag(rd, c.substr_id_offset, cur, next);
+                const uint32_t e = (c.half_row_base + next) | (tag & 0x3fu) << 8 | ((tag >> 8) & 3u) << 14;
+                s.half_image[half_addr(c.half_row_base + cur, ch) / 2] = (uint16_t)e;
             }
         }
     }

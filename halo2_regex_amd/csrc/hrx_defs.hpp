@@ -50,6 +50,8 @@ struct DefConsts {
     uint32_t dead_entry;   // (row_base + largest+2) << 10 : absorbing sink of undefined transitions (lib.rs:817)
     uint32_t accepted_state;
     uint32_t substr_id_offset;
+    uint32_t half_row_base;  // first row of this def inside the HALF image (real states only: largest+1 rows per def)
+    uint32_t first_state, dummy_state;  // first_state_val, largest+1
 };
 
 struct DefsSet {
@@ -60,6 +62,9 @@ struct DefsSet {
     // WIDE image (hrx_lane.h): n_rows x 128 u64 entries per def, same row numbering; empty unless every transition
     // symbol is < 128 and the rows fit an 8-bit row number
     std::vector<uint64_t> wide_image;
+    // HALF image (hrx_lane.h): the exact LDS image, half_image_bytes(total real states) bytes; empty unless all defs
+    // together have <= 256 real states and every substr id is <= kHalfMaxSid
+    std::vector<uint16_t> half_image;
     std::vector<DefConsts> consts;
     // (cur,next) -> {sid, is_start(cur), is_end(next)} per def, for the states-in entry points (lib.rs:825-888)
     std::vector<std::vector<uint16_t>> pair_tags;  // [(largest+1)^2], entry = tag bits as in the fused table

@@ -13,6 +13,8 @@
 // Pure integer/indexing work: no MFMA, HBM-bound by construction (1 B read, 4*D+2 B written per row).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "hrx_kernel.hpp"
 #include "hrx_lane.h"
 
@@ -857,7 +859,14 @@ __device__ __forceinline__ void store16(unsigned char *p, const uint4 &v, const 
     else *reinterpret_cast<uint4 *>(p) = v;
 }
 
-template <int D, bool FULL, bool GTAB>
+typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+__device__ __forceinline__ uint32_t lds_u16(uint32_t off) { return *(lds_cu16 *)(uintptr_t)off; }
+// HALF table (hrx_lane.h): address of entry (row of `e`, byte c) from e and c2 = c << 1 — one v_perm_b32:
+// byte 0 = c2.byte0 = (c & 127) << 1, byte 1 = e.byte0 = row, byte 2 = c2.byte1 = c >> 7, byte 3 = 0
+__device__ __forceinline__ uint32_t half_next_addr(uint32_t e, uint32_t c2) { return __builtin_amdgcn_perm(e, c2, 0x0c010400u); }
+__device__ __forceinline__ uint32_t half_tag(uint32_t e) { return ((e >> 8) & 0x3fu) | ((e >> 14) << 8); }  // -> the narrow format's 10-bit tag
+
+template <int D, bool FULL, bool GTAB, bool HALF = false>
 __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, unsigned char *&rp,
                                                  const size_t rstep, const bool do_store, int rem, int mrem, uint32_t t0,
                                                  uint32_t (&sidq)[16], uint32_t (&acc_state)[D], const uint4 (&pend)[8],
@@ -875,9 +884,10 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
         uint32_t sid = 0, stn = 0, enn = 0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const uint32_t state = (es[d] >> kNextShift) - (d ? a.dc[d].row_base : 0u);
-            uint32_t tag = et[d] & kTagMask;
+            uint32_t state = HALF ? (es[d] & 0xffu) - (d ? a.dc[d].half_row_base : 0u) : (es[d] >> kNextShift) - (d ? a.dc[d].row_base : 0u);
+            uint32_t tag = HALF ? half_tag(et[d]) : et[d] & kTagMask;
             if (!FULL) {
+                if (HALF && p > rem) state = a.dc[d].dummy_state;  // the HALF image has no dummy row (lib.rs:413)
                 if (p >= mrem) tag &= ~kTagEnd;
                 if (p == rem) acc_state[d] = state;  // the state at row n (lib.rs:437-457)
             }
@@ -888,7 +898,7 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
                     store16(rp + (size_t)d * plane, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]), (a.debug & 32u) != 0);
                 if (d == D - 1) rp += rstep;
             }
-            if (!FULL) L.mx[d] = max(L.mx[d], et[d]);
+            if (!FULL || HALF) L.mx[d] = max(L.mx[d], et[d]);  // HALF: an undefined transition is a marked entry, not an absorbing row
             sid += tag & 0xffu;
             stn += (tag >> 8) & 1u;
             enn += (tag >> 9) & 1u;
@@ -913,14 +923,15 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int p = q * 4 + k;
-            const uint32_t c4 = ((cw[q] >> (8 * k)) & 0xffu) << 2;
+            const uint32_t c4 = ((cw[q] >> (8 * k)) & 0xffu) << (HALF ? 1 : 2);
 #pragma unroll
-            for (int d = 0; d < D; ++d) raw[d] = table_at<GTAB>(a, (e1[d] & ~kTagMask) | c4);  // delta(state, byte): lib.rs:810
+            for (int d = 0; d < D; ++d)  // delta(state, byte): lib.rs:810
+                raw[d] = HALF ? lds_u16(half_next_addr(e1[d], c4)) : table_at<GTAB>(a, (e1[d] & ~kTagMask) | c4);
             if (p > 0) {
                 post(p - 1, e2, e1);
                 asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(ch[(p - 1) >> 5]), "+v"(L.sid_prev),
                              "+v"(sidq[(p - 1) >> 2]));
-                if (!FULL) {
+                if (!FULL || HALF) {
 #pragma unroll
                     for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]));
                 }
@@ -930,7 +941,8 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 e2[d] = e1[d];
-                e1[d] = (FULL || p < rem) ? raw[d] : a.dc[d].dummy_entry;  // rows >= n: lib.rs:404-418
+                // rows >= n: lib.rs:404-418 (HALF: any valid row with an empty tag; post() writes the dummy state)
+                e1[d] = (FULL || p < rem) ? raw[d] : (HALF ? a.dc[d].half_row_base : a.dc[d].dummy_entry);
             }
         }
     }
@@ -1060,7 +1072,7 @@ __device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint
     return tb;
 }
 
-template <int D, bool GTAB, bool WIDE>
+template <int D, bool GTAB, bool WIDE, bool HALF = false>
 __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1069,15 +1081,18 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     const uint32_t pair = is_walker ? wave : wave - pairs;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
-    const uint32_t pair_bytes = nring * kPmTileBytes + kPmTileBytes + 16u;  // ring + the walker's 4-KiB scratch + counters
-    const uint32_t ring_base = (GTAB ? 0u : a.table_bytes) + pair * pair_bytes;
+    // ring + the walker's 4-KiB scratch (HALF: none, its slow path re-walks out of registers) + counters
+    const uint32_t pair_bytes = nring * kPmTileBytes + (HALF ? 0u : kPmTileBytes) + 16u;
+    const uint32_t tab_bytes = GTAB ? 0u : HALF ? a.half_bytes : a.table_bytes;
+    const uint32_t ring_base = tab_bytes + pair * pair_bytes;
     const uint32_t scratch_off = ring_base + nring * kPmTileBytes;
-    const uint32_t ready_off = scratch_off + kPmTileBytes, freed_off = ready_off + 4u;
+    const uint32_t ready_off = scratch_off + (HALF ? 0u : kPmTileBytes), freed_off = ready_off + 4u;
     {
-        const uint4 *src = WIDE ? reinterpret_cast<const uint4 *>(a.wide_image) : reinterpret_cast<const uint4 *>(a.table_image);
+        const uint4 *src = WIDE ? reinterpret_cast<const uint4 *>(a.wide_image)
+                                : HALF ? reinterpret_cast<const uint4 *>(a.half_image) : reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         if (!GTAB)
-            for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+            for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) dst[i] = src[i];
         if (is_walker && lane == 0) { lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0); }
     }
     __syncthreads();
@@ -1161,7 +1176,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
             LaneRegs<D> L;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                L.e[d] = a.dc[d].first_entry;  // states[d][0] = first_state_val: lib.rs:807
+                L.e[d] = HALF ? a.dc[d].half_row_base + a.dc[d].first_state : a.dc[d].first_entry;  // states[d][0] = first_state_val: lib.rs:807
                 L.mx[d] = 0;
             }
             L.sid_prev = 0;
@@ -1172,7 +1187,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 err_pos[d] = err_state[d] = err_char[d] = 0;
-                acc_state[d] = (uint32_t)(a.dc[d].first_entry >> kNextShift) - a.dc[d].row_base;  // n == 0
+                acc_state[d] = a.dc[d].first_state;  // n == 0
             }
             const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
             unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * ((a.debug & 0x100000u) ? D : 1);
@@ -1223,9 +1238,9 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                         hb &= 0x80808080u;
                     }
                 } else if (full)
-                    tb = walk_tile_pm<D, true, GTAB>(L, cq, a, rp, rstep, do_store, 0, 0, t0, sidq, acc_state, pend, pend_mp, mstep, pend_store);
+                    tb = walk_tile_pm<D, true, GTAB, HALF>(L, cq, a, rp, rstep, do_store, 0, 0, t0, sidq, acc_state, pend, pend_mp, mstep, pend_store);
                 else
-                    tb = walk_tile_pm<D, false, GTAB>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state,
+                    tb = walk_tile_pm<D, false, GTAB, HALF>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state,
                                                 pend, pend_mp, mstep, pend_store);
 
                 // ---------------- undefined transition (lib.rs:817): rare slow path, re-walk the tile ----------------
@@ -1234,10 +1249,37 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 for (int d = 0; d < D; ++d) {
                     // WIDE: the dead row absorbs, so the last real chain word tells; a byte >= 128 has no column and was
                     // walked through its masked alias, so such a tile is re-walked as well
-                    const bool hit = WIDE ? ((L.mx[d] & kWideRowMask) == a.dc[d].dead_entry || hb != 0) : L.mx[d] >= a.dc[d].dead_entry;
+                    const bool hit = WIDE ? ((L.mx[d] & kWideRowMask) == a.dc[d].dead_entry || hb != 0)
+                                          : HALF ? L.mx[d] >= kHalfDead : L.mx[d] >= a.dc[d].dead_entry;
                     if (!((dead >> d) & 1u) && hit) newly |= 1u << d;
                 }
-                if (__any(newly != 0)) {
+                if (HALF && __any(newly != 0)) {
+                    // no scratch area in this variant (a 256-state table leaves 32 KiB of LDS for all the rings): the tile is
+                    // re-walked out of the byte registers, fully unrolled
+                    const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
+                                              cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+                    const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        if ((newly >> d) & 1u) {
+                            uint32_t e = e_start[d];
+                            bool found = false;
+#pragma unroll
+                            for (int p = 0; p < 64; ++p) {
+                                const uint32_t c = (cwl[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                                const uint32_t nx = lds_u16(half_addr(e & 0xffu, c));
+                                if (!found && (uint32_t)p < live_rows && nx >= kHalfDead) {
+                                    err_pos[d] = t0 + (uint32_t)p;
+                                    err_state[d] = (e & 0xffu) - a.dc[d].half_row_base;
+                                    err_char[d] = c;
+                                    found = true;
+                                }
+                                e = nx;
+                            }
+                            dead |= 1u << d;
+                        }
+                    }
+                } else if (__any(newly != 0)) {
                     // the tile's bytes go to this walker's LDS scratch so that the re-walk can index them at run time
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i)
@@ -1303,21 +1345,25 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 if (!full && n == t0 + 64u && t + 1 == ntiles) {  // n == M: row n does not exist, s[n] is the live state
 #pragma unroll
                     for (int d = 0; d < D; ++d)
-                        acc_state[d] = (WIDE ? ((L.e[d] >> kWideRowShift) & 0xffu) : (L.e[d] >> kNextShift)) - a.dc[d].row_base;
+                        acc_state[d] = HALF ? (L.e[d] & 0xffu) - a.dc[d].half_row_base
+                                            : (WIDE ? ((L.e[d] >> kWideRowShift) & 0xffu) : (L.e[d] >> kNextShift)) - a.dc[d].row_base;
                 }
                 // ---------------- reveal masks: lib.rs:598-764 ----------------
                 TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
                 if (!active) { tm.mask = 0; tm.fix = 0; }
+                // An earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare with real definitions; a
+                // random DFA like cfg 5's takes this path every few tiles, and there each 16-byte piece re-written in a line
+                // that has left L2 is a read-modify-write at the memory: measured 521 vs 357 us with the fix-ups skipped;
+                // a per-lane variant that zeroes whole octets with 16-byte stores was no better — 558 us).
                 uint64_t fixm = __ballot(tm.fix != 0);
-                if (fixm) {  // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare)
-                    while (fixm) {
-                        const int j = __ffsll((unsigned long long)fixm) - 1;
-                        fixm &= fixm - 1;
-                        const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
-                        const uint32_t bj = b0 + (uint32_t)j;
-                        for (uint32_t r = fs + lane; r < t0; r += 64u)
-                            a.masked[((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
-                    }
+                if (a.debug & 0x800000u) fixm = 0;  // profiling only: skip the fix-ups
+                while (fixm) {
+                    const int j = __ffsll((unsigned long long)fixm) - 1;
+                    fixm &= fixm - 1;
+                    const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
+                    const uint32_t bj = b0 + (uint32_t)j;
+                    for (uint32_t r = fs + lane; r < t0; r += 64u)
+                        a.masked[((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
                 }
                 // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8]; stored during the next walk ----------------
                 {
@@ -1384,12 +1430,37 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
     out.gtab = 0;
     out.wide = 0;
+    out.half = 0;
     // DFAs whose fused table leaves no room for the per-wave LDS areas are walked out of global memory (L2-resident)
     const size_t min_stage = (a.layout & 1u) ? (2 * 4096 + 4096 + 16) : wave_stage_bytes((int)a.D, 16);
     if (a.table_bytes + min_stage > kLdsLimit || (a.debug & 0x40000u)) out.gtab = 1;
     const uint32_t table_bytes_saved = a.table_bytes;
     struct Restore { WitnessArgs &a; uint32_t v; ~Restore() { a.table_bytes = v; } } restore{a, table_bytes_saved};
     if (out.gtab) a.table_bytes = 0;  // for the LDS budgeting below only; restored on return
+    if ((a.layout & 1u) && a.half_image && ((out.gtab && !(a.debug & 0x40000u)) || (a.debug & 0x400000u))) {
+        // ---- loader/walker kernel on the HALF table (2-byte entries): DFAs of up to 256 states whose 4-byte table does not
+        // fit LDS (cfg 5: 256 x 256 -> 128 KiB) stay LDS-resident instead of being walked out of L2 (debug 0x400000 forces it)
+        int pairs = 4;
+        while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        for (; pairs >= 1; --pairs) {
+            for (int ns = 4; ns >= 1; --ns) {
+                const size_t lds = a.half_bytes + (size_t)pairs * (ns * 4096 + 16);
+                if (lds > kLdsLimit) continue;
+                out.split = 2; out.gtab = 0; out.wide = 0; out.half = 1;
+                out.waves_per_wg = 2 * pairs;
+                out.nslots = ns;
+                out.lds_bytes = lds;
+                const size_t need = ((size_t)a.n_groups + pairs - 1) / pairs;
+                size_t per_cu = kLdsLimit / lds;
+                if (per_cu * (size_t)(2 * pairs) > 8) per_cu = 8 / (size_t)(2 * pairs);
+                if (per_cu < 1) per_cu = 1;
+                const size_t cap = (size_t)num_cus * per_cu;
+                out.grid = (int)(need < cap ? need : cap);
+                if (out.grid < 1) out.grid = 1;
+                return true;
+            }
+        }
+    }
     if (a.layout & 1u) {
         // ---- loader/walker kernel: table + per pair a ring of up to 4 input tiles (4 KiB each)
         int pairs = 4;
@@ -1470,11 +1541,23 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     return true;
 }
 
+// hipFuncSetAttribute costs several microseconds of host time: raise a kernel's dynamic-LDS limit only when a launch
+// needs more than every earlier launch of that kernel did (the launch path is otherwise one hipLaunchKernelGGL).
+template <class K>
+static hipError_t ensure_lds(K k, std::atomic<size_t> &granted, size_t need) {
+    if (need <= granted.load(std::memory_order_acquire)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+    if (e == hipSuccess) granted.store(need, std::memory_order_release);
+    return e;
+}
+
 template <int D, int T>
 static hipError_t launch_split(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
     auto k = witness_split_kernel<D, T>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)li.lds_bytes);
+    static std::atomic<size_t> granted[64];  // per device: the attribute is set on the current device's function
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t e = ensure_lds(k, granted[dev & 63], li.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(li.grid), dim3(64 * li.waves_per_wg), li.lds_bytes, stream, a, (uint32_t)li.nslots);
     return hipGetLastError();
@@ -1483,18 +1566,22 @@ static hipError_t launch_split(const WitnessArgs &a, const LaunchInfo &li, hipSt
 template <int D, bool ALIGNED, bool GTAB>
 static hipError_t launch_t(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
     auto k = witness_kernel<D, ALIGNED, GTAB>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)li.lds_bytes);
+    static std::atomic<size_t> granted[64];  // per device: the attribute is set on the current device's function
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t e = ensure_lds(k, granted[dev & 63], li.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(li.grid), dim3(64 * li.waves_per_wg), li.lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-template <int D, bool GTAB, bool WIDE = false>
+template <int D, bool GTAB, bool WIDE = false, bool HALF = false>
 static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto k = witness_pm_kernel<D, GTAB, WIDE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)li.lds_bytes);
+    auto k = witness_pm_kernel<D, GTAB, WIDE, HALF>;
+    static std::atomic<size_t> granted[64];  // per device: the attribute is set on the current device's function
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t e = ensure_lds(k, granted[dev & 63], li.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(li.grid), dim3(64 * li.waves_per_wg), li.lds_bytes, stream, a, (uint32_t)li.nslots);
     return hipGetLastError();
@@ -1502,6 +1589,7 @@ static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStrea
 
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
     if (li.split == 2) {
+        if (li.half) return a.D == 1 ? launch_pm<1, false, false, true>(a, li, stream) : a.D == 2 ? launch_pm<2, false, false, true>(a, li, stream) : launch_pm<3, false, false, true>(a, li, stream);
         if (li.wide) return a.D == 1 ? launch_pm<1, false, true>(a, li, stream) : a.D == 2 ? launch_pm<2, false, true>(a, li, stream) : launch_pm<3, false, true>(a, li, stream);
         if (li.gtab) return a.D == 1 ? launch_pm<1, true>(a, li, stream) : a.D == 2 ? launch_pm<2, true>(a, li, stream) : launch_pm<3, true>(a, li, stream);
         return a.D == 1 ? launch_pm<1, false>(a, li, stream) : a.D == 2 ? launch_pm<2, false>(a, li, stream) : launch_pm<3, false>(a, li, stream);

@@ -22,6 +22,8 @@ struct WitnessArgs {
     const uint32_t *table_image;  // device copy of DefsSet::table_image
     uint32_t table_bytes;
     const uint64_t *wide_image;   // device copy of DefsSet::wide_image (same byte size as table_image), or NULL
+    const uint16_t *half_image;   // device copy of DefsSet::half_image (the exact LDS image, half_bytes long), or NULL
+    uint32_t half_bytes;
     uint32_t n_groups;            // ceil(B / gs), set by plan_witness_launch
     uint32_t gs;                  // strings per wave (64, 32 or 16), set by plan_witness_launch
     uint32_t D;
@@ -37,6 +39,7 @@ struct LaunchInfo {
     int nslots;        // split: ring slots per walker/storer pair
     int gtab;          // 1: fused table read from global memory (too large for LDS)
     int wide;          // 1: position-major kernel on the WIDE table (hrx_lane.h)
+    int half;          // 1: position-major kernel on the HALF table (hrx_lane.h)
     int grid;
     size_t lds_bytes;
 };

@@ -45,6 +45,19 @@ constexpr int kWideRowShift = 10;
 constexpr uint32_t kWideRowMask = 0xffu << kWideRowShift;
 constexpr int kWideSidShift = 20, kWideStartShift = 28, kWideEndShift = 30;
 
+// HALF table (position-major kernel; all defs together have at most 256 real states and substr ids <= 62): 2-byte
+// entries, so that a 256-state x 256-symbol DFA (cfg 5) is LDS-resident in 128 KiB instead of being walked out of L2.
+//   bits 0..7   absolute table row of the NEXT state (rows = real states only: no dummy row, no dead row)
+//   bits 8..13  substr_id, bit 14 is_start, bit 15 is_end of the next row; 0xff in the high byte = undefined transition
+//               (lib.rs:817; not absorbing: the walk goes on from row 0 and the running max of the entries tells)
+// LDS byte address of entry (row, c) = (c >> 7) << 16 | row << 8 | (c & 127) << 1: every field is byte-aligned, so the
+// next lookup address is ONE v_perm_b32 of the entry and the pre-shifted byte (c << 1).
+constexpr uint32_t kHalfDead = 0xff00u;
+constexpr uint32_t kHalfUpperBase = 1u << 16;     // LDS byte offset of the columns 128..255
+constexpr uint32_t kHalfMaxSid = 62;
+HRX_HD uint32_t half_addr(uint32_t row, uint32_t c) { return ((c >> 7) << 16) | (row << 8) | ((c & 127u) << 1); }
+HRX_HD uint32_t half_image_bytes(uint32_t rows) { return kHalfUpperBase + rows * 256u; }
+
 // compact witness record (u32): state | substr_id << 16 | start_enable << 24 | end_enable << 25
 constexpr uint32_t kRecEndBit = 1u << 25;
 

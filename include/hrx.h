@@ -145,6 +145,11 @@ enum { HRX_LAYOUT_STRING_MAJOR = 0, HRX_LAYOUT_POSITION_MAJOR = 1, HRX_LAYOUT_IN
 int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,
                                     size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream);
 void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16);
+/* Which kernel and launch geometry the planner picks for a batch of B strings x M rows in `layout` on a gfx950 device
+ * with `num_cus` compute units (MI355X: 256), as text: "hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8
+ * ring=1 lds=147520" — the kernel name a profiler will show (bench.py's roofline.kernel).  Host-only: nothing is
+ * launched and no device is touched.  Returns HRX_OK, HRX_ERR_BOUNDS if nothing fits. */
+int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap);
 /* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers; synchronous. */
 int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
                            size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);

@@ -144,6 +144,29 @@ void sim_witness_batch_w(void *p, int W, const uint8_t *chars, size_t stride, co
     else sim_batch_w<64>(p, chars, stride, lens, B, M, records, masked, status, fixups);
 }
 
+// HALF image (2-byte entries, hrx_lane.h) against the 4-byte fused table, entry by entry.
+// Returns the number of (state, byte) entries compared, -1 if the defs have no HALF image, -2 - index on a mismatch.
+long sim_check_half_image(void *p) {
+    const DefsSet &s = *(DefsSet *)p;
+    if (s.half_image.empty()) return -1;
+    long n = 0;
+    for (size_t d = 0; d < s.defs.size(); ++d) {
+        const DefConsts &c = s.consts[d];
+        for (uint32_t st = 0; st + 3 <= c.n_rows; ++st)   // real states only
+            for (uint32_t ch = 0; ch < 256; ++ch, ++n) {
+                const uint32_t e4 = s.table_image[(size_t)(c.row_base + st) * 256 + ch];
+                const uint32_t e2 = s.half_image[half_addr(c.half_row_base + st, ch) / 2];
+                if ((e4 & ~kTagMask) == c.dead_entry) {
+                    if (e2 < kHalfDead) return -2 - n;
+                    continue;
+                }
+                const uint32_t tag = ((e2 >> 8) & 0x3fu) | ((e2 >> 14) << 8);
+                if (e2 >= kHalfDead || (e2 & 0xffu) - c.half_row_base != (e4 >> kNextShift) - c.row_base || tag != (e4 & kTagMask)) return -2 - n;
+            }
+    }
+    return n;
+}
+
 // direct access to the scan primitives for property tests
 uint64_t sim_fill_up(uint64_t set, uint64_t rst, uint32_t cin) { return fill_up(set, rst, cin); }
 uint64_t sim_fill_down(uint64_t set, uint64_t rst, uint32_t cin) { return fill_down(set, rst, cin); }

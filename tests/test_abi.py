@@ -127,3 +127,24 @@ def test_compute_fails_loudly_without_a_device():
         cfg.derive_states(b"from:a@b.com\r\n")
     with pytest.raises(hra.HrxError):
         cfg.witness_batch_host(np.zeros((1, 16), np.uint8), np.zeros(1, np.uint32))
+
+
+def test_planner_picks_the_documented_kernel_per_config():
+    """hrx_describe_launch (host-only): which kernel and table format serve which shape on a 256-CU MI355X."""
+    from halo2_regex_amd import synth
+    cfg = RegexVerifyConfig.configure(1024, _defs(CFG_A[:1]), device=None)
+    assert cfg.describe_launch(65536, layout=3).startswith("hrx::witness_pm_kernel<1, false, false, false> grid=256 waves=8 ")
+    assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_split_kernel<1, 32> ")
+    cfg = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
+    assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> ")     # WIDE while groups <= 4 x CUs
+    assert cfg.describe_launch(1 << 20, layout=1).startswith("hrx::witness_pm_kernel<2, false, false, false> ")
+    # cfg 5: 256 states x 256 symbols = 258 KiB of 4-byte entries -> the 128-KiB HALF table, LDS-resident
+    a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=np.arange(256, dtype=np.uint8), n_substr_pairs=200)
+    cfg = RegexVerifyConfig.configure(4096, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)
+    d = cfg.describe_launch(65536, layout=3)
+    assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8 ") and "lds=%d" % (128 * 1024 + 4 * (4096 + 16)) in d
+    assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_kernel<1, true, true> ")                # string-major: global table
+    # beyond 256 states there is no HALF image: global-table walk
+    a_txt, sub_txt = synth.random_dfa(300, seed=2)
+    cfg = RegexVerifyConfig.configure(1024, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)
+    assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<1, true, false, false> ")

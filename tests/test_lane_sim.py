@@ -28,6 +28,8 @@ def sim():
     lib.sim_push_allstr.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.sim_push_substr.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.sim_finalize.argtypes = [C.c_void_p]
+    lib.sim_check_half_image.argtypes = [C.c_void_p]
+    lib.sim_check_half_image.restype = C.c_long
     lib.sim_witness_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sim_witness_batch_w.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
@@ -162,3 +164,15 @@ def test_flag_overlap_is_reported(oracle, sim):
     c = np.zeros((2, 32), np.uint8); c[0, :len(inp)] = np.frombuffer(inp, np.uint8)
     st, _, _ = _compare(oracle, sim, cfg, c, np.array([len(inp), 0], np.uint32), 64)
     assert int(st[0]) & 0xff == 2 and int(st[1]) & 0xff == 0
+
+
+def test_half_table_image_equals_the_fused_table(sim):
+    """The 2-byte HALF image (LDS-resident tables for DFAs of up to 256 states, cfg 5) carries exactly the transitions,
+    substr ids and start/end flags of the 4-byte fused table; it does not exist beyond 256 states."""
+    for cfg, states in ((CFG_1, 29), (CFG_A, 29 + 13), (CFG_23, 13 + 20)):
+        assert sim.sim_check_half_image(SimDefs(sim, cfg).h) == states * 256
+    allb = np.arange(256, dtype=np.uint8)
+    a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=200)
+    assert sim.sim_check_half_image(SimDefs(sim, [(a_txt.encode(), [sub_txt.encode()])]).h) == 256 * 256
+    a_txt, sub_txt = synth.random_dfa(300, seed=5, alphabet=allb[:64], n_substr_pairs=50)
+    assert sim.sim_check_half_image(SimDefs(sim, [(a_txt.encode(), [sub_txt.encode()])]).h) == -1

@@ -275,8 +275,9 @@ def test_cfg3_shape_two_defs_2048_byte_strings(hra, oracle):
 
 
 def test_cfg5_shape_256_state_dense_dfa_4096_byte_strings(hra, oracle):
-    """BASELINE configs[4] shape: synthetic total DFA, 256 states x 256 symbols (258 KiB of fused table: global-table
-    kernels), 4096-byte inputs over all byte values."""
+    """BASELINE configs[4] shape: synthetic total DFA, 256 states x 256 symbols (258 KiB of 4-byte fused table: the
+    position-major kernel walks the 128-KiB HALF table in LDS, the string-major one the global table), 4096-byte inputs over
+    all byte values."""
     from halo2_regex_amd import synth
     allstr, sub = synth.random_dfa(256, seed=2, alphabet=np.arange(256, dtype=np.uint8), n_substr_pairs=200)
     defs = [hra.RegexDefs(hra.AllstrRegexDef(allstr), [hra.SubstrRegexDef(sub)])]
@@ -288,6 +289,36 @@ def test_cfg5_shape_256_state_dense_dfa_4096_byte_strings(hra, oracle):
     st = _sample_check(hra, o, cfg, chars, lens, M, 1, 96, 5, position_major=True)
     assert (st & np.uint64(0xff) == 0).all()
     _sample_check(hra, o, cfg, chars, lens, M, 1, 96, 6, position_major=False)
+
+
+def test_half_table_kernel_on_dfas_of_up_to_256_states(hra, oracle):
+    """DFAs of 141..256 states: the 4-byte fused table does not fit LDS next to the input rings, the 2-byte HALF table does
+    (position-major kernel).  Total and partial DFAs (undefined transitions -> status 1 with the reference's state/char),
+    ragged lengths, bytes outside the alphabet."""
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    for nstates, total, seed, alpha in ((200, False, 7, synth.ALPHABET98), (256, True, 2, np.arange(256, dtype=np.uint8)),
+                                        (160, False, 9, np.arange(256, dtype=np.uint8))):
+        allstr, sub = synth.random_dfa(nstates, seed=seed, total=total, alphabet=alpha, n_substr_pairs=120)
+        defs = [hra.RegexDefs(hra.AllstrRegexDef(allstr), [hra.SubstrRegexDef(sub)])]
+        M = 328
+        cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+        assert cfg.table_bytes() == (nstates + 2) * 1024
+        o = OracleDefs(oracle, [(allstr, [sub])])
+        chars, lens = synth.ragged(700, M, seed=nstates, planted=False, alphabet=alpha)
+        if len(alpha) < 256:
+            chars[3, 17] = 200
+            chars[4, 0] = 255
+        orec, omsk, ost = o.witness_batch(chars, lens, M)
+        ok = (ost & np.uint64(0xff)) == 0
+        assert ok.any() and (total or (~ok).any())
+        wide = torch.from_numpy(chars).to(dev)
+        rec, msk, st = cfg.witness_batch_position_major(wide, torch.from_numpy(lens.astype(np.int32)).to(dev))
+        torch.cuda.synchronize()
+        r1, m1 = hra.position_major_to_string_major(rec, msk, 700, M, 1)
+        assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+        assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
 
 
 def test_cfg4_shape_three_header_defs_five_substrs(hra, oracle):
@@ -314,7 +345,7 @@ def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
     _check_batch_pm(hra, oracle, CFG_123, chars, lens, 704)
 
 
-@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000)], ids=["narrow-table", "wide-table"])
+@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000), str(0x400000)], ids=["narrow-table", "wide-table", "half-table"])
 def test_position_major_kernel_on_both_table_formats(hra, oracle, flags, monkeypatch):
     """The position-major kernel picks the WIDE table (8-byte entries: chain word + finished record) for D >= 2 while
     every group has a walker slot; force each format through the same batches, D = 1..3, including strings with
