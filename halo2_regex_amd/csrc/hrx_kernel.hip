@@ -859,6 +859,35 @@ __device__ __forceinline__ void store16(unsigned char *p, const uint4 &v, const 
     else *reinterpret_cast<uint4 *>(p) = v;
 }
 
+// Where a walker's finished rows go: straight to memory from its registers.  quad(d, p, ..) stores four rows of def d
+// (16 B per lane, 1 KiB contiguous per wave) into its plane of [ceil(M/4)][D][B][4]; row(p) lets the previous tile's masked
+// rows leave one 16-byte piece every 8 rows.  (The walk functions take the sink as a policy: a variant that handed the
+// rows to a third "storer" wave through an LDS out-ring, so that the walker issued no vector-memory instruction at all, was
+// built and measured in round 1 — every global store does cost the issuing wave 75-125 cycles, but the ds_write_b128 +
+// hand-over cost the walker as much, and where all walker slots are busy the launch is bound by the memory system's mixed
+// read/write rate anyway: 97 vs 89 us on the headline workload, 3.41 vs 3.39 ms on cfg 4.  Dropped)
+template <int D>
+struct GlobalSink {
+    static constexpr bool kSidq = true;
+    unsigned char *rp;
+    size_t plane, rstep;
+    bool do_store, nt_rec, nt_msk;
+    const uint4 (&pend)[8];
+    unsigned char *pend_mp;
+    size_t mstep;
+    bool pend_store;
+    __device__ __forceinline__ void quad(const int d, const int p, const bool full, const int mrem, const uint4 &v) {
+        // quads that start at or beyond row M do not exist in [ceil(M/4)][D][B][4]
+        if (do_store && (full || (p & ~3) <= mrem)) store16(rp + (size_t)d * plane, v, nt_rec);
+        if (d == D - 1) rp += rstep;
+    }
+    __device__ __forceinline__ void row(const int p) {
+        // the PREVIOUS tile's masked rows leave one 16-byte piece every 8 rows instead of as a burst of 8 stores at the
+        // tile boundary (the burst filled the store queue and stalled the in-order walk: 98.7 -> 93.8 us)
+        if (D == 1 && (p & 7) == 5 && pend_store) store16(pend_mp + (size_t)(p >> 3) * mstep, pend[p >> 3], nt_msk);
+    }
+};
+
 typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
 __device__ __forceinline__ uint32_t lds_u16(uint32_t off) { return *(lds_cu16 *)(uintptr_t)off; }
 // HALF table (hrx_lane.h): address of entry (row of `e`, byte c) from e and c2 = c << 1 — one v_perm_b32:
@@ -866,14 +895,11 @@ __device__ __forceinline__ uint32_t lds_u16(uint32_t off) { return *(lds_cu16 *)
 __device__ __forceinline__ uint32_t half_next_addr(uint32_t e, uint32_t c2) { return __builtin_amdgcn_perm(e, c2, 0x0c010400u); }
 __device__ __forceinline__ uint32_t half_tag(uint32_t e) { return ((e >> 8) & 0x3fu) | ((e >> 14) << 8); }  // -> the narrow format's 10-bit tag
 
-template <int D, bool FULL, bool GTAB, bool HALF = false>
-__device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, unsigned char *&rp,
-                                                 const size_t rstep, const bool do_store, int rem, int mrem, uint32_t t0,
-                                                 uint32_t (&sidq)[16], uint32_t (&acc_state)[D], const uint4 (&pend)[8],
-                                                 unsigned char *pend_mp, const size_t mstep, const bool pend_store) {
+template <int D, bool FULL, bool GTAB, bool HALF, class Sink>
+__device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, Sink &sink, int rem, int mrem,
+                                                 uint32_t t0, uint32_t (&sidq)[16], uint32_t (&acc_state)[D]) {
     uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
     uint32_t rbuf[D][4];
-    const size_t plane = (a.debug & 0x100000u) ? (size_t)16u : (size_t)a.B * 16u;   // [ceil(M/4)][D][B][4]: one def's quads of all strings (0x100000, profiling: [M/4][B][D][4])
     const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                              cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
     uint32_t e1[D], e2[D], raw[D];
@@ -892,12 +918,8 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
                 if (p == rem) acc_state[d] = state;  // the state at row n (lib.rs:437-457)
             }
             rbuf[d][p & 3] = state | (tag << 16);
-            if ((p & 3) == 3) {  // four rows of def d of this string: 16 bytes, a 1-KiB contiguous run across the wave
-                // quads that start at or beyond row M do not exist in [ceil(M/4)][D][B][4]
-                if (do_store && (FULL || (p & ~3) <= mrem))
-                    store16(rp + (size_t)d * plane, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]), (a.debug & 32u) != 0);
-                if (d == D - 1) rp += rstep;
-            }
+            // four rows of def d of this string: 16 bytes, a 1-KiB contiguous run across the wave
+            if ((p & 3) == 3) sink.quad(d, p, FULL, mrem, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]));
             if (!FULL || HALF) L.mx[d] = max(L.mx[d], et[d]);  // HALF: an undefined transition is a marked entry, not an absorbing row
             sid += tag & 0xffu;
             stn += (tag >> 8) & 1u;
@@ -911,10 +933,8 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
         en1[p >> 5] |= (enn ? 1u : 0u) << (p & 31);
         ch[p >> 5] |= (sid != L.sid_prev ? 1u : 0u) << (p & 31);
         L.sid_prev = sid;
-        sidq[p >> 2] |= sid << (8 * (p & 3));  // the tile's substr-id sums, one byte per row (masked rows need them)
-        // the PREVIOUS tile's masked rows leave one 16-byte piece every 8 rows instead of as a burst of 8 stores at the
-        // tile boundary (the burst filled the store queue and stalled the in-order walk: 99 -> ? us)
-        if (D == 1 && (p & 7) == 5 && pend_store) store16(pend_mp + (size_t)(p >> 3) * mstep, pend[p >> 3], (a.debug & 64u) != 0);
+        if (Sink::kSidq) sidq[p >> 2] |= sid << (8 * (p & 3));  // the tile's substr-id sums, one byte per row (masked rows need them)
+        sink.row(p);
     };
 #pragma unroll
     for (int i = 0; i < 16; ++i) sidq[i] = 0;
@@ -929,11 +949,15 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
                 raw[d] = HALF ? lds_u16(half_next_addr(e1[d], c4)) : table_at<GTAB>(a, (e1[d] & ~kTagMask) | c4);
             if (p > 0) {
                 post(p - 1, e2, e1);
-                asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(ch[(p - 1) >> 5]), "+v"(L.sid_prev),
-                             "+v"(sidq[(p - 1) >> 2]));
+                asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(ch[(p - 1) >> 5]), "+v"(L.sid_prev));
+                if (Sink::kSidq) asm volatile("" : "+v"(sidq[(p - 1) >> 2]));
                 if (!FULL || HALF) {
 #pragma unroll
                     for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]));
+                }
+                if (!FULL) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(acc_state[d]));
                 }
                 if (D > 1) asm volatile("" : "+v"(L.ov_row));  // or the 64 per-row flag counts stay live until the tile end
             }
@@ -973,14 +997,11 @@ __device__ __forceinline__ uint2 lds_u64(uint32_t off) {
     return make_uint2(v.x, v.y);
 }
 
-template <int D, bool FULL>
-__device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, unsigned char *&rp,
-                                                      const size_t rstep, const bool do_store, int rem, int mrem, uint32_t &tile_ov,
-                                                      uint32_t (&sidq)[16], uint32_t (&acc_state)[D], const uint4 (&pend)[8],
-                                                      unsigned char *pend_mp, const size_t mstep, const bool pend_store) {
+template <int D, bool FULL, class Sink>
+__device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, Sink &sink, int rem, int mrem,
+                                                      uint32_t &tile_ov, uint32_t (&sidq)[16], uint32_t (&acc_state)[D]) {
     uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
     uint32_t rbuf[D][4];
-    const size_t plane = (a.debug & 0x100000u) ? (size_t)16u : (size_t)a.B * 16u;   // [ceil(M/4)][D][B][4]: one def's quads of all strings (0x100000, profiling: [M/4][B][D][4])
     uint32_t ov = 0;
     // bytes >= 128 have no column: they are masked here and the tile is re-walked by the caller
     const uint32_t cw[16] = {cq[0].x & 0x7f7f7f7fu, cq[0].y & 0x7f7f7f7fu, cq[0].z & 0x7f7f7f7fu, cq[0].w & 0x7f7f7f7fu,
@@ -1006,11 +1027,8 @@ __device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint
                 if (p >= mrem) rec &= ~(1u << 25);
             }
             rbuf[d][p & 3] = rec;
-            if ((p & 3) == 3) {  // four rows of def d of this string: 16 bytes, a 1-KiB contiguous run across the wave
-                if (do_store && (FULL || (p & ~3) <= mrem))
-                    store16(rp + (size_t)d * plane, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]), (a.debug & 32u) != 0);
-                if (d == D - 1) rp += rstep;
-            }
+            // four rows of def d of this string: 16 bytes, a 1-KiB contiguous run across the wave
+            if ((p & 3) == 3) sink.quad(d, p, FULL, mrem, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]));
         }
         const uint32_t sid = (T >> kWideSidShift) & 0xffu;
         const uint32_t F = T >> kWideStartShift;          // bits 0..1 start count, 2..3 end count
@@ -1020,8 +1038,8 @@ __device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint
         // ch = (ch << 1) | (sid != sid_prev): bits arrive in reverse row order, undone once per word below
         asm volatile("v_cmp_ne_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ch[p >> 5]) : "v"(sid), "v"(L.sid_prev) : "vcc");
         L.sid_prev = sid;
-        sidq[p >> 2] |= sid << (8 * (p & 3));
-        if (D == 1 && (p & 7) == 5 && pend_store) store16(pend_mp + (size_t)(p >> 3) * mstep, pend[p >> 3], (a.debug & 64u) != 0);
+        if (Sink::kSidq) sidq[p >> 2] |= sid << (8 * (p & 3));
+        sink.row(p);
     };
 #pragma unroll
     for (int i = 0; i < 16; ++i) sidq[i] = 0;
@@ -1036,8 +1054,13 @@ __device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint
             for (int d = 0; d < D; ++d) raw[d] = lds_u64((lo[d] & kWideRowMask) | c8);   // delta(state, byte): lib.rs:810
             if (p > 0) {
                 post(p - 1);
-                asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(L.sid_prev), "+v"(sidq[(p - 1) >> 2]));
+                asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(L.sid_prev));
+                if (Sink::kSidq) asm volatile("" : "+v"(sidq[(p - 1) >> 2]));
                 if (D > 1) asm volatile("" : "+v"(ov));
+                if (!FULL) {   // or the selects of all 64 rows are deferred to the tile end with every lookup result kept live (300 spills at D = 3)
+#pragma unroll
+                    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]), "+v"(acc_state[d]));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1131,14 +1154,28 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 buf[k * 4u + i] = *reinterpret_cast<const uint4 *>(cptr + off);
             }
         };
+        // The pair's FIRST tile travels alone: requested together with the rest, it queues behind the whole chip's opening
+        // burst (~48 MiB) and reaches the walker ~10 us into the launch (in-kernel stamps, tools/kbench) instead of ~1.5.
+        if (total > 0) {
+            issue(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (uint32_t k = 0; k < RT; ++k)
+            for (uint32_t i = 0; i < 4u; ++i) {
+                uint4 v = buf[i];
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+                *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(ring_base + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
+            }
+            ring_post(ready_off, 1u);
+        }
+#pragma unroll
+        for (uint32_t k = 1; k < RT; ++k)
             if (k < total) issue(k, k);
+        if (RT < total) issue(RT, 0);
         for (uint32_t s0 = 0; s0 < total; s0 += RT) {
 #pragma unroll
             for (uint32_t k = 0; k < RT; ++k) {
                 const uint32_t sq = s0 + k;
-                if (sq < total) {
+                if (sq < total && sq != 0u) {
                     if (sq >= nring) ring_wait(freed_off, sq - nring + 1u);  // the walker has read this slot
                     const uint32_t slot = ring_base + (sq % nring) * kPmTileBytes;
                     // tile sq was requested RT tiles ago; RT-1 younger tiles (4 loads each) may still be in flight
@@ -1191,9 +1228,10 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
             }
             const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
             unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * ((a.debug & 0x100000u) ? D : 1);
-            const size_t rstep = (size_t)B * 16u * D;  // one quad of rows further: [M/4][D][B][4]
+            // (0x1000000, profiling only: every quad / octet of a string lands on the first one — same store instructions, no new lines or pages)
+            const size_t rstep = (a.debug & 0x1000000u) ? (size_t)0 : (size_t)B * 16u * D;  // one quad of rows further: [M/4][D][B][4]
             unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
-            const size_t mstep = (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
+            const size_t mstep = (a.debug & 0x1000000u) ? (size_t)0 : (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
             uint4 pend[8];                             // the previous tile's masked rows, not yet stored
             unsigned char *pend_mp = mp;
             bool have_pend = false;
@@ -1218,17 +1256,19 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 const bool do_store = active && !(a.debug & 1u);
                 const bool pend_store = active && have_pend && !(a.debug & 2u);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
+                // [ceil(M/4)][D][B][4]: one def's quads of all strings (0x100000, profiling: [M/4][B][D][4])
+                GlobalSink<D> sink{rp, (a.debug & 0x100000u) ? (size_t)16u : (size_t)B * 16u, rstep, do_store, (a.debug & 32u) != 0, (a.debug & 64u) != 0,
+                                   pend, pend_mp, mstep, pend_store};
                 if (WIDE) {
                     const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                               cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
                     if (full) {
-                        tb = walk_tile_pm_wide<D, true>(L, cq, a, rp, rstep, do_store, 0, 0, tile_ov, sidq, acc_state, pend, pend_mp, mstep, pend_store);
+                        tb = walk_tile_pm_wide<D, true>(L, cq, a, sink, 0, 0, tile_ov, sidq, acc_state);
 #pragma unroll
                         for (int q = 0; q < 16; ++q) hb |= cwl[q];
                         hb &= 0x80808080u;
                     } else {
-                        tb = walk_tile_pm_wide<D, false>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, tile_ov, sidq,
-                                                         acc_state, pend, pend_mp, mstep, pend_store);
+                        tb = walk_tile_pm_wide<D, false>(L, cq, a, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, tile_ov, sidq, acc_state);
                         const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {   // bytes at or beyond the string's length are not trusted
@@ -1238,10 +1278,10 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                         hb &= 0x80808080u;
                     }
                 } else if (full)
-                    tb = walk_tile_pm<D, true, GTAB, HALF>(L, cq, a, rp, rstep, do_store, 0, 0, t0, sidq, acc_state, pend, pend_mp, mstep, pend_store);
+                    tb = walk_tile_pm<D, true, GTAB, HALF>(L, cq, a, sink, 0, 0, t0, sidq, acc_state);
                 else
-                    tb = walk_tile_pm<D, false, GTAB, HALF>(L, cq, a, rp, rstep, do_store, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state,
-                                                pend, pend_mp, mstep, pend_store);
+                    tb = walk_tile_pm<D, false, GTAB, HALF>(L, cq, a, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state);
+                rp = sink.rp;
 
                 // ---------------- undefined transition (lib.rs:817): rare slow path, re-walk the tile ----------------
                 uint32_t newly = 0;
@@ -1475,8 +1515,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
                 // 32768 x 32768 B, D = 3) and loses 5-10 % once the slots are oversubscribed and the launch is bound by
                 // the store path (profiles/r01_config_sweep).  D = 1 gains nothing: its walk is LDS-latency-bound.
                 // debug 0x80000 forces the narrow table, 0x200000 the wide one.
-                out.wide = (a.wide_image && !out.gtab && !(a.debug & 0x80000u) &&
-                            ((a.D >= 2 && (size_t)a.n_groups <= (size_t)num_cus * 4) || (a.debug & 0x200000u))) ? 1 : 0;
+                out.wide = (a.wide_image && !out.gtab && !(a.debug & 0x80000u) && (a.D >= 2 || (a.debug & 0x200000u))) ? 1 : 0;
                 out.waves_per_wg = 2 * pairs;
                 out.nslots = ns;
                 out.lds_bytes = lds;

@@ -136,8 +136,8 @@ def test_planner_picks_the_documented_kernel_per_config():
     assert cfg.describe_launch(65536, layout=3).startswith("hrx::witness_pm_kernel<1, false, false, false> grid=256 waves=8 ")
     assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_split_kernel<1, 32> ")
     cfg = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
-    assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> ")     # WIDE while groups <= 4 x CUs
-    assert cfg.describe_launch(1 << 20, layout=1).startswith("hrx::witness_pm_kernel<2, false, false, false> ")
+    assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> ")     # D >= 2: the WIDE table
+    assert cfg.describe_launch(1 << 20, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> grid=256 waves=8 ")
     # cfg 5: 256 states x 256 symbols = 258 KiB of 4-byte entries -> the 128-KiB HALF table, LDS-resident
     a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=np.arange(256, dtype=np.uint8), n_substr_pairs=200)
     cfg = RegexVerifyConfig.configure(4096, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)
