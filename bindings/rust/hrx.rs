@@ -24,6 +24,10 @@ extern "C" {
     pub fn hrx_witness_batch_device(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, lens: *const u32, b: usize,
                                     m: usize, records: *mut u32, masked: *mut u16, status: *mut u64,
                                     stream: *mut c_void) -> c_int;
+    /// compact rows -> bn256::Fr cells ([4 + 4 D][b_count][M][4 x u64], Montgomery form; flags 1 = canonical)
+    pub fn hrx_fr_columns_device(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, lens: *const u32,
+                                 records: *const u32, rec_pitch: usize, masked: *const u16, msk_pitch: usize, b: usize, m: usize,
+                                 b_begin: usize, b_count: usize, cells: *mut u64, flags: c_int, stream: *mut c_void) -> c_int;
     pub fn hrx_derive_states(ctx: *mut hrx_ctx, characters: *const u8, n: usize, states: *mut u64) -> c_int;
     pub fn hrx_derive_substr_ids(ctx: *mut hrx_ctx, states: *const u64, n: usize, substr_ids: *mut u64) -> c_int;
     pub fn hrx_derive_is_start_end(ctx: *mut hrx_ctx, states: *const u64, substr_ids: *const u64, n: usize,

@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
+    "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
     "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
     "hrx_regex_to_allstr_text", "hrx_regex_to_dfa_json", "hrx_gen_regex_files", "hrx_regex_files_num_substrs",
@@ -90,6 +91,9 @@ def _load():
         "hrx_witness_batch_device_layout": (i, [vp, i, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_describe_launch": (i, [vp, i, sz, sz, i, C.c_char_p, sz]),
+        "hrx_fr_num_columns": (sz, [sz]),
+        "hrx_fr_columns_device": (i, [vp, i, vp, sz, vp, vp, sz, vp, sz, sz, sz, sz, sz, vp, i, vp]),
+        "hrx_fr_from_u64": (None, [C.c_uint64, i, _u64p]),
         "hrx_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
         "hrx_shard_range": (None, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_derive_states": (i, [vp, _u8p, sz, _u64p]),
@@ -520,6 +524,32 @@ class RegexVerifyConfig:
                                                    st.data_ptr(), s.cuda_stream))
         return rec, msk, st
 
+    def fr_columns(self, chars, lens, out, b_begin=0, b_count=None, position_major=False, chars_pm_stride=None, canonical=False,
+                   stream=None):
+        """expand the compact rows `out` = (records, masked, status) of a finished witness_batch* call into
+        bn256::Fr cells for strings [b_begin, b_begin + b_count): int64 CUDA tensor [4 + 4 D][b_count][M][4] (limbs)."""
+        rec, msk, _ = out
+        B = lens.numel()
+        b_count = B - b_begin if b_count is None else b_count
+        M, D = self.max_chars_size, self.num_defs
+        ncols = lib.hrx_fr_num_columns(D)
+        cells = torch.empty((ncols, b_count, M, 4), dtype=torch.int64, device=lens.device)
+        layout, rp, mp = LAYOUT_STRING_MAJOR, 0, 0
+        if position_major:
+            layout = LAYOUT_POSITION_MAJOR
+            if chars_pm_stride is not None:
+                layout |= LAYOUT_INPUT_POSITION_MAJOR
+                stride = int(chars_pm_stride)
+            else:
+                stride = chars.stride(0)
+        else:
+            stride, rp, mp = chars.stride(0), rec.stride(0) // D, msk.stride(0)
+        s = torch.cuda.current_stream(lens.device) if stream is None else stream
+        _check(lib.hrx_fr_columns_device(self._need_ctx(), layout, chars.data_ptr(), stride, lens.data_ptr(), rec.data_ptr(), rp,
+                                         msk.data_ptr(), mp, B, M, b_begin, b_count, cells.data_ptr(),
+                                         FR_CANONICAL if canonical else 0, s.cuda_stream))
+        return cells
+
     def witness_batch(self, chars, lens, out=None, stream=None):
         """Device-resident batch: chars (B, stride) uint8 CUDA tensor (stride % 16 == 0), lens (B,) int32 CUDA tensor.
         Asynchronous on `stream` (default: torch's current stream).  Returns (records, masked, status) tensors whose
@@ -537,6 +567,18 @@ class RegexVerifyConfig:
                                                     self.max_chars_size, rec.data_ptr(), rec.stride(0) // D,
                                                     msk.data_ptr(), msk.stride(0), st.data_ptr(), s.cuda_stream))
         return rec, msk, st
+
+
+FR_CANONICAL = 1                       # HRX_FR_CANONICAL
+FR_COLUMN_NAMES = lambda D: (["char_enable", "characters"] + [n % d for d in range(D) for n in ("states[%d]", "substr_ids[%d]", "start_enable[%d]", "end_enable[%d]")]
+                             + ["masked_characters", "all_substr_ids"])
+
+
+def fr_from_u64(v, canonical=False):
+    """F::from(v) for F = bn256::Fr as the library computes it: 4 little-endian u64 limbs (Montgomery form unless canonical)."""
+    out = (C.c_uint64 * 4)()
+    lib.hrx_fr_from_u64(int(v), FR_CANONICAL if canonical else 0, out)
+    return [int(x) for x in out]
 
 
 def decode_status(s):

@@ -14,6 +14,7 @@
 
 #include "../../include/hrx.h"
 #include "hrx_defs.hpp"
+#include "hrx_fr.h"
 #include "hrx_kernel.hpp"
 #include "hrx_lane.h"
 
@@ -348,6 +349,44 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u>", a.D, 32u / a.D);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
     std::snprintf(out, cap, "%s grid=%d waves=%d ring=%d lds=%zu", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+    return HRX_OK;
+}
+
+size_t hrx_fr_num_columns(size_t D) { return 4 + 4 * D; }
+
+void hrx_fr_from_u64(uint64_t v, int flags, uint64_t *limbs) {
+    uint64_t w[4];
+    if (v >> 32) {
+        fr_from_u64(v, w, (flags & HRX_FR_CANONICAL) != 0);
+    } else {   // the kernel's route (every witness value fits 32 bits)
+        uint32_t h[8];
+        fr_from_u32((uint32_t)v, h, (flags & HRX_FR_CANONICAL) != 0);
+        for (int i = 0; i < 4; ++i) w[i] = (uint64_t)h[2 * i] | (uint64_t)h[2 * i + 1] << 32;
+    }
+    if (limbs) { limbs[0] = w[0]; limbs[1] = w[1]; limbs[2] = w[2]; limbs[3] = w[3]; }
+}
+
+int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,
+                          const uint32_t *records, size_t rec_pitch, const uint16_t *masked, size_t msk_pitch, size_t B,
+                          size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (b_count == 0) return HRX_OK;
+    if (!chars || !lens || !records || !masked || !cells) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (b_begin > B || b_count > B - b_begin) return fail(HRX_ERR_ARG, "string range outside the batch");
+    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64 || b_count > 65535) return fail(HRX_ERR_ARG, "shape out of range (at most 65535 strings per call)");
+    if (layout != HRX_LAYOUT_STRING_MAJOR && layout != HRX_LAYOUT_POSITION_MAJOR &&
+        layout != (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR))
+        return fail(HRX_ERR_ARG, "unknown layout");
+    if ((uintptr_t)cells & 15) return fail(HRX_ERR_ARG, "cells must be 16-byte aligned");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    FrArgs a{};
+    a.chars = chars; a.stride = stride; a.lens = lens; a.records = records; a.masked = masked;
+    a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)ctx->s.defs.size(); a.layout = (uint32_t)layout;
+    a.rec_pitch = (uint32_t)(rec_pitch ? rec_pitch : M); a.msk_pitch = (uint32_t)(msk_pitch ? msk_pitch : M);
+    a.b_begin = (uint32_t)b_begin; a.b_count = (uint32_t)b_count; a.canonical = (flags & HRX_FR_CANONICAL) ? 1u : 0u;
+    a.cells = cells;
+    HIP_TRY(launch_fr_columns(a, (hipStream_t)stream));
     return HRX_OK;
 }
 

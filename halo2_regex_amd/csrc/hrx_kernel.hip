@@ -15,6 +15,7 @@
 
 #include <atomic>
 
+#include "hrx_fr.h"
 #include "hrx_kernel.hpp"
 #include "hrx_lane.h"
 
@@ -1707,6 +1708,53 @@ hipError_t launch_endpoint_flags(const EndpointArgs &a, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;
     const uint64_t total = a.n * a.D;
     hipLaunchKernelGGL(endpoint_flags_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// compact witness -> field cells.  One thread per (string, row) expands the row's integers into what
+// `Value::known(F::from(v))` holds for every advice cell the reference assigns (lib.rs:339-418, 473-519) and for its two
+// result columns (lib.rs:752-771), F = bn256::Fr in Montgomery form (hrx_fr.h), column-major [col][string][row][4 limbs]:
+// consecutive lanes are consecutive rows, so every column is written in contiguous 2-KiB runs per wave.  Write-bound:
+// 32 B per cell x (4 + 4 D) cells per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t bi = blockIdx.y;              // index inside the requested range
+    const uint32_t b = a.b_begin + bi;
+    if (r >= a.M) return;
+    const uint32_t n = min(a.lens[b], a.M);
+    const bool pm = (a.layout & 1u) != 0, in_pm = (a.layout & 2u) != 0;
+    const uint32_t live = r < n ? 1u : 0u;
+    uint32_t c = 0;
+    if (live) c = in_pm ? a.chars[((size_t)(r >> 4) * a.B + b) * 16u + (r & 15u)] : a.chars[(size_t)b * a.stride + r];
+    const size_t col_cells = (size_t)a.b_count * a.M;   // cells per column
+    uint64_t *out = a.cells + ((size_t)bi * a.M + r) * 4u;
+    auto put = [&](const uint32_t col, const uint32_t v) {
+        uint32_t w[8];
+        fr_from_u32(v, w, a.canonical != 0);
+        uint4 *p = reinterpret_cast<uint4 *>(out + (size_t)col * col_cells * 4u);
+        p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    };
+    put(0, live);   // char_enable                        lib.rs:342,346
+    put(1, c);      // characters                         lib.rs:343,347
+    for (uint32_t d = 0; d < a.D; ++d) {
+        const uint32_t rec = pm ? a.records[(((size_t)(r >> 2) * a.D + d) * a.B + b) * 4u + (r & 3u)]
+                                : a.records[((size_t)b * a.rec_pitch + r) * a.D + d];
+        put(2 + 4 * d, rec & 0xffffu);            // states[d]         lib.rs:390,415
+        put(3 + 4 * d, (rec >> 16) & 0xffu);      // substr_ids[d]     lib.rs:394,405
+        put(4 + 4 * d, (rec >> 24) & 1u);         // start_enable[d]   lib.rs:483-491
+        put(5 + 4 * d, (rec >> 25) & 1u);         // end_enable[d]     lib.rs:502-511
+    }
+    const uint32_t mk = pm ? a.masked[((size_t)(r >> 3) * a.B + b) * 8u + (r & 7u)] : a.masked[(size_t)b * a.msk_pitch + r];
+    put(2 + 4 * a.D, mk & 0xffu);                 // masked_characters  lib.rs:752-757
+    put(3 + 4 * a.D, mk >> 8);                    // all_substr_ids     lib.rs:758-761
+}
+
+hipError_t launch_fr_columns(const FrArgs &a, hipStream_t stream) {
+    if (a.b_count == 0 || a.M == 0) return hipSuccess;
+    hipLaunchKernelGGL(fr_columns_kernel, dim3((a.M + 255u) / 256u, a.b_count), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -69,4 +69,18 @@ struct EndpointArgs {
 };
 hipError_t launch_endpoint_flags(const EndpointArgs &a, hipStream_t stream);
 
+// compact witness rows of strings [b_begin, b_begin + b_count) -> bn256::Fr cells, [col][string][row][4]
+struct FrArgs {
+    const uint8_t *chars;
+    uint64_t stride;
+    const uint32_t *lens;
+    const uint32_t *records;
+    const uint16_t *masked;
+    uint32_t B, M, D, layout, rec_pitch, msk_pitch;
+    uint32_t b_begin, b_count;
+    uint32_t canonical;   // 1: plain integers instead of Montgomery form
+    uint64_t *cells;
+};
+hipError_t launch_fr_columns(const FrArgs &a, hipStream_t stream);
+
 }  // namespace hrx

@@ -154,6 +154,28 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
 int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
                            size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);
 
+/* ------------------------------------------------------------------ */
+/* SURVEY §8 f4 — compact witness -> field cells (the step after the path)        */
+/* ------------------------------------------------------------------ */
+/* Expands the compact rows of strings [b_begin, b_begin + b_count) of a finished batch into what
+ * `Value::known(F::from(v))` holds for every advice cell the reference assigns (src/lib.rs:339-418, 473-519) and for the
+ * two result columns of AssignedRegexResult (lib.rs:752-771), with F = halo2curves bn256::Fr, the field the reference's
+ * circuits use (lib.rs:896): 4 little-endian u64 limbs per cell in Montgomery form (v * 2^256 mod r — the in-memory
+ * representation of Fr, so that a device-side prover or an `assign_advice` loop can take the cells as they are);
+ * HRX_FR_CANONICAL in `flags`: the plain integer instead.
+ * cells: device buffer [n_cols][b_count][M][4] u64, n_cols = hrx_fr_num_columns(D) = 4 + 4 D, in column order
+ *   0 char_enable, 1 characters, 2+4d states[d], 3+4d substr_ids[d], 4+4d start_enable[d], 5+4d end_enable[d],
+ *   2+4D masked_characters, 3+4D all_substr_ids.
+ * `layout`, chars/stride/lens, records/masked (and rec_pitch/msk_pitch, string-major only; 0 = M) are those of the
+ * hrx_witness_batch_device* call that produced the rows.  Asynchronous on `stream`. */
+enum { HRX_FR_CANONICAL = 1 };
+size_t hrx_fr_num_columns(size_t D);
+int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,
+                          const uint32_t *records, size_t rec_pitch, const uint16_t *masked, size_t msk_pitch, size_t B,
+                          size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream);
+/* F::from(v) on the host (same arithmetic as the kernel): limbs[4]. */
+void hrx_fr_from_u64(uint64_t v, int flags, uint64_t *limbs);
+
 /* Contiguous shard [begin, begin+count) of a batch of B strings for `rank` of `world` devices
  * (strings are independent given the RegexDefs; no collective on the path). */
 void hrx_shard_range(size_t B, int world, int rank, size_t *begin, size_t *count);

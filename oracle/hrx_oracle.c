@@ -698,3 +698,73 @@ size_t orc_table_endpoint_rows(const orc *o, size_t d, uint64_t *rows, size_t ca
     }
     return nrows;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * F::from(u64) for F = halo2curves bn256::Fr — the value inside `Value::known(F::from(v))` at
+ * src/lib.rs:342-347, 390-417.  The arithmetic lives in a third-party crate that is NOT in /root/reference:
+ * halo2curves, pulled in through halo2-base v0.2.2 (axiom-crypto/halo2-lib @ 9860acc, Cargo.toml:12-15).  Restated from
+ * its published source (src/bn256/fr.rs + the field_arithmetic! macro): an element is 4 little-endian u64 limbs in
+ * Montgomery form, `From<u64>` is `Fr([v, 0, 0, 0]) * R2`, and `mul` is a schoolbook 4x4 product followed by
+ * `montgomery_reduce` with INV = -r^-1 mod 2^64.  Constants as published there:
+ *   MODULUS = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+ *   R  = [ac96341c4ffffffb, 36fc76959f60cd29, 666ea36f7879462e, 0e0a77c19a07df2f]   (2^256 mod r; Fr::one())
+ *   R2 = [1bb8e645ae216da7, 53fe3ab1e35c59e3, 8c49833d53bb8085, 0216d0b17f4e44a5]   (2^512 mod r)
+ *   INV = 0xc2e1f593efffffff
+ * Parity status of this function: PARTIAL — the reference's own tests reach it only through MockProver
+ * (lib.rs:1052-1059 compares F::from(expected) with assigned cells); tests/test_fr.py pins it to the constants above
+ * (from(1) == R, R2 == R*R mod r, INV*r == -1 mod 2^64) and to exact big-integer arithmetic (v * 2^256 mod r).
+ * The product computes the same value by a different route (csrc/hrx_fr.h).
+ * --------------------------------------------------------------------------------------------------------------- */
+static const uint64_t FR_MODULUS[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static const uint64_t FR_R2[4] = {0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull};
+static const uint64_t FR_INV = 0xc2e1f593efffffffull;
+
+typedef unsigned __int128 orc_u128;
+static uint64_t fr_mac(uint64_t a, uint64_t b, uint64_t c, uint64_t *carry) { /* a + b*c + carry */
+    const orc_u128 t = (orc_u128)a + (orc_u128)b * c + *carry;
+    *carry = (uint64_t)(t >> 64);
+    return (uint64_t)t;
+}
+static uint64_t fr_adc(uint64_t a, uint64_t b, uint64_t *carry) {
+    const orc_u128 t = (orc_u128)a + b + *carry;
+    *carry = (uint64_t)(t >> 64);
+    return (uint64_t)t;
+}
+
+/* Fr::mul: 8-limb product, then montgomery_reduce, then one conditional subtraction of the modulus */
+static void fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    uint64_t t[8] = {0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) t[i + j] = fr_mac(t[i + j], a[i], b[j], &carry);
+        t[i + 4] = carry;
+    }
+    uint64_t carry2 = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint64_t k = t[i] * FR_INV;
+        uint64_t carry = 0;
+        (void)fr_mac(t[i], k, FR_MODULUS[0], &carry);
+        for (int j = 1; j < 4; j++) t[i + j] = fr_mac(t[i + j], k, FR_MODULUS[j], &carry);
+        t[i + 4] = fr_adc(t[i + 4], carry2, &carry);
+        carry2 = carry;
+    }
+    /* result = t[4..8] (+ carry2 * 2^256) - (modulus if >= modulus) */
+    uint64_t r[4], borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        const orc_u128 d = (orc_u128)t[4 + i] - FR_MODULUS[i] - borrow;
+        r[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1u;
+    }
+    const int ge = carry2 || !borrow;
+    for (int i = 0; i < 4; i++) out[i] = ge ? r[i] : t[4 + i];
+}
+
+void orc_fr_from_u64(uint64_t v, uint64_t out[4]) {
+    const uint64_t a[4] = {v, 0, 0, 0};
+    fr_mul(a, FR_R2, out);
+}
+void orc_fr_constants(uint64_t modulus[4], uint64_t r2[4], uint64_t *inv) {
+    memcpy(modulus, FR_MODULUS, 32);
+    memcpy(r2, FR_R2, 32);
+    *inv = FR_INV;
+}

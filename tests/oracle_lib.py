@@ -57,6 +57,10 @@ def load_oracle():
     lib.orc_table_transition_rows.argtypes = [C.c_void_p, C.c_size_t, _u64p, C.c_size_t]
     lib.orc_table_transition_rows.restype = C.c_size_t
     lib.orc_table_endpoint_rows.argtypes = [C.c_void_p, C.c_size_t, _u64p, C.c_size_t]
+    lib.orc_fr_from_u64.argtypes = [C.c_uint64, _u64p]
+    lib.orc_fr_from_u64.restype = None
+    lib.orc_fr_constants.argtypes = [_u64p, _u64p, _u64p]
+    lib.orc_fr_constants.restype = None
     lib.orc_table_endpoint_rows.restype = C.c_size_t
     return lib
 
@@ -190,3 +194,10 @@ def decode_status(s):
     if code == 2:
         return {"code": 2, "pos": s >> 40}
     return {"code": code}
+
+
+def oracle_fr_from_u64(lib, v):
+    """F::from(v), F = bn256::Fr, by the oracle's restatement of halo2curves' Montgomery multiplication: 4 u64 limbs."""
+    out = (C.c_uint64 * 4)()
+    lib.orc_fr_from_u64(int(v), out)
+    return [int(x) for x in out]

@@ -1,0 +1,145 @@
+"""compact witness rows -> bn256::Fr cells (what `Value::known(F::from(v))` holds, src/lib.rs:342-347, 390-417).
+
+The arithmetic lives in halo2curves (third party, not in the reference checkout).  Three independent routes must agree:
+exact big-integer arithmetic (v * 2^256 mod r), the oracle's restatement of halo2curves' Montgomery multiplication
+(oracle/hrx_oracle.c: Fr([v,0,0,0]) * R2) and the product's direct reduction (csrc/hrx_fr.h), on the host and on the GPU."""
+import random
+
+import numpy as np
+import pytest
+
+import halo2_regex_amd as hra
+from oracle_lib import OracleDefs, DFA_DIR, oracle_fr_from_u64, reference_cases
+
+FR_MODULUS = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001     # BN254 scalar field
+# the limbs halo2curves publishes (src/bn256/fr.rs): R = Fr::one(), R2, INV
+R_LIMBS = [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f]
+R2_LIMBS = [0x1bb8e645ae216da7, 0x53fe3ab1e35c59e3, 0x8c49833d53bb8085, 0x0216d0b17f4e44a5]
+INV = 0xc2e1f593efffffff
+
+
+def _int(limbs):
+    return sum(int(l) << (64 * i) for i, l in enumerate(limbs))
+
+
+def _mont(v):
+    return (int(v) << 256) % FR_MODULUS
+
+
+def test_published_constants_are_consistent():
+    assert _int(R_LIMBS) == (1 << 256) % FR_MODULUS
+    assert _int(R2_LIMBS) == (1 << 512) % FR_MODULUS
+    assert (INV * FR_MODULUS) % (1 << 64) == (1 << 64) - 1
+
+
+def test_oracle_carries_the_published_constants(oracle):
+    import ctypes as C
+    mod, r2, inv = (C.c_uint64 * 4)(), (C.c_uint64 * 4)(), C.c_uint64(0)
+    oracle.orc_fr_constants(mod, r2, C.byref(inv))
+    assert _int(mod) == FR_MODULUS and [int(x) for x in r2] == R2_LIMBS and inv.value == INV
+    assert oracle_fr_from_u64(oracle, 1) == R_LIMBS               # Fr::from(1) == Fr::one()
+    assert oracle_fr_from_u64(oracle, 0) == [0, 0, 0, 0]
+
+
+def test_from_u64_three_routes_agree(oracle):
+    rng = random.Random(4)
+    values = [0, 1, 2, 3, 29, 255, 256, 65535, 65536, 2**32 - 1, 2**32, 2**63, 2**64 - 1] + [rng.getrandbits(64) for _ in range(20000)] \
+        + [rng.getrandbits(16) for _ in range(2000)] + [rng.getrandbits(32) for _ in range(20000)] + list(range(70000))   # < 2^32: the kernel's 32-bit route
+    for v in values:
+        want = _mont(v)
+        assert _int(oracle_fr_from_u64(oracle, v)) == want
+        assert _int(hra.fr_from_u64(v)) == want
+        assert hra.fr_from_u64(v, canonical=True) == [v, 0, 0, 0]
+    assert hra.fr_from_u64(1) == R_LIMBS
+
+
+CFG_A = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]], ["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]]]
+
+
+def _expected_cells(o, chars, lens, M, D, lut):
+    """[4 + 4D][B][M][4] from the oracle's match_substrs integer columns, each value through `lut` (int -> 4 limbs)."""
+    B = len(lens)
+    out = np.zeros((4 + 4 * D, B, M, 4), np.uint64)
+    for b in range(B):
+        cols = o.match_substrs(bytes(chars[b, :lens[b]]), M)
+        seq = [cols["enable"], cols["character"]]
+        for d in range(D):
+            seq += [cols["state"][d], cols["substr_id"][d], cols["start_enable"][d], cols["end_enable"][d]]
+        seq += [cols["masked_char"], cols["masked_substr_id"]]
+        for c, col in enumerate(seq):
+            out[c, b] = lut[np.asarray(col, np.int64)]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["string-major", "position-major", "position-major-input"])
+def test_fr_columns_match_f_from_of_every_assigned_cell(oracle, layout):
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    M, D = 200, 2
+    defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(DFA_DIR + "/" + a), [hra.SubstrRegexDef.read_from_text(DFA_DIR + "/" + s) for s in subs])
+            for a, subs in CFG_A]
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    chars, lens = synth.reveal_stress(96, 200, seed=5)
+    lens = np.minimum(lens, M).astype(np.uint32)
+    lens[0], lens[1] = 0, M
+    o = OracleDefs.from_files(oracle, CFG_A)
+    ost = o.witness_batch(chars, lens, M)[2]
+    ok = np.nonzero((ost & np.uint64(0xff)) == 0)[0]
+    lut_m = np.array([[(_mont(v) >> (64 * i)) & (2**64 - 1) for i in range(4)] for v in range(65536)], np.uint64)
+    lut_c = np.zeros((65536, 4), np.uint64)
+    lut_c[:, 0] = np.arange(65536)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    if layout == "string-major":
+        out = cfg.witness_batch(d_chars, d_lens)
+        kw = dict(position_major=False)
+        src = d_chars
+    elif layout == "position-major":
+        out = cfg.witness_batch_position_major(d_chars, d_lens)
+        kw = dict(position_major=True)
+        src = d_chars
+    else:
+        src = hra.chars_to_position_major(d_chars)
+        out = cfg.witness_batch_position_major(src, d_lens, chars_pm_stride=chars.shape[1])
+        kw = dict(position_major=True, chars_pm_stride=chars.shape[1])
+    for canonical, lut in ((False, lut_m), (True, lut_c)):
+        cells = cfg.fr_columns(src, d_lens, out, canonical=canonical, **kw)
+        torch.cuda.synchronize()
+        got = cells.cpu().numpy().view(np.uint64)
+        assert got.shape == (4 + 4 * D, 96, M, 4)
+        want = _expected_cells(o, chars, lens, M, D, lut)
+        assert np.array_equal(got[:, ok], want[:, ok])
+    # a sub-range of the batch lands at the start of the output
+    full = cfg.fr_columns(src, d_lens, out, **kw)
+    part = cfg.fr_columns(src, d_lens, out, b_begin=40, b_count=17, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(part, full[:, 40:57])
+
+
+@pytest.mark.gpu
+def test_reference_expectations_as_field_elements(oracle):
+    """lib.rs:1052-1059: the assigned masked_characters / all_substr_ids cells equal F::from(expected) row by row."""
+    import torch
+    dev = torch.device("cuda", 0)
+    for case in reference_cases():
+        if not case["masked_outputs_asserted"]:
+            continue
+        M = case["max_chars_size"]
+        defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(DFA_DIR + "/" + a), [hra.SubstrRegexDef.read_from_text(DFA_DIR + "/" + s) for s in subs])
+                for a, subs in case["defs"]]
+        D = len(defs)
+        cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+        inp = case["input"].encode("latin-1")
+        chars = np.zeros((1, (len(inp) + 15) // 16 * 16 or 16), np.uint8)
+        chars[0, :len(inp)] = np.frombuffer(inp, np.uint8)
+        d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.tensor([len(inp)], dtype=torch.int32, device=dev)
+        out = cfg.witness_batch(d_chars, d_lens)
+        cells = cfg.fr_columns(d_chars, d_lens, out).cpu().numpy().view(np.uint64)
+        exp_c, exp_s = np.zeros(M, np.int64), np.zeros(M, np.int64)
+        for k, (start, sub) in enumerate(case["expected_substrs"]):
+            for i, ch in enumerate(sub.encode("latin-1")):
+                exp_c[start + i], exp_s[start + i] = ch, k + 1
+        for r in range(M):
+            assert _int(cells[2 + 4 * D, 0, r]) == _mont(exp_c[r])
+            assert _int(cells[3 + 4 * D, 0, r]) == _mont(exp_s[r])
