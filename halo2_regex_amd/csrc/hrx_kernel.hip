@@ -229,13 +229,6 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
     const uint32_t M = a.M;
     const uint32_t ntiles = (M + 63u) >> 6;
 
-    // De-phase the waves of the chip: every wave alternates a long compute phase (walk) with a short store burst;
-    // started together they would all burst together and leave HBM idle in between.
-    if (a.debug & 0xf0u) {
-        const uint32_t slots = (a.debug >> 4) & 0xfu, unit = (a.debug >> 8) & 0xffu;
-        const uint32_t ph = ((blockIdx.x * waves + wave) >> 2) % (slots + 1u);  // waves i and i+4 share a SIMD
-        for (uint32_t i = 0; i < ph * unit; ++i) __builtin_amdgcn_s_sleep(4);
-    }
     for (uint32_t g = blockIdx.x * waves + wave; g < a.n_groups; g += gridDim.x * waves) {
         const uint32_t b0 = g * GS;
         const uint32_t b = b0 + lane;
@@ -348,7 +341,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) cq[i] = nq[i];
             }
-            if (t + 2 < ntiles && !(a.debug & 4u)) load_chars(nq, cptr, t0 + 128u, last_chunk);
+            if (t + 2 < ntiles && !(a.debug & kDbgInputFromL2)) load_chars(nq, cptr, t0 + 128u, last_chunk);
 
             // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare)
             uint64_t fixm = __ballot(tm.fix != 0);
@@ -378,7 +371,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                 uint32_t lds_a = rec_base + js0 * RSB + w * 16u;
                 unsigned char *gp = reinterpret_cast<unsigned char *>(a.records + ((size_t)(b0 + js0) * a.rec_pitch + t0) * D + w * 4u);
                 const size_t gstep = (size_t)SPI * a.rec_pitch * D * 4u;
-                if (!(a.debug & 1u)) {
+                if (!(a.debug & kDbgSkipRecords)) {
                     const uint32_t nit = CPS * GS / 64u;  // wave-instructions that cover the group's GS string-tiles
                     for (uint32_t it0 = 0; it0 < nit; it0 += 8u) {
                         uint4 v[8];
@@ -396,7 +389,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                 const uint32_t mj0 = lane >> 3, mw = lane & 7u;
                 unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked + (size_t)(b0 + mj0) * a.msk_pitch + t0 + mw * 8u);
                 const size_t mstep = (size_t)8u * a.msk_pitch * 2u;
-                if (!(a.debug & 2u)) {
+                if (!(a.debug & kDbgSkipMasked)) {
                     if (!any_mask) {
                         for (uint32_t it = 0; it < GS / 8u; ++it) {
                             *reinterpret_cast<uint4 *>(mp) = make_uint4(0, 0, 0, 0);
@@ -417,7 +410,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                 for (uint32_t it = 0; it < CPS; ++it) {
                     const uint32_t chunk = it * 64u + lane;
                     const uint32_t js = chunk / CPS, w = chunk % CPS;
-                    if (js < GS && b0 + js < a.B && w < lim && !(a.debug & 1u)) {
+                    if (js < GS && b0 + js < a.B && w < lim && !(a.debug & kDbgSkipRecords)) {
                         const uint4 v = lds_u128(rec_base + js * RSB + w * 16u);
                         uint32_t *dst = a.records + ((size_t)(b0 + js) * a.rec_pitch + t0) * D + w * 4u;
                         *reinterpret_cast<uint4 *>(dst) = v;
@@ -429,7 +422,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                     const uint32_t js = it * 8u + (lane >> 3), w = lane & 7u;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (any_mask && js < GS) v = masked_chunk<D>(js, w, rec_base, chr_base, mb_base);
-                    if (js < GS && b0 + js < a.B && w < mlim && !(a.debug & 2u))
+                    if (js < GS && b0 + js < a.B && w < mlim && !(a.debug & kDbgSkipMasked))
                         *reinterpret_cast<uint4 *>(a.masked + (size_t)(b0 + js) * a.msk_pitch + t0 + w * 8u) = v;
                 }
             } else {
@@ -611,7 +604,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 // ---------------- walk + tag: lib.rs:804-888 ----------------
                 TileBits tb = {0, 0, 0};
                 const bool full = (t0 + T < min_n);
-                if (a.debug & 16u) {
+                if (a.debug & kDbgSplitNoWalk) {
                     // profiling only: no walk, the storer moves whatever the slot holds
                 } else if (full)
                     tb = walk_tile<D, true, T>(L, act, a, chunks, 0, 0, t0);
@@ -680,7 +673,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
 #pragma unroll
                     for (int i = 0; i < kSuper * CPT; ++i) act[i] = pen[i];
                     settle_n(act);
-                    if (!(a.debug & 4u)) load_batch(pen, t0 + T + kSuper * T);
+                    if (!(a.debug & kDbgInputFromL2)) load_batch(pen, t0 + T + kSuper * T);
                 }
                 if (stamp && lane == 0) stamp[3] = __builtin_amdgcn_s_memtime();
             }
@@ -717,7 +710,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
             const uint32_t last_line = n_s ? ((n_s - 1u) & ~127u) : 0u;
             const uint8_t *tptr = a.chars + (size_t)(active ? b : a.B - 1u) * a.stride;
             auto touch = [&](uint32_t row) {
-                if (!(a.debug & 8u)) {
+                if (!(a.debug & kDbgNoTouch)) {
                     uint32_t saved_m0;  // M0 = LDS base of the DMA; restored, the compiler does not expect it to change
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                                  : "=&s"(saved_m0)
@@ -785,7 +778,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                     unsigned char *gp = reinterpret_cast<unsigned char *>(a.records + ((size_t)(b0 + js0) * a.rec_pitch + t0) * D + w * 4u);
                     const size_t gstep = (size_t)8u * a.rec_pitch * D * 4u;
                     const uint32_t lim = rows * D / 4u;
-                    if (!(a.debug & 1u)) {
+                    if (!(a.debug & kDbgSkipRecords)) {
 #pragma unroll
                         for (uint32_t it = 0; it < 8u; ++it) {
                             if (whole || (b0 + it * 8u + js0 < a.B && w < lim)) *reinterpret_cast<uint4 *>(gp) = v[it];
@@ -823,7 +816,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 }
                 ring_post(cons_off, seq + 1u);  // every LDS read of the slot has returned; the stores may still be in flight
                 if (t0 % kTouchRows == 0) touch(t0 + kTouchAhead + kTouchRows);
-                if (blk_last && !(a.debug & 2u)) {
+                if (blk_last && !(a.debug & kDbgSkipMasked)) {
                     unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked + (size_t)(b0 + mj0) * a.msk_pitch + blk0 + mw * 8u);
                     const size_t mstep = (size_t)8u * a.msk_pitch * 2u;
                     const bool blk_whole = (b0 + 64u <= a.B) && (blk0 + kBlk <= M);
@@ -1143,7 +1136,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         const uint32_t total = my_groups * ntiles;
         const uint32_t row_cap = (uint32_t)a.stride - 16u;  // last 16-byte chunk that exists for every string
         const size_t cmul = in_pm ? (size_t)B : (size_t)1;  // byte offset of chunk-start row r: r * cmul
-        const size_t cmul_eff = (a.debug & 4u) ? (size_t)0 : cmul;  // (4: profiling only, every tile re-reads the hot first lines)
+        const size_t cmul_eff = (a.debug & kDbgInputFromL2) ? (size_t)0 : cmul;  // (4: profiling only, every tile re-reads the hot first lines)
         uint4 buf[RT * 4u];
         auto issue = [&](const uint32_t q, const uint32_t k) {  // tile q of the pair's sequence -> register tile k
             const uint32_t g = g_first + (q / ntiles) * g_stride, t = q % ntiles;
@@ -1228,11 +1221,11 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 acc_state[d] = a.dc[d].first_state;  // n == 0
             }
             const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
-            unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * ((a.debug & 0x100000u) ? D : 1);
-            // (0x1000000, profiling only: every quad / octet of a string lands on the first one — same store instructions, no new lines or pages)
-            const size_t rstep = (a.debug & 0x1000000u) ? (size_t)0 : (size_t)B * 16u * D;  // one quad of rows further: [M/4][D][B][4]
+            unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * ((a.debug & kDbgInterleavedDefs) ? D : 1);
+            // (kDbgFixedLines, profiling only: every quad / octet of a string lands on the first one — same store instructions, no new lines or pages)
+            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : (size_t)B * 16u * D;  // one quad of rows further: [M/4][D][B][4]
             unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
-            const size_t mstep = (a.debug & 0x1000000u) ? (size_t)0 : (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
+            const size_t mstep = (a.debug & kDbgFixedLines) ? (size_t)0 : (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
             uint4 pend[8];                             // the previous tile's masked rows, not yet stored
             unsigned char *pend_mp = mp;
             bool have_pend = false;
@@ -1254,11 +1247,11 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 uint32_t sidq[16];
                 TileBits tb;
                 const bool full = (t0 + 64u < min_n);
-                const bool do_store = active && !(a.debug & 1u);
-                const bool pend_store = active && have_pend && !(a.debug & 2u);
+                const bool do_store = active && !(a.debug & kDbgSkipRecords);
+                const bool pend_store = active && have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
-                // [ceil(M/4)][D][B][4]: one def's quads of all strings (0x100000, profiling: [M/4][B][D][4])
-                GlobalSink<D> sink{rp, (a.debug & 0x100000u) ? (size_t)16u : (size_t)B * 16u, rstep, do_store, (a.debug & 32u) != 0, (a.debug & 64u) != 0,
+                // [ceil(M/4)][D][B][4]: one def's quads of all strings (kDbgInterleavedDefs, profiling: [M/4][B][D][4])
+                GlobalSink<D> sink{rp, (a.debug & kDbgInterleavedDefs) ? (size_t)16u : (size_t)B * 16u, rstep, do_store, (a.debug & kDbgNtRecords) != 0, (a.debug & kDbgNtMasked) != 0,
                                    pend, pend_mp, mstep, pend_store};
                 if (WIDE) {
                     const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
@@ -1397,7 +1390,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 // that has left L2 is a read-modify-write at the memory: measured 521 vs 357 us with the fix-ups skipped;
                 // a per-lane variant that zeroes whole octets with 16-byte stores was no better — 558 us).
                 uint64_t fixm = __ballot(tm.fix != 0);
-                if (a.debug & 0x800000u) fixm = 0;  // profiling only: skip the fix-ups
+                if (a.debug & kDbgSkipFixups) fixm = 0;  // profiling only: skip the fix-ups
                 while (fixm) {
                     const int j = __ffsll((unsigned long long)fixm) - 1;
                     fixm &= fixm - 1;
@@ -1427,7 +1420,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                             v = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
                         }
                         if (D == 1) pend[k] = v;  // leaves during the next tile's walk
-                        else if (active && t0 + (uint32_t)k * 8u < M && !(a.debug & 2u))
+                        else if (active && t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked))
                             store16(mp + (size_t)k * mstep, v, false);  // D >= 2: the walk needs the registers; store now
                     }
                     pend_mp = mp;
@@ -1436,7 +1429,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 }
             }
             // the last tile's masked rows (only the octets that exist: [ceil(M/8)][B][8])
-            if (active && have_pend && !(a.debug & 2u)) {
+            if (active && have_pend && !(a.debug & kDbgSkipMasked)) {
                 const uint32_t t0 = (ntiles - 1u) << 6;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -1474,13 +1467,13 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     out.half = 0;
     // DFAs whose fused table leaves no room for the per-wave LDS areas are walked out of global memory (L2-resident)
     const size_t min_stage = (a.layout & 1u) ? (2 * 4096 + 4096 + 16) : wave_stage_bytes((int)a.D, 16);
-    if (a.table_bytes + min_stage > kLdsLimit || (a.debug & 0x40000u)) out.gtab = 1;
+    if (a.table_bytes + min_stage > kLdsLimit || (a.debug & kDbgForceGlobalTable)) out.gtab = 1;
     const uint32_t table_bytes_saved = a.table_bytes;
     struct Restore { WitnessArgs &a; uint32_t v; ~Restore() { a.table_bytes = v; } } restore{a, table_bytes_saved};
     if (out.gtab) a.table_bytes = 0;  // for the LDS budgeting below only; restored on return
-    if ((a.layout & 1u) && a.half_image && ((out.gtab && !(a.debug & 0x40000u)) || (a.debug & 0x400000u))) {
+    if ((a.layout & 1u) && a.half_image && ((out.gtab && !(a.debug & kDbgForceGlobalTable)) || (a.debug & kDbgForceHalf))) {
         // ---- loader/walker kernel on the HALF table (2-byte entries): DFAs of up to 256 states whose 4-byte table does not
-        // fit LDS (cfg 5: 256 x 256 -> 128 KiB) stay LDS-resident instead of being walked out of L2 (debug 0x400000 forces it)
+        // fit LDS (cfg 5: 256 x 256 -> 128 KiB) stay LDS-resident instead of being walked out of L2 (kDbgForceHalf forces it)
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
         for (; pairs >= 1; --pairs) {
@@ -1511,12 +1504,10 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
                 const size_t lds = a.table_bytes + (size_t)pairs * (ns * 4096 + 4096 + 16);
                 if (lds > kLdsLimit) continue;
                 out.split = 2;
-                // WIDE table: ~3x fewer VALU ops per row at D = 3, which shortens a string's serial walk — it wins while
-                // every group has a walker slot to itself (the launch then lasts one string's walk: 4.39 vs 5.09 ms at
-                // 32768 x 32768 B, D = 3) and loses 5-10 % once the slots are oversubscribed and the launch is bound by
-                // the store path (profiles/r01_config_sweep).  D = 1 gains nothing: its walk is LDS-latency-bound.
-                // debug 0x80000 forces the narrow table, 0x200000 the wide one.
-                out.wide = (a.wide_image && !out.gtab && !(a.debug & 0x80000u) && (a.D >= 2 || (a.debug & 0x200000u))) ? 1 : 0;
+                // WIDE table: ~4x fewer instructions per row at D = 3; every D >= 2 batch takes it (same-box A/B
+                // with spill-free kernels: 1.20 vs 1.33 ms at 262144 x 2048 B, D = 2; 3.48 vs 4.59 ms at 32768 x 32768 B, D = 3).
+                // D = 1 gains nothing: its walk is LDS-latency-bound either way.
+                out.wide = (a.wide_image && !out.gtab && !(a.debug & kDbgForceNarrow) && (a.D >= 2 || (a.debug & kDbgForceWide))) ? 1 : 0;
                 out.waves_per_wg = 2 * pairs;
                 out.nslots = ns;
                 out.lds_bytes = lds;
@@ -1533,7 +1524,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
         return false;
     }
     // ---- walker/storer kernel: D in {1,2}, rows in multiples of 8, ring of >= 2 slots per pair
-    if ((a.D == 1 || a.D == 2) && a.M % 8u == 0 && !(a.debug & 0x10000u) && !out.gtab) {
+    if ((a.D == 1 || a.D == 2) && a.M % 8u == 0 && !(a.debug & kDbgForceOneWave) && !out.gtab) {
         const size_t slot = 64 * 128 + 64 * 8 + 64 * (a.D == 1 ? 32 : 16), fixed = 16 + 256;  // + the storer's LDS-DMA sink
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;  // small batches: spread over the CUs
@@ -1558,7 +1549,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     // group size: 64 strings per wave; smaller groups only for batches that would otherwise leave CUs without a wave
     // (two half-empty waves per SIMD were measured slower than one full one: the walk is issue-bound, not latency-bound)
     uint32_t gs = 64;
-    if (a.debug & 0x20000u) gs = 32;
+    if (a.debug & kDbgGroups32) gs = 32;
     while (gs > 16 && ((size_t)a.B + gs - 1) / gs < (size_t)num_cus) gs >>= 1;
     a.gs = gs;
     a.n_groups = (uint32_t)(((size_t)a.B + gs - 1) / gs);

@@ -27,9 +27,31 @@ struct WitnessArgs {
     uint32_t n_groups;            // ceil(B / gs), set by plan_witness_launch
     uint32_t gs;                  // strings per wave (64, 32 or 16), set by plan_witness_launch
     uint32_t D;
-    uint32_t debug;               // HRX_DEBUG_FLAGS (profiling ablations only): 1 skip record stores, 2 skip masked stores
+    uint32_t debug;               // HRX_DEBUG_FLAGS: the kDbg* bits below (profiling ablations and forced kernel / table choices for the tests)
     unsigned long long *stamps;   // profiling only (tools/kbench): per wave and tile 4 s_memtime stamps; NULL in the product
     DefConsts dc[3];
+};
+
+// HRX_DEBUG_FLAGS (environment, read per launch): never set in production.  The "force" bits let the parity tests drive
+// every kernel / table format through the same batches; the others are ablations used to steer the design
+// and make the OUTPUT WRONG.
+enum : uint32_t {
+    kDbgSkipRecords = 1u,             // ablation: no record stores
+    kDbgSkipMasked = 2u,              // ablation: no masked-row stores
+    kDbgInputFromL2 = 4u,             // ablation: every tile re-reads the first input lines (no HBM reads) / no prefetch of the next tile
+    kDbgNoTouch = 8u,                 // ablation, walker/storer kernel: no L2 touch-ahead of the input
+    kDbgSplitNoWalk = 16u,            // ablation, walker/storer kernel: storers move whatever the slots hold
+    kDbgNtRecords = 32u,              // position-major kernel: non-temporal record stores
+    kDbgNtMasked = 64u,               // position-major kernel: non-temporal masked-row stores
+    kDbgForceOneWave = 0x10000u,      // string-major: the one-wave kernel instead of the walker/storer kernel
+    kDbgGroups32 = 0x20000u,          // one-wave kernel: 32 strings per wave
+    kDbgForceGlobalTable = 0x40000u,  // walk the fused table out of global memory even if it fits LDS
+    kDbgForceNarrow = 0x80000u,       // position-major kernel: 4-byte table even where the planner picks WIDE
+    kDbgInterleavedDefs = 0x100000u,  // ablation: records as [M/4][B][D][4] instead of per-def planes
+    kDbgForceWide = 0x200000u,        // position-major kernel: WIDE table also at D = 1
+    kDbgForceHalf = 0x400000u,        // position-major kernel: HALF table even if the 4-byte one fits LDS
+    kDbgSkipFixups = 0x800000u,       // ablation: no end-mask fix-ups
+    kDbgFixedLines = 0x1000000u,      // ablation: every quad / octet of a string is stored onto its first one
 };
 
 struct LaunchInfo {
