@@ -377,6 +377,80 @@ def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
     _check_batch(hra, oracle, CFG_A, chars, lens, 200)
 
 
+def _random_defs(rng, D):
+    """D random definitions in the reference's text formats: 3..60 states, mostly over one shared alphabet and mostly total
+    (so that walks are long), sometimes 85-95 % dense or over an alphabet of their own; 1-3 substring definitions each with
+    random transition subsets / start / end states."""
+    shared = np.sort(rng.choice(np.arange(1, 256), size=int(rng.integers(2, 24)), replace=False))
+    out = []
+    for _ in range(D):
+        S = int(rng.integers(3, 61))
+        alpha = shared if rng.random() < 0.8 else np.sort(rng.choice(np.arange(1, 256), size=int(rng.integers(2, 40)), replace=False))
+        dens = float(rng.choice([1.0, 1.0, 1.0, 0.97, 0.9]))
+        lines = [str(int(rng.integers(0, S))), str(int(rng.integers(0, S))), str(S - 1)]
+        pairs = set()
+        for st in range(S):
+            for ch in alpha:
+                if rng.random() < dens:
+                    nx = int(rng.integers(0, S)) if rng.random() < 0.5 else int(rng.integers(0, min(S, 4)))   # a few hub states: pairs recur
+                    lines.append("%d %d %d" % (st, nx, int(ch)))
+                    pairs.add((st, nx))
+        pairs = sorted(pairs)
+        subs = []
+        for _ in range(int(rng.integers(1, 4))):
+            pick = [pairs[i] for i in rng.choice(len(pairs), size=min(len(pairs), int(rng.integers(4, 40))), replace=False)]
+            starts = sorted({a for a, _ in pick[: max(1, len(pick) // 3)]})
+            ends = sorted({b for _, b in pick[len(pick) // 2:]}) or [pick[0][1]]
+            subs.append("\n".join(["8", "0", "99", " ".join(map(str, starts)) + " ", " ".join(map(str, ends)) + " "] +
+                                  ["%d %d" % p for p in sorted(pick)]) + "\n")
+        out.append(("\n".join(lines) + "\n", subs, alpha))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
+    """Seeded fuzz: random DFAs (partial ones included: status 1 must carry the reference's state/char), 1-3 defs (overlapping
+    flags -> status 2), random M incl. odd values, ragged lengths incl. 0 and > M, bytes outside the alphabets; the
+    string-major and the position-major kernels against the oracle, bit for bit."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.integers(1, 4))
+    defs_t = _random_defs(rng, D)
+    M = int(rng.choice([5, 31, 64, 100, 129, 256, 321, 520, 777]))
+    B = int(rng.choice([1, 63, 64, 65, 200, 333, 500]))
+    stride = (M + 40 + 15) // 16 * 16
+    alpha = np.unique(np.concatenate([a for _, _, a in defs_t]))
+    common = defs_t[0][2]
+    for _, _, a in defs_t[1:]:
+        common = np.intersect1d(common, a)
+    pool = common if len(common) >= 2 and rng.random() < 0.7 else alpha     # mostly bytes every def knows: long valid walks
+    chars = pool[rng.integers(0, len(pool), size=(B, stride))].astype(np.uint8)
+    lens = rng.integers(0, M + 1, size=B).astype(np.uint32)
+    lens[rng.random(B) < 0.05] = M + 3                                      # BadLength
+    lens[0] = M if B > 1 else lens[0]
+    for b in np.nonzero(rng.random(B) < 0.1)[0]:                            # a byte no def has a column for
+        chars[b, int(rng.integers(0, stride))] = 0
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs, _ in defs_t]
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    o = OracleDefs(oracle, [(a, subs) for a, subs, _ in defs_t])
+    orec, omsk, ost = o.witness_batch(chars, lens, M)
+    ok = (ost & np.uint64(0xff)) == 0
+    grec, gmsk, gst = cfg.witness_batch_host(chars, lens)                   # string-major kernels
+    assert np.array_equal(ost, gst)
+    assert np.array_equal(orec[ok], grec[ok]) and np.array_equal(omsk[ok], gmsk[ok])
+    dev = torch.device("cuda", 0)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    for pm_input in (False, True):                                          # position-major kernel, both input layouts
+        if pm_input:
+            rec, msk, st = cfg.witness_batch_position_major(hra.chars_to_position_major(d_chars), d_lens, chars_pm_stride=stride)
+        else:
+            rec, msk, st = cfg.witness_batch_position_major(d_chars, d_lens)
+        torch.cuda.synchronize()
+        r1, m1 = hra.position_major_to_string_major(rec, msk, B, M, D)
+        assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+        assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
+
+
 def test_invalid_bytes_bad_lengths_and_overlap_status(hra, oracle):
     from halo2_regex_amd import synth
     chars, lens = synth.ragged(257, 300, seed=3)
