@@ -1703,30 +1703,34 @@ hipError_t launch_endpoint_flags(const EndpointArgs &a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// compact witness -> field cells.  One thread per (string, row) expands the row's integers into what
+// compact witness -> field cells.  A pair of threads per (string, row) expands the row's integers into what
 // `Value::known(F::from(v))` holds for every advice cell the reference assigns (lib.rs:339-418, 473-519) and for its two
-// result columns (lib.rs:752-771), F = bn256::Fr in Montgomery form (hrx_fr.h), column-major [col][string][row][4 limbs]:
-// consecutive lanes are consecutive rows, so every column is written in contiguous 2-KiB runs per wave.  Write-bound:
-// 32 B per cell x (4 + 4 D) cells per row.
+// result columns (lib.rs:752-771), F = bn256::Fr in Montgomery form (hrx_fr.h), column-major [col][string][row][4 limbs].
+// Write-bound: 32 B per cell x (4 + 4 D) cells per row.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kFrRowsPerBlock = 512u;
 __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    // thread = (row, half of the 32-byte cell): both lanes of a pair compute the cell, each stores its 16 bytes, so that a
+    // store instruction writes 1 KiB of full lines (one lane per row stored half of every 32 bytes per instruction)
+    const uint32_t half = threadIdx.x & 1u;
     const uint32_t bi = blockIdx.y;              // index inside the requested range
     const uint32_t b = a.b_begin + bi;
-    if (r >= a.M) return;
     const uint32_t n = min(a.lens[b], a.M);
     const bool pm = (a.layout & 1u) != 0, in_pm = (a.layout & 2u) != 0;
+#pragma unroll 2
+    for (uint32_t it = 0; it < kFrRowsPerBlock / 128u; ++it) {
+    const uint32_t r = blockIdx.x * kFrRowsPerBlock + it * 128u + (threadIdx.x >> 1);
+    if (r >= a.M) return;
     const uint32_t live = r < n ? 1u : 0u;
     uint32_t c = 0;
     if (live) c = in_pm ? a.chars[((size_t)(r >> 4) * a.B + b) * 16u + (r & 15u)] : a.chars[(size_t)b * a.stride + r];
     const size_t col_cells = (size_t)a.b_count * a.M;   // cells per column
-    uint64_t *out = a.cells + ((size_t)bi * a.M + r) * 4u;
+    uint64_t *out = a.cells + ((size_t)bi * a.M + r) * 4u + half * 2u;
     auto put = [&](const uint32_t col, const uint32_t v) {
         uint32_t w[8];
         fr_from_u32(v, w, a.canonical != 0);
         uint4 *p = reinterpret_cast<uint4 *>(out + (size_t)col * col_cells * 4u);
-        p[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        *p = half ? make_uint4(w[4], w[5], w[6], w[7]) : make_uint4(w[0], w[1], w[2], w[3]);
     };
     put(0, live);   // char_enable                        lib.rs:342,346
     put(1, c);      // characters                         lib.rs:343,347
@@ -1741,11 +1745,12 @@ __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
     const uint32_t mk = pm ? a.masked[((size_t)(r >> 3) * a.B + b) * 8u + (r & 7u)] : a.masked[(size_t)b * a.msk_pitch + r];
     put(2 + 4 * a.D, mk & 0xffu);                 // masked_characters  lib.rs:752-757
     put(3 + 4 * a.D, mk >> 8);                    // all_substr_ids     lib.rs:758-761
+    }
 }
 
 hipError_t launch_fr_columns(const FrArgs &a, hipStream_t stream) {
     if (a.b_count == 0 || a.M == 0) return hipSuccess;
-    hipLaunchKernelGGL(fr_columns_kernel, dim3((a.M + 255u) / 256u, a.b_count), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(fr_columns_kernel, dim3((a.M + kFrRowsPerBlock - 1u) / kFrRowsPerBlock, a.b_count), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
