@@ -1104,6 +1104,24 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     const uint32_t ring_base = tab_bytes + pair * pair_bytes;
     const uint32_t scratch_off = ring_base + nring * kPmTileBytes;
     const uint32_t ready_off = scratch_off + (HALF ? 0u : kPmTileBytes), freed_off = ready_off + 4u;
+    const uint32_t M = a.M, B = a.B;
+    const uint32_t ntiles = (M + 63u) >> 6;
+    uint32_t seq = 0;
+    const uint32_t g_first = blockIdx.x * pairs + pair, g_stride = gridDim.x * pairs;
+    // The loaders request their pair's first input tile BEFORE the table is staged: the HBM round trip (~2 us) then runs
+    // under the staging instead of after it.
+    uint32_t first_len = M;   // ... and the walkers their first group's lengths
+    if (is_walker && g_first < a.n_groups && g_first * 64u + lane < B) first_len = a.lens[g_first * 64u + lane];
+    uint4 first_tile[4];
+    if (!is_walker && g_first < a.n_groups) {
+        const bool in_pm0 = (a.layout & 2u) != 0;
+        const uint32_t bl = min(g_first * 64u + lane, B - 1u);
+        const uint8_t *cptr = in_pm0 ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
+        const uint32_t row_cap0 = (uint32_t)a.stride - 16u;
+        const size_t cmul0 = (a.debug & kDbgInputFromL2) ? (size_t)0 : in_pm0 ? (size_t)B : (size_t)1;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) first_tile[i] = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(16u * i, row_cap0) * cmul0);
+    }
     {
         const uint4 *src = WIDE ? reinterpret_cast<const uint4 *>(a.wide_image)
                                 : HALF ? reinterpret_cast<const uint4 *>(a.half_image) : reinterpret_cast<const uint4 *>(a.table_image);
@@ -1113,11 +1131,6 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         if (is_walker && lane == 0) { lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0); }
     }
     __syncthreads();
-
-    const uint32_t M = a.M, B = a.B;
-    const uint32_t ntiles = (M + 63u) >> 6;
-    uint32_t seq = 0;
-    const uint32_t g_first = blockIdx.x * pairs + pair, g_stride = gridDim.x * pairs;
 
     if (!is_walker) {
         // ================================ loader ================================
@@ -1150,12 +1163,11 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         };
         // The pair's FIRST tile travels alone: requested together with the rest, it queues behind the whole chip's opening
         // burst (~48 MiB) and reaches the walker ~10 us into the launch (in-kernel stamps, tools/kbench) instead of ~1.5.
-        if (total > 0) {
-            issue(0, 0);
+        if (total > 0) {   // (requested before the table staging; see the kernel's prologue)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
-                uint4 v = buf[i];
+                uint4 v = first_tile[i];
                 asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
                 *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(ring_base + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
             }
@@ -1197,7 +1209,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
         const bool active = b < B;
-        const uint32_t n_raw = active ? a.lens[b] : M;
+        const uint32_t n_raw = g == g_first ? first_len : (active ? a.lens[b] : M);
         const bool badlen = n_raw > M;
         const uint32_t n = badlen ? M : n_raw;
 
