@@ -1,0 +1,77 @@
+// hrx_device.h — device-side helpers shared by the kernel translation units (hrx_kernel_sm.hip: string-major kernels,
+// hrx_kernel_pm.hip: position-major kernel): LDS access by byte offset, the fused-table lookup, the per-lane walk state,
+// the LDS ring hand-over between the waves of a pair, and the cached dynamic-LDS attribute.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+
+#include "hrx_kernel.hpp"
+#include "hrx_lane.h"
+
+namespace hrx {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+// The kernels declare no static LDS, so the dynamic segment starts at LDS address 0 and a byte offset IS the
+// LDS address: reads go through integer->address_space(3) casts so that no base add sits on the walk's
+// dependent chain (witness_kernel traps if the assumption ever breaks).
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const v4u32 lds_cv4u32;
+__device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *(lds_cu32 *)(uintptr_t)off; }
+__device__ __forceinline__ uint4 lds_u128(uint32_t off) {
+    const v4u32 v = *(lds_cv4u32 *)(uintptr_t)off;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// delta lookup.  GTAB: the fused table did not fit the LDS budget and is read from global memory (it stays L2/MALL
+// resident: every wave hammers the same few hundred KiB); same entry format, same byte offsets, ~10x the latency.
+template <bool GTAB>
+__device__ __forceinline__ uint32_t table_at(const WitnessArgs &a, uint32_t off) {
+    if (GTAB) return a.table_image[off >> 2];
+    return lds_u32(off);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, s, 64));
+    return v;
+}
+
+template <int D>
+struct LaneRegs {
+    uint32_t e[D];   // current fused entry of def d: bits 10.. = absolute table row of the CURRENT state
+    uint32_t mx[D];  // running max of entries (reaching the dead row = an undefined transition)
+    uint32_t sid_prev;
+    uint32_t ov_row;  // D > 1: lowest row where two defs raise the same flag
+};
+
+constexpr uint32_t kNoFix = 0xffffffffu;
+
+__device__ __forceinline__ uint32_t lds_vol_u32(uint32_t off) { return *(volatile lds_cu32 *)(uintptr_t)off; }
+__device__ __forceinline__ void lds_store_u32(uint32_t off, uint32_t v) {
+    *(volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)off = v;
+}
+// wait until the tile counter at LDS offset `off` reaches `want`
+__device__ __forceinline__ void ring_wait(uint32_t off, uint32_t want) {
+    while ((int32_t)(lds_vol_u32(off) - want) < 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void ring_post(uint32_t off, uint32_t v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt lgkmcnt(0): the slot's LDS traffic is done
+    lds_store_u32(off, v);
+}
+
+// hipFuncSetAttribute costs several microseconds of host time: raise a kernel's dynamic-LDS limit only when a launch
+// needs more than every earlier launch of that kernel did (the launch path is otherwise one hipLaunchKernelGGL).
+template <class K>
+static hipError_t ensure_lds(K k, std::atomic<size_t> &granted, size_t need) {
+    if (need <= granted.load(std::memory_order_acquire)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+    if (e == hipSuccess) granted.store(need, std::memory_order_release);
+    return e;
+}
+
+}  // namespace hrx

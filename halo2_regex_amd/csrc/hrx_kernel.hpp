@@ -1,4 +1,4 @@
-// hrx_kernel.hpp — host-visible launch interface of the HIP kernels (hrx_kernel.hip).
+// hrx_kernel.hpp — host-visible launch interface of the HIP kernels (hrx_kernel.hip: planner, dispatch, auxiliary kernels; hrx_kernel_pm.hip / hrx_kernel_sm.hip: the witness kernels).
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -73,6 +73,9 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // Picks the launch geometry for `a` on a device with `num_cus` CUs; returns false if nothing fits.
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out);
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
+// the two kernel translation units behind launch_witness: li.split == 2 -> hrx_kernel_pm.hip, else hrx_kernel_sm.hip
+hipError_t launch_witness_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
+hipError_t launch_witness_sm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 
 // states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])
 hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,

@@ -3,7 +3,7 @@
 // Compiled by g++ from tests/test_lane_sim.py.  It drives the product's own host code — the dense
 // fused-table builder (csrc/hrx_defs.cpp) and the per-lane tile algebra incl. the optimistic end-mask
 // protocol (csrc/hrx_lane.h: tile_masks, fill_up/fill_down, status packers) — tile by tile exactly as
-// the kernel does (csrc/hrx_kernel.hip: walk_tile<D,false> + the per-tile epilogue), so that the
+// the kernel does (csrc/hrx_kernel_sm.hip: walk_tile<D,false> + the per-tile epilogue), so that the
 // algorithm can be checked against the oracle without a GPU.  It is not a fallback: nothing in the
 // product loads it.
 #include <cstdint>

@@ -1,6 +1,6 @@
 // kbench.cpp — on-box kernel micro-harness (profiling only; not part of the product or the tests).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench.cpp halo2_regex_amd/csrc/hrx_defs.cpp \
-//         halo2_regex_amd/csrc/hrx_kernel.hip -o tools/kbench
+//         halo2_regex_amd/csrc/hrx_kernel.hip halo2_regex_amd/csrc/hrx_kernel_pm.hip halo2_regex_amd/csrc/hrx_kernel_sm.hip -o tools/kbench
 //   tools/kbench <allstr.txt> <substr.txt> [B] [n] [M] [steps] [debug] [stamps]
 // Runs the witness kernel on alphabet-uniform noise and prints the average launch time; with stamps=1 it also
 // dumps the per-tile s_memtime stamps of a few waves (walk / epilogue / store phases).
