@@ -44,7 +44,10 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
             }
         }
     }
-    if (a.layout & 1u) {
+    // string-major D = 3 (no walker/storer kernel: its string-tiles are 128 bytes = 32 / 16 rows of 1 / 2 defs): the
+    // loader/walker kernel with the lane's own string-major strides, 5x the one-wave kernel
+    const bool sm3 = !(a.layout & 1u) && a.D == 3 && a.M % 8u == 0 && !out.gtab && !(a.debug & kDbgForceOneWave);
+    if ((a.layout & 1u) || sm3) {
         // ---- loader/walker kernel: table + per pair a ring of up to 4 input tiles (4 KiB each)
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void store16(unsigned char *p, const uint4 &v, const 
 // built and measured in round 1 — every global store does cost the issuing wave 75-125 cycles, but the ds_write_b128 +
 // hand-over cost the walker as much, and where all walker slots are busy the launch is bound by the memory system's mixed
 // read/write rate anyway: 97 vs 89 us on the headline workload, 3.41 vs 3.39 ms on cfg 4.  Dropped)
-template <int D>
+template <int D, bool SM = false>
 struct GlobalSink {
     static constexpr bool kSidq = true;
     unsigned char *rp;
@@ -43,7 +43,27 @@ struct GlobalSink {
     unsigned char *pend_mp;
     size_t mstep;
     bool pend_store;
+    uint4 held[SM ? D : 1];   // SM: the quads of defs 0..D-2, until the last def's arrives
     __device__ __forceinline__ void quad(const int d, const int p, const bool full, const int mrem, const uint4 &v) {
+        if (SM) {
+            // string-major records [B][pitch][D]: four rows of this string are 16*D contiguous bytes, rows outermost — the
+            // lane writes them itself (16-byte pieces that L2 merges into lines), no LDS transpose.  M % 4 == 0 here.
+            // (At D = 1 / 2 the walker/storer kernel's LDS transpose is 2x faster than this: 100 vs 236 us, 1.29 vs 2.31 ms.)
+            held[d] = v;
+            if (d == D - 1) {
+                uint32_t w[4 * D];
+#pragma unroll
+                for (int dd = 0; dd < D; ++dd) {
+                    w[0 * D + dd] = held[dd].x; w[1 * D + dd] = held[dd].y; w[2 * D + dd] = held[dd].z; w[3 * D + dd] = held[dd].w;
+                }
+                if (do_store && (full || (p & ~3) <= mrem)) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) store16(rp + 16 * k, make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]), nt_rec);
+                }
+                rp += rstep;
+            }
+            return;
+        }
         // quads that start at or beyond row M do not exist in [ceil(M/4)][D][B][4]
         if (do_store && (full || (p & ~3) <= mrem)) store16(rp + (size_t)d * plane, v, nt_rec);
         if (d == D - 1) rp += rstep;
@@ -262,7 +282,7 @@ __device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint
     return tb;
 }
 
-template <int D, bool GTAB, bool WIDE, bool HALF = false>
+template <int D, bool GTAB, bool WIDE, bool HALF = false, bool SM = false>
 __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -406,11 +426,14 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 acc_state[d] = a.dc[d].first_state;  // n == 0
             }
             const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
-            unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * ((a.debug & kDbgInterleavedDefs) ? D : 1);
+            // SM (string-major outputs from this kernel: D = 3, which the walker/storer kernel's 128-byte string-tiles do not
+            // cover): records [B][pitch][D], masked [B][pitch] — same walk, the lane's own strides
+            unsigned char *rp = SM ? reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * a.rec_pitch * D * 4u
+                                   : reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * ((a.debug & kDbgInterleavedDefs) ? D : 1);
             // (kDbgFixedLines, profiling only: every quad / octet of a string lands on the first one — same store instructions, no new lines or pages)
-            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : (size_t)B * 16u * D;  // one quad of rows further: [M/4][D][B][4]
-            unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
-            const size_t mstep = (a.debug & kDbgFixedLines) ? (size_t)0 : (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
+            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u * D : (size_t)B * 16u * D;  // one quad of rows further: [M/4][D][B][4]
+            unsigned char *mp = SM ? reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * a.msk_pitch * 2u : reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
+            const size_t mstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u : (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
             uint4 pend[8];                             // the previous tile's masked rows, not yet stored
             unsigned char *pend_mp = mp;
             bool have_pend = false;
@@ -436,8 +459,8 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 const bool pend_store = active && have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
                 // [ceil(M/4)][D][B][4]: one def's quads of all strings (kDbgInterleavedDefs, profiling: [M/4][B][D][4])
-                GlobalSink<D> sink{rp, (a.debug & kDbgInterleavedDefs) ? (size_t)16u : (size_t)B * 16u, rstep, do_store, (a.debug & kDbgNtRecords) != 0, (a.debug & kDbgNtMasked) != 0,
-                                   pend, pend_mp, mstep, pend_store};
+                GlobalSink<D, SM> sink{rp, (a.debug & kDbgInterleavedDefs) ? (size_t)16u : (size_t)B * 16u, rstep, do_store, (a.debug & kDbgNtRecords) != 0, (a.debug & kDbgNtMasked) != 0,
+                                       pend, pend_mp, mstep, pend_store, {}};
                 if (WIDE) {
                     const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                               cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
@@ -582,7 +605,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                     const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
                     const uint32_t bj = b0 + (uint32_t)j;
                     for (uint32_t r = fs + lane; r < t0; r += 64u)
-                        a.masked[((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
+                        a.masked[SM ? (size_t)bj * a.msk_pitch + r : ((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
                 }
                 // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8]; stored during the next walk ----------------
                 {
@@ -644,9 +667,9 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     }
 }
 
-template <int D, bool GTAB, bool WIDE = false, bool HALF = false>
+template <int D, bool GTAB, bool WIDE = false, bool HALF = false, bool SM = false>
 static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto k = witness_pm_kernel<D, GTAB, WIDE, HALF>;
+    auto k = witness_pm_kernel<D, GTAB, WIDE, HALF, SM>;
     static std::atomic<size_t> granted[64];  // per device: the attribute is set on the current device's function
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -657,6 +680,10 @@ static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStrea
 }
 
 hipError_t launch_witness_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
+    if (!(a.layout & 1u)) {   // string-major outputs, D = 3 (plan_witness_launch)
+        if (a.D != 3 || li.half || li.gtab) return hipErrorInvalidValue;
+        return li.wide ? launch_pm<3, false, true, false, true>(a, li, stream) : launch_pm<3, false, false, false, true>(a, li, stream);
+    }
     if (li.half) return a.D == 1 ? launch_pm<1, false, false, true>(a, li, stream) : a.D == 2 ? launch_pm<2, false, false, true>(a, li, stream) : launch_pm<3, false, false, true>(a, li, stream);
     if (li.wide) return a.D == 1 ? launch_pm<1, false, true>(a, li, stream) : a.D == 2 ? launch_pm<2, false, true>(a, li, stream) : launch_pm<3, false, true>(a, li, stream);
     if (li.gtab) return a.D == 1 ? launch_pm<1, true>(a, li, stream) : a.D == 2 ? launch_pm<2, true>(a, li, stream) : launch_pm<3, true>(a, li, stream);

@@ -138,6 +138,9 @@ def test_planner_picks_the_documented_kernel_per_config():
     cfg = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
     assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> ")     # D >= 2: the WIDE table
     assert cfg.describe_launch(1 << 20, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> grid=256 waves=8 ")
+    cfg3 = RegexVerifyConfig.configure(1024, _defs(CFG_A + CFG_3), device=None)
+    assert cfg3.describe_launch(65536, layout=0).startswith("hrx::witness_pm_kernel<3, false, true, false, true> ")   # string-major D = 3: lane-direct stores
+    assert RegexVerifyConfig.configure(1001, _defs(CFG_A + CFG_3), device=None).describe_launch(65536, layout=0).startswith("hrx::witness_kernel<3, false, false> ")
     # cfg 5: 256 states x 256 symbols = 258 KiB of 4-byte entries -> the 128-KiB HALF table, LDS-resident
     a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=np.arange(256, dtype=np.uint8), n_substr_pairs=200)
     cfg = RegexVerifyConfig.configure(4096, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)
