@@ -470,15 +470,17 @@ class RegexVerifyConfig:
                                    status=int(status[0]))
 
     # -- the batch surface (the build's addition; parity is per string with match_substrs) --------
-    def witness_batch_host(self, chars2d, lens):
-        """chars2d (B, stride) uint8 numpy, lens (B,) -> records (B,M,D) u32, masked (B,M) u16, status (B,) u64."""
+    def witness_batch_host(self, chars2d, lens, out=None):
+        """chars2d (B, stride) uint8 numpy, lens (B,) -> records (B,M,D) u32, masked (B,M) u16, status (B,) u64.
+        out=(rec, msk, st): reuse the caller's arrays (fresh arrays cost a page fault per 4 KiB while the copy lands)."""
         chars2d = _np(chars2d, np.uint8)
         lens = _np(lens, np.uint32)
         B, stride = chars2d.shape
         M, D = self.max_chars_size, self.num_defs
-        rec = np.zeros((B, M, D), np.uint32)
-        msk = np.zeros((B, M), np.uint16)
-        st = np.zeros(B, np.uint64)
+        if out is None:
+            out = np.zeros((B, M, D), np.uint32), np.zeros((B, M), np.uint16), np.zeros(B, np.uint64)
+        rec, msk, st = out
+        assert rec.shape == (B, M, D) and msk.shape == (B, M) and st.shape == (B,) and rec.flags.c_contiguous and msk.flags.c_contiguous
         _check(lib.hrx_witness_batch_host(self._need_ctx(), _ptr(chars2d, _u8p), stride, _ptr(lens, _u32p), B, M,
                                           _ptr(rec, _u32p), _ptr(msk, _u16p), _ptr(st, _u64p)))
         return rec, msk, st
