@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "hrx_device.h"
+#include "hrx_walk_pm.h"
 
 namespace hrx {
 
@@ -19,269 +20,6 @@ namespace hrx {
 // (global_load_lds_dwordx4: no VGPRs, kRing tiles in flight, counted s_waitcnt) and the walker picks its 64 bytes per
 // tile up with four ds_read_b128.
 // =============================================================================================
-constexpr uint32_t kPmTileBytes = 64u * 64u;  // 64 strings x 64 input bytes per tile
-
-__device__ __forceinline__ void store16(unsigned char *p, const uint4 &v, const bool nt) {
-    if (nt) __builtin_nontemporal_store(v4u32{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u32 *>(p));
-    else *reinterpret_cast<uint4 *>(p) = v;
-}
-
-// Where a walker's finished rows go: straight to memory from its registers.  quad(d, p, ..) stores four rows of def d
-// (16 B per lane, 1 KiB contiguous per wave) into its plane of [ceil(M/4)][D][B][4]; row(p) lets the previous tile's masked
-// rows leave one 16-byte piece every 8 rows.  (The walk functions take the sink as a policy: a variant that handed the
-// rows to a third "storer" wave through an LDS out-ring, so that the walker issued no vector-memory instruction at all, was
-// built and measured in round 1 — every global store does cost the issuing wave 75-125 cycles, but the ds_write_b128 +
-// hand-over cost the walker as much, and where all walker slots are busy the launch is bound by the memory system's mixed
-// read/write rate anyway: 97 vs 89 us on the headline workload, 3.41 vs 3.39 ms on cfg 4.  Dropped)
-template <int D, bool SM = false>
-struct GlobalSink {
-    static constexpr bool kSidq = true;
-    unsigned char *rp;
-    size_t plane, rstep;
-    bool do_store, nt_rec, nt_msk;
-    const uint4 (&pend)[8];
-    unsigned char *pend_mp;
-    size_t mstep;
-    bool pend_store;
-    uint4 held[SM ? D : 1];   // SM: the quads of defs 0..D-2, until the last def's arrives
-    __device__ __forceinline__ void quad(const int d, const int p, const bool full, const int mrem, const uint4 &v) {
-        if (SM) {
-            // string-major records [B][pitch][D]: four rows of this string are 16*D contiguous bytes, rows outermost — the
-            // lane writes them itself (16-byte pieces that L2 merges into lines), no LDS transpose.  M % 4 == 0 here.
-            // (At D = 1 / 2 the walker/storer kernel's LDS transpose is 2x faster than this: 100 vs 236 us, 1.29 vs 2.31 ms.)
-            held[d] = v;
-            if (d == D - 1) {
-                uint32_t w[4 * D];
-#pragma unroll
-                for (int dd = 0; dd < D; ++dd) {
-                    w[0 * D + dd] = held[dd].x; w[1 * D + dd] = held[dd].y; w[2 * D + dd] = held[dd].z; w[3 * D + dd] = held[dd].w;
-                }
-                if (do_store && (full || (p & ~3) <= mrem)) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) store16(rp + 16 * k, make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]), nt_rec);
-                }
-                rp += rstep;
-            }
-            return;
-        }
-        // quads that start at or beyond row M do not exist in [ceil(M/4)][D][B][4]
-        if (do_store && (full || (p & ~3) <= mrem)) store16(rp + (size_t)d * plane, v, nt_rec);
-        if (d == D - 1) rp += rstep;
-    }
-    __device__ __forceinline__ void row(const int p) {
-        // the PREVIOUS tile's masked rows leave one 16-byte piece every 8 rows instead of as a burst of 8 stores at the
-        // tile boundary (the burst filled the store queue and stalled the in-order walk: 98.7 -> 93.8 us)
-        if (D == 1 && (p & 7) == 5 && pend_store) store16(pend_mp + (size_t)(p >> 3) * mstep, pend[p >> 3], nt_msk);
-    }
-};
-
-typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
-__device__ __forceinline__ uint32_t lds_u16(uint32_t off) { return *(lds_cu16 *)(uintptr_t)off; }
-// HALF table (hrx_lane.h): address of entry (row of `e`, byte c) from e and c2 = c << 1 — one v_perm_b32:
-// byte 0 = c2.byte0 = (c & 127) << 1, byte 1 = e.byte0 = row, byte 2 = c2.byte1 = c >> 7, byte 3 = 0
-__device__ __forceinline__ uint32_t half_next_addr(uint32_t e, uint32_t c2) { return __builtin_amdgcn_perm(e, c2, 0x0c010400u); }
-__device__ __forceinline__ uint32_t half_tag(uint32_t e) { return ((e >> 8) & 0x3fu) | ((e >> 14) << 8); }  // -> the narrow format's 10-bit tag
-
-template <int D, bool FULL, bool GTAB, bool HALF, class Sink>
-__device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, Sink &sink, int rem, int mrem,
-                                                 uint32_t t0, uint32_t (&sidq)[16], uint32_t (&acc_state)[D]) {
-    uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
-    uint32_t rbuf[D][4];
-    const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
-                             cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
-    uint32_t e1[D], e2[D], raw[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) e1[d] = e2[d] = L.e[d];
-
-    auto post = [&](const int p, const uint32_t (&es)[D], const uint32_t (&et)[D]) {
-        uint32_t sid = 0, stn = 0, enn = 0;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            uint32_t state = HALF ? (es[d] & 0xffu) - (d ? a.dc[d].half_row_base : 0u) : (es[d] >> kNextShift) - (d ? a.dc[d].row_base : 0u);
-            uint32_t tag = HALF ? half_tag(et[d]) : et[d] & kTagMask;
-            if (!FULL) {
-                if (HALF && p > rem) state = a.dc[d].dummy_state;  // the HALF image has no dummy row (lib.rs:413)
-                if (p >= mrem) tag &= ~kTagEnd;
-                if (p == rem) acc_state[d] = state;  // the state at row n (lib.rs:437-457)
-            }
-            rbuf[d][p & 3] = state | (tag << 16);
-            // four rows of def d of this string: 16 bytes, a 1-KiB contiguous run across the wave
-            if ((p & 3) == 3) sink.quad(d, p, FULL, mrem, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]));
-            if (!FULL || HALF) L.mx[d] = max(L.mx[d], et[d]);  // HALF: an undefined transition is a marked entry, not an absorbing row
-            sid += tag & 0xffu;
-            stn += (tag >> 8) & 1u;
-            enn += (tag >> 9) & 1u;
-        }
-        if (D > 1) {
-            if (stn > 1) L.ov_row = min(L.ov_row, t0 + (uint32_t)p);
-            if (enn > 1) L.ov_row = min(L.ov_row, t0 + (uint32_t)p + 1u);
-        }
-        st[p >> 5] |= (stn ? 1u : 0u) << (p & 31);
-        en1[p >> 5] |= (enn ? 1u : 0u) << (p & 31);
-        ch[p >> 5] |= (sid != L.sid_prev ? 1u : 0u) << (p & 31);
-        L.sid_prev = sid;
-        if (Sink::kSidq) sidq[p >> 2] |= sid << (8 * (p & 3));  // the tile's substr-id sums, one byte per row (masked rows need them)
-        sink.row(p);
-    };
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sidq[i] = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = q * 4 + k;
-            const uint32_t c4 = ((cw[q] >> (8 * k)) & 0xffu) << (HALF ? 1 : 2);
-#pragma unroll
-            for (int d = 0; d < D; ++d)  // delta(state, byte): lib.rs:810
-                raw[d] = HALF ? lds_u16(half_next_addr(e1[d], c4)) : table_at<GTAB>(a, (e1[d] & ~kTagMask) | c4);
-            if (p > 0) {
-                post(p - 1, e2, e1);
-                asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(ch[(p - 1) >> 5]), "+v"(L.sid_prev));
-                if (Sink::kSidq) asm volatile("" : "+v"(sidq[(p - 1) >> 2]));
-                if (!FULL || HALF) {
-#pragma unroll
-                    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]));
-                }
-                if (!FULL) {
-#pragma unroll
-                    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(acc_state[d]));
-                }
-                if (D > 1) asm volatile("" : "+v"(L.ov_row));  // or the 64 per-row flag counts stay live until the tile end
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                e2[d] = e1[d];
-                // rows >= n: lib.rs:404-418 (HALF: any valid row with an empty tag; post() writes the dummy state)
-                e1[d] = (FULL || p < rem) ? raw[d] : (HALF ? a.dc[d].half_row_base : a.dc[d].dummy_entry);
-            }
-        }
-    }
-    post(63, e2, e1);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        L.e[d] = e1[d];
-        L.mx[d] = max(L.mx[d], e1[d]);
-    }
-    TileBits tb;
-    tb.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
-    tb.en1 = (uint64_t)en1[0] | ((uint64_t)en1[1] << 32);
-    tb.ch = (uint64_t)ch[0] | ((uint64_t)ch[1] << 32);
-    return tb;
-}
-
-// ---------------------------------------------------------------------------------------------
-// WIDE-table walk (hrx_lane.h): one ds_read_b64 per row and def returns the chain word AND the finished record, so a
-// row costs, beyond the lookups,  v_add3 (per-row sums of substr ids and flag counts over the defs, straight from the
-// chain words) + v_bfe (substr id) + 2 shifts + 2 v_alignbit (start / end bit into the tile bitvectors) +
-// v_cmp/v_addc (id-changed bit) + 1 v_lshl_or (the id byte kept for the masked rows)  —  ~14 VALU at D = 3 against
-// ~65 for the narrow entry format, which made the D = 3 walk issue-bound (a wave64 VALU op occupies its SIMD for
-// 4 cycles).  Two defs flagging the same row only set tile_ov != 0 here; the exact row is found by the tile re-walk.
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) const v2u32 lds_cv2u32;
-__device__ __forceinline__ uint2 lds_u64(uint32_t off) {
-    const v2u32 v = *(lds_cv2u32 *)(uintptr_t)off;
-    return make_uint2(v.x, v.y);
-}
-
-template <int D, bool FULL, class Sink>
-__device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, Sink &sink, int rem, int mrem,
-                                                      uint32_t &tile_ov, uint32_t (&sidq)[16], uint32_t (&acc_state)[D]) {
-    uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
-    uint32_t rbuf[D][4];
-    uint32_t ov = 0;
-    // bytes >= 128 have no column: they are masked here and the tile is re-walked by the caller
-    const uint32_t cw[16] = {cq[0].x & 0x7f7f7f7fu, cq[0].y & 0x7f7f7f7fu, cq[0].z & 0x7f7f7f7fu, cq[0].w & 0x7f7f7f7fu,
-                             cq[1].x & 0x7f7f7f7fu, cq[1].y & 0x7f7f7f7fu, cq[1].z & 0x7f7f7f7fu, cq[1].w & 0x7f7f7f7fu,
-                             cq[2].x & 0x7f7f7f7fu, cq[2].y & 0x7f7f7f7fu, cq[2].z & 0x7f7f7f7fu, cq[2].w & 0x7f7f7f7fu,
-                             cq[3].x & 0x7f7f7f7fu, cq[3].y & 0x7f7f7f7fu, cq[3].z & 0x7f7f7f7fu, cq[3].w & 0x7f7f7f7fu};
-    uint32_t lo[D], plo[D], phi[D];   // lo: chain word after the newest row; plo/phi: chain word and record of the row being posted
-#pragma unroll
-    for (int d = 0; d < D; ++d) { lo[d] = plo[d] = L.e[d]; phi[d] = 0; }
-
-    auto post = [&](const int p) {    // row p: chain words plo[], records phi[]
-        uint32_t T;
-        if (D == 1) T = plo[0];
-        else if (D == 2) T = plo[0] + plo[1];
-        else T = plo[0] + plo[1] + plo[D - 1];
-        if (!FULL) {
-            if (p >= mrem) T &= ~(3u << kWideEndShift);   // end_enable of row M-1 is never assigned (lib.rs:501)
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            uint32_t rec = phi[d];
-            if (!FULL) {
-                if (p >= mrem) rec &= ~(1u << 25);
-            }
-            rbuf[d][p & 3] = rec;
-            // four rows of def d of this string: 16 bytes, a 1-KiB contiguous run across the wave
-            if ((p & 3) == 3) sink.quad(d, p, FULL, mrem, make_uint4(rbuf[d][0], rbuf[d][1], rbuf[d][2], rbuf[d][3]));
-        }
-        const uint32_t sid = (T >> kWideSidShift) & 0xffu;
-        const uint32_t F = T >> kWideStartShift;          // bits 0..1 start count, 2..3 end count
-        if (D > 1) ov |= F & 0xau;                        // a count of 2 or 3: two defs flag the same row
-        st[p >> 5] = __builtin_amdgcn_alignbit(F, st[p >> 5], 1);
-        en1[p >> 5] = __builtin_amdgcn_alignbit(T >> kWideEndShift, en1[p >> 5], 1);
-        // ch = (ch << 1) | (sid != sid_prev): bits arrive in reverse row order, undone once per word below
-        asm volatile("v_cmp_ne_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ch[p >> 5]) : "v"(sid), "v"(L.sid_prev) : "vcc");
-        L.sid_prev = sid;
-        if (Sink::kSidq) sidq[p >> 2] |= sid << (8 * (p & 3));
-        sink.row(p);
-    };
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sidq[i] = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = q * 4 + k;
-            const uint32_t c8 = ((cw[q] >> (8 * k)) & 0xffu) << 3;
-            uint2 raw[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) raw[d] = lds_u64((lo[d] & kWideRowMask) | c8);   // delta(state, byte): lib.rs:810
-            if (p > 0) {
-                post(p - 1);
-                asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(L.sid_prev));
-                if (Sink::kSidq) asm volatile("" : "+v"(sidq[(p - 1) >> 2]));
-                if (D > 1) asm volatile("" : "+v"(ov));
-                if (!FULL) {   // or the selects of all 64 rows are deferred to the tile end with every lookup result kept live (300 spills at D = 3)
-#pragma unroll
-                    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(L.mx[d]), "+v"(acc_state[d]));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const uint32_t prev = lo[d];             // chain word after row p-1: its row field is the state at row p
-                if (FULL) {
-                    lo[d] = raw[d].x;
-                    phi[d] = raw[d].y;
-                } else {
-                    const bool live = p < rem;
-                    const uint32_t state_here = ((prev >> kWideRowShift) & 0xffu) - a.dc[d].row_base;
-                    if (p == rem) acc_state[d] = state_here;                       // the state at row n (lib.rs:437-457)
-                    lo[d] = live ? raw[d].x : a.dc[d].dummy_entry;                 // rows >= n: lib.rs:404-418
-                    phi[d] = live ? raw[d].y : (p == rem ? state_here : (a.dc[d].dummy_entry >> kWideRowShift) - a.dc[d].row_base);
-                    L.mx[d] = live ? raw[d].x : L.mx[d];                           // last real chain word (dead-row check)
-                }
-                plo[d] = lo[d];
-            }
-        }
-    }
-    post(63);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        L.e[d] = lo[d];
-        if (FULL) L.mx[d] = lo[d];
-    }
-    tile_ov = ov;
-    TileBits tb;
-    tb.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
-    tb.en1 = (uint64_t)en1[0] | ((uint64_t)en1[1] << 32);
-    tb.ch = (uint64_t)__builtin_bitreverse32(ch[0]) | ((uint64_t)__builtin_bitreverse32(ch[1]) << 32);
-    return tb;
-}
-
 template <int D, bool GTAB, bool WIDE, bool HALF = false, bool SM = false>
 __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
     const uint32_t lane = threadIdx.x & 63u;
