@@ -207,7 +207,8 @@ def main():
                     for _ in range(args.steps):
                         step()
             torch.cuda.current_stream(dev).wait_stream(side)
-            g.replay()                                     # one untimed replay: graph upload
+            for _ in range(2):                             # untimed replays: graph upload, caches, clocks
+                g.replay()
             torch.cuda.synchronize()
             run_steps, launch_mode = g.replay, "hipGraph of %d kernel nodes" % args.steps
         except Exception as e:                              # capture unsupported: fall back to plain launches
