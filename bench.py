@@ -203,7 +203,8 @@ def main():
             side.wait_stream(torch.cuda.current_stream(dev))
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side):
+                # thread_local: the RCCL watchdog thread of a multi-GPU run may poll events while this thread captures
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     for _ in range(args.steps):
                         step()
             torch.cuda.current_stream(dev).wait_stream(side)
