@@ -373,7 +373,7 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
     if (b_count == 0) return HRX_OK;
     if (!chars || !lens || !records || !masked || !cells) return fail(HRX_ERR_ARG, "NULL buffer");
     if (b_begin > B || b_count > B - b_begin) return fail(HRX_ERR_ARG, "string range outside the batch");
-    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64 || b_count > 65535) return fail(HRX_ERR_ARG, "shape out of range (at most 65535 strings per call)");
+    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
     if (layout != HRX_LAYOUT_STRING_MAJOR && layout != HRX_LAYOUT_POSITION_MAJOR &&
         layout != (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR))
         return fail(HRX_ERR_ARG, "unknown layout");
@@ -384,9 +384,16 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
     a.chars = chars; a.stride = stride; a.lens = lens; a.records = records; a.masked = masked;
     a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)ctx->s.defs.size(); a.layout = (uint32_t)layout;
     a.rec_pitch = (uint32_t)(rec_pitch ? rec_pitch : M); a.msk_pitch = (uint32_t)(msk_pitch ? msk_pitch : M);
-    a.b_begin = (uint32_t)b_begin; a.b_count = (uint32_t)b_count; a.canonical = (flags & HRX_FR_CANONICAL) ? 1u : 0u;
-    a.cells = cells;
-    HIP_TRY(launch_fr_columns(a, (hipStream_t)stream));
+    a.canonical = (flags & HRX_FR_CANONICAL) ? 1u : 0u;
+    // one launch per 32768 strings (the grid's y dimension); every launch writes its slice of each column
+    const size_t total = b_count;
+    for (size_t done = 0; done < total; done += 32768) {
+        const size_t nb = total - done < 32768 ? total - done : 32768;
+        a.b_begin = (uint32_t)(b_begin + done); a.b_count = (uint32_t)nb;
+        a.cells = cells + done * M * 4;
+        a.col_cells = total * M;
+        HIP_TRY(launch_fr_columns(a, (hipStream_t)stream));
+    }
     return HRX_OK;
 }
 

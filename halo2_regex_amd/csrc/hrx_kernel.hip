@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
     const uint32_t live = r < n ? 1u : 0u;
     uint32_t c = 0;
     if (live) c = in_pm ? a.chars[((size_t)(r >> 4) * a.B + b) * 16u + (r & 15u)] : a.chars[(size_t)b * a.stride + r];
-    const size_t col_cells = (size_t)a.b_count * a.M;   // cells per column
+    const size_t col_cells = (size_t)a.col_cells;   // cells per column
     uint64_t *out = a.cells + ((size_t)bi * a.M + r) * 4u + half * 2u;
     auto put = [&](const uint32_t col, const uint32_t v) {
         uint32_t w[8];

@@ -104,7 +104,8 @@ struct FrArgs {
     uint32_t B, M, D, layout, rec_pitch, msk_pitch;
     uint32_t b_begin, b_count;
     uint32_t canonical;   // 1: plain integers instead of Montgomery form
-    uint64_t *cells;
+    uint64_t *cells;      // first cell of string b_begin in column 0
+    uint64_t col_cells;   // cells between consecutive columns (= strings of the whole request x M)
 };
 hipError_t launch_fr_columns(const FrArgs &a, hipStream_t stream);
 

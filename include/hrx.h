@@ -167,7 +167,7 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
  *   0 char_enable, 1 characters, 2+4d states[d], 3+4d substr_ids[d], 4+4d start_enable[d], 5+4d end_enable[d],
  *   2+4D masked_characters, 3+4D all_substr_ids.
  * `layout`, chars/stride/lens, records/masked (and rec_pitch/msk_pitch, string-major only; 0 = M) are those of the
- * hrx_witness_batch_device* call that produced the rows.  Asynchronous on `stream`. */
+ * hrx_witness_batch_device* call that produced the rows.  Any b_count (served 32768 strings per launch).  Asynchronous on `stream`. */
 enum { HRX_FR_CANONICAL = 1 };
 size_t hrx_fr_num_columns(size_t D);
 int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,

@@ -118,6 +118,27 @@ def test_fr_columns_match_f_from_of_every_assigned_cell(oracle, layout):
 
 
 @pytest.mark.gpu
+def test_fr_columns_of_more_strings_than_one_launch_covers(oracle):
+    """40000 strings x 8 rows: the request is served by two launches that write their slices of every column."""
+    import torch
+    dev = torch.device("cuda", 0)
+    M, B = 8, 40000
+    defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(DFA_DIR + "/" + CFG_A[0][0]), [hra.SubstrRegexDef.read_from_text(DFA_DIR + "/" + CFG_A[0][1][0])])]
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    rng = np.random.default_rng(0)
+    chars = rng.integers(97, 123, size=(B, 16)).astype(np.uint8)
+    lens = rng.integers(0, M + 1, size=B).astype(np.int32)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens).to(dev)
+    out = cfg.witness_batch(d_chars, d_lens)
+    cells = cfg.fr_columns(d_chars, d_lens, out, canonical=True).cpu().numpy().view(np.uint64)
+    rec = out[0].cpu().numpy().view(np.uint32)[:, :, 0]
+    assert cells.shape == (8, B, M, 4) and (cells[..., 1:] == 0).all()
+    assert np.array_equal(cells[0, :, :, 0], (np.arange(M)[None, :] < lens[:, None]).astype(np.uint64))        # char_enable
+    assert np.array_equal(cells[1, :, :, 0], np.where(np.arange(M)[None, :] < lens[:, None], chars[:, :M], 0))  # characters
+    assert np.array_equal(cells[2, :, :, 0], rec & 0xffff) and np.array_equal(cells[3, :, :, 0], (rec >> 16) & 0xff)
+
+
+@pytest.mark.gpu
 def test_reference_expectations_as_field_elements(oracle):
     """lib.rs:1052-1059: the assigned masked_characters / all_substr_ids cells equal F::from(expected) row by row."""
     import torch
