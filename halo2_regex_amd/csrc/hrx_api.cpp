@@ -345,7 +345,8 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
     if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
     char name[128];
     const char *tf[2] = {"false", "true"};
-    if (li.split == 2) std::snprintf(name, sizeof name, (layout & 1) ? "hrx::witness_pm_kernel<%u, %s, %s, %s>" : "hrx::witness_pm_kernel<%u, %s, %s, %s, true>", a.D, tf[li.gtab], tf[li.wide], tf[li.half]);
+    if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u>", a.D);
+    else if (li.split == 2) std::snprintf(name, sizeof name, (layout & 1) ? "hrx::witness_pm_kernel<%u, %s, %s, %s>" : "hrx::witness_pm_kernel<%u, %s, %s, %s, true>", a.D, tf[li.gtab], tf[li.wide], tf[li.half]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u>", a.D, 32u / a.D);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
     std::snprintf(out, cap, "%s grid=%d waves=%d ring=%d lds=%zu", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);

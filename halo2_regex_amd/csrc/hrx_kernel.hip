@@ -44,6 +44,26 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
             }
         }
     }
+    // ---- def-parallel loader/walker kernel (hrx_kernel_pmd.hip): position-major, D >= 2 on the WIDE table, batches of at
+    // most two groups per CU — one walker wave per def, so that a group advances at the single-def rate
+    if ((a.layout & 1u) && a.D >= 2 && a.wide_image && !out.gtab &&
+        !(a.debug & (kDbgNoDefParallel | kDbgForceNarrow | kDbgForceHalf | kDbgForceGlobalTable)) &&
+        ((size_t)a.n_groups <= (size_t)num_cus * 2 || (a.debug & kDbgForceDefParallel))) {
+        const int G = (size_t)a.n_groups <= (size_t)num_cus && !(a.debug & kDbgForceDefParallel) ? 1 : 2;
+        for (int ns = 4; ns >= 2; --ns) {
+            const size_t lds = a.table_bytes + (size_t)G * pmd_group_bytes((int)a.D, ns);
+            if (lds > kLdsLimit) continue;
+            out.split = 5;
+            out.wide = 1;
+            out.waves_per_wg = G * ((int)a.D + 1);
+            out.nslots = ns;
+            out.lds_bytes = lds;
+            const size_t need = ((size_t)a.n_groups + G - 1) / G;
+            out.grid = (int)(need < (size_t)num_cus ? need : (size_t)num_cus);
+            if (out.grid < 1) out.grid = 1;
+            return true;
+        }
+    }
     // string-major D = 3 (no walker/storer kernel: its string-tiles are 128 bytes = 32 / 16 rows of 1 / 2 defs): the
     // loader/walker kernel with the lane's own string-major strides, 5x the one-wave kernel
     const bool sm3 = !(a.layout & 1u) && a.D == 3 && a.M % 8u == 0 && !out.gtab && !(a.debug & kDbgForceOneWave);
@@ -125,6 +145,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
 }
 
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
+    if (li.split == 5) return launch_witness_pmd(a, li, stream);
     return li.split == 2 ? launch_witness_pm(a, li, stream) : launch_witness_sm(a, li, stream);
 }
 

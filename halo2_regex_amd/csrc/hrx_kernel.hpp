@@ -52,10 +52,13 @@ enum : uint32_t {
     kDbgForceHalf = 0x400000u,        // position-major kernel: HALF table even if the 4-byte one fits LDS
     kDbgSkipFixups = 0x800000u,       // ablation: no end-mask fix-ups
     kDbgFixedLines = 0x1000000u,      // ablation: every quad / octet of a string is stored onto its first one
+    kDbgNoDefParallel = 0x2000000u,   // position-major: never the def-parallel kernel
+    kDbgForceDefParallel = 0x4000000u,// position-major, D >= 2, WIDE table: the def-parallel kernel whatever the batch size (tests)
 };
 
 struct LaunchInfo {
-    int split;         // 2: loader/walker kernel for the position-major layout (witness_pm_kernel),
+    int split;         // 5: def-parallel loader/walker kernel for D >= 2 batches that leave walker slots empty (witness_pmd_kernel),
+                       // 2: loader/walker kernel for the position-major layout (witness_pm_kernel),
                        // 1: walker/storer kernel (witness_split_kernel), 0: one-wave-does-all kernel (witness_kernel)
     int waves_per_wg;  // split: 2 * pairs
     int nslots;        // split: ring slots per walker/storer pair
@@ -76,6 +79,9 @@ hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_
 // the two kernel translation units behind launch_witness: li.split == 2 -> hrx_kernel_pm.hip, else hrx_kernel_sm.hip
 hipError_t launch_witness_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 hipError_t launch_witness_sm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
+hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);   // hrx_kernel_pmd.hip (split == 5)
+// LDS bytes per group of the def-parallel kernel: input ring + (D - 1) x (2 summaries of 5 KiB + a 2-KiB status piece) + counters
+constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 64; }
 
 // states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])
 hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,

@@ -1,0 +1,324 @@
+// hrx_kernel_pmd.hip — DEF-PARALLEL position-major kernel: D >= 2 batches that leave walker slots empty (cfg 4 gives a GPU
+// 32768 strings = 2 groups per CU, and a group's launch time is one string's serial walk).
+//
+// With every def walked by the same lane a row costs ~100 ns at D = 3 (three dependent chains share one wave's issue
+// slots); a single def walks at ~50 ns per row.  Here a group of 64 strings gets D walker waves — one per def — and one
+// loader: each walker runs the D = 1 walk over its own def's rows of the WIDE table and stores its own record plane, so
+// the group advances at the single-def rate.  What the defs share is the reveal mask (lib.rs:598-764 works on the SUMS of
+// substr ids and flags over the defs): per tile every walker but the last publishes its start / end bitvectors and its
+// byte-per-row substr ids in LDS (80 B per lane), and the last def's walker — the combiner — ORs the flags, adds the ids
+// (one packed add per four rows), derives the id-changed bits, runs tile_masks and stores the masked rows.  Exact: nothing
+// is speculated.  Status pieces (first undefined transition of a def, accept state) are merged by the combiner as well.
+//   waves of a workgroup: G groups x D walkers, then G loaders (G = 2: 8 waves at D = 3, 6 at D = 2; 256 VGPRs each).
+//   LDS: table | per group: input ring (nring x 4 KiB, freed when all D walkers have taken the tile; slow paths re-walk out
+//   of the slot before freeing it) | per walker: 2 summary slots x 5 KiB, a 2-KiB status piece | counters.
+#include <hip/hip_runtime.h>
+
+#include "hrx_device.h"
+#include "hrx_walk_pm.h"
+
+namespace hrx {
+
+constexpr uint32_t kSumBytes = 64u * 80u;     // per lane: st (8 B), en1 (8 B), 64 substr-id bytes
+constexpr uint32_t kPmdPiece = 64u * 32u;     // per lane: dead, err_pos, err_state, err_char, acc_state
+
+template <int D>
+__global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t G = (blockDim.x >> 6) / (D + 1u);      // groups a workgroup walks at a time
+    const bool is_walker = wave < G * D;
+    const uint32_t lg = is_walker ? wave / D : wave - G * D;
+    const uint32_t d = is_walker ? wave % D : 0u;         // the def this walker walks
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+
+    // LDS per group: ring | (D - 1) x (2 summaries + piece) | counters: ready, freed[D], per publishing walker sum_prod, sum_cons, piece_prod; merged
+    const uint32_t walker_bytes = 2u * kSumBytes + kPmdPiece;
+    const uint32_t group_bytes = nring * kPmTileBytes + (D - 1u) * walker_bytes + 64u;   // the combiner publishes nothing
+    const uint32_t ring_base = a.table_bytes + lg * group_bytes;
+    const uint32_t wbase = ring_base + nring * kPmTileBytes;                  // walker areas of this group
+    const uint32_t cnt = wbase + (D - 1u) * walker_bytes;
+    const uint32_t ready_off = cnt, freed0 = cnt + 4u;                        // freed0 + 4 d
+    auto sum_prod_off = [&](uint32_t dd) { return cnt + 16u + 12u * dd; };    // + 4: sum_cons, + 8: piece_prod
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.wide_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        if (!is_walker && lane < 16u) lds_store_u32(cnt + 4u * lane, 0);
+    }
+    __syncthreads();
+
+    const uint32_t M = a.M, B = a.B;
+    const uint32_t ntiles = (M + 63u) >> 6;
+    const uint32_t g_first = blockIdx.x * G + lg, g_stride = gridDim.x * G;
+    uint32_t seq = 0;
+
+    if (!is_walker) {
+        // ================================ loader ================================  (one per group, D consumers)
+        constexpr uint32_t RT = 8u;
+        const bool in_pm = (a.layout & 2u) != 0;
+        const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
+        const uint32_t total = my_groups * ntiles;
+        const uint32_t row_cap = (uint32_t)a.stride - 16u;
+        const size_t cmul = in_pm ? (size_t)B : (size_t)1;
+        uint4 buf[RT * 4u];
+        auto issue = [&](const uint32_t q, const uint32_t r) {
+            const uint32_t g = g_first + (q / ntiles) * g_stride, t = q % ntiles;
+            const uint32_t bl = min(g * 64u + lane, B - 1u);
+            const uint8_t *cptr = in_pm ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) buf[r * 4u + i] = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(t * 64u + 16u * i, row_cap) * cmul);
+        };
+#pragma unroll
+        for (uint32_t r = 0; r < RT; ++r)
+            if (r < total) issue(r, r);
+        for (uint32_t s0 = 0; s0 < total; s0 += RT) {
+#pragma unroll
+            for (uint32_t r = 0; r < RT; ++r) {
+                const uint32_t sq = s0 + r;
+                if (sq < total) {
+                    if (sq >= nring) {
+#pragma unroll
+                        for (uint32_t dd = 0; dd < (uint32_t)D; ++dd) ring_wait(freed0 + 4u * dd, sq - nring + 1u);   // every walker is done with this slot
+                    }
+                    const uint32_t slot = ring_base + (sq % nring) * kPmTileBytes;
+                    if (sq + RT <= total) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // RT-1 younger tiles x 4 loads may be in flight
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        uint4 v = buf[r * 4u + i];
+                        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+                        *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
+                    }
+                    ring_post(ready_off, sq + 1u);
+                    if (sq + RT < total) issue(sq + RT, r);
+                }
+            }
+        }
+        return;
+    }
+
+    // ================================ walkers ================================
+    WitnessArgs ad = a;           // the single-def view the D = 1 walk sees: its def's constants in slot 0
+    ad.dc[0] = a.dc[d];
+    const bool combiner = d == (uint32_t)D - 1u;
+    const uint32_t my_area = wbase + d * walker_bytes;
+    uint32_t gi = 0;
+    for (uint32_t g = g_first; g < a.n_groups; g += g_stride, ++gi) {
+        const uint32_t b0 = g * 64u;
+        const uint32_t b = b0 + lane;
+        const bool active = b < B;
+        const uint32_t n_raw = active ? a.lens[b] : M;
+        const bool badlen = n_raw > M;
+        const uint32_t n = badlen ? M : n_raw;
+        const uint32_t min_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(n));
+        LaneRegs<1> L;
+        L.e[0] = ad.dc[0].first_entry;  // states[d][0] = first_state_val: lib.rs:807
+        L.mx[0] = 0;
+        L.sid_prev = 0;
+        L.ov_row = 0xffffffffu;
+        uint32_t dead = 0, err_pos = 0, err_state = 0, err_char = 0;
+        uint32_t acc_state[1] = {ad.dc[0].first_state};   // n == 0
+        const uint32_t bc = active ? b : B - 1u;
+        unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u + (size_t)d * B * 16u;   // this def's plane of [M/4][D][B][4]
+        const size_t rstep = (size_t)B * 16u * D;
+        unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
+        const size_t mstep = (size_t)B * 16u;
+        // combiner state
+        MaskCarry mc = {0, 0, 0, 0};
+        uint32_t sum_prev = 0, ov_row = 0xffffffffu;
+        const uint4 no_pend[8] = {};
+
+        for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
+            const uint32_t t0 = t << 6;
+            const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
+            ring_wait(ready_off, seq + 1u);
+            uint4 cq[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) cq[i] = lds_u128(slot + i * 1024u + lane * 16u);
+            const uint32_t e_start = L.e[0];
+            uint32_t sidq[16];
+            TileBits tb;
+            const bool full = (t0 + 64u < min_n);
+            uint32_t tile_ov = 0, hb = 0;
+            GlobalSink<1> sink{rp, 0, rstep, active && !(a.debug & kDbgSkipRecords), false, false, no_pend, mp, mstep, false, {}};
+            const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
+                                      cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+            if (full) {
+                tb = walk_tile_pm_wide<1, true>(L, cq, ad, sink, 0, 0, tile_ov, sidq, acc_state);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) hb |= cwl[q];
+                hb &= 0x80808080u;
+            } else {
+                tb = walk_tile_pm_wide<1, false>(L, cq, ad, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, tile_ov, sidq, acc_state);
+                const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {   // bytes at or beyond the string's length are not trusted
+                    const uint32_t nb = live_rows > 4u * q ? min(live_rows - 4u * q, 4u) : 0u;
+                    hb |= cwl[q] & (nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u));
+                }
+                hb &= 0x80808080u;
+            }
+            rp = sink.rp;
+            // ---------------- undefined transition (lib.rs:817): rare slow path, re-walk the tile out of the ring slot ----------------
+            if (__any(!dead && ((L.mx[0] & kWideRowMask) == ad.dc[0].dead_entry || hb != 0))) {
+                if (!dead && ((L.mx[0] & kWideRowMask) == ad.dc[0].dead_entry || hb != 0)) {
+                    uint32_t e = e_start;
+                    const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
+                    for (uint32_t p = 0; p < live_rows; ++p) {
+                        const uint32_t c = smem[slot + (p >> 4) * 1024u + lane * 16u + (p & 15u)];
+                        const uint32_t nx = c < 128u ? lds_u32((e & kWideRowMask) | (c << 3)) : ad.dc[0].dead_entry;
+                        if ((nx & kWideRowMask) == ad.dc[0].dead_entry) {
+                            err_pos = t0 + p;
+                            err_state = ((e >> kWideRowShift) & 0xffu) - ad.dc[0].row_base;
+                            err_char = c;
+                            dead = 1;
+                            break;
+                        }
+                        e = nx;
+                    }
+                }
+            }
+            ring_post(freed0 + 4u * d, seq + 1u);   // done with the slot's bytes (the combiner keeps cq in registers)
+            // ---------------- accept state when n == M: row n does not exist, s[n] is the live state ----------------
+            if (!full && n == t0 + 64u && t + 1 == ntiles) acc_state[0] = ((L.e[0] >> kWideRowShift) & 0xffu) - ad.dc[0].row_base;
+
+            if (!combiner) {
+                // ---- publish this def's share of the tile: start / end bitvectors and the byte-per-row substr ids
+                const uint32_t sa = my_area + (seq & 1u) * kSumBytes + lane * 80u;
+                if (seq >= 2u) ring_wait(sum_prod_off(d) + 4u, seq - 1u);   // the combiner has read the summary that used this slot
+                *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)sa = v4u32{(uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32)};
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i)
+                    *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(sa + 16u + 16u * i) = v4u32{sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]};
+                ring_post(sum_prod_off(d), seq + 1u);
+                continue;
+            }
+            // ================= combiner (the last def's walker): sums over the defs, reveal mask, masked rows =================
+            uint64_t st = tb.st, en1 = tb.en1, ov_st = 0, ov_en = 0;
+#pragma unroll
+            for (uint32_t dd = 0; dd + 1u < (uint32_t)D; ++dd) {
+                ring_wait(sum_prod_off(dd), seq + 1u);
+                const uint32_t sa = wbase + dd * walker_bytes + (seq & 1u) * kSumBytes + lane * 80u;
+                const uint4 h = lds_u128(sa);
+                const uint64_t ost = (uint64_t)h.x | ((uint64_t)h.y << 32), oen = (uint64_t)h.z | ((uint64_t)h.w << 32);
+                ov_st |= st & ost;   // two defs raise is_start on the same row: out of contract
+                ov_en |= en1 & oen;
+                st |= ost;
+                en1 |= oen;
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint4 v = lds_u128(sa + 16u + 16u * i);
+                    sidq[4 * i] += v.x; sidq[4 * i + 1] += v.y; sidq[4 * i + 2] += v.z; sidq[4 * i + 3] += v.w;   // byte sums <= 255 (finalize_defs)
+                }
+                ring_post(sum_prod_off(dd) + 4u, seq + 1u);
+            }
+            if (ov_row == 0xffffffffu) {
+                if (ov_st) ov_row = t0 + (uint32_t)ctz64(ov_st);
+                if (ov_en) ov_row = min(ov_row, t0 + (uint32_t)ctz64(ov_en) + 1u);
+            }
+            // id-changed bits: byte p of the sums against byte p - 1 (the previous tile's last byte for p = 0)
+            uint64_t ch = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t x = sidq[q], y = (x << 8) | (q ? (sidq[q - 1] >> 24) : sum_prev);
+                const uint32_t dxy = x ^ y;
+                const uint32_t nz = ((dxy | ((dxy & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;   // 1 per non-zero byte
+                ch |= (uint64_t)(((nz * 0x01020408u) >> 24) & 0xfu) << (4 * q);                       // byte i -> bit i
+            }
+            sum_prev = sidq[15] >> 24;
+            TileBits all{st, en1, ch};
+            TileMasks tm = tile_masks<64>(all, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
+            if (!active) { tm.mask = 0; tm.fix = 0; }
+            uint64_t fixm = __ballot(tm.fix != 0);
+            if (a.debug & kDbgSkipFixups) fixm = 0;
+            while (fixm) {   // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare)
+                const int j = __ffsll((unsigned long long)fixm) - 1;
+                fixm &= fixm - 1;
+                const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
+                const uint32_t bj = b0 + (uint32_t)j;
+                for (uint32_t r = fs + lane; r < t0; r += 64u)
+                    a.masked[((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
+            }
+            {
+                const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t mbyte = ((q < 4 ? mlo : mhi) >> (8 * (q & 3))) & 0xffu;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (mbyte) {  // lib.rs:752-761
+                        uint32_t o[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int p = q * 8 + i;
+                            const uint32_t c = (cwl[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                            const uint32_t sid = (sidq[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                            o[i] = ((mbyte >> i) & 1u) ? (c | (sid << 8)) : 0u;
+                        }
+                        v = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+                    }
+                    if (active && t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, false);
+                }
+                mp += 8u * mstep;
+            }
+        }
+        // ---------------- per-string status: every def's walker publishes its piece, the combiner merges ----------------
+        const uint32_t pa = my_area + 2u * kSumBytes + lane * 32u;
+        if (!combiner) {
+            *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)pa = v4u32{dead, err_pos, err_state, err_char};
+            *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(pa + 16u) = v4u32{acc_state[0], 0u, 0u, 0u};
+            ring_post(sum_prod_off(d) + 8u, gi + 1u);
+            // wait until the combiner has merged before the next group's piece overwrites this one
+            ring_wait(cnt + 60u, gi + 1u);
+            continue;
+        }
+        uint32_t m_dead = 0, accept = 0;
+        uint32_t m_pos[D], m_state[D], m_char[D];
+#pragma unroll
+        for (uint32_t dd = 0; dd < (uint32_t)D; ++dd) {
+            uint32_t w_dead, w_pos, w_state, w_char, w_acc;
+            if (dd + 1u < (uint32_t)D) {
+                ring_wait(sum_prod_off(dd) + 8u, gi + 1u);
+                const uint32_t oa = wbase + dd * walker_bytes + 2u * kSumBytes + lane * 32u;
+                const uint4 x0 = lds_u128(oa), x1 = lds_u128(oa + 16u);
+                w_dead = x0.x; w_pos = x0.y; w_state = x0.z; w_char = x0.w; w_acc = x1.x;
+            } else {
+                w_dead = dead; w_pos = err_pos; w_state = err_state; w_char = err_char; w_acc = acc_state[0];
+            }
+            m_dead |= (w_dead & 1u) << dd;
+            m_pos[dd] = w_pos; m_state[dd] = w_state; m_char[dd] = w_char;
+            accept |= (w_acc == a.dc[dd].accepted_state ? 1u : 0u) << dd;
+        }
+        ring_post(cnt + 60u, gi + 1u);
+        if (active) {
+            uint64_t sw;
+            if (badlen) sw = kStatusBadLength;
+            else if (m_dead) {
+                sw = 0;
+#pragma unroll
+                for (int dd = D - 1; dd >= 0; --dd)  // lowest def wins: the reference walks defs in order (lib.rs:806)
+                    if ((m_dead >> dd) & 1u) sw = status_invalid((uint32_t)dd, m_pos[dd], m_state[dd], m_char[dd]);
+            } else if (ov_row != 0xffffffffu) sw = status_overlap(ov_row);
+            else sw = status_ok(accept);
+            a.status[b] = sw;
+        }
+    }
+}
+
+template <int D>
+static hipError_t launch_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
+    auto kern = witness_pmd_kernel<D>;
+    static std::atomic<size_t> granted[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t e = ensure_lds(kern, granted[dev & 63], li.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(li.grid), dim3(64 * li.waves_per_wg), li.lds_bytes, stream, a, (uint32_t)li.nslots);
+    return hipGetLastError();
+}
+
+hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
+    return a.D == 2 ? launch_pmd<2>(a, li, stream) : a.D == 3 ? launch_pmd<3>(a, li, stream) : hipErrorInvalidValue;
+}
+
+}  // namespace hrx

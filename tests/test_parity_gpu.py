@@ -345,11 +345,13 @@ def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
     _check_batch_pm(hra, oracle, CFG_123, chars, lens, 704)
 
 
-@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000), str(0x400000)], ids=["narrow-table", "wide-table", "half-table"])
+@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000 | 0x2000000), str(0x400000), str(0x4000000)],
+                         ids=["narrow-table", "wide-table", "half-table", "def-parallel"])
 def test_position_major_kernel_on_both_table_formats(hra, oracle, flags, monkeypatch):
-    """The position-major kernel picks the WIDE table (8-byte entries: chain word + finished record) for D >= 2 while
-    every group has a walker slot; force each format through the same batches, D = 1..3, including strings with
-    undefined transitions, bytes >= 128 (no column in the WIDE table) and two defs flagging the same row."""
+    """The position-major path has three table formats (4-byte, WIDE for D >= 2, HALF for big DFAs) and, for D >= 2 batches
+    that leave walker slots empty, a def-parallel kernel (one walker wave per def, flags combined through LDS); force each
+    through the same batches, D = 1..3, including strings with undefined transitions, bytes >= 128 (no column in the WIDE
+    table) and two defs flagging the same row."""
     from halo2_regex_amd import synth
     monkeypatch.setenv("HRX_DEBUG_FLAGS", flags)
     chars, lens = synth.reveal_stress(700, 700, seed=21)
