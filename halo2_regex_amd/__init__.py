@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
+    "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_witness_batch_host",
     "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
     "hrx_regex_to_allstr_text", "hrx_regex_to_dfa_json", "hrx_gen_regex_files", "hrx_regex_files_num_substrs",
@@ -91,6 +92,10 @@ def _load():
         "hrx_witness_batch_device_layout": (i, [vp, i, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_describe_launch": (i, [vp, i, sz, sz, i, C.c_char_p, sz]),
+        "hrx_multi_create": (i, [vp, C.POINTER(i), i, C.POINTER(vp)]),
+        "hrx_multi_destroy": (None, [vp]),
+        "hrx_multi_num_shards": (i, [vp]),
+        "hrx_multi_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
         "hrx_fr_num_columns": (sz, [sz]),
         "hrx_fr_columns_device": (i, [vp, i, vp, sz, vp, vp, sz, vp, sz, sz, sz, sz, sz, vp, i, vp]),
         "hrx_fr_from_u64": (None, [C.c_uint64, i, _u64p]),
@@ -581,6 +586,38 @@ def fr_from_u64(v, canonical=False):
     out = (C.c_uint64 * 4)()
     lib.hrx_fr_from_u64(int(v), FR_CANONICAL if canonical else 0, out)
     return [int(x) for x in out]
+
+
+class MultiDevice:
+    """hrx_multi_*: one batch of host strings sharded by index over several devices (or several shards of one device), no
+    collective.  MultiDevice(config, [0, 1, 2, 3]).witness_batch_host(chars, lens) == config.witness_batch_host(chars, lens)."""
+
+    def __init__(self, config, devices):
+        self._cfg = config
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib.hrx_multi_create(config._defs.h, arr, len(devices), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.hrx_multi_destroy(self._h)
+            self._h = None
+
+    @property
+    def num_shards(self):
+        return lib.hrx_multi_num_shards(self._h)
+
+    def witness_batch_host(self, chars2d, lens, out=None):
+        chars2d = _np(chars2d, np.uint8)
+        lens = _np(lens, np.uint32)
+        B, stride = chars2d.shape
+        M, D = self._cfg.max_chars_size, self._cfg.num_defs
+        if out is None:
+            out = np.zeros((B, M, D), np.uint32), np.zeros((B, M), np.uint16), np.zeros(B, np.uint64)
+        rec, msk, st = out
+        _check(lib.hrx_multi_witness_batch_host(self._h, _ptr(chars2d, _u8p), stride, _ptr(lens, _u32p), B, M,
+                                                _ptr(rec, _u32p), _ptr(msk, _u16p), _ptr(st, _u64p)))
+        return rec, msk, st
 
 
 def decode_status(s):

@@ -10,6 +10,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hrx.h"
@@ -444,6 +445,64 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     return batch_host_locked(ctx, chars, stride, lens, B, M, records, masked, status);
+}
+
+/* ------------------------------ multi-GPU driver (host buffers) ------------------------------ */
+
+struct hrx_multi {
+    std::vector<hrx_ctx *> ctxs;   // one per shard, in shard order
+    size_t D = 0;
+};
+
+int hrx_multi_create(const hrx_defs *defs, const int *devices, int n_devices, hrx_multi **out) {
+    if (!defs || !devices || !out || n_devices < 1) return fail(HRX_ERR_ARG, "NULL argument or no device");
+    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
+    hrx_multi *m = new hrx_multi();
+    m->D = defs->s.defs.size();
+    for (int i = 0; i < n_devices; ++i) {
+        hrx_ctx *c = nullptr;
+        const int rc = hrx_ctx_create(defs, devices[i], &c);
+        if (rc != HRX_OK) {
+            hrx_multi_destroy(m);
+            return rc;
+        }
+        m->ctxs.push_back(c);
+    }
+    *out = m;
+    return HRX_OK;
+}
+
+void hrx_multi_destroy(hrx_multi *m) {
+    if (!m) return;
+    for (hrx_ctx *c : m->ctxs) hrx_ctx_destroy(c);
+    delete m;
+}
+
+int hrx_multi_num_shards(const hrx_multi *m) { return m ? (int)m->ctxs.size() : 0; }
+
+int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                                 uint32_t *records, uint16_t *masked, uint64_t *status) {
+    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
+    if (B == 0) return HRX_OK;
+    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
+    const int world = (int)m->ctxs.size();
+    std::vector<int> rc((size_t)world, HRX_OK);
+    std::vector<std::string> msg((size_t)world);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r) {
+        th.emplace_back([&, r] {
+            size_t begin = 0, count = 0;
+            hrx_shard_range(B, world, r, &begin, &count);
+            if (count == 0) return;
+            rc[(size_t)r] = hrx_witness_batch_host(m->ctxs[(size_t)r], chars + begin * stride, stride, lens + begin, count, M,
+                                                   records + begin * M * m->D, masked + begin * M, status + begin);
+            if (rc[(size_t)r] != HRX_OK) msg[(size_t)r] = hrx_last_error();   // thread-local: carry it to the caller's thread
+        });
+    }
+    for (std::thread &t : th) t.join();
+    for (int r = 0; r < world; ++r)
+        if (rc[(size_t)r] != HRX_OK) return fail(rc[(size_t)r], "shard " + std::to_string(r) + ": " + msg[(size_t)r]);
+    return HRX_OK;
 }
 
 /* ------------------------------ single-string entry points ------------------------------ */

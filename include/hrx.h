@@ -176,6 +176,20 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
 /* F::from(v) on the host (same arithmetic as the kernel): limbs[4]. */
 void hrx_fr_from_u64(uint64_t v, int flags, uint64_t *limbs);
 
+/* ------------------------------------------------------------------ */
+/* Multi-GPU driver for host buffers: strings are independent given the RegexDefs, so a batch shards by string index with
+ * no collective.  One context per listed device (a device may be listed more than once: its shards then
+ * run on separate streams); hrx_multi_witness_batch_host cuts the batch with hrx_shard_range, runs the shards
+ * concurrently (one host thread per shard: staging copies and kernels of different devices overlap) and returns when
+ * all are done.  Results are identical to one hrx_witness_batch_host call over the whole batch.  On error the first
+ * failing shard's status is returned and hrx_last_error() tells which. */
+typedef struct hrx_multi hrx_multi;
+int hrx_multi_create(const hrx_defs *defs, const int *devices, int n_devices, hrx_multi **out);
+void hrx_multi_destroy(hrx_multi *m);
+int hrx_multi_num_shards(const hrx_multi *m);
+int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                                 uint32_t *records, uint16_t *masked, uint64_t *status);
+
 /* Contiguous shard [begin, begin+count) of a batch of B strings for `rank` of `world` devices
  * (strings are independent given the RegexDefs; no collective on the path). */
 void hrx_shard_range(size_t B, int world, int rank, size_t *begin, size_t *count);

@@ -453,6 +453,27 @@ def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
         assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
 
 
+def test_multi_device_driver_shards_by_string_index(hra, oracle):
+    """hrx_multi_*: the batch is cut with hrx_shard_range and the shards run concurrently, one context each (here three
+    contexts on the one device: the same code path as three devices); results equal the single-call ones, including the
+    empty trailing shard of a tiny batch and the error / bad-length statuses."""
+    from halo2_regex_amd import synth
+    chars, lens = synth.reveal_stress(1000, 300, seed=9)
+    chars[7, 50] = 250
+    lens[11] = 400
+    cfg = _cfg(hra, CFG_A, 304)
+    one = cfg.witness_batch_host(chars, lens)
+    multi = hra.MultiDevice(cfg, [0, 0, 0])
+    assert multi.num_shards == 3
+    many = multi.witness_batch_host(chars, lens)
+    for x, y in zip(one, many):
+        assert np.array_equal(x, y)
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_A).witness_batch(chars, lens, 304)
+    assert np.array_equal(many[2], ost) and (ost & np.uint64(0xff) == 1).any() and (ost & np.uint64(0xff) == 3).any()
+    two = multi.witness_batch_host(chars[:2], lens[:2])                  # 2 strings over 3 shards: the last shard is empty
+    assert np.array_equal(two[0], one[0][:2]) and np.array_equal(two[1], one[1][:2]) and np.array_equal(two[2], one[2][:2])
+
+
 def test_invalid_bytes_bad_lengths_and_overlap_status(hra, oracle):
     from halo2_regex_amd import synth
     chars, lens = synth.ragged(257, 300, seed=3)
