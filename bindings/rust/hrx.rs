@@ -6,6 +6,7 @@ use std::ffi::{c_char, c_int, c_void, CStr};
 
 #[repr(C)] pub struct hrx_defs { _p: [u8; 0] }
 #[repr(C)] pub struct hrx_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct hrx_multi { _p: [u8; 0] }
 
 #[link(name = "hrx")]
 extern "C" {
@@ -24,6 +25,11 @@ extern "C" {
     pub fn hrx_witness_batch_device(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, lens: *const u32, b: usize,
                                     m: usize, records: *mut u32, masked: *mut u16, status: *mut u64,
                                     stream: *mut c_void) -> c_int;
+    /// multi-GPU driver for host buffers: shards by string index, one context and host thread per listed device
+    pub fn hrx_multi_create(defs: *const hrx_defs, devices: *const c_int, n_devices: c_int, out: *mut *mut hrx_multi) -> c_int;
+    pub fn hrx_multi_destroy(m: *mut hrx_multi);
+    pub fn hrx_multi_witness_batch_host(m: *mut hrx_multi, chars: *const u8, stride: usize, lens: *const u32, b: usize, max_chars_size: usize,
+                                        records: *mut u32, masked: *mut u16, status: *mut u64) -> c_int;
     /// compact rows -> bn256::Fr cells ([4 + 4 D][b_count][M][4 x u64], Montgomery form; flags 1 = canonical)
     pub fn hrx_fr_columns_device(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, lens: *const u32,
                                  records: *const u32, rec_pitch: usize, masked: *const u16, msk_pitch: usize, b: usize, m: usize,
