@@ -453,6 +453,39 @@ def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
         assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
 
 
+def test_three_defs_every_kernel_agrees_at_a_chip_filling_size(hra, oracle, monkeypatch):
+    """D = 3, 16384 x 1024-byte strings (one group per CU): the def-parallel kernel (the planner's choice), the regular
+    position-major kernel, its narrow-table build and the string-major path must produce the same bytes; a seeded sample
+    against the oracle."""
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    B, n, M = 16384, 1023, 1024
+    chars, lens = synth.regex23_planted(B, n, seed=5, stride=1024)
+    lens[:128] = np.random.default_rng(2).integers(0, n + 1, 128)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    results = {}
+    for name, flags in (("def-parallel", "0"), ("regular", str(0x2000000)), ("narrow", str(0x2000000 | 0x80000))):
+        monkeypatch.setenv("HRX_DEBUG_FLAGS", flags)
+        cfg = _cfg(hra, CFG_123, M)
+        kern = cfg.describe_launch(B, layout=1)
+        assert ("pmd_kernel" in kern) == (name == "def-parallel")
+        rec, msk, st = cfg.witness_batch_position_major(d_chars, d_lens)
+        torch.cuda.synchronize()
+        results[name] = hra.position_major_to_string_major(rec, msk, B, M, 3) + (st,)
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", "0")
+    results["string-major"] = _cfg(hra, CFG_123, M).witness_batch(d_chars, d_lens)
+    torch.cuda.synchronize()
+    ref = results["regular"]
+    for name, r in results.items():
+        assert torch.equal(r[0], ref[0]) and torch.equal(r[1], ref[1]) and torch.equal(r[2], ref[2]), name
+    idx = np.sort(np.random.default_rng(3).choice(B, 256, replace=False))
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_123).witness_batch(chars[idx], lens[idx], M)
+    tidx = torch.from_numpy(idx).to(dev)
+    assert np.array_equal(ref[2][tidx].cpu().numpy().view(np.uint64), ost)
+    assert np.array_equal(ref[0][tidx].cpu().numpy().view(np.uint32), orec) and np.array_equal(ref[1][tidx].cpu().numpy().view(np.uint16), omsk)
+
+
 def test_multi_device_driver_shards_by_string_index(hra, oracle):
     """hrx_multi_*: the batch is cut with hrx_shard_range and the shards run concurrently, one context each (here three
     contexts on the one device: the same code path as three devices); results equal the single-call ones, including the
