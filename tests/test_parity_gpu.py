@@ -379,14 +379,14 @@ def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
     _check_batch(hra, oracle, CFG_A, chars, lens, 200)
 
 
-def _random_defs(rng, D):
+def _random_defs(rng, D, big=False):
     """D random definitions in the reference's text formats: 3..60 states, mostly over one shared alphabet and mostly total
     (so that walks are long), sometimes 85-95 % dense or over an alphabet of their own; 1-3 substring definitions each with
     random transition subsets / start / end states."""
     shared = np.sort(rng.choice(np.arange(1, 256), size=int(rng.integers(2, 24)), replace=False))
     out = []
     for _ in range(D):
-        S = int(rng.integers(3, 61))
+        S = int(rng.integers(150, 320)) if big else int(rng.integers(3, 61))   # big: HALF table (<= 256 states) or global table
         alpha = shared if rng.random() < 0.8 else np.sort(rng.choice(np.arange(1, 256), size=int(rng.integers(2, 40)), replace=False))
         dens = float(rng.choice([1.0, 1.0, 1.0, 0.97, 0.9]))
         lines = [str(int(rng.integers(0, S))), str(int(rng.integers(0, S))), str(S - 1)]
@@ -409,15 +409,16 @@ def _random_defs(rng, D):
     return out
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", list(range(16)) + [100, 101, 102, 103, 104, 105])
 def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
     """Seeded fuzz: random DFAs (partial ones included: status 1 must carry the reference's state/char), 1-3 defs (overlapping
     flags -> status 2), random M incl. odd values, ragged lengths incl. 0 and > M, bytes outside the alphabets; the
     string-major and the position-major kernels against the oracle, bit for bit."""
     import torch
     rng = np.random.default_rng(1000 + seed)
-    D = int(rng.integers(1, 4))
-    defs_t = _random_defs(rng, D)
+    big = seed >= 100                                                        # one big DFA: the HALF-table / global-table kernels
+    D = 1 if big else int(rng.integers(1, 4))
+    defs_t = _random_defs(rng, D, big)
     M = int(rng.choice([5, 31, 64, 100, 129, 256, 321, 520, 777]))
     B = int(rng.choice([1, 63, 64, 65, 200, 333, 500]))
     stride = (M + 40 + 15) // 16 * 16
