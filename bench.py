@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--config", choices=["regex1", "regex23", "regex123", "headers3", "dfa256"], default="regex1",
                     help="regex1: BASELINE configs[1] (the metric's workload); regex23: configs[2] shape (D=2); regex123: D=3 with the "
                     "reference's three DFAs; headers3: configs[3] shape (D=3 from/to/subject header definitions, 5 substrs); dfa256: configs[4] shape (synthetic total 256-state DFA over all 256 byte values)")
+    ap.add_argument("--substr-pairs", type=int, default=200, help="dfa256: transitions in the random substring definition (sets how often "
+                    "start / end events occur and how long optimistic reveal spans run before they are confirmed or repaired; DESIGN.md §4.2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch the timed steps one by one instead of replaying a HIP graph of them")
     ap.add_argument("--dense", action="store_true", help="string-major: power-of-two pitches (M rows per string, n rounded to 16 "
@@ -155,7 +157,7 @@ def main():
         gen = synth.headers_planted if args.dist == "planted" else synth.noise
     else:
         allb = np.arange(256, dtype=np.uint8)
-        a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=200)
+        a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=args.substr_pairs)
         names, label, alphabet = [(a_txt.encode(), [sub_txt.encode()])], "synthetic total DFA 256 states x 256 symbols (seed 2)", "all 256 byte values"
         gen = lambda B, n, seed=0, stride=None: synth.noise(B, n, seed=seed, alphabet=allb, stride=stride)
     D = len(names)
