@@ -253,7 +253,7 @@ def main():
                                    % (label, D, B, stride, n, M, "uniform noise over the %s%s" % (
                                        alphabet, " + planted match" if gen in (synth.regex1_planted, synth.regex23_planted, synth.headers_planted) else "")),
                        "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
-                       "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR: chars [%d/16][B][16], records "
+                       "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of 65536 strings): chars [%d/16][B][16], records "
                                    "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h)" % stride) if pm else
                                   ("string-major; input stride %d B, records pitch %d rows, masked pitch %d rows"
                                    % (stride, rec_pitch, msk_pitch)),

@@ -352,21 +352,41 @@ def recommended_pitches(M):
 LAYOUT_STRING_MAJOR, LAYOUT_POSITION_MAJOR, LAYOUT_INPUT_POSITION_MAJOR = 0, 1, 2
 
 
+PM_BLOCK = 65536          # kPmBlock of csrc/hrx_lane.h: position-major buffers are blocked by this many strings
+
+
+def _cat(parts):
+    return parts[0] if len(parts) == 1 else (torch.cat(parts) if hasattr(parts[0], "permute") else np.concatenate(parts))
+
+
 def chars_to_position_major(chars):
-    """(B, stride) bytes, stride % 16 == 0  ->  flat [stride/16][B][16] (HRX_LAYOUT_INPUT_POSITION_MAJOR); torch or numpy."""
+    """(B, stride) bytes, stride % 16 == 0  ->  flat HRX_LAYOUT_INPUT_POSITION_MAJOR buffer: per block of PM_BLOCK strings
+    [stride/16][nb][16], blocks back to back (one block = the plain layout for B <= PM_BLOCK); torch or numpy."""
     B, stride = chars.shape
-    c = chars.reshape(B, stride // 16, 16)
-    c = c.permute(1, 0, 2).contiguous() if hasattr(c, "permute") else np.ascontiguousarray(c.transpose(1, 0, 2))
-    return c.reshape(-1)
+    parts = []
+    for k0 in range(0, B, PM_BLOCK):
+        c = chars[k0:k0 + PM_BLOCK]
+        c = c.reshape(c.shape[0], stride // 16, 16)
+        c = c.permute(1, 0, 2).contiguous() if hasattr(c, "permute") else np.ascontiguousarray(c.transpose(1, 0, 2))
+        parts.append(c.reshape(-1))
+    return _cat(parts)
 
 
 def position_major_to_string_major(records_pm, masked_pm, B, M, D):
-    """View-level inverse of HRX_LAYOUT_POSITION_MAJOR (include/hrx.h): records [ceil(M/4)][D][B][4] -> (B, M, D),
-    masked [ceil(M/8)][B][8] -> (B, M).  Works on torch tensors and numpy arrays alike; no values change."""
-    r = records_pm.reshape(-1, D, B, 4)
-    rec = r.permute(2, 0, 3, 1) if hasattr(r, "permute") else r.transpose(2, 0, 3, 1)      # (B, M/4, 4, D)
-    msk = masked_pm.reshape(-1, B, 8).permute(1, 0, 2) if hasattr(masked_pm, "permute") else masked_pm.reshape(-1, B, 8).transpose(1, 0, 2)
-    return rec.reshape(B, -1, D)[:, :M], msk.reshape(B, -1)[:, :M]
+    """Inverse of HRX_LAYOUT_POSITION_MAJOR (include/hrx.h): per block of PM_BLOCK strings records [ceil(M/4)][D][nb][4] ->
+    (nb, M, D), masked [ceil(M/8)][nb][8] -> (nb, M); returns (B, M, D) and (B, M).  Works on torch tensors and numpy arrays
+    alike; no values change (a view for a single block)."""
+    q4, q8 = (M + 3) // 4, (M + 7) // 8
+    recs, msks = [], []
+    for k0 in range(0, B, PM_BLOCK):
+        nb = min(PM_BLOCK, B - k0)
+        r = records_pm[k0 * q4 * 4 * D:(k0 + nb) * q4 * 4 * D].reshape(q4, D, nb, 4)
+        m = masked_pm[k0 * q8 * 8:(k0 + nb) * q8 * 8].reshape(q8, nb, 8)
+        r = r.permute(2, 0, 3, 1) if hasattr(r, "permute") else r.transpose(2, 0, 3, 1)      # (nb, M/4, 4, D)
+        m = m.permute(1, 0, 2) if hasattr(m, "permute") else m.transpose(1, 0, 2)
+        recs.append(r.reshape(nb, -1, D)[:, :M])
+        msks.append(m.reshape(nb, -1)[:, :M])
+    return _cat(recs), _cat(msks)
 
 
 def shard_range(B, world, rank):

@@ -48,6 +48,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     // most two groups per CU — one walker wave per def, so that a group advances at the single-def rate
     if ((a.layout & 1u) && a.D >= 2 && a.wide_image && !out.gtab &&
         !(a.debug & (kDbgNoDefParallel | kDbgForceNarrow | kDbgForceHalf | kDbgForceGlobalTable)) &&
+        a.B <= kPmBlock &&   // one block of the position-major buffers (hrx_lane.h): its strides are the whole batch's
         ((size_t)a.n_groups <= (size_t)num_cus * 2 || (a.debug & kDbgForceDefParallel))) {
         const int G = (size_t)a.n_groups <= (size_t)num_cus && !(a.debug & kDbgForceDefParallel) ? 1 : 2;
         for (int ns = 4; ns >= 2; --ns) {
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
     if (r >= a.M) return;
     const uint32_t live = r < n ? 1u : 0u;
     uint32_t c = 0;
-    if (live) c = in_pm ? a.chars[((size_t)(r >> 4) * a.B + b) * 16u + (r & 15u)] : a.chars[(size_t)b * a.stride + r];
+    const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0), bl = b - blk0;   // the string's block of the position-major buffers
+    if (live) c = in_pm ? a.chars[(size_t)blk0 * a.stride + ((size_t)(r >> 4) * nb + bl) * 16u + (r & 15u)] : a.chars[(size_t)b * a.stride + r];
     const size_t col_cells = (size_t)a.col_cells;   // cells per column
     uint64_t *out = a.cells + ((size_t)bi * a.M + r) * 4u + half * 2u;
     auto put = [&](const uint32_t col, const uint32_t v) {
@@ -241,14 +243,14 @@ __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
     put(0, live);   // char_enable                        lib.rs:342,346
     put(1, c);      // characters                         lib.rs:343,347
     for (uint32_t d = 0; d < a.D; ++d) {
-        const uint32_t rec = pm ? a.records[(((size_t)(r >> 2) * a.D + d) * a.B + b) * 4u + (r & 3u)]
+        const uint32_t rec = pm ? a.records[((size_t)blk0 * ((a.M + 3u) / 4u) * a.D + ((size_t)(r >> 2) * a.D + d) * nb + bl) * 4u + (r & 3u)]
                                 : a.records[((size_t)b * a.rec_pitch + r) * a.D + d];
         put(2 + 4 * d, rec & 0xffffu);            // states[d]         lib.rs:390,415
         put(3 + 4 * d, (rec >> 16) & 0xffu);      // substr_ids[d]     lib.rs:394,405
         put(4 + 4 * d, (rec >> 24) & 1u);         // start_enable[d]   lib.rs:483-491
         put(5 + 4 * d, (rec >> 25) & 1u);         // end_enable[d]     lib.rs:502-511
     }
-    const uint32_t mk = pm ? a.masked[((size_t)(r >> 3) * a.B + b) * 8u + (r & 7u)] : a.masked[(size_t)b * a.msk_pitch + r];
+    const uint32_t mk = pm ? a.masked[((size_t)blk0 * ((a.M + 7u) / 8u) + (size_t)(r >> 3) * nb + bl) * 8u + (r & 7u)] : a.masked[(size_t)b * a.msk_pitch + r];
     put(2 + 4 * a.D, mk & 0xffu);                 // masked_characters  lib.rs:752-757
     put(3 + 4 * a.D, mk >> 8);                    // all_substr_ids     lib.rs:758-761
     }

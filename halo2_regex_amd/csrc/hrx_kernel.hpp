@@ -47,7 +47,6 @@ enum : uint32_t {
     kDbgGroups32 = 0x20000u,          // one-wave kernel: 32 strings per wave
     kDbgForceGlobalTable = 0x40000u,  // walk the fused table out of global memory even if it fits LDS
     kDbgForceNarrow = 0x80000u,       // position-major kernel: 4-byte table even where the planner picks WIDE
-    kDbgInterleavedDefs = 0x100000u,  // ablation: records as [M/4][B][D][4] instead of per-def planes
     kDbgForceWide = 0x200000u,        // position-major kernel: WIDE table also at D = 1
     kDbgForceHalf = 0x400000u,        // position-major kernel: HALF table even if the 4-byte one fits LDS
     kDbgSkipFixups = 0x800000u,       // ablation: no end-mask fix-ups

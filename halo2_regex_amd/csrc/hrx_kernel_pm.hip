@@ -47,9 +47,10 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     if (!is_walker && g_first < a.n_groups) {
         const bool in_pm0 = (a.layout & 2u) != 0;
         const uint32_t bl = min(g_first * 64u + lane, B - 1u);
-        const uint8_t *cptr = in_pm0 ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
+        const uint32_t blk0 = (g_first * 64u / kPmBlock) * kPmBlock, nb0 = min(kPmBlock, B - blk0);   // this group's block (hrx_lane.h)
+        const uint8_t *cptr = in_pm0 ? a.chars + (size_t)blk0 * a.stride + (size_t)(bl - blk0) * 16u : a.chars + (size_t)bl * a.stride;
         const uint32_t row_cap0 = (uint32_t)a.stride - 16u;
-        const size_t cmul0 = (a.debug & kDbgInputFromL2) ? (size_t)0 : in_pm0 ? (size_t)B : (size_t)1;
+        const size_t cmul0 = (a.debug & kDbgInputFromL2) ? (size_t)0 : in_pm0 ? (size_t)nb0 : (size_t)1;
 #pragma unroll
         for (uint32_t i = 0; i < 4u; ++i) first_tile[i] = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(16u * i, row_cap0) * cmul0);
     }
@@ -79,13 +80,14 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
         const uint32_t total = my_groups * ntiles;
         const uint32_t row_cap = (uint32_t)a.stride - 16u;  // last 16-byte chunk that exists for every string
-        const size_t cmul = in_pm ? (size_t)B : (size_t)1;  // byte offset of chunk-start row r: r * cmul
-        const size_t cmul_eff = (a.debug & kDbgInputFromL2) ? (size_t)0 : cmul;  // (4: profiling only, every tile re-reads the hot first lines)
         uint4 buf[RT * 4u];
         auto issue = [&](const uint32_t q, const uint32_t k) {  // tile q of the pair's sequence -> register tile k
             const uint32_t g = g_first + (q / ntiles) * g_stride, t = q % ntiles;
             const uint32_t bl = min(g * 64u + lane, B - 1u);
-            const uint8_t *cptr = in_pm ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
+            const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);   // the group's block (hrx_lane.h)
+            const uint8_t *cptr = in_pm ? a.chars + (size_t)blk0 * a.stride + (size_t)(bl - blk0) * 16u : a.chars + (size_t)bl * a.stride;
+            // byte offset of chunk-start row r: r * cmul  (kDbgInputFromL2, profiling only: every tile re-reads the hot first lines)
+            const size_t cmul_eff = (a.debug & kDbgInputFromL2) ? (size_t)0 : in_pm ? (size_t)nb : (size_t)1;
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
                 const size_t off = (size_t)min(t * 64u + 16u * i, row_cap) * cmul_eff;
@@ -164,14 +166,18 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 acc_state[d] = a.dc[d].first_state;  // n == 0
             }
             const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
+            // the group's block of the position-major buffers (hrx_lane.h kPmBlock): nb strings starting at string blk0
+            const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);
+            const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
             // SM (string-major outputs from this kernel: D = 3, which the walker/storer kernel's 128-byte string-tiles do not
             // cover): records [B][pitch][D], masked [B][pitch] — same walk, the lane's own strides
             unsigned char *rp = SM ? reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * a.rec_pitch * D * 4u
-                                   : reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u * ((a.debug & kDbgInterleavedDefs) ? D : 1);
+                                   : reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * D + (bc - blk0)) * 16u;
             // (kDbgFixedLines, profiling only: every quad / octet of a string lands on the first one — same store instructions, no new lines or pages)
-            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u * D : (size_t)B * 16u * D;  // one quad of rows further: [M/4][D][B][4]
-            unsigned char *mp = SM ? reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * a.msk_pitch * 2u : reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
-            const size_t mstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u : (size_t)B * 16u;      // 8 rows further: [M/8][B][8]
+            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u * D : (size_t)nb * 16u * D;  // one quad of rows further: [M/4][D][nb][4]
+            unsigned char *mp = SM ? reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * a.msk_pitch * 2u
+                                   : reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
+            const size_t mstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u : (size_t)nb * 16u;      // 8 rows further: [M/8][nb][8]
             uint4 pend[8];                             // the previous tile's masked rows, not yet stored
             unsigned char *pend_mp = mp;
             bool have_pend = false;
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 const bool do_store = active && !(a.debug & kDbgSkipRecords);
                 const bool pend_store = active && have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
-                // [ceil(M/4)][D][B][4]: one def's quads of all strings (kDbgInterleavedDefs, profiling: [M/4][B][D][4])
-                GlobalSink<D, SM> sink{rp, (a.debug & kDbgInterleavedDefs) ? (size_t)16u : (size_t)B * 16u, rstep, do_store, (a.debug & kDbgNtRecords) != 0, (a.debug & kDbgNtMasked) != 0,
+                // [ceil(M/4)][D][nb][4]: one def's quads of all strings of the block
+                GlobalSink<D, SM> sink{rp, (size_t)nb * 16u, rstep, do_store, (a.debug & kDbgNtRecords) != 0, (a.debug & kDbgNtMasked) != 0,
                                        pend, pend_mp, mstep, pend_store, {}};
                 if (WIDE) {
                     const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                     const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
                     const uint32_t bj = b0 + (uint32_t)j;
                     for (uint32_t r = fs + lane; r < t0; r += 64u)
-                        a.masked[SM ? (size_t)bj * a.msk_pitch + r : ((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
+                        a.masked[SM ? (size_t)bj * a.msk_pitch + r : ((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;
                 }
                 // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8]; stored during the next walk ----------------
                 {

@@ -487,6 +487,39 @@ def test_three_defs_every_kernel_agrees_at_a_chip_filling_size(hra, oracle, monk
     assert np.array_equal(ref[0][tidx].cpu().numpy().view(np.uint32), orec) and np.array_equal(ref[1][tidx].cpu().numpy().view(np.uint16), omsk)
 
 
+def test_position_major_buffers_are_blocked_by_65536_strings(hra, oracle):
+    """B = 65536 + 4200: two blocks of the position-major buffers (a full one and a partial one), both input layouts, D = 1 and
+    D = 2; the field-cell expansion reads the same blocked buffers."""
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    B, M = hra.PM_BLOCK + 4200, 72
+    for names, D in ((CFG_1, 1), (CFG_A, 2)):
+        chars, lens = synth.ragged(B, M, seed=17)
+        cfg = _cfg(hra, names, M)
+        o = OracleDefs.from_files(oracle, names)
+        orec, omsk, ost = o.witness_batch(chars, lens, M)
+        ok = (ost & np.uint64(0xff)) == 0
+        d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+        for pm_input in (False, True):
+            src = hra.chars_to_position_major(d_chars) if pm_input else d_chars
+            kw = dict(chars_pm_stride=chars.shape[1]) if pm_input else {}
+            rec, msk, st = cfg.witness_batch_position_major(src, d_lens, **kw)
+            torch.cuda.synchronize()
+            r1, m1 = hra.position_major_to_string_major(rec, msk, B, M, D)
+            assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+            assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
+            # the first string of the second block, by the documented formula
+            b, r, d = hra.PM_BLOCK, 5, D - 1
+            nb, q4 = B - hra.PM_BLOCK, (M + 3) // 4
+            flat = rec.cpu().numpy().view(np.uint32)
+            assert flat[hra.PM_BLOCK * q4 * D * 4 + ((r // 4 * D + d) * nb + (b - hra.PM_BLOCK)) * 4 + r % 4] == orec[b, r, d]
+            cells = cfg.fr_columns(src, d_lens, (rec, msk, st), b_begin=hra.PM_BLOCK - 3, b_count=6, position_major=True, canonical=True, **kw)
+            got = cells.cpu().numpy().view(np.uint64)[..., 0]
+            assert np.array_equal(got[2], orec[hra.PM_BLOCK - 3:hra.PM_BLOCK + 3, :, 0] & 0xffff)                 # states[0]
+            assert np.array_equal(got[2 + 4 * D], omsk[hra.PM_BLOCK - 3:hra.PM_BLOCK + 3] & 0xff)                  # masked_characters
+
+
 def test_multi_device_driver_shards_by_string_index(hra, oracle):
     """hrx_multi_*: the batch is cut with hrx_shard_range and the shards run concurrently, one context each (here three
     contexts on the one device: the same code path as three devices); results equal the single-call ones, including the
