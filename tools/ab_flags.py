@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Same-process A/B of HRX_DEBUG_FLAGS variants on the bench line (the library reads the variable at every launch): the variants
+are interleaved in blocks of launches, many times over, so that box-to-box and run-to-run drift (±5 %) cancels.
+  python tools/ab_flags.py 0 32 64 96"""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import halo2_regex_amd as hra
+from halo2_regex_amd import synth
+flags = sys.argv[1:] or ["0", "32", "64", "96"]
+D_DIR = os.path.join(ROOT, "tests", "golden", "dfa")
+rd = lambda f: open(os.path.join(D_DIR, f), "rb").read()
+defs = [hra.RegexDefs(hra.AllstrRegexDef(rd("regex1_test_lookup.txt")), [hra.SubstrRegexDef(rd("substr1_test_lookup.txt"))])]
+cfg = hra.RegexVerifyConfig.configure(1024, defs, device=0)
+dev = torch.device("cuda", 0)
+chars, lens = synth.regex1_planted(65536, 1023, seed=0, stride=1024)
+d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
+d_chars = hra.chars_to_position_major(torch.from_numpy(chars).to(dev))
+out = cfg.alloc_outputs_position_major(65536, dev)
+step = lambda: cfg.witness_batch_position_major(d_chars, d_lens, out=out, chars_pm_stride=1024)
+res = {f: [] for f in flags}
+for rep in range(12):
+    for f in flags:
+        os.environ["HRX_DEBUG_FLAGS"] = f
+        for _ in range(10): step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(60): step()
+        e1.record(); torch.cuda.synchronize()
+        res[f].append(e0.elapsed_time(e1) / 60 * 1e3)
+for f in flags:
+    v = res[f][2:]
+    print("flags %-10s  median %.2f us  mean %.2f  min %.2f  max %.2f" % (f, statistics.median(v), statistics.mean(v), min(v), max(v)))
