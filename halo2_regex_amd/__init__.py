@@ -16,11 +16,13 @@ import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhrx.so")
+LIB_PATH = os.environ.get("HRX_LIB_PATH") or os.path.join(_HERE, "csrc", "libhrx.so")   # (HRX_LIB_PATH: tools/ load the ablation build)
 
 HRX_OK = 0
 HRX_ERR_PARSE, HRX_ERR_BOUNDS, HRX_ERR_ARG, HRX_ERR_HIP, HRX_ERR_STATE = 1, 2, 3, 4, 5
 HRX_ERR_INVALID_TRANSITION, HRX_ERR_OUT_OF_CONTRACT, HRX_ERR_IO = 6, 7, 8
+HRX_DEVICE_NONE = -1                 # hrx_ctx_create: host-only context (the native small-batch host walk)
+HRX_DEFAULT_HOST_THRESHOLD = 32768   # rows (B x M) below which host-buffer batches are walked on the host
 
 #: every symbol include/hrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = [
@@ -29,10 +31,11 @@ ABI_SYMBOLS = [
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
     "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count",
-    "hrx_ctx_create", "hrx_ctx_destroy", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
+    "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
-    "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_witness_batch_host",
+    "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_shard_device", "hrx_multi_witness_batch_host",
+    "hrx_multi_witness_batch_device", "hrx_multi_synchronize",
     "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
     "hrx_regex_to_allstr_text", "hrx_regex_to_dfa_json", "hrx_gen_regex_files", "hrx_regex_files_num_substrs",
@@ -85,6 +88,9 @@ def _load():
         "hrx_device_count": (i, [C.POINTER(i)]),
         "hrx_ctx_create": (i, [vp, i, C.POINTER(vp)]),
         "hrx_ctx_destroy": (None, [vp]),
+        "hrx_ctx_device": (i, [vp]),
+        "hrx_ctx_set_host_threshold": (i, [vp, sz]),
+        "hrx_ctx_host_threshold": (sz, [vp]),
         "hrx_last_error": (C.c_char_p, []),
         "hrx_witness_batch_device": (i, [vp, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_witness_batch_device_pitched": (i, [vp, vp, sz, vp, sz, sz, vp, sz, vp, sz, vp, vp]),
@@ -95,6 +101,9 @@ def _load():
         "hrx_multi_create": (i, [vp, C.POINTER(i), i, C.POINTER(vp)]),
         "hrx_multi_destroy": (None, [vp]),
         "hrx_multi_num_shards": (i, [vp]),
+        "hrx_multi_shard_device": (i, [vp, i]),
+        "hrx_multi_witness_batch_device": (i, [vp, i, C.POINTER(vp), sz, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "hrx_multi_synchronize": (i, [vp]),
         "hrx_multi_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
         "hrx_fr_num_columns": (sz, [sz]),
         "hrx_fr_columns_device": (i, [vp, i, vp, sz, vp, vp, sz, vp, sz, sz, sz, sz, sz, vp, i, vp]),
@@ -400,7 +409,9 @@ class RegexVerifyConfig:
 
     configure() takes what the reference's configure (lib.rs:126-131) takes minus the halo2 objects
     (ConstraintSystem, FlexGateConfig): max_chars_size and the Vec<RegexDefs>.  `device=None` builds the
-    host-side tables only (table rows, constants); any compute call then raises.
+    host-side tables only (table rows, constants); any compute call then raises.  `device=HRX_DEVICE_NONE`
+    makes a host-only context: match_substrs / derive_* / witness_batch_host run the library's native
+    small-batch host walk (what a drop-in for the one-string-per-call lib.rs:316-318 needs), device batches raise.
     """
 
     def __init__(self, max_chars_size, regex_defs, device=0):
@@ -411,7 +422,7 @@ class RegexVerifyConfig:
         self.table_array = [RegexTableConfig(self._defs, d) for d in range(self.num_defs)]
         self._ctx = None
         self.device = device
-        if device is not None:
+        if device is not None:   # a GPU index, or HRX_DEVICE_NONE for the host-only context
             ctx = C.c_void_p()
             _check(lib.hrx_ctx_create(self._defs.h, int(device), C.byref(ctx)))
             self._ctx = ctx
@@ -427,8 +438,23 @@ class RegexVerifyConfig:
 
     def _need_ctx(self):
         if not self._ctx:
-            raise HrxError(HRX_ERR_HIP, "no device context: the witness path runs on a gfx950 GPU only")
+            raise HrxError(HRX_ERR_HIP, "no context: configure(..., device=k) for a gfx950 GPU or device=HRX_DEVICE_NONE for the host walk")
         return self._ctx
+
+    def _need_device(self, *tensors):
+        """The batch kernels run on this config's device: every tensor must live there."""
+        ctx = self._need_ctx()
+        for t in tensors:
+            if t is not None and (not t.is_cuda or t.device.index != self.device):
+                raise HrxError(HRX_ERR_ARG, "tensor on %s but the config's context is on cuda:%s" % (t.device, self.device))
+        return ctx
+
+    def set_host_threshold(self, rows):
+        """hrx_ctx_set_host_threshold: host-buffer batches of fewer than `rows` witness rows take the host walk."""
+        _check(lib.hrx_ctx_set_host_threshold(self._need_ctx(), int(rows)))
+
+    def host_threshold(self):
+        return lib.hrx_ctx_host_threshold(self._need_ctx())
 
     # -- lookup tables: RegexVerifyConfig::load (lib.rs:779-785) ---------------------------------
     def load(self):
@@ -546,7 +572,7 @@ class RegexVerifyConfig:
             out = self.alloc_outputs_position_major(B, chars.device)
         rec, msk, st = out
         s = torch.cuda.current_stream(chars.device) if stream is None else stream
-        _check(lib.hrx_witness_batch_device_layout(self._need_ctx(), layout, chars.data_ptr(), stride,
+        _check(lib.hrx_witness_batch_device_layout(self._need_device(chars, lens, rec, msk, st), layout, chars.data_ptr(), stride,
                                                    lens.data_ptr(), B, self.max_chars_size, rec.data_ptr(), msk.data_ptr(),
                                                    st.data_ptr(), s.cuda_stream))
         return rec, msk, st
@@ -572,7 +598,7 @@ class RegexVerifyConfig:
         else:
             stride, rp, mp = chars.stride(0), rec.stride(0) // D, msk.stride(0)
         s = torch.cuda.current_stream(lens.device) if stream is None else stream
-        _check(lib.hrx_fr_columns_device(self._need_ctx(), layout, chars.data_ptr(), stride, lens.data_ptr(), rec.data_ptr(), rp,
+        _check(lib.hrx_fr_columns_device(self._need_device(chars, lens, rec, msk, cells), layout, chars.data_ptr(), stride, lens.data_ptr(), rec.data_ptr(), rp,
                                          msk.data_ptr(), mp, B, M, b_begin, b_count, cells.data_ptr(),
                                          FR_CANONICAL if canonical else 0, s.cuda_stream))
         return cells
@@ -590,7 +616,7 @@ class RegexVerifyConfig:
         D = self.num_defs
         assert rec.stride(2) == 1 and rec.stride(1) == D and rec.stride(0) % D == 0 and msk.stride(1) == 1
         s = torch.cuda.current_stream(chars.device) if stream is None else stream
-        _check(lib.hrx_witness_batch_device_pitched(self._need_ctx(), chars.data_ptr(), stride, lens.data_ptr(), B,
+        _check(lib.hrx_witness_batch_device_pitched(self._need_device(chars, lens, rec, msk, st), chars.data_ptr(), stride, lens.data_ptr(), B,
                                                     self.max_chars_size, rec.data_ptr(), rec.stride(0) // D,
                                                     msk.data_ptr(), msk.stride(0), st.data_ptr(), s.cuda_stream))
         return rec, msk, st
@@ -626,6 +652,31 @@ class MultiDevice:
     @property
     def num_shards(self):
         return lib.hrx_multi_num_shards(self._h)
+
+    def shard_device(self, shard):
+        return lib.hrx_multi_shard_device(self._h, shard)
+
+    def witness_batch_device(self, shards, layout=LAYOUT_POSITION_MAJOR | LAYOUT_INPUT_POSITION_MAJOR, chars_stride=None):
+        """hrx_multi_witness_batch_device: `shards` = one (chars, lens, (records, masked, status)) per shard, CUDA tensors on
+        that shard's device (outputs as made by alloc_outputs_position_major / alloc_outputs on that device).  Asynchronous:
+        one kernel per shard on the shard's own stream; synchronize() waits for all.  No PCIe traffic, no collective."""
+        n = self.num_shards
+        assert len(shards) == n
+        vpa, sza = C.c_void_p * n, C.c_size_t * n
+        chars, lens, recs, msks, sts, counts = vpa(), vpa(), vpa(), vpa(), vpa(), sza()
+        stride = None
+        for r, (c, l, (rec, msk, st)) in enumerate(shards):
+            for t in (c, l, rec, msk, st):
+                if t.numel() and t.device.index != self.shard_device(r):
+                    raise HrxError(HRX_ERR_ARG, "shard %d: tensor on %s, shard lives on cuda:%d" % (r, t.device, self.shard_device(r)))
+            chars[r], lens[r], recs[r], msks[r], sts[r], counts[r] = c.data_ptr(), l.data_ptr(), rec.data_ptr(), msk.data_ptr(), st.data_ptr(), l.numel()
+            if chars_stride is None and l.numel():
+                stride = c.stride(0) if c.dim() == 2 else stride
+        stride = int(chars_stride) if chars_stride is not None else stride
+        _check(lib.hrx_multi_witness_batch_device(self._h, layout, chars, stride or 16, lens, counts, self._cfg.max_chars_size, recs, msks, sts))
+
+    def synchronize(self):
+        _check(lib.hrx_multi_synchronize(self._h))
 
     def witness_batch_host(self, chars2d, lens, out=None):
         chars2d = _np(chars2d, np.uint8)

@@ -1,6 +1,7 @@
 // hrx_api.cpp — the C ABI (include/hrx.h) over the host data model and the HIP kernels.
-// There is deliberately no CPU implementation of the compute entry points: without a gfx950
-// device they fail with HRX_ERR_HIP.
+// Batches run on the gfx950 kernels; device-pointer entry points fail with HRX_ERR_HIP without a device.  The one
+// host-side compute path is the native small-batch walk (hrx_host_walk.cpp): single strings and host-buffer batches
+// below the context's threshold — a GPU launch cannot beat a host core on ~1000 rows.
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
@@ -16,6 +17,7 @@
 #include "../../include/hrx.h"
 #include "hrx_defs.hpp"
 #include "hrx_fr.h"
+#include "hrx_host_walk.hpp"
 #include "hrx_kernel.hpp"
 #include "hrx_lane.h"
 
@@ -33,6 +35,28 @@ static int fail(int code, const std::string &msg) {
         hipError_t _e = (expr);                                                                         \
         if (_e != hipSuccess) return fail(HRX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
+
+// Entry points select the context's device for their HIP calls and restore the caller's current device on return
+// (a torch process keeps its own notion of the current device).
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    hipError_t set(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == device) return hipSuccess;
+        hipError_t e = hipSetDevice(device);
+        active = (e == hipSuccess && prev >= 0);
+        return e;
+    }
+    ~DeviceGuard() { if (active) (void)hipSetDevice(prev); }
+};
+
+namespace hrx {
+uint32_t debug_flags_from_env() {
+    const char *dbg = std::getenv("HRX_DEBUG_FLAGS");
+    return dbg ? ((uint32_t)std::strtoul(dbg, nullptr, 0) & kDbgHonoured) : 0u;
+}
+}  // namespace hrx
 
 struct hrx_defs {
     DefsSet s;
@@ -54,12 +78,15 @@ struct DevBuf {
 
 struct hrx_ctx {
     DefsSet s;  // private copy: the ctx outlives / is independent of the hrx_defs it was made from
-    int device = 0;
+    int device = 0;          // HRX_DEVICE_NONE: no device, host walk only
     int num_cus = 0;
+    uint32_t debug = 0;      // HRX_DEBUG_FLAGS, read once at creation (hrx_kernel.hpp)
+    size_t host_threshold = HRX_DEFAULT_HOST_THRESHOLD;   // rows (B x M) below which host-buffer batches take the host walk
     hipStream_t stream = nullptr;
     uint32_t *d_table = nullptr;
     uint64_t *d_wide = nullptr;
     uint16_t *d_half = nullptr;
+    uint8_t *d_pairtab = nullptr;
     std::vector<uint16_t *> d_pair;
     std::vector<uint8_t *> d_member;
     std::mutex mu;
@@ -139,13 +166,14 @@ int hrx_defs_push_allstr(hrx_defs *defs, uint64_t first_state_val, uint64_t acce
 
 int hrx_defs_push_substr(hrx_defs *defs, size_t n_pairs, const uint64_t *pair_cur, const uint64_t *pair_next,
                          size_t n_start, const uint64_t *start_states, size_t n_end, const uint64_t *end_states) {
-    if (!defs) return fail(HRX_ERR_ARG, "NULL argument");
+    if (!defs || (n_pairs && (!pair_cur || !pair_next)) || (n_start && !start_states) || (n_end && !end_states))
+        return fail(HRX_ERR_ARG, "NULL argument");
     if (defs->s.finalized) return fail(HRX_ERR_STATE, "defs already finalized");
     if (defs->s.defs.empty()) return fail(HRX_ERR_STATE, "push an allstr definition first");
     SubstrRegexDef sd;
     for (size_t i = 0; i < n_pairs; ++i) sd.valid_state_transitions.insert({pair_cur[i], pair_next[i]});
-    sd.start_states.assign(start_states, start_states + n_start);
-    sd.end_states.assign(end_states, end_states + n_end);
+    if (n_start) sd.start_states.assign(start_states, start_states + n_start);
+    if (n_end) sd.end_states.assign(end_states, end_states + n_end);
     defs->s.defs.back().substrs.push_back(std::move(sd));
     return HRX_OK;
 }
@@ -159,11 +187,15 @@ int hrx_defs_finalize(hrx_defs *defs) {
 
 size_t hrx_defs_num_defs(const hrx_defs *defs) { return defs ? defs->s.defs.size() : 0; }
 size_t hrx_defs_num_substrs(const hrx_defs *defs, size_t d) { return defs && d < defs->s.defs.size() ? defs->s.defs[d].substrs.size() : 0; }
-uint64_t hrx_defs_first_state(const hrx_defs *defs, size_t d) { return defs->s.defs[d].allstr.first_state_val; }
-uint64_t hrx_defs_accepted_state(const hrx_defs *defs, size_t d) { return defs->s.defs[d].allstr.accepted_state_val; }
-uint64_t hrx_defs_largest_state(const hrx_defs *defs, size_t d) { return defs->s.defs[d].allstr.largest_state_val; }
-size_t hrx_defs_num_transitions(const hrx_defs *defs, size_t d) { return defs->s.defs[d].allstr.state_lookup.size(); }
+static const AllstrRegexDef *allstr_of(const hrx_defs *defs, size_t d) {   // NULL handle or def out of range -> NULL (accessors then return 0)
+    return defs && d < defs->s.defs.size() ? &defs->s.defs[d].allstr : nullptr;
+}
+uint64_t hrx_defs_first_state(const hrx_defs *defs, size_t d) { const AllstrRegexDef *a = allstr_of(defs, d); return a ? a->first_state_val : 0; }
+uint64_t hrx_defs_accepted_state(const hrx_defs *defs, size_t d) { const AllstrRegexDef *a = allstr_of(defs, d); return a ? a->accepted_state_val : 0; }
+uint64_t hrx_defs_largest_state(const hrx_defs *defs, size_t d) { const AllstrRegexDef *a = allstr_of(defs, d); return a ? a->largest_state_val : 0; }
+size_t hrx_defs_num_transitions(const hrx_defs *defs, size_t d) { const AllstrRegexDef *a = allstr_of(defs, d); return a ? a->state_lookup.size() : 0; }
 uint64_t hrx_defs_substr_id_offset(const hrx_defs *defs, size_t d) {
+    if (!defs) return 0;
     uint64_t off = 1;
     for (size_t i = 0; i < d && i < defs->s.defs.size(); ++i) off += defs->s.defs[i].substrs.size();
     return off;
@@ -203,10 +235,19 @@ void hrx_shard_range(size_t B, int world, int rank, size_t *begin, size_t *count
 int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     if (!defs || !out) return fail(HRX_ERR_ARG, "NULL argument");
     if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
+    if (device == HRX_DEVICE_NONE) {   // host-only context: single strings and host-buffer batches through the native host walk
+        hrx_ctx *c = new hrx_ctx();
+        c->s = defs->s;
+        c->device = HRX_DEVICE_NONE;
+        c->debug = debug_flags_from_env();
+        *out = c;
+        return HRX_OK;
+    }
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) return fail(HRX_ERR_ARG, "no such device");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard;
+    HIP_TRY(guard.set(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -215,6 +256,7 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     c->s = defs->s;
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
+    c->debug = debug_flags_from_env();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_table, c->s.table_image.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(c->d_table, c->s.table_image.data(), c->s.table_image.size() * 4, hipMemcpyHostToDevice);
@@ -225,6 +267,10 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     if (e == hipSuccess && !c->s.half_image.empty()) {
         e = hipMalloc((void **)&c->d_half, c->s.half_image.size() * 2);
         if (e == hipSuccess) e = hipMemcpy(c->d_half, c->s.half_image.data(), c->s.half_image.size() * 2, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !c->s.pair.image.empty()) {
+        e = hipMalloc((void **)&c->d_pairtab, c->s.pair.image.size());
+        if (e == hipSuccess) e = hipMemcpy(c->d_pairtab, c->s.pair.image.data(), c->s.pair.image.size(), hipMemcpyHostToDevice);
     }
     for (size_t d = 0; e == hipSuccess && d < c->s.pair_tags.size(); ++d) {
         uint16_t *p = nullptr;
@@ -250,13 +296,25 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     return HRX_OK;
 }
 
+int hrx_ctx_set_host_threshold(hrx_ctx *ctx, size_t rows) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->host_threshold = rows;
+    return HRX_OK;
+}
+
+size_t hrx_ctx_host_threshold(const hrx_ctx *ctx) { return ctx ? ctx->host_threshold : 0; }
+int hrx_ctx_device(const hrx_ctx *ctx) { return ctx ? ctx->device : HRX_DEVICE_NONE; }
+
 void hrx_ctx_destroy(hrx_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard;
+    if (c->device != HRX_DEVICE_NONE) (void)guard.set(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_half) (void)hipFree(c->d_half);
+    if (c->d_pairtab) (void)hipFree(c->d_pairtab);
     for (uint16_t *p : c->d_pair) (void)hipFree(p);
     for (uint8_t *p : c->d_member) (void)hipFree(p);
     c->chars.release(); c->lens.release(); c->records.release(); c->masked.release();
@@ -271,6 +329,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
                         size_t msk_pitch = 0, int layout = 0) {
     if (!rec_pitch) rec_pitch = M;
     if (!msk_pitch) msk_pitch = M;
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
     if (B == 0) return HRX_OK;
     if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
     if (M == 0 || M > (1u << 24)) return fail(HRX_ERR_ARG, "max_chars_size must be in 1..2^24");
@@ -294,9 +353,14 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     a.table_image = ctx->d_table; a.table_bytes = (uint32_t)(ctx->s.table_image.size() * 4);
     a.wide_image = ctx->d_wide;
     a.half_image = ctx->d_half; a.half_bytes = (uint32_t)(ctx->s.half_image.size() * 2);
+    a.pair_image = ctx->d_pairtab; a.pair_bytes = ctx->s.pair.bytes; a.pair_classes = ctx->s.pair.n_classes;
+    a.pair_blk_bytes = ctx->s.pair.blk_bytes; a.pair_lut_off = ctx->s.pair.lut_off;
     a.D = (uint32_t)ctx->s.defs.size();
-    if (const char *dbg = std::getenv("HRX_DEBUG_FLAGS")) a.debug = (uint32_t)std::atoi(dbg);
-    for (uint32_t d = 0; d < a.D; ++d) a.dc[d] = ctx->s.consts[d];
+    a.debug = ctx->debug;
+#ifdef HRX_ABLATION
+    a.debug = debug_flags_from_env();   // tools/ab_flags.py switches ablations between launches of one process
+#endif
+    for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = ctx->s.consts[d];
     LaunchInfo li;
     if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
     HIP_TRY(launch_witness(a, li, st));
@@ -307,7 +371,8 @@ int hrx_witness_batch_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
                              uint32_t *records, uint16_t *masked, uint64_t *status, void *stream) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceGuard guard;
+    if (ctx->device != HRX_DEVICE_NONE) HIP_TRY(guard.set(ctx->device));
     return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream);
 }
 
@@ -316,7 +381,8 @@ int hrx_witness_batch_device_pitched(hrx_ctx *ctx, const uint8_t *chars, size_t 
                                      void *stream) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceGuard guard;
+    if (ctx->device != HRX_DEVICE_NONE) HIP_TRY(guard.set(ctx->device));
     return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream, rec_pitch, msk_pitch);
 }
 
@@ -324,7 +390,8 @@ int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *cha
                                     size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceGuard guard;
+    if (ctx->device != HRX_DEVICE_NONE) HIP_TRY(guard.set(ctx->device));
     return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream, 0, 0, layout);
 }
 
@@ -340,13 +407,16 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
     a.wide_image = s.wide_image.empty() ? nullptr : s.wide_image.data();
     a.half_image = s.half_image.empty() ? nullptr : s.half_image.data();
     a.half_bytes = (uint32_t)(s.half_image.size() * 2);
+    a.pair_image = s.pair.image.empty() ? nullptr : s.pair.image.data(); a.pair_bytes = s.pair.bytes; a.pair_classes = s.pair.n_classes;
+    a.pair_blk_bytes = s.pair.blk_bytes; a.pair_lut_off = s.pair.lut_off;
     a.D = (uint32_t)s.defs.size();
-    if (const char *dbg = std::getenv("HRX_DEBUG_FLAGS")) a.debug = (uint32_t)std::atoi(dbg);
+    a.debug = debug_flags_from_env();   // what a context created now would run with (kernel-selection bits only in a release build)
     LaunchInfo li;
     if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
     char name[128];
     const char *tf[2] = {"false", "true"};
-    if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u>", a.D);
+    if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
+    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u>", a.D);
     else if (li.split == 2) std::snprintf(name, sizeof name, (layout & 1) ? "hrx::witness_pm_kernel<%u, %s, %s, %s>" : "hrx::witness_pm_kernel<%u, %s, %s, %s, true>", a.D, tf[li.gtab], tf[li.wide], tf[li.half]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u>", a.D, 32u / a.D);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
@@ -380,8 +450,10 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
         layout != (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR))
         return fail(HRX_ERR_ARG, "unknown layout");
     if ((uintptr_t)cells & 15) return fail(HRX_ERR_ARG, "cells must be 16-byte aligned");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
     FrArgs a{};
     a.chars = chars; a.stride = stride; a.lens = lens; a.records = records; a.masked = masked;
     a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)ctx->s.defs.size(); a.layout = (uint32_t)layout;
@@ -439,15 +511,39 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
     return HRX_OK;
 }
 
+// host-buffer batches below the context's threshold (and every batch of a host-only context) take the native host walk
+static bool use_host_walk(const hrx_ctx *ctx, size_t B, size_t M) {
+    if (ctx->device == HRX_DEVICE_NONE) return true;
+    if (ctx->debug & kDbgNoHost) return false;
+    if (ctx->debug & kDbgForceHost) return true;
+    return B * M < ctx->host_threshold;
+}
+
+static int check_host_shape(size_t B, size_t M) {
+    if (M == 0 || M > (1u << 24)) return fail(HRX_ERR_ARG, "max_chars_size must be in 1..2^24");
+    if (B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "batch too large");
+    return HRX_OK;
+}
+
 int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                            uint32_t *records, uint16_t *masked, uint64_t *status) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (B == 0) return HRX_OK;
+    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (int rc = check_host_shape(B, M)) return rc;
+    if (use_host_walk(ctx, B, M)) {   // re-entrant: reads the context's tables only
+        for (size_t b = 0; b < B; ++b)
+            if (lens[b] <= M && lens[b] > stride) return fail(HRX_ERR_ARG, "a string is longer than the stride");
+        host_witness_batch(ctx->s, chars, stride, lens, B, M, records, masked, status, ctx->device == HRX_DEVICE_NONE ? 0 : 1);
+        return HRX_OK;
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
     return batch_host_locked(ctx, chars, stride, lens, B, M, records, masked, status);
 }
 
-/* ------------------------------ multi-GPU driver (host buffers) ------------------------------ */
+/* ------------------------------ multi-GPU driver ------------------------------ */
 
 struct hrx_multi {
     std::vector<hrx_ctx *> ctxs;   // one per shard, in shard order
@@ -461,7 +557,7 @@ int hrx_multi_create(const hrx_defs *defs, const int *devices, int n_devices, hr
     m->D = defs->s.defs.size();
     for (int i = 0; i < n_devices; ++i) {
         hrx_ctx *c = nullptr;
-        const int rc = hrx_ctx_create(defs, devices[i], &c);
+        const int rc = hrx_ctx_create(defs, devices[i], &c);   // restores the caller's current device itself
         if (rc != HRX_OK) {
             hrx_multi_destroy(m);
             return rc;
@@ -479,6 +575,7 @@ void hrx_multi_destroy(hrx_multi *m) {
 }
 
 int hrx_multi_num_shards(const hrx_multi *m) { return m ? (int)m->ctxs.size() : 0; }
+int hrx_multi_shard_device(const hrx_multi *m, int shard) { return m && shard >= 0 && shard < (int)m->ctxs.size() ? m->ctxs[(size_t)shard]->device : HRX_DEVICE_NONE; }
 
 int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                                  uint32_t *records, uint16_t *masked, uint64_t *status) {
@@ -505,6 +602,33 @@ int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stri
     return HRX_OK;
 }
 
+int hrx_multi_witness_batch_device(hrx_multi *m, int layout, const uint8_t *const *chars, size_t stride, const uint32_t *const *lens,
+                                   const size_t *counts, size_t M, uint32_t *const *records, uint16_t *const *masked,
+                                   uint64_t *const *status) {
+    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
+    if (!chars || !lens || !counts || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL argument");
+    // one kernel per shard on the shard's own stream: the launches are asynchronous, so one host thread keeps all devices busy
+    for (size_t r = 0; r < m->ctxs.size(); ++r) {
+        if (counts[r] == 0) continue;
+        hrx_ctx *c = m->ctxs[r];
+        const int rc = hrx_witness_batch_device_layout(c, layout, chars[r], stride, lens[r], counts[r], M, records[r], masked[r], status[r],
+                                                       (void *)c->stream);
+        if (rc != HRX_OK) return fail(rc, "shard " + std::to_string(r) + ": " + g_err);
+    }
+    return HRX_OK;
+}
+
+int hrx_multi_synchronize(hrx_multi *m) {
+    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
+    for (hrx_ctx *c : m->ctxs) {
+        if (c->device == HRX_DEVICE_NONE) continue;
+        DeviceGuard guard;
+        HIP_TRY(guard.set(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return HRX_OK;
+}
+
 /* ------------------------------ single-string entry points ------------------------------ */
 
 static int status_to_error(uint64_t sw) {
@@ -523,45 +647,67 @@ static int status_to_error(uint64_t sw) {
     }
 }
 
-// one string through the batch kernel with M rows; returns host copies of the compact outputs
+// One string with M rows -> host copies of the compact outputs.  A single string is the host walk's case (one GPU lane
+// needs ~50 ns per row, a host core ~3); the batch kernel serves it only when HRX_DEBUG_FLAGS says so (the GPU tests).
 static int run_one(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t M, std::vector<uint32_t> &rec,
                    std::vector<uint16_t> &msk, uint64_t &sw) {
     const size_t D = ctx->s.defs.size();
     rec.assign(M * D, 0);
     msk.assign(M, 0);
+    if (int rc = check_host_shape(1, M)) return rc;
+    if (ctx->device == HRX_DEVICE_NONE || !(ctx->debug & kDbgNoHost)) {
+        sw = host_witness_one(ctx->s, characters, n, M, rec.data(), msk.data());
+        return HRX_OK;
+    }
     const uint32_t len = (uint32_t)n;
     std::vector<uint8_t> tmp((n + 15) & ~(size_t)15, 0);
     if (n) std::memcpy(tmp.data(), characters, n);
     if (tmp.empty()) tmp.resize(16, 0);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
     return batch_host_locked(ctx, tmp.data(), tmp.size(), &len, 1, M, rec.data(), msk.data(), &sw);
 }
 
+static bool single_on_device(const hrx_ctx *ctx) { return ctx->device != HRX_DEVICE_NONE && (ctx->debug & kDbgNoHost); }
+
 int hrx_derive_states(hrx_ctx *ctx, const uint8_t *characters, size_t n, uint64_t *states) {
     if (!ctx || (!characters && n) || !states) return fail(HRX_ERR_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
-    const size_t D = ctx->s.defs.size(), M = n + 1;  // row n holds states[d][n] (lib.rs:406-411)
+    const size_t D = ctx->s.defs.size();
+    if (!single_on_device(ctx)) {
+        uint32_t bs = 0, bc = 0;
+        if (!host_derive_states(ctx->s, characters, n, states, bs, bc)) return status_to_error(status_invalid(0, 0, bs, bc));
+        return HRX_OK;
+    }
+    const size_t M = n + 1;  // row n holds states[d][n] (lib.rs:406-411)
     std::vector<uint32_t> rec;
     std::vector<uint16_t> msk;
     uint64_t sw = 0;
     if (int rc = run_one(ctx, characters, n, M, rec, msk, sw)) return rc;
-    if ((sw & 0xff) == kStatusInvalidTransition) return status_to_error(sw);
+    if ((sw & 0xff) == kStatusInvalidTransition) return status_to_error(sw);   // (records of such a string are unspecified)
     for (size_t d = 0; d < D; ++d)
         for (size_t i = 0; i <= n; ++i) states[d * (n + 1) + i] = rec[i * D + d] & 0xffffu;
     return HRX_OK;
 }
 
-static int pair_tags_host(hrx_ctx *ctx, const uint64_t *states, size_t n, std::vector<uint16_t> &tags) {
+static int pair_tags_any(hrx_ctx *ctx, const uint64_t *states, size_t n, std::vector<uint16_t> &tags) {
     const size_t D = ctx->s.defs.size();
     tags.assign(n * D, 0);
     if (n == 0) return HRX_OK;
+    if (!single_on_device(ctx)) {
+        host_pair_tags(ctx->s, states, n, tags.data());
+        return HRX_OK;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
     HIP_TRY(ctx->states.reserve(8 * D * (n + 1)));
     HIP_TRY(ctx->tags.reserve(2 * D * n));
     HIP_TRY(hipMemcpyAsync(ctx->states.p, states, 8 * D * (n + 1), hipMemcpyHostToDevice, ctx->stream));
-    uint32_t ns[3];
-    const uint16_t *pt[3];
+    std::vector<uint32_t> ns(D);
+    std::vector<const uint16_t *> pt(D);
     for (size_t d = 0; d < D; ++d) { ns[d] = (uint32_t)ctx->s.defs[d].allstr.largest_state_val + 1; pt[d] = ctx->d_pair[d]; }
-    HIP_TRY(launch_pair_tags((const uint64_t *)ctx->states.p, n, (uint32_t)D, pt, ns, (uint16_t *)ctx->tags.p, ctx->stream));
+    HIP_TRY(launch_pair_tags((const uint64_t *)ctx->states.p, n, (uint32_t)D, pt.data(), ns.data(), (uint16_t *)ctx->tags.p, ctx->stream));
     HIP_TRY(hipMemcpyAsync(tags.data(), ctx->tags.p, 2 * D * n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return HRX_OK;
@@ -569,10 +715,8 @@ static int pair_tags_host(hrx_ctx *ctx, const uint64_t *states, size_t n, std::v
 
 int hrx_derive_substr_ids(hrx_ctx *ctx, const uint64_t *states, size_t n, uint64_t *substr_ids) {
     if (!ctx || !states || (!substr_ids && n)) return fail(HRX_ERR_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
     std::vector<uint16_t> tags;
-    if (int rc = pair_tags_host(ctx, states, n, tags)) return rc;
+    if (int rc = pair_tags_any(ctx, states, n, tags)) return rc;
     for (size_t i = 0; i < tags.size(); ++i) substr_ids[i] = tags[i] & 0xffu;
     return HRX_OK;
 }
@@ -580,11 +724,14 @@ int hrx_derive_substr_ids(hrx_ctx *ctx, const uint64_t *states, size_t n, uint64
 int hrx_derive_is_start_end(hrx_ctx *ctx, const uint64_t *states, const uint64_t *substr_ids, size_t n,
                             uint8_t *is_start, uint8_t *is_end) {
     if (!ctx || !states || !is_start || !is_end || (!substr_ids && n)) return fail(HRX_ERR_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
     const size_t D = ctx->s.defs.size();
     std::vector<uint8_t> flags(n * D, 0);
-    if (n) {
+    if (n && !single_on_device(ctx)) {
+        host_endpoint_flags(ctx->s, states, substr_ids, n, flags.data());
+    } else if (n) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        DeviceGuard guard;
+        HIP_TRY(guard.set(ctx->device));
         HIP_TRY(ctx->states.reserve(8 * D * (n + 1)));
         HIP_TRY(ctx->tags.reserve(8 * D * n + D * n));
         uint64_t *d_sids = (uint64_t *)ctx->tags.p;
@@ -593,13 +740,15 @@ int hrx_derive_is_start_end(hrx_ctx *ctx, const uint64_t *states, const uint64_t
         HIP_TRY(hipMemcpyAsync(d_sids, substr_ids, 8 * D * n, hipMemcpyHostToDevice, ctx->stream));
         EndpointArgs a{};
         a.states = (const uint64_t *)ctx->states.p; a.substr_ids = d_sids; a.n = n; a.D = (uint32_t)D; a.flags = d_flags;
+        std::vector<const uint8_t *> member(D);
+        std::vector<uint32_t> dims(3 * D);
         for (size_t d = 0; d < D; ++d) {
-            a.member[d] = ctx->d_member[d];
-            a.n_states[d] = (uint32_t)ctx->s.defs[d].allstr.largest_state_val + 1;
-            a.n_substrs[d] = (uint32_t)ctx->s.defs[d].substrs.size();
-            a.id_offset[d] = ctx->s.consts[d].substr_id_offset;
+            member[d] = ctx->d_member[d];
+            dims[3 * d] = (uint32_t)ctx->s.defs[d].allstr.largest_state_val + 1;
+            dims[3 * d + 1] = (uint32_t)ctx->s.defs[d].substrs.size();
+            dims[3 * d + 2] = ctx->s.consts[d].substr_id_offset;
         }
-        HIP_TRY(launch_endpoint_flags(a, ctx->stream));
+        HIP_TRY(launch_endpoint_flags(a, member.data(), dims.data(), ctx->stream));
         HIP_TRY(hipMemcpyAsync(flags.data(), d_flags, D * n, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
@@ -619,8 +768,6 @@ int hrx_match_substrs(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t 
                       uint64_t *masked_char, uint64_t *masked_substr_id, uint64_t *status) {
     if (!ctx || (!characters && n)) return fail(HRX_ERR_ARG, "NULL argument");
     if (n > M) return fail(HRX_ERR_OUT_OF_CONTRACT, "input longer than max_chars_size");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
     const size_t D = ctx->s.defs.size();
     std::vector<uint32_t> rec;
     std::vector<uint16_t> msk;

@@ -103,6 +103,58 @@ static uint32_t pair_tag(const RegexDefs &rd, uint64_t off, uint64_t cur, uint64
     return 0;
 }
 
+// PAIR image (hrx_lane.h) from the dense 4-byte table of def 0: byte classes = identical columns over the real states.
+static void build_pair_table(DefsSet &s) {
+    s.pair = PairTable();
+    if (s.defs.size() != 1) return;
+    const DefConsts &c = s.consts[0];
+    const uint32_t L = (uint32_t)s.defs[0].allstr.largest_state_val;
+    if (L + 1 > 254) return;
+    const uint32_t *T = s.table_image.data() + (size_t)c.row_base * 256;
+    // classes in order of their first byte
+    std::vector<int> cls(256, -1);
+    std::vector<int> rep;
+    for (int ch = 0; ch < 256; ++ch) {
+        for (size_t k = 0; k < rep.size() && cls[ch] < 0; ++k) {
+            bool same = true;
+            for (uint32_t st = 0; st <= L && same; ++st) same = T[st * 256 + ch] == T[st * 256 + rep[k]];
+            if (same) cls[ch] = (int)k;
+        }
+        if (cls[ch] < 0) { cls[ch] = (int)rep.size(); rep.push_back(ch); }
+    }
+    const uint32_t C = (uint32_t)rep.size();
+    if (C > kPairMaxClasses) return;
+    PairTable p;
+    p.n_classes = C;
+    p.n_blocks = L + 2;
+    p.blk_bytes = C * C * 8;
+    p.lut_off = p.n_blocks * p.blk_bytes;
+    p.bytes = (p.lut_off + 256 + 15) & ~15u;
+    if (p.bytes > kPairMaxBytes || p.lut_off / 8 > 0xffffu) return;
+    p.image.assign(p.bytes, 0);
+    const uint32_t dead = L + 1;
+    auto step = [&](uint32_t st, int ch, uint32_t &next, uint32_t &tag) {   // delta + tag of the fused 4-byte entry
+        if (st == dead) { next = dead; tag = 0; return; }
+        const uint32_t e = T[st * 256 + ch];
+        if (e >= c.dead_entry) { next = dead; tag = 0; return; }
+        next = (e >> kNextShift) - c.row_base;
+        tag = e & kTagMask;
+    };
+    for (uint32_t st = 0; st <= dead; ++st)
+        for (uint32_t a = 0; a < C; ++a)
+            for (uint32_t b = 0; b < C; ++b) {
+                uint32_t mid, nxt, t0, t1;
+                step(st, rep[a], mid, t0);
+                step(mid, rep[b], nxt, t1);
+                const uint64_t lo = (uint64_t)(nxt * p.blk_bytes / 8) | (uint64_t)(t0 & 0xffu) << 16 | (uint64_t)(t1 & 0xffu) << 24;
+                const uint64_t hi = (uint64_t)st | (uint64_t)mid << 8 | (uint64_t)((t0 >> 8) & 3u) << 16 | (uint64_t)((t1 >> 8) & 3u) << 24;
+                const uint64_t e = lo | hi << 32;
+                std::memcpy(&p.image[(size_t)st * p.blk_bytes + (a * C + b) * 8], &e, 8);
+            }
+    for (int ch = 0; ch < 256; ++ch) p.image[p.lut_off + ch] = (uint8_t)(cls[ch] * 8);
+    s.pair = std::move(p);
+}
+
 int finalize_defs(DefsSet &s, std::string &err) {
     if (s.finalized) return HRX_OK;
     if (s.defs.empty()) { err = "no RegexDefs pushed"; return HRX_ERR_STATE; }
@@ -216,6 +268,7 @@ int finalize_defs(DefsSet &s, std::string &err) {
             }
         }
     }
+    build_pair_table(s);
     s.finalized = true;
     return HRX_OK;
 }

@@ -54,6 +54,19 @@ struct DefConsts {
     uint32_t first_state, dummy_state;  // first_state_val, largest+1
 };
 
+// PAIR table (hrx_lane.h; position-major kernel hrx_kernel_pp.hip, one def): two input bytes per dependent lookup.
+// Bytes are first mapped to their equivalence class (bytes whose table columns are identical over all real states; all
+// bytes no state has a transition for form one class).  Block b = state b (real states 0..L, then the absorbing dead
+// block L+1), n_classes^2 8-byte entries each, entry (a, b) at block + (a * n_classes + b) * 8.
+struct PairTable {
+    uint32_t n_classes = 0;     // <= kPairMaxClasses
+    uint32_t n_blocks = 0;      // largest + 2
+    uint32_t blk_bytes = 0;     // n_classes^2 * 8
+    uint32_t lut_off = 0;       // LDS byte offset of the 256-byte class LUT (value = class * 8), right behind the blocks
+    uint32_t bytes = 0;         // size of the LDS image (blocks + LUT), a multiple of 16
+    std::vector<uint8_t> image; // the exact LDS image
+};
+
 struct DefsSet {
     std::vector<RegexDefs> defs;
     bool finalized = false;
@@ -65,6 +78,9 @@ struct DefsSet {
     // HALF image (hrx_lane.h): the exact LDS image, half_image_bytes(total real states) bytes; empty unless all defs
     // together have <= 256 real states and every substr id is <= kHalfMaxSid
     std::vector<uint16_t> half_image;
+    // PAIR image (hrx_lane.h): empty unless there is exactly one def with <= kPairMaxClasses byte classes, <= 254 real
+    // states and a table of at most kPairMaxBytes
+    PairTable pair;
     std::vector<DefConsts> consts;
     // (cur,next) -> {sid, is_start(cur), is_end(next)} per def, for the states-in entry points (lib.rs:825-888)
     std::vector<std::vector<uint16_t>> pair_tags;  // [(largest+1)^2], entry = tag bits as in the fused table

@@ -44,6 +44,31 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
             }
         }
     }
+    // ---- pair-step loader/walker kernel (hrx_kernel_pp.hip): position-major, one def whose PAIR table exists (few byte classes):
+    // two bytes per dependent lookup.  Table + per pair a ring of >= 2 slots of 8 KiB (pair indices + raw bytes).
+    if ((a.layout & 1u) && a.D == 1 && a.pair_image &&
+        !(a.debug & (kDbgNoPair | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf | kDbgForceGlobalTable))) {
+        int pairs = 4;
+        while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        for (; pairs >= 1; --pairs) {
+            for (int ns = 4; ns >= 2; --ns) {
+                const size_t lds = a.pair_bytes + (size_t)pairs * (ns * kPpSlotBytes + 16);
+                if (lds > kLdsLimit) continue;
+                out.split = 6; out.gtab = 0; out.wide = 0; out.half = 0;
+                out.waves_per_wg = 2 * pairs;
+                out.nslots = ns;
+                out.lds_bytes = lds;
+                const size_t need = ((size_t)a.n_groups + pairs - 1) / pairs;
+                size_t per_cu = kLdsLimit / lds;
+                if (per_cu * (size_t)(2 * pairs) > 8) per_cu = 8 / (size_t)(2 * pairs);
+                if (per_cu < 1) per_cu = 1;
+                const size_t cap = (size_t)num_cus * per_cu;
+                out.grid = (int)(need < cap ? need : cap);
+                if (out.grid < 1) out.grid = 1;
+                return true;
+            }
+        }
+    }
     // ---- def-parallel loader/walker kernel (hrx_kernel_pmd.hip): position-major, D >= 2 on the WIDE table, batches of at
     // most two groups per CU — one walker wave per def, so that a group advances at the single-def rate
     if ((a.layout & 1u) && a.D >= 2 && a.wide_image && !out.gtab &&
@@ -146,6 +171,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
 }
 
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
+    if (li.split == 6) return launch_witness_pp(a, li, stream);
     if (li.split == 5) return launch_witness_pmd(a, li, stream);
     return li.split == 2 ? launch_witness_pm(a, li, stream) : launch_witness_sm(a, li, stream);
 }
@@ -153,59 +179,64 @@ hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_
 // ---------------------------------------------------------------------------------------------
 // states-in entry points (lib.rs:825-888): one thread per (def, row) looks the pair (s[i], s[i+1]) up.
 // ---------------------------------------------------------------------------------------------
-struct PairArgs {
-    const uint64_t *states;
+struct PairArgs {     // one def per launch
+    const uint64_t *states;   // this def's n + 1 states
     uint64_t n;
-    uint32_t D;
-    const uint16_t *pt[3];
-    uint32_t ns[3];
-    uint16_t *tags;
+    const uint16_t *pt;
+    uint32_t ns;
+    uint16_t *tags;           // this def's n tags
 };
 
 __global__ void pair_tags_kernel(const PairArgs a) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n * a.D) return;
-    const uint32_t d = (uint32_t)(i / a.n);
-    const uint64_t r = i % a.n;
-    const uint64_t cur = a.states[d * (a.n + 1) + r], next = a.states[d * (a.n + 1) + r + 1];
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const uint64_t cur = a.states[r], next = a.states[r + 1];
     uint16_t t = 0;
-    if (cur < a.ns[d] && next < a.ns[d]) t = a.pt[d][cur * a.ns[d] + next];
-    a.tags[i] = t;
+    if (cur < a.ns && next < a.ns) t = a.pt[cur * a.ns + next];
+    a.tags[r] = t;
 }
 
 hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,
                             const uint32_t *n_states, uint16_t *tags, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    PairArgs a{};
-    a.states = states; a.n = n; a.D = D; a.tags = tags;
-    for (uint32_t d = 0; d < D; ++d) { a.pt[d] = pair_tags[d]; a.ns[d] = n_states[d]; }
-    const uint64_t total = (uint64_t)n * D;
-    hipLaunchKernelGGL(pair_tags_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    for (uint32_t d = 0; d < D; ++d) {
+        PairArgs a{states + (size_t)d * (n + 1), n, pair_tags[d], n_states[d], tags + (size_t)d * n};
+        hipLaunchKernelGGL(pair_tags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
-__global__ void endpoint_flags_kernel(const EndpointArgs a) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n * a.D) return;
-    const uint32_t d = (uint32_t)(i / a.n);
-    const uint64_t r = i % a.n;
-    const uint64_t sid = a.substr_ids[i];
+struct EndpointDefArgs {     // one def per launch
+    const uint64_t *states, *substr_ids;
+    uint64_t n;
+    const uint8_t *member;
+    uint32_t n_states, n_substrs, id_offset;
+    uint8_t *flags;
+};
+
+__global__ void endpoint_flags_kernel(const EndpointDefArgs a) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const uint64_t sid = a.substr_ids[r];
     uint8_t f = 0;
     if (sid != 0) {  // lib.rs:861-866, 874-879
-        const uint64_t j = sid - a.id_offset[d];
-        const uint64_t cur = a.states[d * (a.n + 1) + r], next = a.states[d * (a.n + 1) + r + 1];
-        if (j < a.n_substrs[d]) {
-            if (cur < a.n_states[d]) f |= a.member[d][j * a.n_states[d] + cur] & 1;
-            if (next < a.n_states[d]) f |= a.member[d][j * a.n_states[d] + next] & 2;
+        const uint64_t j = sid - a.id_offset;
+        const uint64_t cur = a.states[r], next = a.states[r + 1];
+        if (j < a.n_substrs) {
+            if (cur < a.n_states) f |= a.member[j * a.n_states + cur] & 1;
+            if (next < a.n_states) f |= a.member[j * a.n_states + next] & 2;
         }
     }
-    a.flags[i] = f;
+    a.flags[r] = f;
 }
 
-hipError_t launch_endpoint_flags(const EndpointArgs &a, hipStream_t stream) {
+hipError_t launch_endpoint_flags(const EndpointArgs &a, const uint8_t *const *member, const uint32_t *dims, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;
-    const uint64_t total = a.n * a.D;
-    hipLaunchKernelGGL(endpoint_flags_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    for (uint32_t d = 0; d < a.D; ++d) {
+        EndpointDefArgs e{a.states + (size_t)d * (a.n + 1), a.substr_ids + (size_t)d * a.n, a.n, member[d], dims[3 * d], dims[3 * d + 1], dims[3 * d + 2],
+                          a.flags + (size_t)d * a.n};
+        hipLaunchKernelGGL(endpoint_flags_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, e);
+    }
     return hipGetLastError();
 }
 

@@ -9,6 +9,8 @@
 
 namespace hrx {
 
+constexpr uint32_t kMaxDefsPerLaunch = 8;   // RegexDefs per config: the status word carries 8 accept bits (include/hrx.h)
+
 struct WitnessArgs {
     const uint8_t *chars;
     uint64_t stride;
@@ -24,39 +26,67 @@ struct WitnessArgs {
     const uint64_t *wide_image;   // device copy of DefsSet::wide_image (same byte size as table_image), or NULL
     const uint16_t *half_image;   // device copy of DefsSet::half_image (the exact LDS image, half_bytes long), or NULL
     uint32_t half_bytes;
+    const uint8_t *pair_image;    // device copy of DefsSet::pair.image (the exact LDS image: blocks + class LUT), or NULL
+    uint32_t pair_bytes, pair_classes, pair_blk_bytes, pair_lut_off;
     uint32_t n_groups;            // ceil(B / gs), set by plan_witness_launch
     uint32_t gs;                  // strings per wave (64, 32 or 16), set by plan_witness_launch
     uint32_t D;
-    uint32_t debug;               // HRX_DEBUG_FLAGS: the kDbg* bits below (profiling ablations and forced kernel / table choices for the tests)
+    uint32_t debug;               // the context's kDbg* bits below (forced kernel / table choices for the tests; ablations only with -DHRX_ABLATION)
     unsigned long long *stamps;   // profiling only (tools/kbench): per wave and tile 4 s_memtime stamps; NULL in the product
-    DefConsts dc[3];
+    DefConsts dc[kMaxDefsPerLaunch];
 };
 
-// HRX_DEBUG_FLAGS (environment, read per launch): never set in production.  The "force" bits let the parity tests drive
-// every kernel / table format through the same batches; the others are ablations used to steer the design
-// and make the OUTPUT WRONG.
+// HRX_DEBUG_FLAGS (environment; read ONCE per context in hrx_ctx_create, never per launch).  The "force" bits let the
+// parity tests drive every kernel / table format through the same batches; they change which kernel runs, never what it
+// computes.  The ablation bits (stores skipped, input re-read from L2, ...) make the OUTPUT WRONG: they exist only in a
+// library built with -DHRX_ABLATION (`make ablation` -> libhrx_ablation.so, used by tools/ only); in the release
+// libhrx.so their enumerators are 0, so every `a.debug & kDbgSkip...` test folds to false at compile time and no
+// environment variable can make a launch skip work.
+#ifdef HRX_ABLATION
+#define HRX_ABL(x) (x)
+#else
+#define HRX_ABL(x) 0u
+#endif
 enum : uint32_t {
-    kDbgSkipRecords = 1u,             // ablation: no record stores
-    kDbgSkipMasked = 2u,              // ablation: no masked-row stores
-    kDbgInputFromL2 = 4u,             // ablation: every tile re-reads the first input lines (no HBM reads) / no prefetch of the next tile
-    kDbgNoTouch = 8u,                 // ablation, walker/storer kernel: no L2 touch-ahead of the input
-    kDbgSplitNoWalk = 16u,            // ablation, walker/storer kernel: storers move whatever the slots hold
-    kDbgNtRecords = 32u,              // position-major kernel: non-temporal record stores
-    kDbgNtMasked = 64u,               // position-major kernel: non-temporal masked-row stores
+    kDbgSkipRecords = HRX_ABL(1u),             // ablation: no record stores
+    kDbgSkipMasked = HRX_ABL(2u),              // ablation: no masked-row stores
+    kDbgInputFromL2 = HRX_ABL(4u),             // ablation: every tile re-reads the first input lines (no HBM reads) / no prefetch of the next tile
+    kDbgNoTouch = HRX_ABL(8u),                 // ablation, walker/storer kernel: no L2 touch-ahead of the input
+    kDbgSplitNoWalk = HRX_ABL(16u),            // ablation, walker/storer kernel: storers move whatever the slots hold
+    kDbgNoNtRecords = HRX_ABL(32u),            // ablation, position-major kernels: ordinary record stores
+    kDbgNoNtMasked = HRX_ABL(64u),             // ablation, position-major kernels: ordinary masked-row stores
+    kDbgPpNoTranslate = HRX_ABL(0x100u),      // ablation, pair-step kernel: the loader skips the class lookups (pair index 0 everywhere)
+    kDbgPpNoPost = HRX_ABL(0x200u),            // ablation, pair-step kernel: the walker only follows the chain (no records, flags, ids)
+    kDbgPpNoMask = HRX_ABL(0x400u),            // ablation, pair-step kernel: no reveal-mask work at the tile end
+    kDbgSkipFixups = HRX_ABL(0x800000u),       // ablation: no end-mask fix-ups
+    kDbgFixedLines = HRX_ABL(0x1000000u),      // ablation: every quad / octet of a string is stored onto its first one
     kDbgForceOneWave = 0x10000u,      // string-major: the one-wave kernel instead of the walker/storer kernel
     kDbgGroups32 = 0x20000u,          // one-wave kernel: 32 strings per wave
     kDbgForceGlobalTable = 0x40000u,  // walk the fused table out of global memory even if it fits LDS
     kDbgForceNarrow = 0x80000u,       // position-major kernel: 4-byte table even where the planner picks WIDE
     kDbgForceWide = 0x200000u,        // position-major kernel: WIDE table also at D = 1
     kDbgForceHalf = 0x400000u,        // position-major kernel: HALF table even if the 4-byte one fits LDS
-    kDbgSkipFixups = 0x800000u,       // ablation: no end-mask fix-ups
-    kDbgFixedLines = 0x1000000u,      // ablation: every quad / octet of a string is stored onto its first one
     kDbgNoDefParallel = 0x2000000u,   // position-major: never the def-parallel kernel
     kDbgForceDefParallel = 0x4000000u,// position-major, D >= 2, WIDE table: the def-parallel kernel whatever the batch size (tests)
+    kDbgNoPair = 0x8000000u,          // position-major, D = 1: never the pair-step kernel (hrx_kernel_pp.hip)
+    kDbgForceHost = 0x10000000u,      // host-buffer entry points: always the native host walk (hrx_host_walk.cpp)
+    kDbgNoHost = 0x20000000u,         // host-buffer entry points: never the native host walk
+    kDbgNoNtStores = 0x40000000u,     // position-major kernels: ordinary write-back stores instead of non-temporal ones
+    // every bit that merely selects a kernel (the only ones a release build honours)
+    kDbgForceMask = kDbgForceOneWave | kDbgGroups32 | kDbgForceGlobalTable | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf |
+                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForceHost | kDbgNoHost | kDbgNoNtStores,
+#ifdef HRX_ABLATION
+    kDbgHonoured = 0xffffffffu,
+#else
+    kDbgHonoured = kDbgForceMask,
+#endif
 };
+// HRX_DEBUG_FLAGS from the environment, reduced to the bits this build honours
+uint32_t debug_flags_from_env();
 
 struct LaunchInfo {
-    int split;         // 5: def-parallel loader/walker kernel for D >= 2 batches that leave walker slots empty (witness_pmd_kernel),
+    int split;         // 6: pair-step loader/walker kernel, position-major, D = 1 (witness_pp_kernel: two bytes per dependent lookup),
+                       // 5: def-parallel loader/walker kernel for D >= 2 batches that leave walker slots empty (witness_pmd_kernel),
                        // 2: loader/walker kernel for the position-major layout (witness_pm_kernel),
                        // 1: walker/storer kernel (witness_split_kernel), 0: one-wave-does-all kernel (witness_kernel)
     int waves_per_wg;  // split: 2 * pairs
@@ -79,8 +109,10 @@ hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_
 hipError_t launch_witness_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 hipError_t launch_witness_sm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);   // hrx_kernel_pmd.hip (split == 5)
+hipError_t launch_witness_pp(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);    // hrx_kernel_pp.hip (split == 6)
+constexpr size_t kPpSlotBytes = 8192;   // pair-step kernel: one ring slot = 4 KiB of pair indices + 4 KiB of raw bytes
 // LDS bytes per group of the def-parallel kernel: input ring + (D - 1) x (2 summaries of 5 KiB + a 2-KiB status piece) + counters
-constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 64; }
+constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 128; }
 
 // states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])
 hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,
@@ -93,11 +125,10 @@ struct EndpointArgs {
     const uint64_t *substr_ids;
     uint64_t n;
     uint32_t D;
-    const uint8_t *member[3];
-    uint32_t n_states[3], n_substrs[3], id_offset[3];
     uint8_t *flags;
 };
-hipError_t launch_endpoint_flags(const EndpointArgs &a, hipStream_t stream);
+// member[d]: device membership bytes of def d; dims[3 d .. 3 d + 2] = {n_states, n_substrs, id_offset} of def d (one launch per def)
+hipError_t launch_endpoint_flags(const EndpointArgs &a, const uint8_t *const *member, const uint32_t *dims, hipStream_t stream);
 
 // compact witness rows of strings [b_begin, b_begin + b_count) -> bn256::Fr cells, [col][string][row][4]
 struct FrArgs {

@@ -200,10 +200,12 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 TileBits tb;
                 const bool full = (t0 + 64u < min_n);
                 const bool do_store = active && !(a.debug & kDbgSkipRecords);
+                // full-line position-major stores stream past L2 (non-temporal); the string-major lane-direct pieces do not (L2 merges them into lines)
+                const bool nt_rec = !SM && !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), nt_msk = !SM && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
                 const bool pend_store = active && have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
                 // [ceil(M/4)][D][nb][4]: one def's quads of all strings of the block
-                GlobalSink<D, SM> sink{rp, (size_t)nb * 16u, rstep, do_store, (a.debug & kDbgNtRecords) != 0, (a.debug & kDbgNtMasked) != 0,
+                GlobalSink<D, SM> sink{rp, (size_t)nb * 16u, rstep, do_store, nt_rec, nt_msk,
                                        pend, pend_mp, mstep, pend_store, {}};
                 if (WIDE) {
                     const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                         }
                         if (D == 1) pend[k] = v;  // leaves during the next tile's walk
                         else if (active && t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked))
-                            store16(mp + (size_t)k * mstep, v, false);  // D >= 2: the walk needs the registers; store now
+                            store16(mp + (size_t)k * mstep, v, nt_msk);  // D >= 2: the walk needs the registers; store now
                     }
                     pend_mp = mp;
                     mp += 8u * mstep;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 const uint32_t t0 = (ntiles - 1u) << 6;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (t0 + (uint32_t)k * 8u < M) *reinterpret_cast<uint4 *>(pend_mp + (size_t)k * mstep) = pend[k];
+                    if (t0 + (uint32_t)k * 8u < M) store16(pend_mp + (size_t)k * mstep, pend[k], !SM && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)));
             }
             // ---------------- per-string status ----------------
             if (active) {

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
         MaskCarry mc = {0, 0, 0, 0};
         uint32_t sum_prev = 0, ov_row = 0xffffffffu;
         const uint4 no_pend[8] = {};
+        const bool nt_rec = !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), nt_msk = !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));   // streaming stores (hrx_walk_pm.h)
 
         for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
             const uint32_t t0 = t << 6;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             TileBits tb;
             const bool full = (t0 + 64u < min_n);
             uint32_t tile_ov = 0, hb = 0;
-            GlobalSink<1> sink{rp, 0, rstep, active && !(a.debug & kDbgSkipRecords), false, false, no_pend, mp, mstep, false, {}};
+            GlobalSink<1> sink{rp, 0, rstep, active && !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
             const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                       cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
             if (full) {
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
                         }
                         v = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
                     }
-                    if (active && t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, false);
+                    if (active && t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, nt_msk);
                 }
                 mp += 8u * mstep;
             }

@@ -58,6 +58,21 @@ constexpr uint32_t kHalfMaxSid = 62;
 HRX_HD uint32_t half_addr(uint32_t row, uint32_t c) { return ((c >> 7) << 16) | (row << 8) | ((c & 127u) << 1); }
 HRX_HD uint32_t half_image_bytes(uint32_t rows) { return kHalfUpperBase + rows * 256u; }
 
+// PAIR table (position-major kernel hrx_kernel_pp.hip; one def, at most kPairMaxClasses byte-equivalence classes): one
+// dependent lookup per TWO input bytes.  Bytes are mapped to classes first (class LUT, value = class * 8); block s holds
+// the n_classes^2 entries of state s (real states, then one absorbing dead block), entry (a, b) = the walk from s over a
+// byte of class a and then one of class b:
+//   lo: bits 0..15  LDS byte address / 8 of the block of the state after BOTH bytes   (next lookup = lo.u16 * 8 + index)
+//       bits 16..23 substr_id of the first transition, bits 24..31 substr_id of the second
+//   hi: byte 0 state s itself, byte 1 the state between the two bytes, byte 2 is_start | is_end << 1 of the first
+//       transition, byte 3 the same of the second
+// so that either row's compact record state | substr_id << 16 | flags << 24 is ONE v_perm_b32 of (lo, hi), and the dependent
+// chain per two rows is one v_mad_u32_u16 + one ds_read_b64.  An undefined transition enters the dead block (state id
+// largest + 1 in the hi bytes).
+constexpr uint32_t kPairMaxClasses = 31;          // class * 8 fits the u8 LUT
+constexpr uint32_t kPairMaxBytes = 120u * 1024u;  // leaves room for one loader/walker pair with a 2-slot ring
+HRX_HD uint32_t pair_index(uint32_t cls8_a, uint32_t cls8_b, uint32_t n_classes) { return cls8_a * n_classes + cls8_b; }  // byte offset inside a block
+
 // Position-major buffers are BLOCKED: strings [k * kPmBlock, (k + 1) * kPmBlock) form block k, and each block is a complete
 // position-major array of its own strings ([M/4][D][nb][4] records, [M/8][nb][8] masked, [stride/16][nb][16] input, nb = strings
 // in the block), blocks back to back.  A batch of at most kPmBlock strings is one block — the plain layout.  Reason: the

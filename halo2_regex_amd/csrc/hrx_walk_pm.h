@@ -7,8 +7,13 @@ namespace hrx {
 
 constexpr uint32_t kPmTileBytes = 64u * 64u;  // 64 strings x 64 input bytes per tile
 
+// 16 bytes per lane, 1 KiB of full lines per wave.  nt: a non-temporal (streaming) store.  The nt form is inline asm on
+// purpose: with `if (nt) __builtin_nontemporal_store(..) else *p = v` LLVM merges the two stores of the diamond into ONE
+// ordinary store and drops the hint (round 1's "nt changes nothing" A/B measured exactly that: no store in the code object
+// carried the nt bit).  The trailing s_nop covers the one wait state a >64-bit VMEM store needs before a VALU may overwrite
+// its data registers (the hazard recogniser does not look into inline asm).
 __device__ __forceinline__ void store16(unsigned char *p, const uint4 &v, const bool nt) {
-    if (nt) __builtin_nontemporal_store(v4u32{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u32 *>(p));
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" : : "v"(p), "v"(v4u32{v.x, v.y, v.z, v.w}));
     else *reinterpret_cast<uint4 *>(p) = v;
 }
 

@@ -12,7 +12,10 @@
  *
  * Conventions: plain pointers and sizes, caller-owned buffers, integer status
  * returns (0 = HRX_OK), nothing unwinds.  Text of the last error: hrx_last_error().
- * Compute entry points need a gfx950 device; there is no CPU fallback.
+ * Batches run on a gfx950 device: the device-pointer entry points fail with HRX_ERR_HIP without one.  The library's one
+ * host-side compute path is its native small-batch walk (the same lane algorithm on a host core): the reference-shaped
+ * single-string entry points and host-buffer batches below the context's threshold take it — match_substrs hands over ONE
+ * string per call (src/lib.rs:316-318) and a GPU launch cannot beat a host core on ~1000 rows.
  */
 #ifndef HRX_H
 #define HRX_H
@@ -92,9 +95,22 @@ size_t hrx_table_endpoint_rows(const hrx_defs *defs, size_t def, uint64_t *rows3
 
 int hrx_device_count(int *count);
 /* Uploads the tables to `device` and creates a stream.  The handle may be shared by clones of a
- * RegexVerifyConfig (lib.rs:96 derives Clone); calls on one ctx are serialised internally. */
+ * RegexVerifyConfig (lib.rs:96 derives Clone); device work of one ctx is serialised internally.  Every entry point
+ * leaves the caller's current HIP device as it found it.
+ * device = HRX_DEVICE_NONE: a host-only context (no HIP call is made): the single-string entry points and
+ * hrx_witness_batch_host run the native host walk, device-pointer entry points return HRX_ERR_HIP.
+ * HRX_DEBUG_FLAGS (environment; kernel-selection bits for the tests, csrc/hrx_kernel.hpp) is read here, once. */
+#define HRX_DEVICE_NONE (-1)
 int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out);
 void hrx_ctx_destroy(hrx_ctx *ctx);
+int hrx_ctx_device(const hrx_ctx *ctx);
+/* Host-buffer batches (hrx_witness_batch_host, hrx_multi_witness_batch_host) of fewer than `rows` witness rows (B x M)
+ * are walked on the calling host thread instead of being staged to the device; default HRX_DEFAULT_HOST_THRESHOLD
+ * (the measured crossover); 0 = always the device.  The single-string entry points below always take the
+ * host walk (one GPU lane needs ~50 ns per row, a host core ~3).  Results are identical either way. */
+#define HRX_DEFAULT_HOST_THRESHOLD 32768
+int hrx_ctx_set_host_threshold(hrx_ctx *ctx, size_t rows);
+size_t hrx_ctx_host_threshold(const hrx_ctx *ctx);
 /* thread-local text of the last failing call (any entry point) */
 const char *hrx_last_error(void);
 
@@ -158,7 +174,8 @@ void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32,
  * ring=1 lds=147520" — the kernel name a profiler will show (bench.py's roofline.kernel).  Host-only: nothing is
  * launched and no device is touched.  Returns HRX_OK, HRX_ERR_BOUNDS if nothing fits. */
 int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap);
-/* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers; synchronous. */
+/* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers, or — below the
+ * context's host threshold, and always on a host-only context — walked on the host; synchronous. */
 int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
                            size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);
 
@@ -195,8 +212,18 @@ typedef struct hrx_multi hrx_multi;
 int hrx_multi_create(const hrx_defs *defs, const int *devices, int n_devices, hrx_multi **out);
 void hrx_multi_destroy(hrx_multi *m);
 int hrx_multi_num_shards(const hrx_multi *m);
+int hrx_multi_shard_device(const hrx_multi *m, int shard);
 int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                                  uint32_t *records, uint16_t *masked, uint64_t *status);
+/* Device-resident shards: the same driver without the PCIe copies, for a single-process host (the Rust prover) whose
+ * inputs already sit in each device's HBM.  Shard r = counts[r] strings whose buffers chars[r], lens[r], records[r],
+ * masked[r], status[r] are DEVICE pointers on the device of shard r (hrx_multi_shard_device), in `layout` (one of the
+ * hrx_witness_batch_device_layout layouts, each shard a complete array of its own strings).  One kernel per shard is
+ * enqueued on the shard's own stream — asynchronous; hrx_multi_synchronize waits for all of them.  No collective. */
+int hrx_multi_witness_batch_device(hrx_multi *m, int layout, const uint8_t *const *chars, size_t stride, const uint32_t *const *lens,
+                                   const size_t *counts, size_t M, uint32_t *const *records, uint16_t *const *masked,
+                                   uint64_t *const *status);
+int hrx_multi_synchronize(hrx_multi *m);
 
 /* Contiguous shard [begin, begin+count) of a batch of B strings for `rank` of `world` devices
  * (strings are independent given the RegexDefs; no collective on the path). */

@@ -1,0 +1,170 @@
+"""The library's native small-batch host walk (csrc/hrx_host_walk.cpp) against the oracle and against the reference's own
+known answers — CPU only, through the C ABI on a host-only context (hrx_ctx_create(defs, HRX_DEVICE_NONE)).
+
+This is the path the reference-shaped single-string surface takes (match_substrs hands over ONE string per call,
+src/lib.rs:316-318).  It is the lane algorithm of csrc/hrx_lane.h (dense fused table, per-tile position bitvectors,
+carry-chain mask scans with the optimistic end-mask protocol) on a host core; it neither links nor calls the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import halo2_regex_amd as hra
+from halo2_regex_amd import synth
+from oracle_lib import OracleDefs, DFA_DIR, reference_cases
+
+CFG_1 = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]]]
+CFG_A = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]], ["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]]]
+CFG_3 = [["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
+CFG_23 = [["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]], ["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
+CFG_123 = CFG_A + CFG_3
+CFG_EX = [["ex_allstr.txt", ["ex_substr_id1.txt"]]]
+
+
+def _cfg(names, M):
+    defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(os.path.join(DFA_DIR, a)),
+                          [hra.SubstrRegexDef.read_from_text(os.path.join(DFA_DIR, s)) for s in subs]) for a, subs in names]
+    return hra.RegexVerifyConfig.configure(M, defs, device=hra.HRX_DEVICE_NONE)
+
+
+def _check_batch(oracle, names, chars, lens, M, cfg=None, o=None):
+    cfg = cfg or _cfg(names, M)
+    o = o or OracleDefs.from_files(oracle, names)
+    orec, omsk, ost = o.witness_batch(chars, lens, M, threads=8)
+    grec, gmsk, gst = cfg.witness_batch_host(chars, lens)
+    assert np.array_equal(ost, gst)
+    ok = (ost & np.uint64(0xff)) == 0
+    assert np.array_equal(orec[ok], grec[ok])
+    assert np.array_equal(omsk[ok], gmsk[ok])
+    return ost, omsk
+
+
+@pytest.mark.parametrize("case", reference_cases(), ids=[c["name"] for c in reference_cases()])
+def test_reference_known_answers_on_the_host_walk(oracle, case):
+    """src/lib.rs:1067-1470 + examples/regex.rs:185-199, through match_substrs of a host-only config."""
+    M = case["max_chars_size"]
+    cfg = _cfg(case["defs"], M)
+    inp = case["input"].encode("latin-1")
+    result = cfg.match_substrs(inp)                                   # lib.rs:1042
+    expected_masked_chars = np.zeros(M, np.uint64)
+    expected_substr_ids = np.zeros(M, np.uint64)
+    for substr_idx, (start, chars) in enumerate(case["expected_substrs"]):   # lib.rs:1046-1051
+        for idx, ch in enumerate(chars.encode("latin-1")):
+            expected_masked_chars[start + idx] = ch
+            expected_substr_ids[start + idx] = substr_idx + 1
+    if case["masked_outputs_asserted"]:
+        assert np.array_equal(result.masked_characters, expected_masked_chars)   # lib.rs:1052-1059
+        assert np.array_equal(result.all_substr_ids, expected_substr_ids)
+    accepted = hra.decode_status(result.status)["accept"] == (1 << cfg.num_defs) - 1
+    assert accepted == case["verify_ok"]                              # MockProver::verify() outcome
+    o = OracleDefs.from_files(oracle, case["defs"]).match_substrs(inp, M)
+    for mine, theirs in (("all_enable_flags", "enable"), ("all_characters", "character"), ("states", "state"), ("substr_ids", "substr_id"),
+                         ("start_enables", "start_enable"), ("end_enables", "end_enable"), ("masked_characters", "masked_char"),
+                         ("all_substr_ids", "masked_substr_id")):
+        assert np.array_equal(getattr(result, mine), o[theirs]), mine
+
+
+@pytest.mark.parametrize("case", reference_cases()[:6], ids=[c["name"] for c in reference_cases()[:6]])
+def test_derive_functions_match_lib_rs_804_888(oracle, case):
+    cfg = _cfg(case["defs"], case["max_chars_size"])
+    o = OracleDefs.from_files(oracle, case["defs"])
+    inp = case["input"].encode("latin-1")
+    states = cfg.derive_states(inp)
+    assert states.shape == (cfg.num_defs, len(inp) + 1) and np.array_equal(states, o.derive_states(inp))
+    sids = cfg.derive_substr_ids(states)
+    assert np.array_equal(sids, o.derive_substr_ids(states))
+    st, en = cfg.derive_is_start_end(states, sids)
+    ost, oen = o.derive_is_start_end(states, sids)
+    assert np.array_equal(st, ost) and np.array_equal(en, oen)
+
+
+def test_invalid_transition_panics_with_the_reference_message():
+    cfg = _cfg(CFG_EX, 128)
+    with pytest.raises(hra.HrxError, match=r"^The transition from 2 by 33 is invalid!$") as e:   # lib.rs:817
+        cfg.derive_states(b"email was meant for @vitalik.!")
+    assert e.value.code == hra.HRX_ERR_INVALID_TRANSITION
+    with pytest.raises(hra.HrxError, match=r"The transition from 0 by 200 is invalid!"):
+        _cfg(CFG_1, 64).match_substrs(bytes([200]))
+    assert _cfg(CFG_1, 64).derive_states(b"").tolist() == [[0]]
+    with pytest.raises(hra.HrxError) as e:
+        _cfg(CFG_1, 8).match_substrs(b"123456789")               # n > max_chars_size
+    assert e.value.code == hra.HRX_ERR_OUT_OF_CONTRACT
+
+
+@pytest.mark.parametrize("M", [1, 7, 8, 63, 64, 65, 72, 128, 200, 1024])
+def test_ragged_batches_every_row_count(oracle, M):
+    chars, lens = synth.ragged(200, M, seed=M)
+    _check_batch(oracle, CFG_1, chars, lens, M)
+    _check_batch(oracle, CFG_A, chars, lens, M)
+
+
+@pytest.mark.parametrize("names", [CFG_1, CFG_3, CFG_A, CFG_23, CFG_123], ids=["r1", "r3", "r1r2", "r2r3", "r1r2r3"])
+def test_reveal_mask_stress_and_errors(oracle, names):
+    chars, lens = synth.reveal_stress(600, 700, seed=11)
+    st, msk = _check_batch(oracle, names, chars, lens, 704)
+    assert msk.any()
+    chars, lens = synth.reveal_stress(100, 2000, seed=12)
+    _check_batch(oracle, names, chars, lens, 2003)               # unaligned row count
+    chars, lens = synth.ragged(257, 300, seed=3)
+    rng = np.random.default_rng(1)
+    for b in range(0, 257, 3):
+        if lens[b]:
+            chars[b, int(rng.integers(0, lens[b]))] = 200 + b % 50   # bytes the DFAs have no transition for
+    lens[5] = 400                                                    # n > M
+    st, _ = _check_batch(oracle, names, chars, lens, 304)
+    codes = set(int(s) & 0xff for s in st)
+    assert 1 in codes and 3 in codes
+
+
+def test_flag_overlap_and_full_length_strings(oracle):
+    chars, lens = synth.ragged(300, 200, seed=4)
+    st, _ = _check_batch(oracle, [CFG_1[0], CFG_1[0]], chars, lens, 200)     # the same def twice: every flag overlaps
+    assert any((int(s) & 0xff) == 2 for s in st)
+    chars, lens = synth.regex1_planted(64, 128, seed=1, stride=128)           # n == M: the final state row does not exist
+    _check_batch(oracle, CFG_1, chars, lens, 128)
+    lens[:] = 0                                                               # n == 0
+    _check_batch(oracle, CFG_A, chars, lens, 128)
+
+
+def test_planted_cfg2_sample(oracle):
+    """BASELINE configs[1]'s workload (regex1+substr1, n = 1023, M = 1024), a slice of it"""
+    chars, lens = synth.regex1_planted(2048, 1023, seed=0, stride=1024)
+    st, msk = _check_batch(oracle, CFG_1, chars, lens, 1024)
+    assert (st == np.uint64(0x100)).mean() > 0.9 and msk.any()
+
+
+def test_host_threshold_is_settable_and_host_only_configs_refuse_device_batches():
+    cfg = _cfg(CFG_1, 64)
+    assert cfg.host_threshold() == hra.HRX_DEFAULT_HOST_THRESHOLD
+    cfg.set_host_threshold(1234)
+    assert cfg.host_threshold() == 1234
+    assert hra.lib.hrx_ctx_device(cfg._ctx) == hra.HRX_DEVICE_NONE
+    rc = hra.lib.hrx_witness_batch_device(cfg._ctx, 16, 16, 16, 1, 64, 16, 16, 16, None)
+    assert rc == hra.HRX_ERR_HIP
+
+
+def test_random_definitions(oracle):
+    """random DFAs / substring definitions in the reference's text formats (the generator of the GPU parity tests), D = 1..3"""
+    from test_parity_gpu import _random_defs
+    for seed in range(12):
+        rng = np.random.default_rng(2000 + seed)
+        D = 1 + seed % 3
+        defs_t = _random_defs(rng, D)
+        M = int(rng.choice([5, 31, 64, 100, 129, 256, 321]))
+        B = 48
+        stride = (M + 40 + 15) // 16 * 16
+        alpha = np.unique(np.concatenate([a for _, _, a in defs_t]))
+        common = defs_t[0][2]
+        for _, _, a in defs_t[1:]:
+            common = np.intersect1d(common, a)
+        pool = common if len(common) >= 2 and rng.random() < 0.7 else alpha
+        chars = pool[rng.integers(0, len(pool), size=(B, stride))].astype(np.uint8)
+        lens = rng.integers(0, M + 1, size=B).astype(np.uint32)
+        lens[rng.random(B) < 0.05] = M + 3                                      # BadLength
+        lens[0] = M
+        for b in np.nonzero(rng.random(B) < 0.1)[0]:                            # a byte no def has a column for
+            chars[b, int(rng.integers(0, stride))] = 0
+        defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs, _ in defs_t]
+        cfg = hra.RegexVerifyConfig.configure(M, defs, device=hra.HRX_DEVICE_NONE)
+        _check_batch(oracle, None, chars, lens, M, cfg=cfg, o=OracleDefs(oracle, [(a, subs) for a, subs, _ in defs_t]))

@@ -10,6 +10,19 @@ from oracle_lib import OracleDefs, DFA_DIR, reference_cases
 
 pytestmark = pytest.mark.gpu
 
+NO_HOST = 0x20000000     # kDbgNoHost (csrc/hrx_kernel.hpp): single strings and small host batches go to the device as well
+
+
+def _flags(bits=0):
+    return str(int(bits) | NO_HOST)
+
+
+@pytest.fixture(autouse=True)
+def _device_paths_only(monkeypatch):
+    """These tests are about the kernels: the library's native small-batch host walk (tests/test_host_walk.py) stays out
+    of the way.  HRX_DEBUG_FLAGS is read once per context, and every test makes its configs after this point."""
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags())
+
 CFG_1 = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]]]
 CFG_A = [["regex1_test_lookup.txt", ["substr1_test_lookup.txt"]], ["regex2_test_lookup.txt", ["substr2_test_lookup.txt"]]]
 CFG_3 = [["regex3_test_lookup.txt", ["substr3_test_lookup.txt"]]]
@@ -339,21 +352,21 @@ def test_cfg4_shape_three_header_defs_five_substrs(hra, oracle):
 
 def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
     from halo2_regex_amd import synth
-    monkeypatch.setenv("HRX_DEBUG_FLAGS", str(0x40000))
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(0x40000))
     chars, lens = synth.reveal_stress(500, 700, seed=31)
     _check_batch(hra, oracle, CFG_A, chars, lens, 704)
     _check_batch_pm(hra, oracle, CFG_123, chars, lens, 704)
 
 
-@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000 | 0x2000000), str(0x400000), str(0x4000000)],
-                         ids=["narrow-table", "wide-table", "half-table", "def-parallel"])
+@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000 | 0x2000000), str(0x400000), str(0x4000000), "0", str(0x8000000), str(0x40000000)],
+                         ids=["narrow-table", "wide-table", "half-table", "def-parallel", "planner-default", "no-pair-step", "write-back-stores"])
 def test_position_major_kernel_on_both_table_formats(hra, oracle, flags, monkeypatch):
-    """The position-major path has three table formats (4-byte, WIDE for D >= 2, HALF for big DFAs) and, for D >= 2 batches
-    that leave walker slots empty, a def-parallel kernel (one walker wave per def, flags combined through LDS); force each
-    through the same batches, D = 1..3, including strings with undefined transitions, bytes >= 128 (no column in the WIDE
+    """The position-major path has four table formats (4-byte, WIDE for D >= 2, HALF for big DFAs, PAIR — two bytes per lookup —
+    for one def with few byte classes: the planner's default at D = 1) and, for D >= 2 batches that leave walker slots empty,
+    a def-parallel kernel (one walker wave per def, flags combined through LDS); force each through the same batches, D = 1..3, including strings with undefined transitions, bytes >= 128 (no column in the WIDE
     table) and two defs flagging the same row."""
     from halo2_regex_amd import synth
-    monkeypatch.setenv("HRX_DEBUG_FLAGS", flags)
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(int(flags, 0)))
     chars, lens = synth.reveal_stress(700, 700, seed=21)
     chars[5, 100] = 200                      # a byte the DFAs have no column for
     chars[6, 699] = 255
@@ -371,7 +384,7 @@ def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
     """D <= 2 normally takes the walker/storer kernel; force the one-wave kernel (used for D = 3 and unaligned M)
     through the same batches, at its regular and its small-batch group size."""
     from halo2_regex_amd import synth
-    monkeypatch.setenv("HRX_DEBUG_FLAGS", flags)
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(int(flags, 0)))
     chars, lens = synth.reveal_stress(700, 700, seed=21)
     _check_batch(hra, oracle, CFG_1, chars, lens, 704)
     _check_batch(hra, oracle, CFG_23, chars, lens, 704)
@@ -467,14 +480,14 @@ def test_three_defs_every_kernel_agrees_at_a_chip_filling_size(hra, oracle, monk
     d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
     results = {}
     for name, flags in (("def-parallel", "0"), ("regular", str(0x2000000)), ("narrow", str(0x2000000 | 0x80000))):
-        monkeypatch.setenv("HRX_DEBUG_FLAGS", flags)
+        monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(int(flags, 0)))
         cfg = _cfg(hra, CFG_123, M)
         kern = cfg.describe_launch(B, layout=1)
         assert ("pmd_kernel" in kern) == (name == "def-parallel")
         rec, msk, st = cfg.witness_batch_position_major(d_chars, d_lens)
         torch.cuda.synchronize()
         results[name] = hra.position_major_to_string_major(rec, msk, B, M, 3) + (st,)
-    monkeypatch.setenv("HRX_DEBUG_FLAGS", "0")
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags())
     results["string-major"] = _cfg(hra, CFG_123, M).witness_batch(d_chars, d_lens)
     torch.cuda.synchronize()
     ref = results["regular"]

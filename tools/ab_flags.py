@@ -4,6 +4,7 @@ are interleaved in blocks of launches, many times over, so that box-to-box and r
   python tools/ab_flags.py 0 32 64 96"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("HRX_LIB_PATH", os.path.join(ROOT, "halo2_regex_amd", "csrc", "libhrx_ablation.so"))   # `make -C halo2_regex_amd/csrc ablation`
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import halo2_regex_amd as hra
@@ -22,7 +23,7 @@ step = lambda: cfg.witness_batch_position_major(d_chars, d_lens, out=out, chars_
 res = {f: [] for f in flags}
 for rep in range(12):
     for f in flags:
-        os.environ["HRX_DEBUG_FLAGS"] = f
+        os.environ["HRX_DEBUG_FLAGS"] = str(int(f, 0))
         for _ in range(10): step()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
