@@ -46,7 +46,13 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     }
     // ---- pair-step loader/walker kernel (hrx_kernel_pp.hip): position-major, one def whose PAIR table exists (few byte classes):
     // two bytes per dependent lookup.  Table + per pair a ring of >= 2 slots of 8 KiB (pair indices + raw bytes).
+    // Only for batches that leave walker slots empty (< 4 groups per CU): there the launch lasts as long as one string's
+    // dependent chain and halving the chain wins (8192 x 32768 B: 1.14 vs 1.57 ms; 16384 x 1023 B: 51.5 vs 58.4 us;
+    // 32768: 54.9 vs 59.8 us).  A full chip (>= 4 groups per CU) is bound by the memory system, and the one-byte kernel,
+    // with fewer instructions per row, sits on the no-compute mix ceiling: 69.8 vs 73.8 us at 65536 x 1023 B, 131 vs 134 us
+    // at 131072 (same-process A/B, profiles/r02_ab_pair_vs_single.txt).
     if ((a.layout & 1u) && a.D == 1 && a.pair_image &&
+        ((size_t)a.n_groups < (size_t)num_cus * 4 || (a.debug & kDbgForcePair)) &&
         !(a.debug & (kDbgNoPair | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf | kDbgForceGlobalTable))) {
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;

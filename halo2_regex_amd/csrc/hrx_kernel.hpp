@@ -55,6 +55,7 @@ enum : uint32_t {
     kDbgSplitNoWalk = HRX_ABL(16u),            // ablation, walker/storer kernel: storers move whatever the slots hold
     kDbgNoNtRecords = HRX_ABL(32u),            // ablation, position-major kernels: ordinary record stores
     kDbgNoNtMasked = HRX_ABL(64u),             // ablation, position-major kernels: ordinary masked-row stores
+    kDbgNoNtStores = HRX_ABL(96u),             // both (the release build's stores are non-temporal at compile time: no branch per store)
     kDbgPpNoTranslate = HRX_ABL(0x100u),      // ablation, pair-step kernel: the loader skips the class lookups (pair index 0 everywhere)
     kDbgPpNoPost = HRX_ABL(0x200u),            // ablation, pair-step kernel: the walker only follows the chain (no records, flags, ids)
     kDbgPpNoMask = HRX_ABL(0x400u),            // ablation, pair-step kernel: no reveal-mask work at the tile end
@@ -69,12 +70,12 @@ enum : uint32_t {
     kDbgNoDefParallel = 0x2000000u,   // position-major: never the def-parallel kernel
     kDbgForceDefParallel = 0x4000000u,// position-major, D >= 2, WIDE table: the def-parallel kernel whatever the batch size (tests)
     kDbgNoPair = 0x8000000u,          // position-major, D = 1: never the pair-step kernel (hrx_kernel_pp.hip)
+    kDbgForcePair = 0x40000000u,      // position-major, D = 1 with a PAIR table: the pair-step kernel whatever the batch size (tests, A/B)
     kDbgForceHost = 0x10000000u,      // host-buffer entry points: always the native host walk (hrx_host_walk.cpp)
     kDbgNoHost = 0x20000000u,         // host-buffer entry points: never the native host walk
-    kDbgNoNtStores = 0x40000000u,     // position-major kernels: ordinary write-back stores instead of non-temporal ones
     // every bit that merely selects a kernel (the only ones a release build honours)
     kDbgForceMask = kDbgForceOneWave | kDbgGroups32 | kDbgForceGlobalTable | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf |
-                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForceHost | kDbgNoHost | kDbgNoNtStores,
+                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForcePair | kDbgForceHost | kDbgNoHost,
 #ifdef HRX_ABLATION
     kDbgHonoured = 0xffffffffu,
 #else

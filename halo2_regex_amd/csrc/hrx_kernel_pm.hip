@@ -42,7 +42,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     // The loaders request their pair's first input tile BEFORE the table is staged: the HBM round trip (~2 us) then runs
     // under the staging instead of after it.
     uint32_t first_len = M;   // ... and the walkers their first group's lengths
-    if (is_walker && g_first < a.n_groups && g_first * 64u + lane < B) first_len = a.lens[g_first * 64u + lane];
+    if (is_walker && g_first < a.n_groups) first_len = a.lens[min(g_first * 64u + lane, B - 1u)];
     uint4 first_tile[4];
     if (!is_walker && g_first < a.n_groups) {
         const bool in_pm0 = (a.layout & 2u) != 0;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
                 const size_t off = (size_t)min(t * 64u + 16u * i, row_cap) * cmul_eff;
-                buf[k * 4u + i] = *reinterpret_cast<const uint4 *>(cptr + off);
+                buf[k * 4u + i] = *reinterpret_cast<const uint4 *>(cptr + off);   // (non-temporal LOADS were tried in round 2: 76.5 vs 75.4 us, dropped)
             }
         };
         // The pair's FIRST tile travels alone: requested together with the rest, it queues behind the whole chip's opening
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
         const bool active = b < B;
-        const uint32_t n_raw = g == g_first ? first_len : (active ? a.lens[b] : M);
+        // Lanes beyond the batch (last group only) are EXACT shadows of string B - 1 — same bytes (the loader clamps the same
+        // way), same length, same output addresses — so the record / masked stores need no per-lane predicate: every lane of
+        // the wave stores, the shadows re-write the last string's values.  Only the status word and the fix-ups are `active`-only.
+        const uint32_t n_raw = g == g_first ? first_len : a.lens[min(b, B - 1u)];
         const bool badlen = n_raw > M;
         const uint32_t n = badlen ? M : n_raw;
 
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 err_pos[d] = err_state[d] = err_char[d] = 0;
                 acc_state[d] = a.dc[d].first_state;  // n == 0
             }
-            const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
+            const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string
             // the group's block of the position-major buffers (hrx_lane.h kPmBlock): nb strings starting at string blk0
             const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);
             const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
@@ -184,14 +187,24 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
 #pragma unroll
             for (int k = 0; k < 8; ++k) pend[k] = make_uint4(0, 0, 0, 0);
 
+#ifdef HRX_STAMPS   // tools/kbench only: s_memtime ticks this walker spent waiting for input / walking / in the tile-end work
+            unsigned long long tk_wait = 0, tk_walk = 0, tk_end = 0;
+            const unsigned long long tk_group = clock64();
+#endif
             for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
                 const uint32_t t0 = t << 6;
                 const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
+#ifdef HRX_STAMPS
+                const unsigned long long tk_a = clock64();
+#endif
                 ring_wait(ready_off, seq + 1u);
                 uint4 cq[4];
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) cq[i] = lds_u128(slot + i * 1024u + lane * 16u);
                 ring_post(freed_off, seq + 1u);
+#ifdef HRX_STAMPS
+                const unsigned long long tk_b = clock64();
+#endif
 
                 uint32_t e_start[D];
 #pragma unroll
@@ -199,10 +212,10 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 uint32_t sidq[16];
                 TileBits tb;
                 const bool full = (t0 + 64u < min_n);
-                const bool do_store = active && !(a.debug & kDbgSkipRecords);
+                const bool do_store = !(a.debug & kDbgSkipRecords);
                 // full-line position-major stores stream past L2 (non-temporal); the string-major lane-direct pieces do not (L2 merges them into lines)
                 const bool nt_rec = !SM && !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), nt_msk = !SM && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
-                const bool pend_store = active && have_pend && !(a.debug & kDbgSkipMasked);
+                const bool pend_store = have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
                 // [ceil(M/4)][D][nb][4]: one def's quads of all strings of the block
                 GlobalSink<D, SM> sink{rp, (size_t)nb * 16u, rstep, do_store, nt_rec, nt_msk,
@@ -230,6 +243,9 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 else
                     tb = walk_tile_pm<D, false, GTAB, HALF>(L, cq, a, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state);
                 rp = sink.rp;
+#ifdef HRX_STAMPS
+                const unsigned long long tk_c = clock64();
+#endif
 
                 // ---------------- undefined transition (lib.rs:817): rare slow path, re-walk the tile ----------------
                 uint32_t newly = 0;
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                 }
                 // ---------------- reveal masks: lib.rs:598-764 ----------------
                 TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
-                if (!active) { tm.mask = 0; tm.fix = 0; }
+                if (!active) tm.fix = 0;   // (tm.mask stays: a shadow lane stores the same masked rows as string B - 1)
                 // An earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare with real definitions; a
                 // random DFA like cfg 5's takes this path every few tiles, and there each 16-byte piece re-written in a line
                 // that has left L2 is a read-modify-write at the memory: measured 521 vs 357 us with the fix-ups skipped;
@@ -362,28 +378,29 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                     for (int k = 0; k < 8; ++k) {
                         const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
                         uint4 v = make_uint4(0, 0, 0, 0);
-                        if (mbyte) {  // lib.rs:752-761
-                            uint32_t o[8];
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const int p = k * 8 + i;
-                                const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
-                                const uint32_t sid = (sidq[p >> 2] >> (8 * (p & 3))) & 0xffu;
-                                o[i] = ((mbyte >> i) & 1u) ? (c | (sid << 8)) : 0u;
-                            }
-                            v = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
-                        }
+                        if (mbyte) v = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);  // lib.rs:752-761
                         if (D == 1) pend[k] = v;  // leaves during the next tile's walk
-                        else if (active && t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked))
+                        else if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked))
                             store16(mp + (size_t)k * mstep, v, nt_msk);  // D >= 2: the walk needs the registers; store now
                     }
                     pend_mp = mp;
                     mp += 8u * mstep;
                     have_pend = (D == 1);
                 }
+#ifdef HRX_STAMPS
+                asm volatile("" : "+v"(pend[0].x), "+v"(pend[7].w));
+                const unsigned long long tk_d = clock64();
+                tk_wait += tk_b - tk_a; tk_walk += tk_c - tk_b; tk_end += tk_d - tk_c;
+#endif
             }
+#ifdef HRX_STAMPS
+            if (a.stamps && lane == 0) {
+                unsigned long long *o = a.stamps + (size_t)(blockIdx.x * pairs + pair) * 4u;
+                o[0] += tk_wait; o[1] += tk_walk; o[2] += tk_end; o[3] += clock64() - tk_group;
+            }
+#endif
             // the last tile's masked rows (only the octets that exist: [ceil(M/8)][B][8])
-            if (active && have_pend && !(a.debug & kDbgSkipMasked)) {
+            if (have_pend && !(a.debug & kDbgSkipMasked)) {
                 const uint32_t t0 = (ntiles - 1u) << 6;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)

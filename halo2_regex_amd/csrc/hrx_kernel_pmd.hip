@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
         const bool active = b < B;
-        const uint32_t n_raw = active ? a.lens[b] : M;
+        const uint32_t n_raw = a.lens[min(b, B - 1u)];   // lanes beyond the batch: exact shadows of string B - 1 (hrx_kernel_pm.hip), stores unpredicated
         const bool badlen = n_raw > M;
         const uint32_t n = badlen ? M : n_raw;
         const uint32_t min_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(n));
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             TileBits tb;
             const bool full = (t0 + 64u < min_n);
             uint32_t tile_ov = 0, hb = 0;
-            GlobalSink<1> sink{rp, 0, rstep, active && !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
+            GlobalSink<1> sink{rp, 0, rstep, !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
             const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                       cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
             if (full) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             sum_prev = sidq[15] >> 24;
             TileBits all{st, en1, ch};
             TileMasks tm = tile_masks<64>(all, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
-            if (!active) { tm.mask = 0; tm.fix = 0; }
+            if (!active) tm.fix = 0;
             uint64_t fixm = __ballot(tm.fix != 0);
             if (a.debug & kDbgSkipFixups) fixm = 0;
             while (fixm) {   // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare)
@@ -247,18 +247,8 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
                 for (int q = 0; q < 8; ++q) {
                     const uint32_t mbyte = ((q < 4 ? mlo : mhi) >> (8 * (q & 3))) & 0xffu;
                     uint4 v = make_uint4(0, 0, 0, 0);
-                    if (mbyte) {  // lib.rs:752-761
-                        uint32_t o[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int p = q * 8 + i;
-                            const uint32_t c = (cwl[p >> 2] >> (8 * (p & 3))) & 0xffu;
-                            const uint32_t sid = (sidq[p >> 2] >> (8 * (p & 3))) & 0xffu;
-                            o[i] = ((mbyte >> i) & 1u) ? (c | (sid << 8)) : 0u;
-                        }
-                        v = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
-                    }
-                    if (active && t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, nt_msk);
+                    if (mbyte) v = masked_octet(cwl[2 * q], cwl[2 * q + 1], sidq[2 * q], sidq[2 * q + 1], mbyte);  // lib.rs:752-761
+                    if (t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, nt_msk);
                 }
                 mp += 8u * mstep;
             }

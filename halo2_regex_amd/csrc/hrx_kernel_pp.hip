@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
     const uint32_t g_first = blockIdx.x * pairs + pair, g_stride = gridDim.x * pairs;
     // the loaders request their pair's first input tile, the walkers their first lengths, BEFORE the table is staged
     uint32_t first_len = M;
-    if (is_walker && g_first < a.n_groups && g_first * 64u + lane < B) first_len = a.lens[g_first * 64u + lane];
+    if (is_walker && g_first < a.n_groups) first_len = a.lens[min(g_first * 64u + lane, B - 1u)];
     uint4 first_tile[4];
     if (!is_walker && g_first < a.n_groups) {
         const bool in_pm0 = (a.layout & 2u) != 0;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
         const bool active = b < B;
-        const uint32_t n_raw = g == g_first ? first_len : (active ? a.lens[b] : M);
+        const uint32_t n_raw = g == g_first ? first_len : a.lens[min(b, B - 1u)];   // lanes beyond the batch: exact shadows of string B - 1 (hrx_kernel_pm.hip)
         const bool badlen = n_raw > M;
         const uint32_t n = badlen ? M : n_raw;
         const uint32_t min_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(n));
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
         MaskCarry mc = {0, 0, 0, 0};
         uint32_t dead = 0, err_pos = 0, err_state = 0, err_char = 0;
         uint32_t acc_state = a.dc[0].first_state;  // n == 0
-        const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string (their stores are masked off)
+        const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string: they store the same values to the same addresses
         const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);   // the group's block of the position-major buffers
         const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
         unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 + (bc - blk0)) * 16u;
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
             for (int i = 0; i < 16; ++i) sidq[i] = 0;
             uint32_t odd_dead = 0;
             const bool full = (t0 + 64u < min_n);
-            GlobalSink<1, false> sink{rp, (size_t)nb * 16u, rstep, active && !(a.debug & kDbgSkipRecords), !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)),
-                                      pend, pend_mp, mstep, active && have_pend && !(a.debug & kDbgSkipMasked), {}};
+            GlobalSink<1, false> sink{rp, (size_t)nb * 16u, rstep, !(a.debug & kDbgSkipRecords), !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)),
+                                      pend, pend_mp, mstep, have_pend && !(a.debug & kDbgSkipMasked), {}};
             TileBits tb;
             if (full) tb = walk_tile_pp<true>(L, iw, a, sink, 0, 0, sidq, acc_state, odd_dead);
             else tb = walk_tile_pp<false>(L, iw, a, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, sidq, acc_state, odd_dead);
@@ -305,7 +305,8 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
             if (!full && n == t0 + 64u && t + 1 == ntiles) acc_state = lds_u32((L.lo & 0xffffu) * 8u + 4u) & 0xffu;
             // ---------------- reveal masks: lib.rs:598-764 ----------------
             TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
-            if (!active || (a.debug & kDbgPpNoMask)) { tm.mask = 0; tm.fix = 0; }
+            if (a.debug & kDbgPpNoMask) { tm.mask = 0; tm.fix = 0; }
+            if (!active) tm.fix = 0;
             uint64_t fixm = __ballot(tm.fix != 0);
             while (fixm) {   // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare with real definitions)
                 const int j = __ffsll((unsigned long long)fixm) - 1;
@@ -329,17 +330,7 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
-                    if (mbyte) {  // lib.rs:752-761
-                        uint32_t o[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int p = k * 8 + i;
-                            const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
-                            const uint32_t sid = (sidq[p >> 2] >> (8 * (p & 3))) & 0xffu;
-                            o[i] = ((mbyte >> i) & 1u) ? (c | (sid << 8)) : 0u;
-                        }
-                        pend[k] = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
-                    }
+                    if (mbyte) pend[k] = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);  // lib.rs:752-761
                 }
             }
             ring_post(freed_off, seq + 1u);   // done with the slot (indices, and raw bytes of the slow paths / masked rows)
@@ -348,7 +339,7 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
             have_pend = true;
         }
         // the last tile's masked rows (only the octets that exist: [ceil(M/8)][B][8])
-        if (active && have_pend) {
+        if (have_pend) {
             const uint32_t t0 = (ntiles - 1u) << 6;
 #pragma unroll
             for (int k = 0; k < 8; ++k)

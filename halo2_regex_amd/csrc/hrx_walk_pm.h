@@ -10,11 +10,33 @@ constexpr uint32_t kPmTileBytes = 64u * 64u;  // 64 strings x 64 input bytes per
 // 16 bytes per lane, 1 KiB of full lines per wave.  nt: a non-temporal (streaming) store.  The nt form is inline asm on
 // purpose: with `if (nt) __builtin_nontemporal_store(..) else *p = v` LLVM merges the two stores of the diamond into ONE
 // ordinary store and drops the hint (round 1's "nt changes nothing" A/B measured exactly that: no store in the code object
-// carried the nt bit).  The trailing s_nop covers the one wait state a >64-bit VMEM store needs before a VALU may overwrite
-// its data registers (the hazard recogniser does not look into inline asm).
+// carried the nt bit).  The trailing s_nop 1 covers the TWO wait states a >64-bit VMEM store needs on gfx940+ before a VALU may
+// overwrite its data registers (one on older parts); the hazard recogniser does not look into inline asm.  With s_nop 0 the
+// def-parallel kernel, which re-initialises the same four registers right after each masked-row store, lost the first dword
+// of some octets (rows 32-33 of a tile, nondeterministically).
 __device__ __forceinline__ void store16(unsigned char *p, const uint4 &v, const bool nt) {
-    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" : : "v"(p), "v"(v4u32{v.x, v.y, v.z, v.w}));
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v4u32{v.x, v.y, v.z, v.w}));
     else *reinterpret_cast<uint4 *>(p) = v;
+}
+
+// One octet of masked rows (lib.rs:752-761): rows 8k .. 8k+7 of a string as 8 x {masked_char, masked_substr_id} = 16 bytes.
+// c0 / c1: the octet's raw bytes (4 rows per dword), s0 / s1: its substr-id sums (one byte per row), mbyte: its 8 mask bits.
+// Per four rows: the nibble of mask bits is spread to one bit per byte (n * 0x204081 puts bit i at bit 8 i: the four partial
+// products land on disjoint bit positions, so nothing carries), widened to 0x00 / 0xff bytes, ANDed onto both sources, and
+// two v_perm_b32 interleave the surviving bytes into u16 {char, id} pairs — 9 VALU per four rows where the row-by-row
+// select took ~6 per row (the tile-end work is serial to the dependent chain of the walk, so it is paid in full).
+__device__ __forceinline__ uint4 masked_octet(const uint32_t c0, const uint32_t c1, const uint32_t s0, const uint32_t s1, const uint32_t mbyte) {
+    auto half = [](const uint32_t c, const uint32_t s, const uint32_t nib, uint32_t &lo, uint32_t &hi) {
+        const uint32_t x = __umul24(nib, 0x204081u) & 0x01010101u;
+        const uint32_t bm = (x << 8) - x;
+        const uint32_t cm = c & bm, sm = s & bm;
+        lo = __builtin_amdgcn_perm(sm, cm, 0x05010400u);   // {c.b0, s.b0, c.b1, s.b1}
+        hi = __builtin_amdgcn_perm(sm, cm, 0x07030602u);   // {c.b2, s.b2, c.b3, s.b3}
+    };
+    uint4 v;
+    half(c0, s0, mbyte & 0xfu, v.x, v.y);
+    half(c1, s1, mbyte >> 4, v.z, v.w);
+    return v;
 }
 
 // Where a walker's finished rows go: straight to memory from its registers.  quad(d, p, ..) stores four rows of def d

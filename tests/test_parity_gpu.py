@@ -359,7 +359,7 @@ def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("flags", [str(0x80000), str(0x200000 | 0x2000000), str(0x400000), str(0x4000000), "0", str(0x8000000), str(0x40000000)],
-                         ids=["narrow-table", "wide-table", "half-table", "def-parallel", "planner-default", "no-pair-step", "write-back-stores"])
+                         ids=["narrow-table", "wide-table", "half-table", "def-parallel", "planner-default", "no-pair-step", "pair-step"])
 def test_position_major_kernel_on_both_table_formats(hra, oracle, flags, monkeypatch):
     """The position-major path has four table formats (4-byte, WIDE for D >= 2, HALF for big DFAs, PAIR — two bytes per lookup —
     for one def with few byte classes: the planner's default at D = 1) and, for D >= 2 batches that leave walker slots empty,

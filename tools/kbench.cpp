@@ -86,7 +86,21 @@ int main(int argc, char **argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / steps;
     printf("debug=0x%x  %.2f us/launch  %.3e rows/s  %.1f%% of 8 TB/s\n", debug, us, (double)B * n / (us * 1e-6), 7.0 * B * n / (us * 1e-6) / 8e12 * 100);
-    if (want_stamps) {
+    if (want_stamps && li.split == 2) {   // position-major kernel built with -DHRX_STAMPS: per walker [input wait, walk, tile end, whole group] ticks
+        CK(hipMemset(d_stamps, 0, nw * ntiles * 128));
+        a.stamps = d_stamps;
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) CK(launch_witness(a, li, 0));
+        CK(hipDeviceSynchronize());
+        const size_t units = (size_t)li.grid * (li.waves_per_wg / 2);
+        std::vector<unsigned long long> st(units * 4);
+        CK(hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        double w = 0, k = 0, e = 0, g = 0, gmax = 0;
+        for (size_t u = 0; u < units; ++u) { w += st[u * 4]; k += st[u * 4 + 1]; e += st[u * 4 + 2]; g += st[u * 4 + 3]; if (st[u * 4 + 3] > gmax) gmax = st[u * 4 + 3]; }
+        const double per = (double)units * reps * ntiles;
+        printf("position-major walker, mean s_memtime ticks per 64-row tile: input wait %.0f, walk %.0f, tile end %.0f; per launch and walker: %.0f ticks in its groups (max %.0f)\n",
+               w / per, k / per, e / per, g / units / reps, gmax / reps);
+    } else if (want_stamps) {
         a.stamps = d_stamps;
         CK(launch_witness(a, li, 0)); CK(hipDeviceSynchronize());
         const int per = li.split ? 8 : 4;

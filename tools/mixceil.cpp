@@ -107,6 +107,30 @@ __global__ __launch_bounds__(512) void pairv_k(const uint4 *__restrict__ in, uin
     }
 }
 
+
+// pair_k with non-temporal stores, a slab pitch of B + PAD 16-byte units (PAD = 0: slabs exactly 1 MiB apart) and PACE x s_sleep 1
+// (64 cycles each) per quad in the writers: what the write stream sustains when the walkers are slower than the memory
+template <int PAD, int PACE>
+__global__ __launch_bounds__(512) void pairp_k(const uint4 *__restrict__ in, uint4 *__restrict__ rec, uint4 *__restrict__ msk, unsigned *sink) {
+    const size_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t g = (size_t)blockIdx.x * 4 + (wave & 3), b = g * 64 + lane;
+    constexpr size_t P = B + PAD;
+    typedef unsigned v4 __attribute__((ext_vector_type(4)));
+    if (wave >= 4) {
+        uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll 16
+        for (size_t c = 0; c < M / 16; ++c) { const uint4 v = in[c * B + b]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+        if (acc.x == 0x12345678u) sink[0] = acc.y ^ acc.z ^ acc.w;
+        return;
+    }
+    for (size_t q = 0; q < M / 4; ++q) {
+        __builtin_nontemporal_store(v4{(unsigned)q, 1, 2, 3}, reinterpret_cast<v4 *>(rec + q * P + b));
+        if (q & 1) __builtin_nontemporal_store(v4{0, 0, 0, (unsigned)q}, reinterpret_cast<v4 *>(msk + (q >> 1) * P + b));
+#pragma unroll
+        for (int i = 0; i < PACE; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 static bool g_brief = false;
 template <class F> static void timeit(const char *name, F &&launch, const char *key = nullptr) {
     if (g_brief && !key) return;
@@ -126,12 +150,39 @@ template <class F> static void timeit(const char *name, F &&launch, const char *
            TOTAL / (us[2] * 1e-6) / 8e12);
 }
 
+// --sustained: `n` back-to-back launches, one event pair per `chunk` launches -> the time series (does the rate hold once the
+// chip has been at full memory load for tens of milliseconds?)
+template <class F> static void series(const char *name, F &&launch, int n = 1600, int chunk = 40) {
+    std::vector<hipEvent_t> ev(n / chunk + 1);
+    for (auto &evt : ev) CK(hipEventCreate(&evt));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(ev[0], 0));
+    for (int i = 0; i < n / chunk; ++i) {
+        for (int k = 0; k < chunk; ++k) launch();
+        CK(hipEventRecord(ev[i + 1], 0));
+    }
+    CK(hipDeviceSynchronize());
+    printf("%-28s us/launch per %d launches:", name, chunk);
+    for (int i = 0; i < n / chunk; ++i) { float ms; CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); printf(" %.1f", ms * 1e3f / chunk); }
+    printf("\n");
+    for (auto &evt : ev) CK(hipEventDestroy(evt));
+}
+
 int main(int argc, char **argv) {
     g_brief = argc > 1 && std::string(argv[1]) == "--brief";   // bench.py: three machine-readable lines
+    const bool sustained = argc > 1 && std::string(argv[1]) == "--sustained";
     uint4 *in, *rec, *msk, *cpy; unsigned *sink;
-    CK(hipMalloc(&in, IN_BYTES)); CK(hipMalloc(&rec, REC_BYTES + MSK_BYTES)); msk = rec + REC_BYTES / 16; /* one allocation: the merged variant uses it as one array */ CK(hipMalloc(&sink, 4)); CK(hipMalloc(&cpy, TOTAL));
+    CK(hipMalloc(&in, IN_BYTES)); CK(hipMalloc(&rec, REC_BYTES + MSK_BYTES + (64u << 20))); msk = rec + REC_BYTES / 16; /* one allocation: the merged variant uses it as one array */ CK(hipMalloc(&sink, 4)); CK(hipMalloc(&cpy, TOTAL));
     CK(hipMemset(in, 1, IN_BYTES));
     if (!g_brief) printf("bench-line traffic mix without compute: %.1f MB per launch (64 MiB read, 384 MiB written)\n", TOTAL / 1e6);
+    if (sustained) {
+        for (int round = 0; round < 2; ++round) {
+            series("pair, non-temporal stores", [&] { hipLaunchKernelGGL(pairv_k<2>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
+            series("copy 8192x256", [&] { hipLaunchKernelGGL(copy_k, dim3(8192), dim3(256), 0, 0, (const uint4 *)cpy, cpy + TOTAL / 32, TOTAL / 32); });
+            series("pair, write-back stores", [&] { hipLaunchKernelGGL(pair_k, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
+        }
+        return 0;
+    }
     for (int round = 0; round < (g_brief ? 1 : 2); ++round) {
         timeit("copy 224 MiB -> 224 MiB, 2048x256", [&] { hipLaunchKernelGGL(copy_k, dim3(2048), dim3(256), 0, 0, (const uint4 *)cpy, cpy + TOTAL / 32, TOTAL / 32); });
         timeit("copy 224 MiB -> 224 MiB, 8192x256", [&] { hipLaunchKernelGGL(copy_k, dim3(8192), dim3(256), 0, 0, (const uint4 *)cpy, cpy + TOTAL / 32, TOTAL / 32); }, "copy");
@@ -148,6 +199,12 @@ int main(int argc, char **argv) {
         timeit("pair, merged, input from L2", [&] { hipLaunchKernelGGL(pairv_k<5>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
         timeit("pair, reads first then writes", [&] { hipLaunchKernelGGL(pairv_k<8>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
         timeit("pair, merged, reads first", [&] { hipLaunchKernelGGL(pairv_k<9>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
+        {
+            uint4 *mskp = rec + (REC_BYTES + (32u << 20)) / 16;   // padded pitches need a little more room per array
+#define PP(PAD, PACE) timeit("pair nt, pitch +" #PAD " x16 B, pace " #PACE, [&] { hipLaunchKernelGGL((pairp_k<PAD, PACE>), dim3(256), dim3(512), 0, 0, in, rec, mskp, sink); })
+            PP(0, 0); PP(0, 1); PP(0, 2); PP(0, 3); PP(0, 4); PP(0, 6);
+            PP(16, 0); PP(64, 0); PP(256, 0); PP(272, 0); PP(1024, 0); PP(4096, 0); PP(64, 2); PP(256, 2); PP(272, 2); PP(4096, 2);
+        }
         timeit("pair, reads only (no writers)", [&] { hipLaunchKernelGGL(pairv_k<16>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
     }
     return 0;
