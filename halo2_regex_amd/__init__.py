@@ -467,14 +467,17 @@ class RegexVerifyConfig:
     def accepted_state(self, d):
         return lib.hrx_defs_accepted_state(self._defs.h, d)
 
+    def first_state(self, d):
+        return lib.hrx_defs_first_state(self._defs.h, d)
+
     def table_bytes(self):
         return lib.hrx_defs_table_bytes(self._defs.h)
 
     def describe_launch(self, B, layout=0, num_cus=256):
         """Kernel name and launch geometry the planner picks for B strings in `layout` (include/hrx.h: 0 string-major, 1 position-major
         outputs, 3 position-major input and outputs); host-only; MI355X has 256 CUs."""
-        buf = C.create_string_buffer(256)
-        _check(lib.hrx_describe_launch(self._defs.h, layout, B, self.max_chars_size, num_cus, buf, 256))
+        buf = C.create_string_buffer(4096)
+        _check(lib.hrx_describe_launch(self._defs.h, layout, B, self.max_chars_size, num_cus, buf, 4096))
         return buf.value.decode()
 
     # -- the three derive_* of lib.rs:804-888 -----------------------------------------------------
@@ -695,7 +698,7 @@ def decode_status(s):
     s = int(s) & 0xFFFFFFFFFFFFFFFF
     code = s & 0xff
     if code == 0:
-        return {"code": 0, "accept": (s >> 8) & 0xff}
+        return {"code": 0, "accept": (s >> 8) & 0xffffffff}
     if code == 1:
         return {"code": 1, "def": (s >> 8) & 0xff, "char": (s >> 16) & 0xff, "state": (s >> 24) & 0xffff, "pos": s >> 40}
     if code == 2:

@@ -91,7 +91,39 @@ struct hrx_ctx {
     std::vector<uint8_t *> d_member;
     std::mutex mu;
     DevBuf chars, lens, records, masked, status, states, tags;
+    // multi-pass configs (more than kMaxDefsPerPass defs, hrx_defs.hpp): per group the device images of its own DefsSet and its
+    // private records / status buffers; one scratch array takes the passes' (meaningless) masked rows
+    struct GroupDev {
+        uint32_t *d_table = nullptr;
+        uint64_t *d_wide = nullptr;
+        uint16_t *d_half = nullptr;
+        uint8_t *d_pairtab = nullptr;
+        DevBuf records, status;
+    };
+    std::vector<GroupDev> groups;
+    DevBuf mp_masked;
+    hipEvent_t mp_done = nullptr;   // the last combine launch: the group buffers are free again once it has run
+    bool mp_pending = false;
 };
+
+// device copies of one DefsSet's kernel-side images
+static hipError_t upload_images(const DefsSet &s, uint32_t *&d_table, uint64_t *&d_wide, uint16_t *&d_half, uint8_t *&d_pairtab) {
+    hipError_t e = hipMalloc((void **)&d_table, s.table_image.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_table, s.table_image.data(), s.table_image.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !s.wide_image.empty()) {
+        e = hipMalloc((void **)&d_wide, s.wide_image.size() * 8);
+        if (e == hipSuccess) e = hipMemcpy(d_wide, s.wide_image.data(), s.wide_image.size() * 8, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !s.half_image.empty()) {
+        e = hipMalloc((void **)&d_half, s.half_image.size() * 2);
+        if (e == hipSuccess) e = hipMemcpy(d_half, s.half_image.data(), s.half_image.size() * 2, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !s.pair.image.empty()) {
+        e = hipMalloc((void **)&d_pairtab, s.pair.image.size());
+        if (e == hipSuccess) e = hipMemcpy(d_pairtab, s.pair.image.data(), s.pair.image.size(), hipMemcpyHostToDevice);
+    }
+    return e;
+}
 
 extern "C" {
 
@@ -258,19 +290,13 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     c->num_cus = prop.multiProcessorCount;
     c->debug = debug_flags_from_env();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_table, c->s.table_image.size() * 4);
-    if (e == hipSuccess) e = hipMemcpy(c->d_table, c->s.table_image.data(), c->s.table_image.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !c->s.wide_image.empty()) {
-        e = hipMalloc((void **)&c->d_wide, c->s.wide_image.size() * 8);
-        if (e == hipSuccess) e = hipMemcpy(c->d_wide, c->s.wide_image.data(), c->s.wide_image.size() * 8, hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess && !c->s.half_image.empty()) {
-        e = hipMalloc((void **)&c->d_half, c->s.half_image.size() * 2);
-        if (e == hipSuccess) e = hipMemcpy(c->d_half, c->s.half_image.data(), c->s.half_image.size() * 2, hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess && !c->s.pair.image.empty()) {
-        e = hipMalloc((void **)&c->d_pairtab, c->s.pair.image.size());
-        if (e == hipSuccess) e = hipMemcpy(c->d_pairtab, c->s.pair.image.data(), c->s.pair.image.size(), hipMemcpyHostToDevice);
+    if (c->s.groups.empty()) {
+        if (e == hipSuccess) e = upload_images(c->s, c->d_table, c->d_wide, c->d_half, c->d_pairtab);
+    } else {   // multi-pass: the kernels only ever see a group's images
+        c->groups.resize(c->s.groups.size());
+        for (size_t g = 0; e == hipSuccess && g < c->s.groups.size(); ++g)
+            e = upload_images(c->s.groups[g], c->groups[g].d_table, c->groups[g].d_wide, c->groups[g].d_half, c->groups[g].d_pairtab);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->mp_done, hipEventDisableTiming);
     }
     for (size_t d = 0; e == hipSuccess && d < c->s.pair_tags.size(); ++d) {
         uint16_t *p = nullptr;
@@ -315,6 +341,15 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_half) (void)hipFree(c->d_half);
     if (c->d_pairtab) (void)hipFree(c->d_pairtab);
+    for (auto &g : c->groups) {
+        if (g.d_table) (void)hipFree(g.d_table);
+        if (g.d_wide) (void)hipFree(g.d_wide);
+        if (g.d_half) (void)hipFree(g.d_half);
+        if (g.d_pairtab) (void)hipFree(g.d_pairtab);
+        g.records.release(); g.status.release();
+    }
+    c->mp_masked.release();
+    if (c->mp_done) { (void)hipEventSynchronize(c->mp_done); (void)hipEventDestroy(c->mp_done); }
     for (uint16_t *p : c->d_pair) (void)hipFree(p);
     for (uint8_t *p : c->d_member) (void)hipFree(p);
     c->chars.release(); c->lens.release(); c->records.release(); c->masked.release();
@@ -342,28 +377,64 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         return fail(HRX_ERR_ARG, "row pitches must be >= max_chars_size");
     if ((M % 8 == 0) && ((rec_pitch % 8) || (msk_pitch % 8)))
         return fail(HRX_ERR_ARG, "row pitches must be multiples of 8 rows when max_chars_size is");
-    WitnessArgs a{};
-    a.rec_pitch = (uint32_t)rec_pitch; a.msk_pitch = (uint32_t)msk_pitch;
     if (layout != HRX_LAYOUT_STRING_MAJOR && layout != HRX_LAYOUT_POSITION_MAJOR &&
         layout != (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR))
         return fail(HRX_ERR_ARG, "unknown layout");
-    a.layout = (uint32_t)layout;
-    a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
-    a.records = records; a.masked = masked; a.status = status;
-    a.table_image = ctx->d_table; a.table_bytes = (uint32_t)(ctx->s.table_image.size() * 4);
-    a.wide_image = ctx->d_wide;
-    a.half_image = ctx->d_half; a.half_bytes = (uint32_t)(ctx->s.half_image.size() * 2);
-    a.pair_image = ctx->d_pairtab; a.pair_bytes = ctx->s.pair.bytes; a.pair_classes = ctx->s.pair.n_classes;
-    a.pair_blk_bytes = ctx->s.pair.blk_bytes; a.pair_lut_off = ctx->s.pair.lut_off;
-    a.D = (uint32_t)ctx->s.defs.size();
-    a.debug = ctx->debug;
+    // one launch over `set` (a config of up to kMaxDefsPerPass defs, or one group of a larger one) with that set's device images
+    auto launch_set = [&](const DefsSet &set, const uint32_t *d_table, const uint64_t *d_wide, const uint16_t *d_half, const uint8_t *d_pairtab,
+                          int lay, uint32_t *rec, uint16_t *msk, uint64_t *stat, size_t rp, size_t mp) -> int {
+        WitnessArgs a{};
+        a.rec_pitch = (uint32_t)rp; a.msk_pitch = (uint32_t)mp;
+        a.layout = (uint32_t)lay;
+        a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
+        a.records = rec; a.masked = msk; a.status = stat;
+        a.table_image = d_table; a.table_bytes = (uint32_t)(set.table_image.size() * 4);
+        a.wide_image = d_wide;
+        a.half_image = d_half; a.half_bytes = (uint32_t)(set.half_image.size() * 2);
+        a.pair_image = d_pairtab; a.pair_bytes = set.pair.bytes; a.pair_classes = set.pair.n_classes;
+        a.pair_blk_bytes = set.pair.blk_bytes; a.pair_lut_off = set.pair.lut_off;
+        a.D = (uint32_t)set.defs.size();
+        a.debug = ctx->debug;
 #ifdef HRX_ABLATION
-    a.debug = debug_flags_from_env();   // tools/ab_flags.py switches ablations between launches of one process
+        a.debug = debug_flags_from_env();   // tools/ab_flags.py switches ablations between launches of one process
 #endif
-    for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = ctx->s.consts[d];
-    LaunchInfo li;
-    if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
-    HIP_TRY(launch_witness(a, li, st));
+        for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = set.consts[d];
+        LaunchInfo li;
+        if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+        HIP_TRY(launch_witness(a, li, st));
+        return HRX_OK;
+    };
+    if (ctx->s.groups.empty())
+        return launch_set(ctx->s, ctx->d_table, ctx->d_wide, ctx->d_half, ctx->d_pairtab, layout, records, masked, status, rec_pitch, msk_pitch);
+    // ---- more than kMaxDefsPerPass defs: one ordinary launch per group into its private position-major buffers, then the
+    // combine kernel (hrx_kernel_mp.hip) writes the caller's buffers.  The group buffers belong to the context: a launch
+    // on another stream first waits for the previous combine.
+    const size_t G = ctx->s.groups.size();
+    if (G > kMaxGroups) return fail(HRX_ERR_BOUNDS, "too many def groups");
+    if (ctx->mp_pending) HIP_TRY(hipStreamWaitEvent(st, ctx->mp_done, 0));
+    const size_t q4 = (M + 3) / 4, q8 = (M + 7) / 8;
+    HIP_TRY(ctx->mp_masked.reserve(q8 * 8 * B * 2));
+    CombineArgs ca{};
+    for (size_t g = 0; g < G; ++g) {
+        const DefsSet &gs = ctx->s.groups[g];
+        hrx_ctx::GroupDev &gd = ctx->groups[g];
+        HIP_TRY(gd.records.reserve(q4 * 4 * gs.defs.size() * B * 4));
+        HIP_TRY(gd.status.reserve(B * 8));
+        const int rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR),
+                                  (uint32_t *)gd.records.p, (uint16_t *)ctx->mp_masked.p, (uint64_t *)gd.status.p, M, M);
+        if (rc != HRX_OK) return rc;
+        ca.grec[g] = (const uint32_t *)gd.records.p;
+        ca.gstatus[g] = (const uint64_t *)gd.status.p;
+        ca.gD[g] = (uint8_t)gs.defs.size();
+        ca.gfirst[g] = (uint8_t)ctx->s.group_first[g];
+    }
+    ca.chars = chars; ca.stride = stride; ca.lens = lens; ca.B = (uint32_t)B; ca.M = (uint32_t)M;
+    ca.D = (uint32_t)ctx->s.defs.size(); ca.G = (uint32_t)G; ca.layout = (uint32_t)layout;
+    ca.rec_pitch = (uint32_t)rec_pitch; ca.msk_pitch = (uint32_t)msk_pitch;
+    ca.records = records; ca.masked = masked; ca.status = status;
+    HIP_TRY(launch_combine(ca, st));
+    HIP_TRY(hipEventRecord(ctx->mp_done, st));
+    ctx->mp_pending = true;
     return HRX_OK;
 }
 
@@ -395,11 +466,7 @@ int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *cha
     return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream, 0, 0, layout);
 }
 
-int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap) {
-    if (!defs || !out || !cap) return fail(HRX_ERR_ARG, "NULL argument");
-    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
-    if (num_cus < 1) return fail(HRX_ERR_ARG, "num_cus must be >= 1");
-    const DefsSet &s = defs->s;
+static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int num_cus, std::string &out) {
     WitnessArgs a{};
     a.layout = (uint32_t)layout; a.B = (uint32_t)B; a.M = (uint32_t)M;
     // the planner only looks at which images exist and how large they are
@@ -413,14 +480,38 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
     a.debug = debug_flags_from_env();   // what a context created now would run with (kernel-selection bits only in a release build)
     LaunchInfo li;
     if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
-    char name[128];
+    char name[128], line[256];
     const char *tf[2] = {"false", "true"};
     if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
     else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u>", a.D);
     else if (li.split == 2) std::snprintf(name, sizeof name, (layout & 1) ? "hrx::witness_pm_kernel<%u, %s, %s, %s>" : "hrx::witness_pm_kernel<%u, %s, %s, %s, true>", a.D, tf[li.gtab], tf[li.wide], tf[li.half]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u>", a.D, 32u / a.D);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
-    std::snprintf(out, cap, "%s grid=%d waves=%d ring=%d lds=%zu", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+    std::snprintf(line, sizeof line, "%s grid=%d waves=%d ring=%d lds=%zu", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+    out = line;
+    return HRX_OK;
+}
+
+int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap) {
+    if (!defs || !out || !cap) return fail(HRX_ERR_ARG, "NULL argument");
+    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
+    if (num_cus < 1) return fail(HRX_ERR_ARG, "num_cus must be >= 1");
+    const DefsSet &s = defs->s;
+    std::string text;
+    if (s.groups.empty()) {
+        const int rc = describe_set(s, layout, B, M, num_cus, text);
+        if (rc != HRX_OK) return rc;
+    } else {   // one launch per group of defs (position-major, the caller's input layout), then the combine kernel
+        text = "multi-pass, " + std::to_string(s.groups.size()) + " groups: ";
+        for (size_t g = 0; g < s.groups.size(); ++g) {
+            std::string one;
+            const int rc = describe_set(s.groups[g], HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR), B, M, num_cus, one);
+            if (rc != HRX_OK) return rc;
+            text += "[defs " + std::to_string(s.group_first[g]) + ".." + std::to_string(s.group_first[g] + s.groups[g].defs.size() - 1) + ": " + one + "] ";
+        }
+        text += (layout & 1) ? "+ hrx::witness_combine_kernel<false>" : "+ hrx::witness_combine_kernel<true>";
+    }
+    std::snprintf(out, cap, "%s", text.c_str());
     return HRX_OK;
 }
 

@@ -158,12 +158,13 @@ static void build_pair_table(DefsSet &s) {
 int finalize_defs(DefsSet &s, std::string &err) {
     if (s.finalized) return HRX_OK;
     if (s.defs.empty()) { err = "no RegexDefs pushed"; return HRX_ERR_STATE; }
-    if (s.defs.size() > 3) { err = "at most 3 RegexDefs per config are supported"; return HRX_ERR_BOUNDS; }
+    if (s.defs.size() > kMaxDefs) { err = "at most " + std::to_string(kMaxDefs) + " RegexDefs per config (the status word's accept mask)"; return HRX_ERR_BOUNDS; }
+    const bool passes = s.defs.size() > kMaxDefsPerPass;   // walked in groups; the kernel-side images below belong to the groups then
     s.consts.clear();
     s.pair_tags.clear();
     s.endpoint_member.clear();
     size_t total_rows = 0, half_rows = 0;
-    uint64_t off = 1;          // substr_id_offset, lib.rs:780,827,854
+    uint64_t off = s.sid_base;  // substr_id_offset, lib.rs:780,827,854
     uint64_t max_sid_sum = 0;  // largest value Σ_d substr_id_d can take (masked_substr_id is a u8)
     for (size_t d = 0; d < s.defs.size(); ++d) {
         const RegexDefs &rd = s.defs[d];
@@ -229,7 +230,7 @@ int finalize_defs(DefsSet &s, std::string &err) {
     }
     // WIDE image for the position-major kernel
     s.wide_image.clear();
-    bool ascii = total_rows <= 255;
+    bool ascii = total_rows <= 255 && !passes;
     for (const RegexDefs &rd : s.defs)
         for (const auto &kv : rd.allstr.state_lookup) if (kv.first.first >= 128) ascii = false;
     if (ascii) {
@@ -255,7 +256,7 @@ int finalize_defs(DefsSet &s, std::string &err) {
     }
     // HALF image for the position-major kernel: 2-byte entries, real states only
     s.half_image.clear();
-    if (half_rows <= 256 && off - 1 <= kHalfMaxSid) {
+    if (half_rows <= 256 && off - 1 <= kHalfMaxSid && !passes) {
         s.half_image.assign(half_image_bytes((uint32_t)half_rows) / 2, (uint16_t)kHalfDead);
         for (size_t d = 0; d < s.defs.size(); ++d) {
             const RegexDefs &rd = s.defs[d];
@@ -269,6 +270,26 @@ int finalize_defs(DefsSet &s, std::string &err) {
         }
     }
     build_pair_table(s);
+    // more defs than one launch walks: consecutive groups, each finalized as a DefsSet of its own
+    s.groups.clear();
+    s.group_first.clear();
+    if (passes) {
+        // a group takes up to kMaxDefsPerPass defs while their fused 4-byte tables (1 KiB per row) still fit LDS next to the
+        // input rings (96 KiB); a def that is larger than that on its own walks alone
+        size_t d = 0;
+        while (d < s.defs.size()) {
+            size_t cnt = 1, rows = s.consts[d].n_rows;
+            while (cnt < kMaxDefsPerPass && d + cnt < s.defs.size() && rows + s.consts[d + cnt].n_rows <= 96) { rows += s.consts[d + cnt].n_rows; ++cnt; }
+            DefsSet g;
+            g.defs.assign(s.defs.begin() + (long)d, s.defs.begin() + (long)(d + cnt));
+            g.sid_base = s.consts[d].substr_id_offset;
+            const int rc = finalize_defs(g, err);
+            if (rc != HRX_OK) return rc;
+            s.group_first.push_back((uint32_t)d);
+            s.groups.push_back(std::move(g));
+            d += cnt;
+        }
+    }
     s.finalized = true;
     return HRX_OK;
 }

@@ -67,9 +67,19 @@ struct PairTable {
     std::vector<uint8_t> image; // the exact LDS image
 };
 
+constexpr size_t kMaxDefs = 32;          // RegexDefs per config: the status word's accept mask (bits 8..39, include/hrx.h)
+constexpr size_t kMaxDefsPerPass = 3;    // defs one kernel launch walks side by side (the kernels are instantiated for D = 1..3)
+
 struct DefsSet {
     std::vector<RegexDefs> defs;
     bool finalized = false;
+    // Vec<RegexDefs> of any length (src/lib.rs:112): more than kMaxDefsPerPass defs are walked in PASSES — consecutive defs
+    // in groups of at most kMaxDefsPerPass, each group a complete DefsSet of its own (own table images, substr ids
+    // continuing the config's numbering: sid_base = substr_id_offset of its first def), combined per row afterwards
+    // (hrx_kernel_mp.hip).  Empty for configs of up to kMaxDefsPerPass defs.
+    std::vector<DefsSet> groups;
+    std::vector<uint32_t> group_first;   // index of each group's first def
+    uint64_t sid_base = 1;               // substr_id_offset of def 0: 1 for a config (lib.rs:780), the running offset for a group
     // dense image: for def d, n_rows x 256 u32 entries at table_base (see hrx_lane.h for the entry format)
     std::vector<uint32_t> table_image;
     // WIDE image (hrx_lane.h): n_rows x 128 u64 entries per def, same row numbering; empty unless every transition

@@ -92,7 +92,7 @@ uint64_t host_witness_one(const DefsSet &s, const uint8_t *chars, size_t n_raw, 
         if (dead[d]) return status_invalid((uint32_t)d, err_pos[d], err_state[d], err_char[d]);
     if (D > 1 && ov_row != 0xffffffffu) return status_overlap(ov_row);
     uint32_t accept = 0;
-    for (size_t d = 0; d < D && d < 8; ++d) accept |= (acc_state[d] == s.consts[d].accepted_state ? 1u : 0u) << d;
+    for (size_t d = 0; d < D && d < 32; ++d) accept |= (acc_state[d] == s.consts[d].accepted_state ? 1u : 0u) << d;
     return status_ok(accept);
 }
 

@@ -115,6 +115,28 @@ constexpr size_t kPpSlotBytes = 8192;   // pair-step kernel: one ring slot = 4 K
 // LDS bytes per group of the def-parallel kernel: input ring + (D - 1) x (2 summaries of 5 KiB + a 2-KiB status piece) + counters
 constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 128; }
 
+// Configs of more than kMaxDefsPerPass RegexDefs (hrx_defs.hpp): every group of defs is walked by an ordinary launch into a
+// group-private position-major records buffer [ceil(M/4)][D_g][nb][4] (blocked like every position-major buffer) and its own
+// status array; witness_combine_kernel (hrx_kernel_mp.hip) then reads the groups' rows once, writes them into the caller's
+// records buffer in its layout, and computes what needs ALL defs of a row: Sum(substr_id), Sum(is_start), Sum(is_end) ->
+// reveal masks and masked rows (lib.rs:467-519, 593-764), the flag-overlap row, the merged status word.
+constexpr uint32_t kMaxGroups = 32;
+struct CombineArgs {
+    const uint8_t *chars;
+    uint64_t stride;
+    const uint32_t *lens;
+    uint32_t B, M, D, G;
+    uint32_t layout;                // the CALLER's layout: bit 0 position-major outputs, bit 1 position-major input
+    uint32_t rec_pitch, msk_pitch;  // string-major outputs
+    uint32_t *records;
+    uint16_t *masked;
+    uint64_t *status;
+    const uint32_t *grec[kMaxGroups];
+    const uint64_t *gstatus[kMaxGroups];
+    uint8_t gD[kMaxGroups], gfirst[kMaxGroups];
+};
+hipError_t launch_combine(const CombineArgs &a, hipStream_t stream);
+
 // states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])
 hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,
                             const uint32_t *n_states, uint16_t *tags, hipStream_t stream);

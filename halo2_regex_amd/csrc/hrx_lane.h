@@ -225,7 +225,7 @@ HRX_HD uint64_t rows_below(uint32_t t0, uint32_t n) {
     return k >= 64 ? ~0ull : ((1ull << k) - 1);
 }
 
-HRX_HD uint64_t status_ok(uint32_t accept_mask) { return (uint64_t)(accept_mask & 0xff) << 8; }
+HRX_HD uint64_t status_ok(uint32_t accept_mask) { return (uint64_t)accept_mask << 8; }   // bit 8 + d: def d ends in its accept state (up to 32 defs)
 HRX_HD uint64_t status_invalid(uint32_t def, uint32_t pos, uint32_t state, uint32_t ch) {
     return kStatusInvalidTransition | (uint64_t)(def & 0xff) << 8 | (uint64_t)(ch & 0xff) << 16 |
            (uint64_t)(state & 0xffff) << 24 | (uint64_t)(pos & 0xffffff) << 40;

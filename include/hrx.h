@@ -68,7 +68,12 @@ int hrx_defs_push_allstr(hrx_defs *defs, uint64_t first_state_val, uint64_t acce
 /* SubstrRegexDef::new (defs.rs:147-163); max_length / min_position / max_position are unused by the chip. */
 int hrx_defs_push_substr(hrx_defs *defs, size_t n_pairs, const uint64_t *pair_cur, const uint64_t *pair_next,
                          size_t n_start, const uint64_t *start_states, size_t n_end, const uint64_t *end_states);
-/* Validate and build the dense fused (state,char) tables.  Required before any call below. */
+/* Validate and build the dense fused (state,char) tables.  Required before any call below.
+ * regex_defs is a Vec of any length in the reference (src/lib.rs:112; loops at :387, :806, :828, :855): up to HRX_MAX_DEFS
+ * RegexDefs per config.  Up to three defs are walked side by side by one kernel launch; a larger config is walked in passes
+ * over consecutive groups of defs (each group's tables LDS-resident) and a combine launch forms the per-row sums over all
+ * defs (reveal masks, flag overlap) and the merged status — same buffers, same results, about twice the memory traffic. */
+#define HRX_MAX_DEFS 32
 int hrx_defs_finalize(hrx_defs *defs);
 
 size_t hrx_defs_num_defs(const hrx_defs *defs);
@@ -127,7 +132,7 @@ const char *hrx_last_error(void);
  *   masked   [B][M] u16:   masked_char[r] | masked_substr_id[r] << 8
  *            (AssignedRegexResult.masked_characters / .all_substr_ids, lib.rs:766-771)
  *   status   [B] u64: bits 0..7 code
- *            0 ok: bits 8..15 = accept mask (bit d: state at row n == accepted_state_val of def d, lib.rs:442-457)
+ *            0 ok: bits 8..39 = accept mask (bit d: state at row n == accepted_state_val of def d, lib.rs:442-457)
  *            1 invalid transition (lib.rs:817): bits 8..15 def, 16..23 char, 24..39 state, 40..63 position;
  *              lowest def, then lowest position, like the reference's loop order
  *            2 two defs flag the same row (out of contract): bits 40..63 row

@@ -83,10 +83,11 @@ class IntegerMockProver:
         self.D = len(self.defs)
 
     @classmethod
-    def from_config(cls, cfg, firsts, device="cpu"):
-        """cfg: halo2_regex_amd.RegexVerifyConfig (its load() returns the rows in table.rs assignment order); firsts: first_state_val per def"""
+    def from_config(cls, cfg, device="cpu"):
+        """cfg: halo2_regex_amd.RegexVerifyConfig: load() returns the rows RegexTableConfig::load assigns, in table.rs order;
+        first_state / accepted_state are AllstrRegexDef's header lines (defs.rs:84-99)"""
         rows = cfg.load()
-        return cls([(rows[d][0], rows[d][1], firsts[d], cfg.accepted_state(d)) for d in range(len(rows))], device)
+        return cls([(rows[d][0], rows[d][1], cfg.first_state(d), cfg.accepted_state(d)) for d in range(len(rows))], device)
 
     @torch.no_grad()
     def verify(self, chars, lens, records, masked, M):

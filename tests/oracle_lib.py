@@ -188,7 +188,7 @@ def decode_status(s):
     s = int(s)
     code = s & 0xff
     if code == 0:
-        return {"code": 0, "accept": (s >> 8) & 0xff}
+        return {"code": 0, "accept": (s >> 8) & 0xffffffff}
     if code == 1:
         return {"code": 1, "def": (s >> 8) & 0xff, "char": (s >> 16) & 0xff, "state": (s >> 24) & 0xffff, "pos": s >> 40}
     if code == 2:

@@ -26,27 +26,36 @@ def test_shards_reproduce_the_whole(oracle):
 
 
 WORKER = r"""
-import os, sys, time
-import torch, torch.distributed as dist
+# one rank of a world-size-2 job on gloo: bench.py's own gather + aggregate (the code `torch.distributed.run bench.py --gpus 2`
+# executes after the timed region), fed with this rank's shard and a made-up elapsed time
+import json, os, sys
+import torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
+import bench
 import halo2_regex_amd as hra
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-B = 1000
-b, c = hra.shard_range(B, world, rank)
-dist.barrier()
-elapsed = torch.tensor([0.5 + 0.25 * rank], dtype=torch.float64)     # rank 1 is the slow one
-dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-rows = torch.tensor([c * 1023], dtype=torch.int64)
-dist.all_reduce(rows)
+args = bench.parse_args(["--gpus", "2", "--steps", "7", "--warmup", "1", "--batch", "500"])
+b, c = hra.shard_range(1000, world, rank)
+res = {"rank": rank, "device": rank, "rows": c * 1023 * args.steps, "elapsed_s": 0.5 + 0.25 * rank, "avg_launch_ms": 0.08 + 0.01 * rank,
+       "debug_flags": None}
 if rank == 0:
-    print("RESULT", float(elapsed.item()), int(rows.item()), b, c)
+    res.update(desc="hrx::witness_pm_kernel<1, false, false, false> grid=256 waves=8 ring=4 lds=113728", D=1, rows_per_step=c * 1023,
+               config={"workload": "test"}, verified={"strings": 4, "rows": 4092, "bit_exact": True, "against": "test"})
+dist.barrier()
+line = bench.gather_and_aggregate(res, args)
+assert (line is None) == (rank != 0)
+if rank == 0:
+    print("RESULT " + json.dumps(line))
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
 def test_world_size_2_reduction_on_gloo(tmp_path):
+    """bench.py's gather_and_aggregate / aggregate under torch.distributed (gloo, world size 2): value = rows of ALL ranks /
+    MAX over ranks of the elapsed time; per-rank results and ranks_seen are reported."""
+    import json
     script = tmp_path / "w.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -54,10 +63,24 @@ def test_world_size_2_reduction_on_gloo(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", "29517", str(script), ROOT],
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
-    assert float(line[1]) == 0.75           # max over ranks
-    assert int(line[2]) == 1000 * 1023      # whole-job rows: every string exactly once
-    assert (int(line[3]), int(line[4])) == (0, 500)
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 7
+    assert line["value"] == 1000 * 1023 * 7 / 0.75          # every string exactly once, over the slow rank's time
+    assert abs(line["ms_per_step"] - 750.0 / 7) < 1e-9
+    assert [r["rows"] for r in line["per_rank"]] == [500 * 1023 * 7] * 2 and [r["device"] for r in line["per_rank"]] == [0, 1]
+    assert line["verified"]["bit_exact"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert abs(line["roofline"]["achieved"] - 7 * 500 * 1023 / 0.08e-3 / 1e9) < 1e-6 and line["roofline"]["kernel"].startswith("hrx::witness_pm_kernel")
+
+
+def test_aggregate_of_a_bare_multi_gpu_run():
+    """the same aggregation as the parent of a bare `bench.py --gpus N` run applies it to its children's result lines"""
+    import bench
+    args = bench.parse_args(["--gpus", "4", "--steps", "5"])
+    per = [{"rank": r, "device": r, "rows": 100 * 5, "elapsed_s": 1.0 + 0.1 * r, "avg_launch_ms": 0.1, "debug_flags": None} for r in (2, 0, 3, 1)]
+    per[1].update(desc="k grid=1", D=2, rows_per_step=100, config={"workload": "t"})
+    line = bench.aggregate(per, args)
+    assert line["n_gpus"] == 4 and line["value"] == 2000 / 1.3 and [r["rank"] for r in line["per_rank"]] == [0, 1, 2, 3]
+    assert line["roofline"]["bytes_per_row"] == 11 and line["roofline"]["algorithmic_bytes_per_launch"] == 1100
 
 
 def test_cpp_host_mirror_builds_and_runs():

@@ -127,6 +127,39 @@ def test_flag_overlap_and_full_length_strings(oracle):
     _check_batch(oracle, CFG_A, chars, lens, 128)
 
 
+HDR = [["header_from_lookup.txt", ["header_from_substr0.txt"]], ["header_to_lookup.txt", ["header_to_substr0.txt"]],
+       ["header_subject_lookup.txt", ["header_subject_substr%d.txt" % k for k in range(3)]]]
+CFG_D4 = CFG_123 + [HDR[0]]
+CFG_D5 = [CFG_3[0], HDR[2], CFG_1[0], HDR[1], CFG_A[1]]
+CFG_D7 = CFG_123 + [CFG_EX[0]] + HDR                    # def 3 = the partial example DFA: undefined transitions on almost any noise
+CFG_D8 = CFG_123 + HDR + [CFG_1[0], CFG_A[1]]           # regex1 and regex2 a second time: both copies flag the same rows
+
+
+@pytest.mark.parametrize("names", [CFG_D4, CFG_D5, CFG_D7, CFG_D8], ids=["D4", "D5", "D7", "D8"])
+def test_more_than_three_regex_defs(oracle, names):
+    """regex_defs is a Vec of any length (src/lib.rs:112): substr ids keep counting across the defs (lib.rs:827,842), the accept
+    mask has a bit per def, the lowest def's undefined transition wins, two defs flagging one row is reported with its row."""
+    M = 328
+    cfg = _cfg(names, M)
+    assert [cfg.substr_id_offset(d) for d in range(len(names))] == list(np.cumsum([1] + [len(s) for _, s in names[:-1]]))
+    o = OracleDefs.from_files(oracle, names)
+    chars, lens = synth.reveal_stress(400, 320, seed=31)
+    h_c, h_l = synth.headers_planted(200, 320, seed=3, stride=320)
+    chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
+    chars[7, 50] = 250                                           # a byte no DFA has a transition for
+    lens[11] = 400                                               # n > M
+    st, msk = _check_batch(oracle, names, chars, lens, M, cfg=cfg, o=o)
+    codes = st & np.uint64(0xff)
+    assert (codes == 1).any() and (codes == 3).any()
+    if names is CFG_D7:
+        assert ((st[codes == 1] >> np.uint64(8)) & np.uint64(0xff) == 3).sum() > 300      # the example DFA (def 3) dies on noise; def 0..2 do not
+    elif names is CFG_D8:
+        assert (codes == 2).sum() > 300 and (codes == 0).sum() > 10                       # overlaps wherever a copied def tags a row
+    else:
+        assert (codes == 0).sum() > 100 and msk.any()               # (regex3 and header_from both tag a `from:` line: those strings are overlaps)
+        assert len(set(int(x) for x in st[codes == 0] >> np.uint64(8))) > 2              # different subsets of the defs accept
+
+
 def test_planted_cfg2_sample(oracle):
     """BASELINE configs[1]'s workload (regex1+substr1, n = 1023, M = 1024), a slice of it"""
     chars, lens = synth.regex1_planted(2048, 1023, seed=0, stride=1024)

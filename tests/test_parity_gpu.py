@@ -200,7 +200,7 @@ def test_position_major_reveal_stress_and_errors(hra, oracle, names):
     _check_batch_pm(hra, oracle, names, chars, lens, 304)
 
 
-def test_position_major_full_size_cfg2(hra, oracle):
+def test_position_major_full_size_cfg2(hra, oracle, monkeypatch):
     import torch
     from halo2_regex_amd import synth
     B, n, M = 65536, 1023, 1024
@@ -213,12 +213,16 @@ def test_position_major_full_size_cfg2(hra, oracle):
     torch.cuda.synchronize()
     r1, m1 = hra.position_major_to_string_major(rec, msk, B, M, 1)
     assert torch.equal(r1, r0) and torch.equal(m1, m0) and torch.equal(st, s0)
-    idx = np.random.default_rng(1).choice(B, 512, replace=False)
-    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_1).witness_batch(chars[idx], lens[idx], M)
-    assert np.array_equal(orec, r1.cpu().numpy().view(np.uint32)[idx]) and np.array_equal(omsk, m1.cpu().numpy().view(np.uint16)[idx])
-    rec2, msk2, st2 = cfg.witness_batch_position_major(d_chars, d_lens)
-    torch.cuda.synchronize()
-    assert torch.equal(rec, rec2) and torch.equal(msk, msk2) and torch.equal(st, st2)
+    del r0, m0, s0, r1, m1, rec, msk, st
+    # every string of the batch against the oracle and through the integer MockProver — the planner's kernel for this shape
+    # (one byte per lookup) and the pair-step kernel forced onto the same batch
+    o = OracleDefs.from_files(oracle, CFG_1)
+    for flags in (0, 0x40000000):
+        monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(flags))
+        cfg = _cfg(hra, CFG_1, M)
+        assert ("witness_pp_kernel" in cfg.describe_launch(B, layout=3)) == (flags != 0)
+        st = _full_check(hra, o, cfg, [(chars, lens)], M, 1, need_accept=0.9)
+        assert (st & np.uint64(0xff) == 0).all()
 
 
 def test_large_dfa_walks_out_of_global_memory(hra, oracle):
@@ -249,29 +253,107 @@ def test_large_dfa_walks_out_of_global_memory(hra, oracle):
         assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
 
 
-def _sample_check(hra, oracle_defs, cfg, chars, lens, M, D, nsample, seed, position_major=True):
-    """device-resident run of the whole batch; a seeded sample of strings bit-exact against the oracle; idempotence"""
+def _pm_rows(hra, rec, msk, B, M, D, b0, b1):
+    """strings [b0, b1) — inside one block of the position-major buffers — as string-major VIEWS (b1 - b0, M, D) / (b1 - b0, M)"""
+    q4, q8 = (M + 3) // 4, (M + 7) // 8
+    k0 = b0 // hra.PM_BLOCK * hra.PM_BLOCK
+    nb = min(hra.PM_BLOCK, B - k0)
+    assert b1 <= k0 + nb
+    r = rec[k0 * q4 * 4 * D:(k0 + nb) * q4 * 4 * D].view(q4, D, nb, 4)[:, :, b0 - k0:b1 - k0]
+    m = msk[k0 * q8 * 8:(k0 + nb) * q8 * 8].view(q8, nb, 8)[:, b0 - k0:b1 - k0]
+    return r.permute(2, 0, 3, 1).reshape(b1 - b0, q4 * 4, D)[:, :M], m.permute(1, 0, 2).reshape(b1 - b0, q8 * 8)[:, :M]
+
+
+def _full_check(hra, oracle_defs, cfg, blocks, M, D, position_major=True, elems=1 << 25, need_accept=None):
+    """EVERY string of a device-resident batch against the oracle (all host cores), and through the integer MockProver
+    (tests/mock_prover.py: the reference's gates, lookups and accept chain, src/lib.rs:126-305, 427-457).
+
+    blocks: list of (chars, lens) host arrays, one per block of <= 65536 strings (the position-major buffers are blocked by
+    that many).  The whole batch runs in ONE launch; the comparison then goes chunk by chunk (at most `elems` rows at a
+    time): the oracle's rows for the chunk are uploaded and compared on the device with the kernel's rows, where they lie.
+    Returns the status words."""
     import torch
+    from mock_prover import IntegerMockProver, FAIL_ACCEPT
     dev = torch.device("cuda", 0)
-    B = len(lens)
-    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    ncpu = os.cpu_count() or 1
+    B = sum(len(l) for _, l in blocks)
+    stride = blocks[0][0].shape[1]
+    d_chars = torch.empty((B, stride), dtype=torch.uint8, device=dev)
+    d_lens = torch.empty((B,), dtype=torch.int32, device=dev)
+    k0 = 0
+    for c, l in blocks:
+        assert len(l) <= hra.PM_BLOCK and (len(l) == hra.PM_BLOCK or c is blocks[-1][0])
+        d_chars[k0:k0 + len(l)] = torch.from_numpy(c).to(dev)
+        d_lens[k0:k0 + len(l)] = torch.from_numpy(l.astype(np.int32)).to(dev)
+        k0 += len(l)
     if position_major:
-        rec, msk, st = cfg.witness_batch_position_major(d_chars, d_lens)
-        rec2, msk2, st2 = cfg.witness_batch_position_major(d_chars, d_lens)
+        src = hra.chars_to_position_major(d_chars)
+        rec, msk, st = cfg.witness_batch_position_major(src, d_lens, chars_pm_stride=stride)
+        rec2, msk2, st2 = cfg.witness_batch_position_major(src, d_lens, chars_pm_stride=stride)
         torch.cuda.synchronize()
-        assert torch.equal(rec, rec2) and torch.equal(msk, msk2) and torch.equal(st, st2)
-        rec, msk = hra.position_major_to_string_major(rec, msk, B, M, D)
+        assert torch.equal(rec, rec2) and torch.equal(msk, msk2) and torch.equal(st, st2)      # idempotence
+        del rec2, msk2, st2, src
     else:
         rec, msk, st = cfg.witness_batch(d_chars, d_lens)
         torch.cuda.synchronize()
-    idx = np.sort(np.random.default_rng(seed).choice(B, nsample, replace=False))
-    tidx = torch.from_numpy(idx).to(dev)
-    orec, omsk, ost = oracle_defs.witness_batch(chars[idx], lens[idx], M)
-    assert np.array_equal(ost, st[tidx].cpu().numpy().view(np.uint64))
-    ok = (ost & np.uint64(0xff)) == 0
-    assert np.array_equal(orec[ok], rec[tidx].cpu().numpy().view(np.uint32)[ok])
-    assert np.array_equal(omsk[ok], msk[tidx].cpu().numpy().view(np.uint16)[ok])
+    mp = IntegerMockProver.from_config(cfg, device=dev)
+    all_accept = (1 << D) - 1
+    chunk = max(64, min(hra.PM_BLOCK, elems // M))
+    k0, n_ok, n_clean = 0, 0, 0
+    for c, l in blocks:
+        for c0 in range(0, len(l), chunk):
+            c1 = min(len(l), c0 + chunk)
+            orec, omsk, ost = oracle_defs.witness_batch(c[c0:c1], l[c0:c1], M, threads=ncpu)
+            t_rec = torch.from_numpy(orec.view(np.int32)).to(dev)
+            t_msk = torch.from_numpy(omsk.view(np.int16)).to(dev)
+            t_st = torch.from_numpy(ost.view(np.int64)).to(dev)
+            if position_major:
+                g_rec, g_msk = _pm_rows(hra, rec, msk, B, M, D, k0 + c0, k0 + c1)
+            else:
+                g_rec, g_msk = rec[k0 + c0:k0 + c1], msk[k0 + c0:k0 + c1]
+            g_st = st[k0 + c0:k0 + c1]
+            assert torch.equal(g_st, t_st), "status words differ in strings %d..%d" % (k0 + c0, k0 + c1)
+            ok = (t_st & 0xff) == 0                       # (status != 0: the reference panics / out of contract, rows unspecified)
+            assert bool(((g_rec == t_rec).flatten(1).all(dim=1) | ~ok).all()), "records differ in strings %d..%d" % (k0 + c0, k0 + c1)
+            assert bool(((g_msk == t_msk).all(dim=1) | ~ok).all()), "masked rows differ in strings %d..%d" % (k0 + c0, k0 + c1)
+            # the constraint system itself, on the kernel's rows: every gate and lookup holds; where a def does not end in
+            # its accept state the accept chain — and nothing else — fails (what MockProver::verify() reports for test_substr_fail*)
+            code = mp.verify(d_chars[k0 + c0:k0 + c1], d_lens[k0 + c0:k0 + c1], g_rec, g_msk, M)
+            accepted = (((t_st >> 8) & 0xff) == all_accept) | (d_lens[k0 + c0:k0 + c1] >= M)
+            want = torch.where(accepted, torch.zeros_like(code), torch.full_like(code, FAIL_ACCEPT))
+            bad = ok & (code != want)
+            assert not bool(bad.any()), "MockProver: string %d: %s" % (k0 + c0 + int(bad.nonzero()[0]), mp.explain(code[bad][0]))
+            n_ok += int(ok.sum())
+            n_clean += int((ok & (code == 0)).sum())
+            del t_rec, t_msk, t_st, code
+        k0 += len(l)
+    if need_accept is not None:
+        assert n_clean >= need_accept * B, "only %d of %d strings satisfy the whole constraint system" % (n_clean, B)
     return st.cpu().numpy().view(np.uint64)
+
+
+def test_full_check_detects_a_wrong_witness(hra, oracle):
+    """negative control of the checker itself: the kernels' rows for regex1 compared with the oracle's rows for regex3 must fail"""
+    from halo2_regex_amd import synth
+    chars, lens = synth.regex1_planted(3000, 255, seed=2, stride=256)
+    with pytest.raises(AssertionError):
+        _full_check(hra, OracleDefs.from_files(oracle, CFG_3), _cfg(hra, CFG_1, 256), [(chars, lens)], 256, 1)
+
+
+def _rolled_blocks(base_chars, base_lens, nblocks, last=None, seed=0):
+    """nblocks blocks made from one generated block: block k = the base strings rotated by 977 k places, with 64 strings per
+    block cut to a random shorter length (ragged rows in every block); `last`: strings in the last block (partial block)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(nblocks):
+        c = np.roll(base_chars, 977 * k, axis=0) if k else base_chars
+        l = (np.roll(base_lens, 977 * k) if k else base_lens).copy()
+        idx = rng.choice(len(l), min(64, len(l)), replace=False)
+        l[idx] = rng.integers(0, l[idx] + 1)
+        if last is not None and k == nblocks - 1:
+            c, l = c[:last], l[:last]
+        out.append((np.ascontiguousarray(c), l))
+    return out
 
 
 def test_cfg3_shape_two_defs_2048_byte_strings(hra, oracle):
@@ -282,9 +364,9 @@ def test_cfg3_shape_two_defs_2048_byte_strings(hra, oracle):
     lens[:64] = np.random.default_rng(0).integers(0, n + 1, 64)       # some ragged strings as well
     o = OracleDefs.from_files(oracle, CFG_23)
     cfg = _cfg(hra, CFG_23, M)
-    st = _sample_check(hra, o, cfg, chars, lens, M, 2, 256, 3, position_major=True)
+    st = _full_check(hra, o, cfg, [(chars, lens)], M, 2, position_major=True)
     assert (st & np.uint64(0xff) == 0).all()
-    _sample_check(hra, o, cfg, chars, lens, M, 2, 256, 4, position_major=False)
+    _full_check(hra, o, cfg, [(chars, lens)], M, 2, position_major=False)
 
 
 def test_cfg5_shape_256_state_dense_dfa_4096_byte_strings(hra, oracle):
@@ -299,9 +381,9 @@ def test_cfg5_shape_256_state_dense_dfa_4096_byte_strings(hra, oracle):
     assert cfg.table_bytes() == 258 * 1024
     chars, lens = synth.noise(B, n, seed=2, alphabet=np.arange(256, dtype=np.uint8), stride=4096)
     o = OracleDefs(oracle, [(allstr, [sub])])
-    st = _sample_check(hra, o, cfg, chars, lens, M, 1, 96, 5, position_major=True)
+    st = _full_check(hra, o, cfg, [(chars, lens)], M, 1, position_major=True)
     assert (st & np.uint64(0xff) == 0).all()
-    _sample_check(hra, o, cfg, chars, lens, M, 1, 96, 6, position_major=False)
+    _full_check(hra, o, cfg, [(chars, lens)], M, 1, position_major=False)
 
 
 def test_half_table_kernel_on_dfas_of_up_to_256_states(hra, oracle):
@@ -336,18 +418,18 @@ def test_half_table_kernel_on_dfas_of_up_to_256_states(hra, oracle):
 
 def test_cfg4_shape_three_header_defs_five_substrs(hra, oracle):
     """BASELINE configs[3] shape: D=3 header-style definitions (from / to / subject; substr ids 1..5) compiled by this
-    repo's own regex compiler; 2048-row strings in both layouts and 32768-byte strings, sampled against the oracle."""
+    repo's own regex compiler; 2048-row strings and 32768-byte strings in both layouts, every string against the oracle."""
     from halo2_regex_amd import synth
     from test_substr_gen import header_def_texts
     texts = header_def_texts()
     defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in texts]
     o = OracleDefs(oracle, texts)
-    for B, n, M, ns in ((4096, 2047, 2048, 128), (256, 32767, 32768, 12)):
+    for B, n, M in ((4096, 2047, 2048), (256, 32767, 32768)):
         cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
         chars, lens = synth.headers_planted(B, n, seed=3, stride=M)
-        st = _sample_check(hra, o, cfg, chars, lens, M, 3, ns, 11, position_major=True)
+        st = _full_check(hra, o, cfg, [(chars, lens)], M, 3, position_major=True, need_accept=0.99)
         assert ((st & np.uint64(0xff)) == 0).all() and (st == np.uint64(0x700)).mean() > 0.99    # a block planted at offset 0 is not accepted
-        _sample_check(hra, o, cfg, chars, lens, M, 3, ns, 12, position_major=False)
+        _full_check(hra, o, cfg, [(chars, lens)], M, 3, position_major=False)
 
 
 def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
@@ -469,8 +551,8 @@ def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
 
 def test_three_defs_every_kernel_agrees_at_a_chip_filling_size(hra, oracle, monkeypatch):
     """D = 3, 16384 x 1024-byte strings (one group per CU): the def-parallel kernel (the planner's choice), the regular
-    position-major kernel, its narrow-table build and the string-major path must produce the same bytes; a seeded sample
-    against the oracle."""
+    position-major kernel, its narrow-table build and the string-major path must produce the same bytes, and every string
+    equals the oracle's."""
     import torch
     from halo2_regex_amd import synth
     dev = torch.device("cuda", 0)
@@ -493,11 +575,9 @@ def test_three_defs_every_kernel_agrees_at_a_chip_filling_size(hra, oracle, monk
     ref = results["regular"]
     for name, r in results.items():
         assert torch.equal(r[0], ref[0]) and torch.equal(r[1], ref[1]) and torch.equal(r[2], ref[2]), name
-    idx = np.sort(np.random.default_rng(3).choice(B, 256, replace=False))
-    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_123).witness_batch(chars[idx], lens[idx], M)
-    tidx = torch.from_numpy(idx).to(dev)
-    assert np.array_equal(ref[2][tidx].cpu().numpy().view(np.uint64), ost)
-    assert np.array_equal(ref[0][tidx].cpu().numpy().view(np.uint32), orec) and np.array_equal(ref[1][tidx].cpu().numpy().view(np.uint16), omsk)
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_123).witness_batch(chars, lens, M, threads=os.cpu_count() or 1)
+    assert np.array_equal(ref[2].cpu().numpy().view(np.uint64), ost)
+    assert np.array_equal(ref[0].cpu().numpy().view(np.uint32), orec) and np.array_equal(ref[1].cpu().numpy().view(np.uint16), omsk)
 
 
 def test_position_major_buffers_are_blocked_by_65536_strings(hra, oracle):
@@ -554,6 +634,123 @@ def test_multi_device_driver_shards_by_string_index(hra, oracle):
     assert np.array_equal(two[0], one[0][:2]) and np.array_equal(two[1], one[1][:2]) and np.array_equal(two[2], one[2][:2])
 
 
+HDR = [["header_from_lookup.txt", ["header_from_substr0.txt"]], ["header_to_lookup.txt", ["header_to_substr0.txt"]],
+       ["header_subject_lookup.txt", ["header_subject_substr%d.txt" % k for k in range(3)]]]
+CFG_D4 = CFG_123 + [HDR[0]]
+CFG_D5 = [CFG_3[0], HDR[2], CFG_1[0], HDR[1], CFG_A[1]]
+CFG_D7 = CFG_123 + [CFG_EX[0]] + HDR                    # def 3 = the partial example DFA: undefined transitions on almost any noise
+CFG_D8 = CFG_123 + HDR + [CFG_1[0], CFG_A[1]]           # regex1 and regex2 a second time: both copies flag the same rows
+
+
+@pytest.mark.parametrize("names", [CFG_D4, CFG_D5, CFG_D7, CFG_D8], ids=["D4", "D5", "D7", "D8"])
+def test_more_than_three_regex_defs_multi_pass(hra, oracle, names):
+    """regex_defs is a Vec of any length (src/lib.rs:112): more than three defs are walked in passes (groups of defs) and combined
+    per row by hrx::witness_combine_kernel — every layout (string-major, position-major, position-major input), substr ids counting
+    on across the groups (lib.rs:827,842), merged status words: the lowest def's undefined transition, the flag-overlap row, the
+    accept mask with a bit per def; then every ok string through the integer MockProver."""
+    import torch
+    from halo2_regex_amd import synth
+    from mock_prover import IntegerMockProver, FAIL_ACCEPT
+    D = len(names)
+    for M in (328, 203):                                       # aligned and unaligned row counts
+        cfg = _cfg(hra, names, M)
+        assert cfg.describe_launch(700, layout=3).startswith("multi-pass, ") and "witness_combine_kernel<false>" in cfg.describe_launch(700, layout=3)
+        chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=31)
+        h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=3, stride=chars.shape[1])
+        chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
+        chars[7, 50] = 250                                       # a byte no DFA has a transition for
+        lens[11] = M + 72                                        # n > M
+        lens[12], lens[13] = 0, min(M, chars.shape[1])
+        st, _ = _check_batch(hra, oracle, names, chars, lens, M)              # string-major (host buffers -> device batch kernels)
+        _check_batch_pm(hra, oracle, names, chars, lens, M)                   # position-major outputs, both input layouts
+        codes = st & np.uint64(0xff)
+        assert (codes == 1).any() and (codes == 3).any()
+        if names is CFG_D7:
+            assert ((st[codes == 1] >> np.uint64(8)) & np.uint64(0xff) == 3).sum() > 300
+        elif names is CFG_D8:
+            assert (codes == 2).sum() > 300
+        else:
+            assert (codes == 0).sum() > 100 and len(set(int(x) for x in st[codes == 0] >> np.uint64(8))) > 2
+        # the constraint system on the device rows
+        dev = torch.device("cuda", 0)
+        d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+        rec, msk, dst = cfg.witness_batch(d_chars, d_lens)
+        torch.cuda.synchronize()
+        code = IntegerMockProver.from_config(cfg, device=dev).verify(d_chars, d_lens, rec, msk, M).cpu().numpy()
+        ok = codes == 0
+        accepted = ((st >> np.uint64(8)) == np.uint64((1 << D) - 1)) | (lens >= M)
+        assert (code[ok & accepted] == 0).all() and (code[ok & ~accepted] == FAIL_ACCEPT).all()
+
+
+def test_multi_pass_at_a_chip_filling_size_two_blocks(hra, oracle):
+    """D = 5 at 70000 x 1023 bytes (two blocks of the position-major buffers): every string against the oracle and the MockProver."""
+    from halo2_regex_amd import synth
+    M, n = 1024, 1023
+    base_c, base_l = synth.regex23_planted(hra.PM_BLOCK, n, seed=9, stride=1024)
+    blocks = _rolled_blocks(base_c, base_l, 2, last=70000 - hra.PM_BLOCK, seed=6)
+    cfg = _cfg(hra, CFG_D5, M)
+    st = _full_check(hra, OracleDefs.from_files(oracle, CFG_D5), cfg, blocks, M, 5)
+    assert len(st) == 70000 and (st & np.uint64(0xff) == 0).mean() > 0.9
+    _full_check(hra, OracleDefs.from_files(oracle, CFG_D5), cfg, [(base_c[:5000], base_l[:5000])], M, 5, position_major=False)
+
+
+def test_multi_device_driver_device_resident_shards(hra, oracle):
+    """hrx_multi_witness_batch_device: device pointers per shard, one stream per shard, no PCIe copy, no collective — three shards
+    on the one device (two position-major blocks' worth of strings in the middle shard), every string against the oracle."""
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    M = 136
+    chars, lens = synth.reveal_stress(3000, 130, seed=13)
+    cfg = _cfg(hra, CFG_A, M)
+    multi = hra.MultiDevice(cfg, [0, 0, 0])
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_A).witness_batch(chars, lens, M, threads=8)
+    ok = (ost & np.uint64(0xff)) == 0
+    for layout_pm in (True, False):
+        shards, cuts = [], []
+        for r in range(3):
+            b, c = hra.shard_range(len(lens), 3, r)
+            cuts.append((b, c))
+            d_c = torch.from_numpy(chars[b:b + c]).to(dev)
+            d_l = torch.from_numpy(lens[b:b + c].astype(np.int32)).to(dev)
+            if layout_pm:
+                shards.append((hra.chars_to_position_major(d_c), d_l, cfg.alloc_outputs_position_major(c, dev)))
+            else:
+                shards.append((d_c, d_l, cfg.alloc_outputs(c, dev)))
+        if layout_pm:
+            multi.witness_batch_device(shards, chars_stride=chars.shape[1])
+        else:
+            multi.witness_batch_device(shards, layout=hra.LAYOUT_STRING_MAJOR)
+        multi.synchronize()
+        for (b, c), (_, _, (rec, msk, st)) in zip(cuts, shards):
+            if layout_pm:
+                rec, msk = hra.position_major_to_string_major(rec, msk, c, M, 2)
+            assert np.array_equal(st.cpu().numpy().view(np.uint64), ost[b:b + c])
+            k = ok[b:b + c]
+            assert np.array_equal(rec.cpu().numpy().view(np.uint32)[k], orec[b:b + c][k])
+            assert np.array_equal(msk.cpu().numpy().view(np.uint16)[k], omsk[b:b + c][k])
+
+
+def test_bench_runs_bare_with_two_ranks_on_one_device():
+    """`python3 bench.py --gpus 2` as a bare command: the parent touches no GPU and spawns one child per rank (here both ranks
+    mapped onto device 0: HRX_BENCH_DEVICES=0,0), gloo carries the barrier, the data path has no collective; the line
+    aggregates both ranks and rank 0's timed buffers are verified against the oracle."""
+    import json
+    import subprocess
+    import sys
+    from oracle_lib import ROOT
+    env = dict(os.environ, HRX_BENCH_DEVICES="0,0")
+    env.pop("HRX_DEBUG_FLAGS", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--batch", "16384",
+                          "--no-cpu-baseline", "--no-spread"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["per_rank"]) == 2
+    assert sum(r["rows"] for r in line["per_rank"]) == 2 * 10 * 16384 * 1023
+    assert abs(line["value"] - sum(r["rows"] for r in line["per_rank"]) / max(r["elapsed_s"] for r in line["per_rank"])) < 1e-6 * line["value"]
+    assert line["verified"]["bit_exact"] is True and line["debug_flags"] is None
+
+
 def test_invalid_bytes_bad_lengths_and_overlap_status(hra, oracle):
     from halo2_regex_amd import synth
     chars, lens = synth.ragged(257, 300, seed=3)
@@ -601,11 +798,11 @@ def test_full_size_cfg2_device_resident(hra, oracle):
     msk_h = msk.cpu().numpy().view(np.uint16)
     st_h = st.cpu().numpy().view(np.uint64)
     assert (st_h & np.uint64(0xff) == 0).all()
-    # (1) a seeded sample of strings, bit-exact against the oracle
+    # (1) every string, bit-exact against the oracle
     o = OracleDefs.from_files(oracle, CFG_1)
-    idx = np.random.default_rng(0).choice(B, 768, replace=False)
-    orec, omsk, ost = o.witness_batch(chars[idx], lens[idx], M)
-    assert np.array_equal(orec, rec_h[idx]) and np.array_equal(omsk, msk_h[idx]) and np.array_equal(ost, st_h[idx])
+    orec, omsk, ost = o.witness_batch(chars, lens, M, threads=os.cpu_count() or 1)
+    assert np.array_equal(orec, rec_h) and np.array_equal(omsk, msk_h) and np.array_equal(ost, st_h)
+    del orec, omsk
     # (2) idempotence: a second launch into fresh buffers gives the same bytes (checksum of checksums)
     rec2, msk2, st2 = cfg.witness_batch(d_chars, d_lens)
     torch.cuda.synchronize()
@@ -635,3 +832,53 @@ def test_full_size_cfg2_device_resident(hra, oracle):
     assert ((msk_h != 0) <= (sid != 0)).all()
     assert ((msk_h >> 8)[msk_h != 0] == 1).all()
     assert ((msk_h & 0xff)[msk_h != 0] == chars[:, :M][msk_h != 0]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# The shapes profiles/*config_sweep* quotes throughput at, at FULL size: every string against the oracle and through the
+# integer MockProver.  (Inputs: one generated block, rotated per block — tests/_rolled_blocks — so that generating 2 GiB of
+# planted text does not dominate the test; every block still has its own ragged strings.)
+# ---------------------------------------------------------------------------------------------
+def test_full_size_cfg3_two_defs_2pow20_strings_16_blocks(hra, oracle):
+    """BASELINE configs[2]: regex2 + regex3 with substr extraction, 2^20 x 2048-byte strings = 16 blocks of the position-major
+    buffers (2 GiB in, 21 GiB out), D = 2, one launch."""
+    from halo2_regex_amd import synth
+    n, M = 2047, 2048
+    base_c, base_l = synth.regex23_planted(hra.PM_BLOCK, n, seed=1, stride=2048)
+    blocks = _rolled_blocks(base_c, base_l, 16, seed=3)
+    cfg = _cfg(hra, CFG_23, M)
+    assert "witness_pm_kernel<2, false, true, false>" in cfg.describe_launch(1 << 20, layout=3)
+    st = _full_check(hra, OracleDefs.from_files(oracle, CFG_23), cfg, blocks, M, 2, need_accept=0.0)
+    assert len(st) == 1 << 20 and (st & np.uint64(0xff) == 0).all()
+
+
+def test_full_size_cfg4_share_32768_strings_of_32768_bytes(hra, oracle):
+    """BASELINE configs[3], one GPU's share: D = 3 header definitions (5 substrs), 32768 strings x 32768 bytes (1 GiB in, 15 GiB out)."""
+    from halo2_regex_amd import synth
+    from test_substr_gen import header_def_texts
+    texts = header_def_texts()
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in texts]
+    n, M, B = 32767, 32768, 32768
+    base_c, base_l = synth.headers_planted(4096, n, seed=3, stride=M)
+    parts = _rolled_blocks(base_c, base_l, B // 4096, seed=4)
+    chars = np.concatenate([c for c, _ in parts])
+    lens = np.concatenate([l for _, l in parts])
+    del parts
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    st = _full_check(hra, OracleDefs(oracle, texts), cfg, [(chars, lens)], M, 3, need_accept=0.9)
+    assert (st & np.uint64(0xff) == 0).all()
+
+
+def test_full_size_cfg5_dfa256_131072_strings_of_4096_bytes(hra, oracle):
+    """BASELINE configs[4] shape: 256-state x 256-symbol DFA (HALF table in LDS), 131072 x 4096-byte strings = 2 blocks; the random
+    substring definition makes the optimistic end-mask protocol repair rows every few tiles."""
+    from halo2_regex_amd import synth
+    allb = np.arange(256, dtype=np.uint8)
+    allstr, sub = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=200)
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(allstr), [hra.SubstrRegexDef(sub)])]
+    n, M = 4095, 4096
+    base_c, base_l = synth.noise(hra.PM_BLOCK, n, seed=2, alphabet=allb, stride=4096)
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    assert "witness_pm_kernel<1, false, false, true>" in cfg.describe_launch(131072, layout=3)
+    st = _full_check(hra, OracleDefs(oracle, [(allstr, [sub])]), cfg, _rolled_blocks(base_c, base_l, 2, seed=5), M, 1)
+    assert (st & np.uint64(0xff) == 0).all()
