@@ -68,12 +68,20 @@ struct Ast { NodeType type; uint16_t ch = 0; std::vector<int> parts; int sub = -
 struct Parser {
     std::vector<Ast> nodes;
     std::string err;
+    // parse_sub recurses twice per bracket level.  The reference's JS throws a catchable RangeError when its own stack runs out
+    // (V8: around 10^4 levels); this library promises integer status returns and nothing unwinding (include/hrx.h), so nesting
+    // beyond kMaxNesting levels is refused as a parse error instead of overflowing the native stack.
+    static constexpr int kMaxNesting = 2000;
+    int depth = 0;
+    struct DepthGuard { int &d; explicit DepthGuard(int &x) : d(x) { ++d; } ~DepthGuard() { --d; } };
 
     int add(const Ast &a) { nodes.push_back(a); return (int)nodes.size() - 1; }
     bool raw(const Tok &t, char c) const { return !t.lit && t.ch == (uint16_t)(uint8_t)c; }
 
     // parseSub(text.slice(lo,hi), begin, end, first); returns node index or -1 with err set
     int parse_sub(const std::vector<Tok> &t, size_t lo, size_t hi, size_t begin, bool first) {
+        DepthGuard guard(depth);
+        if (depth > 2 * kMaxNesting + 2) { err = "Error: brackets nested deeper than " + std::to_string(kMaxNesting) + " levels at " + std::to_string(begin) + "."; return -1; }
         const size_t len = hi - lo;
         if (len == 0) { err = "Error: empty input at " + std::to_string(begin) + "."; return -1; }
         std::vector<int> parts;

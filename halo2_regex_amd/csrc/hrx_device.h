@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "hrx_kernel.hpp"
 #include "hrx_lane.h"
@@ -66,8 +67,13 @@ __device__ __forceinline__ void ring_post(uint32_t off, uint32_t v) {
 
 // hipFuncSetAttribute costs several microseconds of host time: raise a kernel's dynamic-LDS limit only when a launch
 // needs more than every earlier launch of that kernel did (the launch path is otherwise one hipLaunchKernelGGL).
+// (Two shards of one device may race here — hrx_multi_* launches from one host thread per shard: the slow path is
+// serialised and re-checks, so `granted` never runs ahead of the attribute actually set.)
 template <class K>
 static hipError_t ensure_lds(K k, std::atomic<size_t> &granted, size_t need) {
+    if (need <= granted.load(std::memory_order_acquire)) return hipSuccess;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (need <= granted.load(std::memory_order_acquire)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
     if (e == hipSuccess) granted.store(need, std::memory_order_release);

@@ -15,7 +15,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     out.wide = 0;
     out.half = 0;
     // DFAs whose fused table leaves no room for the per-wave LDS areas are walked out of global memory (L2-resident)
-    const size_t min_stage = (a.layout & 1u) ? (2 * 4096 + 4096 + 16) : wave_stage_bytes((int)a.D, 16);
+    const size_t min_stage = (a.layout & 1u) ? pm_pair_bytes(2, false, true) : wave_stage_bytes((int)a.D, 16);
     if (a.table_bytes + min_stage > kLdsLimit || (a.debug & kDbgForceGlobalTable)) out.gtab = 1;
     const uint32_t table_bytes_saved = a.table_bytes;
     struct Restore { WitnessArgs &a; uint32_t v; ~Restore() { a.table_bytes = v; } } restore{a, table_bytes_saved};
@@ -27,7 +27,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
         for (; pairs >= 1; --pairs) {
             for (int ns = 4; ns >= 1; --ns) {
-                const size_t lds = a.half_bytes + (size_t)pairs * (ns * 4096 + 16);
+                const size_t lds = a.half_bytes + (size_t)pairs * pm_pair_bytes((size_t)ns, true, false);
                 if (lds > kLdsLimit) continue;
                 out.split = 2; out.gtab = 0; out.wide = 0; out.half = 1;
                 out.waves_per_wg = 2 * pairs;
@@ -105,19 +105,20 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
         for (; pairs >= 1; --pairs) {
             for (int ns = 4; ns >= 2; --ns) {
-                const size_t lds = a.table_bytes + (size_t)pairs * (ns * 4096 + 4096 + 16);
+                const size_t lds = a.table_bytes + (size_t)pairs * pm_pair_bytes((size_t)ns, false, (a.layout & 1u) != 0);   // position-major outputs: the loader finishes the tiles
                 if (lds > kLdsLimit) continue;
                 out.split = 2;
                 // WIDE table: ~4x fewer instructions per row at D = 3; every D >= 2 batch takes it (same-box A/B
                 // with spill-free kernels: 1.20 vs 1.33 ms at 262144 x 2048 B, D = 2; 3.48 vs 4.59 ms at 32768 x 32768 B, D = 3).
                 // D = 1 gains nothing: its walk is LDS-latency-bound either way.
                 out.wide = (a.wide_image && !out.gtab && !(a.debug & kDbgForceNarrow) && (a.D >= 2 || (a.debug & kDbgForceWide))) ? 1 : 0;
-                out.waves_per_wg = 2 * pairs;
+                const int wpp = (a.layout & 1u) ? 3 : 2;       // position-major outputs: walker + loader + finisher per pair (hrx_kernel_pm.hip)
+                out.waves_per_wg = wpp * pairs;
                 out.nslots = ns;
                 out.lds_bytes = lds;
                 const size_t need = ((size_t)a.n_groups + pairs - 1) / pairs;
                 size_t per_cu = kLdsLimit / lds;               // LDS
-                if (per_cu * (size_t)(2 * pairs) > 8) per_cu = 8 / (size_t)(2 * pairs);  // 2 waves per SIMD (VGPRs)
+                if (per_cu * (size_t)(wpp * pairs) > (size_t)(4 * wpp)) per_cu = (size_t)(4 * wpp) / (size_t)(wpp * pairs);  // one pair per SIMD (VGPRs)
                 if (per_cu < 1) per_cu = 1;
                 const size_t cap = (size_t)num_cus * per_cu;
                 out.grid = (int)(need < cap ? need : cap);

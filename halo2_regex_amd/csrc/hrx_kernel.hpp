@@ -111,6 +111,13 @@ hipError_t launch_witness_pm(const WitnessArgs &a, const LaunchInfo &li, hipStre
 hipError_t launch_witness_sm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);   // hrx_kernel_pmd.hip (split == 5)
 hipError_t launch_witness_pp(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);    // hrx_kernel_pp.hip (split == 6)
+// position-major loader/walker kernel (hrx_kernel_pm.hip): LDS bytes per walker/loader pair.  FIN = the loader also finishes
+// the tiles (reveal masks + masked rows) from a 6-KiB summary the walker hands over; not for the HALF table (a 256-state table
+// leaves no LDS for it) nor for string-major outputs.
+constexpr size_t kPmSummaryBytes = 6144;
+template <bool HALF, bool SM> constexpr bool kPmFinisher = !HALF && !SM;
+constexpr int pm_max_threads(bool half, bool sm) { return (!half && !sm) ? 768 : 512; }
+constexpr size_t pm_pair_bytes(size_t nring, bool half, bool fin) { return nring * 4096 + (half ? 0 : 4096) + (fin ? kPmSummaryBytes + 16 : 0) + 16; }
 constexpr size_t kPpSlotBytes = 8192;   // pair-step kernel: one ring slot = 4 KiB of pair indices + 4 KiB of raw bytes
 // LDS bytes per group of the def-parallel kernel: input ring + (D - 1) x (2 summaries of 5 KiB + a 2-KiB status piece) + counters
 constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 128; }

@@ -16,25 +16,42 @@ namespace hrx {
 // rewards: 6.5 TB/s vs 4.3-5.2 TB/s for the string-major comb (tools/fillprobe, tools/wpattern2).
 //
 // The walker's in-order vmcnt would make any wait for an input load also wait for every store issued before it, so
-// the walker issues no loads at all: a LOADER wave per walker streams the strings' bytes into an LDS ring with LDS-DMA
-// (global_load_lds_dwordx4: no VGPRs, kRing tiles in flight, counted s_waitcnt) and the walker picks its 64 bytes per
-// tile up with four ds_read_b128.
+// the walker issues no loads at all: a LOADER wave per walker streams the strings' bytes through its own registers (RT tiles
+// of 16 B per lane in flight, counted s_waitcnt) into an LDS ring and the walker picks its 64 bytes per tile up with four
+// ds_read_b128.
+//
+// FIN (every variant but HALF and the string-major one): a tile FINISHER wave.  In-kernel stamps
+// (tools/kbench, profiles/r02_probes/stamps_*.txt) show the walker, not the memory system, bounding the launch: per 64-row
+// tile ~5600 cycles of dependent chain + hidden VALU, ~1450 cycles of tile-end work (mask scans, masked-row assembly) that is
+// serial to the chain, and ~77 cycles of issue time for EVERY global store (24 per tile at D = 1; the same with all stores
+// aimed at one L2-resident line, so it is issue cost, not back-pressure).  Everything per tile that does not feed the chain
+// therefore moves to a third wave per pair, the FINISHER: the walker hands the tile's three bitvectors, its substr-id bytes
+// and the string's length over through LDS (96 B per lane, six ds_write_b128) and the finisher — which reads the tile's raw
+// bytes from the input ring slot (the loader re-uses a slot only after walker AND finisher are done with it) — runs the
+// reveal-mask scans (lib.rs:598-764), the fix-ups and the eight masked-row stores.  It issues no loads, so nothing it does
+// disturbs the loader's counted vmcnt waits.  The walker keeps the chain, the records and their stores, the error paths and
+// the status word.  Three waves per SIMD: 168 VGPRs each (the loader runs 8 instead of 12 tiles ahead).
 // =============================================================================================
 template <int D, bool GTAB, bool WIDE, bool HALF = false, bool SM = false>
-__global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
+__global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
+    constexpr bool FIN = kPmFinisher<HALF, SM>;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t pairs = blockDim.x >> 7;  // walker waves 0..pairs-1, loader waves pairs..2*pairs-1
-    const bool is_walker = wave < pairs;
-    const uint32_t pair = is_walker ? wave : wave - pairs;
+    const uint32_t pairs = (blockDim.x >> 6) / (FIN ? 3u : 2u);  // walker waves 0..pairs-1, loader waves pairs..2*pairs-1, FIN: finisher waves 2*pairs..3*pairs-1
+    const bool is_walker = wave < pairs, is_finisher = FIN && wave >= 2u * pairs;
+    const uint32_t pair = wave % pairs;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
-    // ring + the walker's 4-KiB scratch (HALF: none, its slow path re-walks out of registers) + counters
-    const uint32_t pair_bytes = nring * kPmTileBytes + (HALF ? 0u : kPmTileBytes) + 16u;
+    // ring + the walker's 4-KiB scratch (HALF: none, its slow path re-walks out of registers) + FIN: the 6-KiB tile summary
+    // + counters (hrx_kernel.hpp pm_pair_bytes: the planner budgets the same bytes)
+    const uint32_t pair_bytes = (uint32_t)pm_pair_bytes(nring, HALF, FIN);
     const uint32_t tab_bytes = GTAB ? 0u : HALF ? a.half_bytes : a.table_bytes;
     const uint32_t ring_base = tab_bytes + pair * pair_bytes;
     const uint32_t scratch_off = ring_base + nring * kPmTileBytes;
-    const uint32_t ready_off = scratch_off + (HALF ? 0u : kPmTileBytes), freed_off = ready_off + 4u;
+    const uint32_t sum_off = scratch_off + (HALF ? 0u : kPmTileBytes);
+    const uint32_t ready_off = sum_off + (FIN ? kPmSummaryBytes : 0u), freed_off = ready_off + 4u;
+    // FIN: freed2 = ring slots the finisher is done with; sum_ready / sum_freed = tile summaries written / consumed
+    const uint32_t freed2_off = ready_off + 8u, sum_ready_off = ready_off + 12u, sum_freed_off = ready_off + 16u;
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
     uint32_t seq = 0;
@@ -44,7 +61,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
     uint32_t first_len = M;   // ... and the walkers their first group's lengths
     if (is_walker && g_first < a.n_groups) first_len = a.lens[min(g_first * 64u + lane, B - 1u)];
     uint4 first_tile[4];
-    if (!is_walker && g_first < a.n_groups) {
+    if (!is_walker && !is_finisher && g_first < a.n_groups) {
         const bool in_pm0 = (a.layout & 2u) != 0;
         const uint32_t bl = min(g_first * 64u + lane, B - 1u);
         const uint32_t blk0 = (g_first * 64u / kPmBlock) * kPmBlock, nb0 = min(kPmBlock, B - blk0);   // this group's block (hrx_lane.h)
@@ -60,10 +77,79 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         if (!GTAB)
             for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) dst[i] = src[i];
-        if (is_walker && lane == 0) { lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0); }
+        if (is_walker && lane == 0) {
+            lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0);
+            if (FIN) { lds_store_u32(freed2_off, 0); lds_store_u32(sum_ready_off, 0); lds_store_u32(sum_freed_off, 0); }
+        }
     }
     __syncthreads();
 
+    if (is_finisher) {
+        // ================================ finisher (FIN) ================================
+        const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
+        const uint32_t total = my_groups * ntiles;
+        const size_t q8 = (M + 7u) / 8u;
+        const bool nt_msk = !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
+        MaskCarry mc = {0, 0, 0, 0};
+        uint32_t b0_f = 0, blk0_f = 0, nb_f = 0;
+        bool active_f = false;
+        unsigned char *mp_f = nullptr;
+        size_t mstep_f = 0;
+        for (uint32_t f = 0; f < total; ++f) {
+            const uint32_t tf = f % ntiles, t0 = tf << 6;
+            if (tf == 0u) {   // a new group: this lane's string
+                b0_f = (g_first + (f / ntiles) * g_stride) * 64u;
+                const uint32_t b = b0_f + lane;
+                active_f = b < B;
+                const uint32_t bc = active_f ? b : B - 1u;     // lanes beyond the batch shadow the last string (same values, same addresses)
+                blk0_f = (b0_f / kPmBlock) * kPmBlock; nb_f = min(kPmBlock, B - blk0_f);
+                mp_f = reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0_f * q8 + (bc - blk0_f)) * 16u;
+                mstep_f = (a.debug & kDbgFixedLines) ? (size_t)0 : (size_t)nb_f * 16u;
+                mc = MaskCarry{0, 0, 0, 0};
+            }
+            ring_wait(sum_ready_off, f + 1u);
+            const uint4 s0 = lds_u128(sum_off + lane * 16u), s1 = lds_u128(sum_off + 1024u + lane * 16u);
+            uint32_t sidq[16], cw[16];
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                const uint4 v = lds_u128(sum_off + 2048u + i * 1024u + lane * 16u);
+                sidq[4 * i] = v.x; sidq[4 * i + 1] = v.y; sidq[4 * i + 2] = v.z; sidq[4 * i + 3] = v.w;
+                const uint4 c = lds_u128(ring_base + (f % nring) * kPmTileBytes + i * 1024u + lane * 16u);
+                cw[4 * i] = c.x; cw[4 * i + 1] = c.y; cw[4 * i + 2] = c.z; cw[4 * i + 3] = c.w;
+            }
+            ring_post(sum_freed_off, f + 1u);   // (its release fence waits for the reads above)
+            lds_store_u32(freed2_off, f + 1u);
+            TileBits tb;
+            tb.st = (uint64_t)s0.x | ((uint64_t)s0.y << 32);
+            tb.en1 = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
+            tb.ch = (uint64_t)s1.x | ((uint64_t)s1.y << 32);
+            const uint32_t n_f = s1.z;          // the string's length (<= M; the walker clamps bad lengths)
+            // ---------------- reveal masks: lib.rs:598-764 ----------------
+            TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n_f, M), rows_below(t0, n_f));
+            if (!active_f) tm.fix = 0;
+            uint64_t fixm = __ballot(tm.fix != 0);
+            if (a.debug & kDbgSkipFixups) fixm = 0;
+            while (fixm) {   // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare with real definitions)
+                const int j = __ffsll((unsigned long long)fixm) - 1;
+                fixm &= fixm - 1;
+                const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
+                const uint32_t bj = b0_f + (uint32_t)j;
+                for (uint32_t r = fs + lane; r < t0; r += 64u)
+                    a.masked[((size_t)blk0_f * q8 + (size_t)(r >> 3) * nb_f + (bj - blk0_f)) * 8u + (r & 7u)] = 0;
+            }
+            // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8] (lib.rs:752-761) ----------------
+            const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
+            unsigned char *mp = mp_f + (size_t)tf * 8u * mstep_f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (mbyte) v = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);
+                if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_msk);
+            }
+        }
+        return;
+    }
     if (!is_walker) {
         // ================================ loader ================================
         // string-major input: string b at chars + b*stride; position-major input: 16-byte chunk i of string b at
@@ -75,7 +161,7 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
         // group's bytes are on their way long before the walker gets there.  It issues nothing but these loads, so the
         // counted s_waitcnt vmcnt(4*(RT-1)) for the oldest tile is exact.  Bytes at or beyond a string's length are
         // read (inside the string's own stride) but never trusted.
-        constexpr uint32_t RT = D == 1 ? 12u : 8u;
+        constexpr uint32_t RT = (D == 1 && !FIN) ? 12u : 8u;   // FIN: three waves per SIMD, 168 VGPRs each
         const bool in_pm = (a.layout & 2u) != 0;
         const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
         const uint32_t total = my_groups * ntiles;
@@ -115,7 +201,10 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
             for (uint32_t k = 0; k < RT; ++k) {
                 const uint32_t sq = s0 + k;
                 if (sq < total && sq != 0u) {
-                    if (sq >= nring) ring_wait(freed_off, sq - nring + 1u);  // the walker has read this slot
+                    if (sq >= nring) {
+                        ring_wait(freed_off, sq - nring + 1u);                // the walker has read this slot
+                        if (FIN) ring_wait(freed2_off, sq - nring + 1u);      // ... and the finisher its raw bytes
+                    }
                     const uint32_t slot = ring_base + (sq % nring) * kPmTileBytes;
                     // tile sq was requested RT tiles ago; RT-1 younger tiles (4 loads each) may still be in flight
                     if (sq + RT <= total) {
@@ -352,6 +441,17 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                         acc_state[d] = HALF ? (L.e[d] & 0xffu) - a.dc[d].half_row_base
                                             : (WIDE ? ((L.e[d] >> kWideRowShift) & 0xffu) : (L.e[d] >> kNextShift)) - a.dc[d].row_base;
                 }
+                if constexpr (FIN) {
+                    // ---------------- hand the tile over to the finisher wave: bitvectors, substr-id bytes, the string's length ----------------
+                    ring_wait(sum_freed_off, seq);   // it has consumed the previous tile's summary (one summary area per pair)
+                    typedef __attribute__((address_space(3))) v4u32 lds_v4u32;
+                    *(lds_v4u32 *)(uintptr_t)(sum_off + lane * 16u) = v4u32{(uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32)};
+                    *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{(uint32_t)tb.ch, (uint32_t)(tb.ch >> 32), n, 0u};
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i)
+                        *(lds_v4u32 *)(uintptr_t)(sum_off + 2048u + i * 1024u + lane * 16u) = v4u32{sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]};
+                    ring_post(sum_ready_off, seq + 1u);
+                } else {
                 // ---------------- reveal masks: lib.rs:598-764 ----------------
                 TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
                 if (!active) tm.fix = 0;   // (tm.mask stays: a shadow lane stores the same masked rows as string B - 1)
@@ -387,8 +487,9 @@ __global__ __launch_bounds__(512) void witness_pm_kernel(const WitnessArgs a, co
                     mp += 8u * mstep;
                     have_pend = (D == 1);
                 }
+                }
 #ifdef HRX_STAMPS
-                asm volatile("" : "+v"(pend[0].x), "+v"(pend[7].w));
+                if (!FIN) asm volatile("" : "+v"(pend[0].x), "+v"(pend[7].w));
                 const unsigned long long tk_d = clock64();
                 tk_wait += tk_b - tk_a; tk_walk += tk_c - tk_b; tk_end += tk_d - tk_c;
 #endif

@@ -133,13 +133,13 @@ def test_planner_picks_the_documented_kernel_per_config():
     """hrx_describe_launch (host-only): which kernel and table format serve which shape on a 256-CU MI355X."""
     from halo2_regex_amd import synth
     cfg = RegexVerifyConfig.configure(1024, _defs(CFG_A[:1]), device=None)
-    assert cfg.describe_launch(65536, layout=3).startswith("hrx::witness_pm_kernel<1, false, false, false> grid=256 waves=8 ring=4 ")   # a full chip: memory-bound, one byte per lookup
+    assert cfg.describe_launch(65536, layout=3).startswith("hrx::witness_pm_kernel<1, false, false, false> grid=256 waves=12 ring=4 ")   # a full chip: one byte per lookup; walker + loader + finisher wave per pair
     assert cfg.describe_launch(32768, layout=3).startswith("hrx::witness_pp_kernel grid=256 waves=4 ")     # walker slots left empty: one def, 18 byte classes -> the pair-step table (76 KiB), two bytes per lookup
     assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_split_kernel<1, 32> ")
     cfg = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
     assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pmd_kernel<2> grid=256 waves=6 ")       # <= 2 groups per CU: one walker per def
     assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> ")     # D >= 2: the WIDE table
-    assert cfg.describe_launch(1 << 20, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> grid=256 waves=8 ")
+    assert cfg.describe_launch(1 << 20, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> grid=256 waves=12 ")
     cfg3 = RegexVerifyConfig.configure(1024, _defs(CFG_A + CFG_3), device=None)
     assert cfg3.describe_launch(65536, layout=0).startswith("hrx::witness_pm_kernel<3, false, true, false, true> ")   # string-major D = 3: lane-direct stores
     assert RegexVerifyConfig.configure(1001, _defs(CFG_A + CFG_3), device=None).describe_launch(65536, layout=0).startswith("hrx::witness_kernel<3, false, false> ")

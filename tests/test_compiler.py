@@ -58,3 +58,13 @@ def test_compiled_definition_feeds_the_defs_parser():
 def test_lone_trailing_backslash_is_rejected():
     with pytest.raises(hra.HrxError):
         hra.regex_to_allstr_text("ab\\")
+
+
+def test_deep_nesting_is_a_parse_error_not_a_crash():
+    """the reference's JS throws a catchable error when its stack runs out; the library returns HRX_ERR_PARSE (include/hrx.h:
+    integer status returns, nothing unwinds) instead of overflowing the native stack"""
+    assert hra.regex_to_allstr_text("(" * 1500 + "a" + ")" * 1500).startswith("0\n")
+    for n in (2500, 200000):
+        with pytest.raises(hra.HrxError) as e:
+            hra.regex_to_allstr_text("(" * n + "a" + ")" * n)
+        assert e.value.code == hra.HRX_ERR_PARSE and "nested deeper" in str(e.value)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# One bench line per BASELINE config shape (per-GPU sizes) -> gpurun_out/r01_config_sweep/*.json; copied to profiles/r01_config_sweep/.
-cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r01_config_sweep; rm -rf $O; mkdir -p $O
+# One bench line per BASELINE config shape (per-GPU sizes) -> gpurun_out/r02_config_sweep/*.json; copied to profiles/r02_config_sweep/.
+cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r02_config_sweep; rm -rf $O; mkdir -p $O
 B="python bench.py --no-cpu-baseline"
 $B                                                                                   > $O/cfg2_regex1_65536x1024.json
 $B --layout string-major                                                             > $O/cfg2_regex1_65536x1024_string_major.json
@@ -15,4 +15,4 @@ $B --config dfa256 --len 4095 --rows 4096 --steps 20 --warmup 3                 
 $B --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 10 --warmup 3       > $O/cfg5_dfa256_131072x4096.json
 $B --config dfa256 --len 4095 --rows 4096 --steps 20 --warmup 3 --layout string-major > $O/cfg5_dfa256_65536x4096_string_major.json
 $B --batch 8192 --len 32767 --rows 32768 --steps 10 --warmup 2                       > $O/regex1_8192x32768_long.json
-for f in $O/*.json; do python -c "import sys,json; d=json.loads(open('$f').read()); r=d['roofline']; print('%-48s %8.3f ms  %.3e rows/s  frac %.3f  copy-ceil %.0f  %s' % ('$(basename $f .json)', d['ms_per_step'], d['value'], r['frac'], r.get('measured_copy_ceiling', 0), r['kernel']))"; done
+for f in $O/*.json; do python -c "import sys,json; d=json.loads(open('$f').read()); r=d['roofline']; print('%-48s %8.3f ms  %.3e rows/s  frac %.3f  copy-ceil %.0f  %s' % ('$(basename $f .json)', d['ms_per_step'], d['value'], r['frac'], 0, r['kernel']))"; done

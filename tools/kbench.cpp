@@ -92,7 +92,7 @@ int main(int argc, char **argv) {
         const int reps = 20;
         for (int i = 0; i < reps; ++i) CK(launch_witness(a, li, 0));
         CK(hipDeviceSynchronize());
-        const size_t units = (size_t)li.grid * (li.waves_per_wg / 2);
+        const size_t units = (size_t)li.grid * (((a.layout & 1u) && !li.half) ? li.waves_per_wg / 3 : li.waves_per_wg / 2);   // pairs per workgroup (walker + loader + finisher)
         std::vector<unsigned long long> st(units * 4);
         CK(hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
         double w = 0, k = 0, e = 0, g = 0, gmax = 0;
