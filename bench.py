@@ -325,7 +325,7 @@ def pmc_traffic(args):
     WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect counters
     itself; None unless the committed passes were taken on the workload and kernel being run."""
     try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r02_pp_pmc.json" if args.layout == "position-major" else "r01_split_pmc.json")))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r02_pm_pmc.json" if args.layout == "position-major" else "r01_split_pmc.json")))
         if (args.config == "regex1" and args.batch == 65536 and args.n == 1023 and args.rows == 1024 and args.dist == "planted"
                 and not args.dense):
             return p["hbm_bytes_per_launch"]["total"]

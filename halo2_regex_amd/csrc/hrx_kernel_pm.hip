@@ -35,6 +35,9 @@ namespace hrx {
 template <int D, bool GTAB, bool WIDE, bool HALF = false, bool SM = false>
 __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
     constexpr bool FIN = kPmFinisher<HALF, SM>;
+#ifdef HRX_STAMPS
+    const unsigned long long wall_entry = wall_clock64();   // 100 MHz, the same clock on every CU
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t pairs = (blockDim.x >> 6) / (FIN ? 3u : 2u);  // walker waves 0..pairs-1, loader waves pairs..2*pairs-1, FIN: finisher waves 2*pairs..3*pairs-1
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
 
 #ifdef HRX_STAMPS   // tools/kbench only: s_memtime ticks this walker spent waiting for input / walking / in the tile-end work
             unsigned long long tk_wait = 0, tk_walk = 0, tk_end = 0;
-            const unsigned long long tk_group = clock64();
+            const unsigned long long tk_group = clock64(), wall_start = wall_clock64();
 #endif
             for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
                 const uint32_t t0 = t << 6;
@@ -496,8 +499,10 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             }
 #ifdef HRX_STAMPS
             if (a.stamps && lane == 0) {
-                unsigned long long *o = a.stamps + (size_t)(blockIdx.x * pairs + pair) * 4u;
+                unsigned long long *o = a.stamps + (size_t)(blockIdx.x * pairs + pair) * 8u;
                 o[0] += tk_wait; o[1] += tk_walk; o[2] += tk_end; o[3] += clock64() - tk_group;
+                if (g == g_first) { o[4] = wall_entry; o[5] = wall_start; }
+                o[6] = wall_clock64();
             }
 #endif
             // the last tile's masked rows (only the octets that exist: [ceil(M/8)][B][8])

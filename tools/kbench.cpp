@@ -6,6 +6,7 @@
 // dumps the per-tile s_memtime stamps of a few waves (walk / epilogue / store phases).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -90,16 +91,24 @@ int main(int argc, char **argv) {
         CK(hipMemset(d_stamps, 0, nw * ntiles * 128));
         a.stamps = d_stamps;
         const int reps = 20;
+        const size_t units = (size_t)li.grid * (((a.layout & 1u) && !li.half) ? li.waves_per_wg / 3 : li.waves_per_wg / 2);   // pairs per workgroup (walker + loader + finisher)
         for (int i = 0; i < reps; ++i) CK(launch_witness(a, li, 0));
         CK(hipDeviceSynchronize());
-        const size_t units = (size_t)li.grid * (((a.layout & 1u) && !li.half) ? li.waves_per_wg / 3 : li.waves_per_wg / 2);   // pairs per workgroup (walker + loader + finisher)
-        std::vector<unsigned long long> st(units * 4);
+        std::vector<unsigned long long> st(units * 8);
         CK(hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
         double w = 0, k = 0, e = 0, g = 0, gmax = 0;
-        for (size_t u = 0; u < units; ++u) { w += st[u * 4]; k += st[u * 4 + 1]; e += st[u * 4 + 2]; g += st[u * 4 + 3]; if (st[u * 4 + 3] > gmax) gmax = st[u * 4 + 3]; }
+        for (size_t u = 0; u < units; ++u) { w += st[u * 8]; k += st[u * 8 + 1]; e += st[u * 8 + 2]; g += st[u * 8 + 3]; if (st[u * 8 + 3] > gmax) gmax = st[u * 8 + 3]; }
         const double per = (double)units * reps * ntiles;
         printf("position-major walker, mean s_memtime ticks per 64-row tile: input wait %.0f, walk %.0f, tile end %.0f; per launch and walker: %.0f ticks in its groups (max %.0f)\n",
                w / per, k / per, e / per, g / units / reps, gmax / reps);
+        // timeline of the LAST launch on the 100-MHz wall clock: workgroup entry, walker start (after the table staging), walker end
+        unsigned long long e0 = ~0ull, e1 = 0, s1 = 0, x0 = ~0ull, x1 = 0; double pro = 0;
+        for (size_t u = 0; u < units; ++u) {
+            const unsigned long long en = st[u * 8 + 4], sr = st[u * 8 + 5], ex = st[u * 8 + 6];
+            e0 = std::min(e0, en); e1 = std::max(e1, en); s1 = std::max(s1, sr); x0 = std::min(x0, ex); x1 = std::max(x1, ex); pro += (double)(sr - en);
+        }
+        printf("last launch, us after the first workgroup's entry: last workgroup enters %.2f, mean staging %.2f, last walker starts %.2f, first walker done %.2f, last walker done %.2f\n",
+               (e1 - e0) / 100.0, pro / units / 100.0, (s1 - e0) / 100.0, (x0 - e0) / 100.0, (x1 - e0) / 100.0);
     } else if (want_stamps) {
         a.stamps = d_stamps;
         CK(launch_witness(a, li, 0)); CK(hipDeviceSynchronize());
