@@ -21,10 +21,10 @@ namespace hrx {
 // ds_read_b128.
 //
 // FIN (every variant but HALF and the string-major one): a tile FINISHER wave.  In-kernel stamps
-// (tools/kbench, profiles/r02_probes/stamps_*.txt) show the walker, not the memory system, bounding the launch: per 64-row
-// tile ~5600 cycles of dependent chain + hidden VALU, ~1450 cycles of tile-end work (mask scans, masked-row assembly) that is
-// serial to the chain, and ~77 cycles of issue time for EVERY global store (24 per tile at D = 1; the same with all stores
-// aimed at one L2-resident line, so it is issue cost, not back-pressure).  Everything per tile that does not feed the chain
+// (tools/kbench, profiles/r02_probes/stamps_*.txt) show the walker pacing the launch: per 64-row tile ~5500 cycles of
+// dependent chain + hidden VALU with all stores skipped, ~2200 more with the stores in (the same for 16 and for 24 store
+// instructions per tile: the wave is held by the write path's back-pressure), and ~1450 cycles of tile-end work (mask scans,
+// masked-row assembly) that is serial to the chain.  Everything per tile that does not feed the chain
 // therefore moves to a third wave per pair, the FINISHER: the walker hands the tile's three bitvectors, its substr-id bytes
 // and the string's length over through LDS (96 B per lane, six ds_write_b128) and the finisher — which reads the tile's raw
 // bytes from the input ring slot (the loader re-uses a slot only after walker AND finisher are done with it) — runs the
