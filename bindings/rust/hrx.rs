@@ -8,6 +8,9 @@ use std::ffi::{c_char, c_int, c_void, CStr};
 #[repr(C)] pub struct hrx_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct hrx_multi { _p: [u8; 0] }
 
+pub const HRX_DEVICE_NONE: c_int = -1;
+pub const HRX_MAX_DEFS: usize = 32;   // RegexDefs per config (more than three are walked in passes)
+
 #[link(name = "hrx")]
 extern "C" {
     pub fn hrx_defs_create(out: *mut *mut hrx_defs) -> c_int;
@@ -30,6 +33,32 @@ extern "C" {
     pub fn hrx_multi_destroy(m: *mut hrx_multi);
     pub fn hrx_multi_witness_batch_host(m: *mut hrx_multi, chars: *const u8, stride: usize, lens: *const u32, b: usize, max_chars_size: usize,
                                         records: *mut u32, masked: *mut u16, status: *mut u64) -> c_int;
+    /// device-resident shards: one set of DEVICE pointers per shard (on hrx_multi_shard_device(m, r)), one kernel per shard on
+    /// its own stream, asynchronous; hrx_multi_synchronize waits.  No PCIe traffic, no collective.
+    pub fn hrx_multi_num_shards(m: *const hrx_multi) -> c_int;
+    pub fn hrx_multi_shard_device(m: *const hrx_multi, shard: c_int) -> c_int;
+    pub fn hrx_multi_witness_batch_device(m: *mut hrx_multi, layout: c_int, chars: *const *const u8, stride: usize, lens: *const *const u32,
+                                          counts: *const usize, max_chars_size: usize, records: *const *mut u32, masked: *const *mut u16,
+                                          status: *const *mut u64) -> c_int;
+    pub fn hrx_multi_synchronize(m: *mut hrx_multi) -> c_int;
+    pub fn hrx_shard_range(b: usize, world: c_int, rank: c_int, begin: *mut usize, count: *mut usize);
+    /// position-major layouts (HRX_LAYOUT_POSITION_MAJOR = 1, | HRX_LAYOUT_INPUT_POSITION_MAJOR = 2): the coalesced fast path
+    pub fn hrx_witness_batch_device_layout(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, lens: *const u32, b: usize,
+                                           m: usize, records: *mut u32, masked: *mut u16, status: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn hrx_position_major_sizes(b: usize, m: usize, d: usize, n_records_u32: *mut usize, n_masked_u16: *mut usize);
+    /// device = HRX_DEVICE_NONE (-1): a host-only context (the native small-batch walk; no GPU needed)
+    pub fn hrx_device_count(count: *mut c_int) -> c_int;
+    pub fn hrx_ctx_device(ctx: *const hrx_ctx) -> c_int;
+    /// host-buffer batches of fewer than `rows` witness rows (B x M) take the native host walk (default 32768)
+    pub fn hrx_ctx_set_host_threshold(ctx: *mut hrx_ctx, rows: usize) -> c_int;
+    pub fn hrx_ctx_host_threshold(ctx: *const hrx_ctx) -> usize;
+    /// match_substrs' integer columns for one string (lib.rs:311-773); any pointer may be null
+    pub fn hrx_match_substrs(ctx: *mut hrx_ctx, characters: *const u8, n: usize, m: usize, enable: *mut u64, character: *mut u64,
+                             state: *mut u64, substr_id: *mut u64, start_enable: *mut u64, end_enable: *mut u64,
+                             masked_char: *mut u64, masked_substr_id: *mut u64, status: *mut u64) -> c_int;
+    /// RegexTableConfig::load rows (table.rs:61-198): two-call pattern, returns the row count
+    pub fn hrx_table_transition_rows(defs: *const hrx_defs, def: usize, rows4: *mut u64, cap_rows: usize) -> usize;
+    pub fn hrx_table_endpoint_rows(defs: *const hrx_defs, def: usize, rows3: *mut u64, cap_rows: usize) -> usize;
     /// compact rows -> bn256::Fr cells ([4 + 4 D][b_count][M][4 x u64], Montgomery form; flags 1 = canonical)
     pub fn hrx_fr_columns_device(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, lens: *const u32,
                                  records: *const u32, rec_pitch: usize, masked: *const u16, msk_pitch: usize, b: usize, m: usize,
