@@ -102,6 +102,9 @@ struct hrx_ctx {
     };
     std::vector<GroupDev> groups;
     DevBuf mp_masked;
+#ifdef HRX_STAMPS
+    DevBuf stamps;                  // tools-only build: 8 u64 per walker pair of the position-major kernel (hrx_kernel_pm.hip)
+#endif
     hipEvent_t mp_done = nullptr;   // the last combine launch: the group buffers are free again once it has run
     bool mp_pending = false;
 };
@@ -401,6 +404,17 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = set.consts[d];
         LaunchInfo li;
         if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+#if defined(HRX_STAMPS) || defined(HRX_ABLATION)
+        if (const char *pe = std::getenv("HRX_PACE")) a.pace_even = (uint32_t)std::strtoul(pe, nullptr, 0);
+#endif
+#ifdef HRX_STAMPS
+        if (li.split == 2) {
+            const size_t bytes = (size_t)li.grid * 8 * 8 * 8;
+            if (ctx->stamps.cap < bytes) { HIP_TRY(ctx->stamps.reserve(bytes)); }
+            HIP_TRY(hipMemsetAsync(ctx->stamps.p, 0, bytes, st));
+            a.stamps = (unsigned long long *)ctx->stamps.p;
+        }
+#endif
         HIP_TRY(launch_witness(a, li, st));
         return HRX_OK;
     };
@@ -437,6 +451,19 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     ctx->mp_pending = true;
     return HRX_OK;
 }
+
+#ifdef HRX_STAMPS
+// tools only (libhrx_stamps.so): the stamps of the LAST position-major launch of this context, 8 u64 per walker pair
+int hrx_debug_read_stamps(hrx_ctx *ctx, unsigned long long *out, size_t n_u64) {
+    if (!ctx || !out) return HRX_ERR_ARG;
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = n_u64 * 8 < ctx->stamps.cap ? n_u64 * 8 : ctx->stamps.cap;
+    HIP_TRY(hipMemcpy(out, ctx->stamps.p, n, hipMemcpyDeviceToHost));
+    return HRX_OK;
+}
+#endif
 
 int hrx_witness_batch_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                              uint32_t *records, uint16_t *masked, uint64_t *status, void *stream) {

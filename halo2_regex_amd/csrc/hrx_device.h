@@ -55,6 +55,25 @@ __device__ __forceinline__ uint32_t lds_vol_u32(uint32_t off) { return *(volatil
 __device__ __forceinline__ void lds_store_u32(uint32_t off, uint32_t v) {
     *(volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)off = v;
 }
+// Workgroup -> slot in the launch's sequence of string groups.  Workgroups are dealt to the 8 XCDs round-robin, so with
+// slot = workgroup index (the default) an XCD's walkers write the 4-KiB pieces of each position-major slab at byte offsets
+// (4 KiB x XCD) mod 32 KiB.  In-kernel stamps (tools/state_probe4.py, profiles/r02_probes/xcd_*.txt) show the walkers of
+// ODD workgroups finishing 5 us (fast per-process state) to 11 us (slow state) after those of even ones, launch after launch.
+// kDbgXcdRemap deals each XCD a CONTIGUOUS eighth of the slots instead (its traffic = a contiguous eighth of every slab,
+// spread evenly over all HBM stacks): the lag stays — it is not about which addresses an XCD writes — and the launch is
+// 1.5 % slower (79.4 vs 78.1 us, six alternations over fresh processes), so it is off by default.  Needs gridDim.x % 8 == 0.
+__device__ __forceinline__ uint32_t xcd_slot(const uint32_t wg, const uint32_t nwg, const bool remap) {
+    return (remap && (nwg & 7u) == 0u) ? (wg & 7u) * (nwg >> 3) + (wg >> 3) : wg;
+}
+
+// 16 bytes per lane as a streaming (non-temporal) store: for output that is written once, in full lines, and never read
+// by the kernel.  Inline asm on purpose (see hrx_walk_pm.h store16: LLVM merges an `if (nt)` diamond of a non-temporal and
+// a plain store into one plain store); s_nop 1 = the two wait states a > 64-bit VMEM store needs on gfx940+ before a VALU
+// may overwrite its data registers.
+__device__ __forceinline__ void store16_nt(void *p, const uint4 &v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v4u32{v.x, v.y, v.z, v.w}) : "memory");
+}
+
 // wait until the tile counter at LDS offset `off` reaches `want`
 __device__ __forceinline__ void ring_wait(uint32_t off, uint32_t want) {
     while ((int32_t)(lds_vol_u32(off) - want) < 0) __builtin_amdgcn_s_sleep(1);

@@ -33,6 +33,7 @@ struct WitnessArgs {
     uint32_t D;
     uint32_t debug;               // the context's kDbg* bits below (forced kernel / table choices for the tests; ablations only with -DHRX_ABLATION)
     unsigned long long *stamps;   // profiling only (tools/kbench): per wave and tile 4 s_memtime stamps; NULL in the product
+    uint32_t pace_even;           // profiling only (HRX_PACE, stamps / ablation builds): x 64 idle cycles per tile for the walkers of even workgroups; 0 in the product
     DefConsts dc[kMaxDefsPerLaunch];
 };
 
@@ -71,11 +72,12 @@ enum : uint32_t {
     kDbgForceDefParallel = 0x4000000u,// position-major, D >= 2, WIDE table: the def-parallel kernel whatever the batch size (tests)
     kDbgNoPair = 0x8000000u,          // position-major, D = 1: never the pair-step kernel (hrx_kernel_pp.hip)
     kDbgForcePair = 0x40000000u,      // position-major, D = 1 with a PAIR table: the pair-step kernel whatever the batch size (tests, A/B)
+    kDbgXcdRemap = 0x100000u,         // position-major kernels: every XCD walks a CONTIGUOUS eighth of the groups (hrx_device.h xcd_slot; measured 1.5 % slower, off by default)
     kDbgForceHost = 0x10000000u,      // host-buffer entry points: always the native host walk (hrx_host_walk.cpp)
     kDbgNoHost = 0x20000000u,         // host-buffer entry points: never the native host walk
     // every bit that merely selects a kernel (the only ones a release build honours)
     kDbgForceMask = kDbgForceOneWave | kDbgGroups32 | kDbgForceGlobalTable | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf |
-                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForcePair | kDbgForceHost | kDbgNoHost,
+                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForcePair | kDbgXcdRemap | kDbgForceHost | kDbgNoHost,
 #ifdef HRX_ABLATION
     kDbgHonoured = 0xffffffffu,
 #else

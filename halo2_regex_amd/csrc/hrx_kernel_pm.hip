@@ -58,7 +58,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
     uint32_t seq = 0;
-    const uint32_t g_first = blockIdx.x * pairs + pair, g_stride = gridDim.x * pairs;
+    const uint32_t g_first = xcd_slot(blockIdx.x, gridDim.x, (a.debug & kDbgXcdRemap) != 0) * pairs + pair, g_stride = gridDim.x * pairs;
     // The loaders request their pair's first input tile BEFORE the table is staged: the HBM round trip (~2 us) then runs
     // under the staging instead of after it.
     uint32_t first_len = M;   // ... and the walkers their first group's lengths
@@ -286,6 +286,10 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
                 const uint32_t t0 = t << 6;
                 const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
+#if defined(HRX_STAMPS) || defined(HRX_ABLATION)
+                if (a.pace_even && !(blockIdx.x & 1u))   // profiling only: hold the walkers of the even workgroups (= even XCDs) back
+                    for (uint32_t i = 0; i < a.pace_even; ++i) __builtin_amdgcn_s_sleep(1);
+#endif
 #ifdef HRX_STAMPS
                 const unsigned long long tk_a = clock64();
 #endif

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
     uint32_t seq = 0;
-    const uint32_t g_first = blockIdx.x * pairs + pair, g_stride = gridDim.x * pairs;
+    const uint32_t g_first = xcd_slot(blockIdx.x, gridDim.x, (a.debug & kDbgXcdRemap) != 0) * pairs + pair, g_stride = gridDim.x * pairs;
     // the loaders request their pair's first input tile, the walkers their first lengths, BEFORE the table is staged
     uint32_t first_len = M;
     if (is_walker && g_first < a.n_groups) first_len = a.lens[min(g_first * 64u + lane, B - 1u)];

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                             if (it0 + i < nit) v[i] = lds_u128(lds_a + (it0 + i) * (SPI * RSB));
 #pragma unroll
                         for (uint32_t i = 0; i < 8u; ++i) {
-                            if (it0 + i < nit) *reinterpret_cast<uint4 *>(gp) = v[i];
+                            if (it0 + i < nit) { if (a.debug & kDbgNoNtStores) *reinterpret_cast<uint4 *>(gp) = v[i]; else store16_nt(gp, v[i]); }   // full lines, written once
                             gp += gstep;
                         }
                     }
@@ -350,12 +350,12 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
                 if (!(a.debug & kDbgSkipMasked)) {
                     if (!any_mask) {
                         for (uint32_t it = 0; it < GS / 8u; ++it) {
-                            *reinterpret_cast<uint4 *>(mp) = make_uint4(0, 0, 0, 0);
+                            store16_nt(mp, make_uint4(0, 0, 0, 0));
                             mp += mstep;
                         }
                     } else {
                         for (uint32_t it = 0; it < GS / 8u; ++it) {
-                            *reinterpret_cast<uint4 *>(mp) = masked_chunk<D>(it * 8u + mj0, mw, rec_base, chr_base, mb_base);
+                            store16_nt(mp, masked_chunk<D>(it * 8u + mj0, mw, rec_base, chr_base, mb_base));
                             mp += mstep;
                         }
                     }
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                     if (!(a.debug & kDbgSkipRecords)) {
 #pragma unroll
                         for (uint32_t it = 0; it < 8u; ++it) {
-                            if (whole || (b0 + it * 8u + js0 < a.B && w < lim)) *reinterpret_cast<uint4 *>(gp) = v[it];
+                            if (whole || (b0 + it * 8u + js0 < a.B && w < lim)) { if (a.debug & kDbgNoNtStores) *reinterpret_cast<uint4 *>(gp) = v[it]; else store16_nt(gp, v[it]); }   // full 128-byte lines, 8 strings per instruction
                             gp += gstep;
                         }
                     }
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                     const bool blk_whole = (b0 + 64u <= a.B) && (blk0 + kBlk <= M);
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
-                        if (blk_whole || (b0 + (uint32_t)it * 8u + mj0 < a.B && blk0 + mw * 8u < M)) *reinterpret_cast<uint4 *>(mp) = mk[it];
+                        if (blk_whole || (b0 + (uint32_t)it * 8u + mj0 < a.B && blk0 + mw * 8u < M)) { if (a.debug & kDbgNoNtStores) *reinterpret_cast<uint4 *>(mp) = mk[it]; else store16_nt(mp, mk[it]); }
                         mp += mstep;
                     }
                 }

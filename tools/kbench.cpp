@@ -107,6 +107,23 @@ int main(int argc, char **argv) {
             const unsigned long long en = st[u * 8 + 4], sr = st[u * 8 + 5], ex = st[u * 8 + 6];
             e0 = std::min(e0, en); e1 = std::max(e1, en); s1 = std::max(s1, sr); x0 = std::min(x0, ex); x1 = std::max(x1, ex); pro += (double)(sr - en);
         }
+        {   // who finishes late?  mean walker-done time by workgroup index mod 8 (the XCD a workgroup lands on, round-robin) and by pair
+            const size_t pw = units / (size_t)li.grid;
+            double xs[8] = {0}, ps[8] = {0}; size_t xn[8] = {0}, pn[8] = {0};
+            for (size_t u = 0; u < units; ++u) {
+                const double t = (double)(st[u * 8 + 6] - e0) / 100.0;
+                xs[(u / pw) % 8] += t; xn[(u / pw) % 8]++; ps[u % pw] += t; pn[u % pw]++;
+            }
+            printf("mean walker-done us by workgroup %% 8:");
+            for (int x = 0; x < 8; ++x) printf(" %.1f", xs[x] / (xn[x] ? xn[x] : 1));
+            printf("; by pair:");
+            for (size_t q = 0; q < pw && q < 8; ++q) printf(" %.1f", ps[q] / (pn[q] ? pn[q] : 1));
+            printf("\n  per workgroup (mean of its pairs), 32 per line:\n");
+            for (size_t w = 0; w < (size_t)li.grid; ++w) {
+                double t = 0; for (size_t q = 0; q < pw; ++q) t += (double)(st[(w * pw + q) * 8 + 6] - e0) / 100.0;
+                printf(" %.0f", t / pw); if (w % 32 == 31) printf("\n");
+            }
+        }
         printf("last launch, us after the first workgroup's entry: last workgroup enters %.2f, mean staging %.2f, last walker starts %.2f, first walker done %.2f, last walker done %.2f\n",
                (e1 - e0) / 100.0, pro / units / 100.0, (s1 - e0) / 100.0, (x0 - e0) / 100.0, (x1 - e0) / 100.0);
     } else if (want_stamps) {
