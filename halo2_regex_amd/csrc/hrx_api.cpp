@@ -102,11 +102,17 @@ struct hrx_ctx {
     };
     std::vector<GroupDev> groups;
     DevBuf mp_masked;
+    // dynamic group assignment (hrx_kernel_pm.hip): a device counter, zeroed on the launch's stream right before the launch
+    // (a memset node when the launches are captured into a HIP graph: replay-safe)
+    uint32_t *d_group_counter = nullptr;
+    // context-owned device scratch (the counter above, the group buffers of multi-pass configs) is shared by the launches of this
+    // context: they must not overlap.  Launches on ONE stream are ordered anyway; a launch on another stream first waits (on the
+    // host) for the stream that used the scratch last.  No events: these calls must stay legal inside a stream capture.
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
 #ifdef HRX_STAMPS
     DevBuf stamps;                  // tools-only build: 8 u64 per walker pair of the position-major kernel (hrx_kernel_pm.hip)
 #endif
-    hipEvent_t mp_done = nullptr;   // the last combine launch: the group buffers are free again once it has run
-    bool mp_pending = false;
 };
 
 // device copies of one DefsSet's kernel-side images
@@ -293,13 +299,15 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     c->num_cus = prop.multiProcessorCount;
     c->debug = debug_flags_from_env();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_group_counter, 64);
+    if (e == hipSuccess) e = hipMemset(c->d_group_counter, 0, 64);
+
     if (c->s.groups.empty()) {
         if (e == hipSuccess) e = upload_images(c->s, c->d_table, c->d_wide, c->d_half, c->d_pairtab);
     } else {   // multi-pass: the kernels only ever see a group's images
         c->groups.resize(c->s.groups.size());
         for (size_t g = 0; e == hipSuccess && g < c->s.groups.size(); ++g)
             e = upload_images(c->s.groups[g], c->groups[g].d_table, c->groups[g].d_wide, c->groups[g].d_half, c->groups[g].d_pairtab);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->mp_done, hipEventDisableTiming);
     }
     for (size_t d = 0; e == hipSuccess && d < c->s.pair_tags.size(); ++d) {
         uint16_t *p = nullptr;
@@ -352,7 +360,10 @@ void hrx_ctx_destroy(hrx_ctx *c) {
         g.records.release(); g.status.release();
     }
     c->mp_masked.release();
-    if (c->mp_done) { (void)hipEventSynchronize(c->mp_done); (void)hipEventDestroy(c->mp_done); }
+    if (c->d_group_counter) (void)hipFree(c->d_group_counter);
+#ifdef HRX_STAMPS
+    c->stamps.release();
+#endif
     for (uint16_t *p : c->d_pair) (void)hipFree(p);
     for (uint8_t *p : c->d_member) (void)hipFree(p);
     c->chars.release(); c->lens.release(); c->records.release(); c->masked.release();
@@ -404,6 +415,15 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = set.consts[d];
         LaunchInfo li;
         if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+        if (li.dyn) {   // launches that share the counter must not overlap: a launch on another stream waits for the previous one
+            if (ctx->scratch_used && ctx->scratch_stream != st) (void)hipStreamSynchronize(ctx->scratch_stream);
+            ctx->scratch_stream = st; ctx->scratch_used = true;
+            const uint32_t slots = (uint32_t)li.grid * (uint32_t)(li.waves_per_wg / ((a.layout & 1u) && !li.half ? 3 : 2));
+            HIP_TRY(hipMemsetAsync(ctx->d_group_counter, 0, 4, st));
+            a.group_counter = ctx->d_group_counter;
+            a.group_base = 0;
+            a.group_first_dyn = slots;
+        }
 #if defined(HRX_STAMPS) || defined(HRX_ABLATION)
         if (const char *pe = std::getenv("HRX_PACE")) a.pace_even = (uint32_t)std::strtoul(pe, nullptr, 0);
 #endif
@@ -425,7 +445,8 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     // on another stream first waits for the previous combine.
     const size_t G = ctx->s.groups.size();
     if (G > kMaxGroups) return fail(HRX_ERR_BOUNDS, "too many def groups");
-    if (ctx->mp_pending) HIP_TRY(hipStreamWaitEvent(st, ctx->mp_done, 0));
+    if (ctx->scratch_used && ctx->scratch_stream != st) (void)hipStreamSynchronize(ctx->scratch_stream);
+    ctx->scratch_stream = st; ctx->scratch_used = true;
     const size_t q4 = (M + 3) / 4, q8 = (M + 7) / 8;
     HIP_TRY(ctx->mp_masked.reserve(q8 * 8 * B * 2));
     CombineArgs ca{};
@@ -447,8 +468,6 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     ca.rec_pitch = (uint32_t)rec_pitch; ca.msk_pitch = (uint32_t)msk_pitch;
     ca.records = records; ca.masked = masked; ca.status = status;
     HIP_TRY(launch_combine(ca, st));
-    HIP_TRY(hipEventRecord(ctx->mp_done, st));
-    ctx->mp_pending = true;
     return HRX_OK;
 }
 
@@ -514,7 +533,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     else if (li.split == 2) std::snprintf(name, sizeof name, (layout & 1) ? "hrx::witness_pm_kernel<%u, %s, %s, %s>" : "hrx::witness_pm_kernel<%u, %s, %s, %s, true>", a.D, tf[li.gtab], tf[li.wide], tf[li.half]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u>", a.D, 32u / a.D);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
-    std::snprintf(line, sizeof line, "%s grid=%d waves=%d ring=%d lds=%zu", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+    std::snprintf(line, sizeof line, "%s grid=%d waves=%d ring=%d lds=%zu%s", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes, li.dyn ? " groups=dynamic" : "");
     out = line;
     return HRX_OK;
 }

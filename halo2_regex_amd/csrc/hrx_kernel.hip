@@ -14,9 +14,22 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     out.gtab = 0;
     out.wide = 0;
     out.half = 0;
+    out.dyn = 0;
     // DFAs whose fused table leaves no room for the per-wave LDS areas are walked out of global memory (L2-resident)
     const size_t min_stage = (a.layout & 1u) ? pm_pair_bytes(2, false, true) : wave_stage_bytes((int)a.D, 16);
     if (a.table_bytes + min_stage > kLdsLimit || (a.debug & kDbgForceGlobalTable)) out.gtab = 1;
+    // position-major loader/walker kernel: from EIGHT groups per walker pair on, the pairs take their groups from a counter
+    // instead of a fixed stride — the walkers of odd XCDs run 8-17 % slower than those of even ones, and with a
+    // fixed split the launch waits for them.  A group is the unit, so this only pays with many groups per pair: 2^20 x 2048 B
+    // (D = 2, 16 groups per pair) 4.68 -> 4.45 ms; with 4 groups per pair the last groups are drawn long before the fast pairs
+    // run dry (262144 x 2048 B: 1.188 vs 1.184 ms), and with 16-tile groups the loader's counter access — it waits for its loads
+    // in flight — costs more than the balance gains (262144 x 1024 B: 0.320 -> 0.334 ms).  Hence >= 8 groups per pair of >= 32 tiles.
+    auto want_dyn = [&](int grid, int pairs) {
+        const size_t slots = (size_t)grid * (size_t)pairs;
+        if (!(a.layout & 1u) || (a.debug & kDbgNoDynamicGroups)) return 0;
+        if (a.debug & kDbgForceDynamicGroups) return (size_t)a.n_groups > slots ? 1 : 0;
+        return ((size_t)a.n_groups >= 8 * slots && (a.M + 63u) / 64u >= 32u) ? 1 : 0;
+    };
     const uint32_t table_bytes_saved = a.table_bytes;
     struct Restore { WitnessArgs &a; uint32_t v; ~Restore() { a.table_bytes = v; } } restore{a, table_bytes_saved};
     if (out.gtab) a.table_bytes = 0;  // for the LDS budgeting below only; restored on return
@@ -40,6 +53,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
                 const size_t cap = (size_t)num_cus * per_cu;
                 out.grid = (int)(need < cap ? need : cap);
                 if (out.grid < 1) out.grid = 1;
+                out.dyn = want_dyn(out.grid, pairs);
                 return true;
             }
         }
@@ -123,6 +137,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
                 const size_t cap = (size_t)num_cus * per_cu;
                 out.grid = (int)(need < cap ? need : cap);
                 if (out.grid < 1) out.grid = 1;
+                out.dyn = want_dyn(out.grid, pairs);   // (0 for the string-major D = 3 use of this kernel: want_dyn checks the layout)
                 return true;
             }
         }

@@ -33,6 +33,10 @@ struct WitnessArgs {
     uint32_t D;
     uint32_t debug;               // the context's kDbg* bits below (forced kernel / table choices for the tests; ablations only with -DHRX_ABLATION)
     unsigned long long *stamps;   // profiling only (tools/kbench): per wave and tile 4 s_memtime stamps; NULL in the product
+    // dynamic group assignment (position-major kernel, batches of >= 8 long groups per walker pair): after its first group a pair
+    // takes the next unclaimed group from a device counter (hrx_kernel_pm.hip); 0 / NULL: groups g_first + j * stride
+    uint32_t *group_counter;
+    uint32_t group_base, group_first_dyn;
     uint32_t pace_even;           // profiling only (HRX_PACE, stamps / ablation builds): x 64 idle cycles per tile for the walkers of even workgroups; 0 in the product
     DefConsts dc[kMaxDefsPerLaunch];
 };
@@ -72,12 +76,14 @@ enum : uint32_t {
     kDbgForceDefParallel = 0x4000000u,// position-major, D >= 2, WIDE table: the def-parallel kernel whatever the batch size (tests)
     kDbgNoPair = 0x8000000u,          // position-major, D = 1: never the pair-step kernel (hrx_kernel_pp.hip)
     kDbgForcePair = 0x40000000u,      // position-major, D = 1 with a PAIR table: the pair-step kernel whatever the batch size (tests, A/B)
+    kDbgNoDynamicGroups = 0x1u << 11,  // position-major kernel: static group assignment whatever the batch size
+    kDbgForceDynamicGroups = 0x1u << 12,   // ... dynamic from two groups per walker and any row count (tests)
     kDbgXcdRemap = 0x100000u,         // position-major kernels: every XCD walks a CONTIGUOUS eighth of the groups (hrx_device.h xcd_slot; measured 1.5 % slower, off by default)
     kDbgForceHost = 0x10000000u,      // host-buffer entry points: always the native host walk (hrx_host_walk.cpp)
     kDbgNoHost = 0x20000000u,         // host-buffer entry points: never the native host walk
     // every bit that merely selects a kernel (the only ones a release build honours)
     kDbgForceMask = kDbgForceOneWave | kDbgGroups32 | kDbgForceGlobalTable | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf |
-                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForcePair | kDbgXcdRemap | kDbgForceHost | kDbgNoHost,
+                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForcePair | kDbgXcdRemap | kDbgNoDynamicGroups | kDbgForceDynamicGroups | kDbgForceHost | kDbgNoHost,
 #ifdef HRX_ABLATION
     kDbgHonoured = 0xffffffffu,
 #else
@@ -98,6 +104,7 @@ struct LaunchInfo {
     int wide;          // 1: position-major kernel on the WIDE table (hrx_lane.h)
     int half;          // 1: position-major kernel on the HALF table (hrx_lane.h)
     int grid;
+    int dyn;           // 1: dynamic group assignment (position-major loader/walker kernel, >= 8 long groups per walker pair)
     size_t lds_bytes;
 };
 
@@ -119,7 +126,8 @@ hipError_t launch_witness_pp(const WitnessArgs &a, const LaunchInfo &li, hipStre
 constexpr size_t kPmSummaryBytes = 6144;
 template <bool HALF, bool SM> constexpr bool kPmFinisher = !HALF && !SM;
 constexpr int pm_max_threads(bool half, bool sm) { return (!half && !sm) ? 768 : 512; }
-constexpr size_t pm_pair_bytes(size_t nring, bool half, bool fin) { return nring * 4096 + (half ? 0 : 4096) + (fin ? kPmSummaryBytes + 16 : 0) + 16; }
+constexpr size_t kPmCounterBytes = 128;   // ready / freed / freed2 / sum_ready / sum_freed / gq_ready + the 16-entry group queue
+constexpr size_t pm_pair_bytes(size_t nring, bool half, bool fin) { return nring * 4096 + (half ? 0 : 4096) + (fin ? kPmSummaryBytes : 0) + kPmCounterBytes; }
 constexpr size_t kPpSlotBytes = 8192;   // pair-step kernel: one ring slot = 4 KiB of pair indices + 4 KiB of raw bytes
 // LDS bytes per group of the def-parallel kernel: input ring + (D - 1) x (2 summaries of 5 KiB + a 2-KiB status piece) + counters
 constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 128; }

@@ -55,10 +55,22 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     const uint32_t ready_off = sum_off + (FIN ? kPmSummaryBytes : 0u), freed_off = ready_off + 4u;
     // FIN: freed2 = ring slots the finisher is done with; sum_ready / sum_freed = tile summaries written / consumed
     const uint32_t freed2_off = ready_off + 8u, sum_ready_off = ready_off + 12u, sum_freed_off = ready_off + 16u;
+    // dynamic groups: gq_ready = groups the loader has published, gq = the queue of their indices (16 entries)
+    const uint32_t gq_ready_off = ready_off + 20u, gq_off = ready_off + 32u;
+    const bool dyn = a.group_counter != nullptr;
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
     uint32_t seq = 0;
     const uint32_t g_first = xcd_slot(blockIdx.x, gridDim.x, (a.debug & kDbgXcdRemap) != 0) * pairs + pair, g_stride = gridDim.x * pairs;
+    // j-th group of this pair (j = 0, 1, ..); >= n_groups: there is none.  Static: a fixed stride.  Dynamic (plan_witness_launch:
+    // batches of >= 8 long groups per pair): the first group is static, every further one is whatever the pair's LOADER drew from
+    // the launch's counter when it got there (it runs ahead of the other two waves) and published in the LDS queue — pairs on
+    // faster XCDs simply draw more often.
+    auto group_at = [&](const uint32_t j) -> uint32_t {
+        if (!dyn || j == 0u) return g_first + j * g_stride;
+        ring_wait(gq_ready_off, j);
+        return lds_vol_u32(gq_off + (j & 15u) * 4u);
+    };
     // The loaders request their pair's first input tile BEFORE the table is staged: the HBM round trip (~2 us) then runs
     // under the staging instead of after it.
     uint32_t first_len = M;   // ... and the walkers their first group's lengths
@@ -82,6 +94,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) dst[i] = src[i];
         if (is_walker && lane == 0) {
             lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0);
+            lds_store_u32(gq_ready_off, 0);
             if (FIN) { lds_store_u32(freed2_off, 0); lds_store_u32(sum_ready_off, 0); lds_store_u32(sum_freed_off, 0); }
         }
     }
@@ -89,8 +102,6 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
 
     if (is_finisher) {
         // ================================ finisher (FIN) ================================
-        const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
-        const uint32_t total = my_groups * ntiles;
         const size_t q8 = (M + 7u) / 8u;
         const bool nt_msk = !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
         MaskCarry mc = {0, 0, 0, 0};
@@ -98,10 +109,14 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
         bool active_f = false;
         unsigned char *mp_f = nullptr;
         size_t mstep_f = 0;
-        for (uint32_t f = 0; f < total; ++f) {
-            const uint32_t tf = f % ntiles, t0 = tf << 6;
+        uint32_t f = 0;
+        for (uint32_t j = 0;; ++j) {
+          const uint32_t gf = group_at(j);
+          if (gf >= a.n_groups) break;
+          for (uint32_t tf = 0; tf < ntiles; ++tf, ++f) {
+            const uint32_t t0 = tf << 6;
             if (tf == 0u) {   // a new group: this lane's string
-                b0_f = (g_first + (f / ntiles) * g_stride) * 64u;
+                b0_f = gf * 64u;
                 const uint32_t b = b0_f + lane;
                 active_f = b < B;
                 const uint32_t bc = active_f ? b : B - 1u;     // lanes beyond the batch shadow the last string (same values, same addresses)
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 if (mbyte) v = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);
                 if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_msk);
             }
+          }
         }
         return;
     }
@@ -166,12 +182,33 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
         // read (inside the string's own stride) but never trusted.
         constexpr uint32_t RT = (D == 1 && !FIN) ? 12u : 8u;   // FIN: three waves per SIMD, 168 VGPRs each
         const bool in_pm = (a.layout & 2u) != 0;
-        const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
-        const uint32_t total = my_groups * ntiles;
         const uint32_t row_cap = (uint32_t)a.stride - 16u;  // last 16-byte chunk that exists for every string
+        // The pair's sequence of (group, tile) pairs, discovered group by group: `total` = tiles of the groups known so far,
+        // `issue_g` = the group whose tiles are being requested.  Static assignment knows the next group by formula; dynamic
+        // assignment draws it from the launch's counter (lane 0, value broadcast) — the compiler waits for every load in flight
+        // before it reads the result, which the RT tiles already in registers cover — and publishes it, or the end mark,
+        // to the walker and the finisher through the LDS queue.
+        uint32_t total = g_first < a.n_groups ? ntiles : 0u, known = 1u, issue_g = g_first;
+        bool ended = total == 0u;
+        auto next_group = [&]() {
+            uint32_t g;
+            if (!dyn) {
+                g = g_first + known * g_stride;
+            } else {
+                uint32_t v = 0;
+                if (lane == 0u) v = atomicAdd(a.group_counter, 1u);
+                v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                g = a.group_first_dyn + (v - a.group_base);
+                if (g >= a.n_groups) g = 0xffffffffu;
+                lds_store_u32(gq_off + (known & 15u) * 4u, g);
+                ring_post(gq_ready_off, known);
+            }
+            if (g < a.n_groups) { issue_g = g; total += ntiles; ++known; }
+            else ended = true;
+        };
         uint4 buf[RT * 4u];
-        auto issue = [&](const uint32_t q, const uint32_t k) {  // tile q of the pair's sequence -> register tile k
-            const uint32_t g = g_first + (q / ntiles) * g_stride, t = q % ntiles;
+        auto issue = [&](const uint32_t q, const uint32_t k) {  // tile q of the pair's sequence (a tile of group issue_g) -> register tile k
+            const uint32_t g = issue_g, t = q % ntiles;
             const uint32_t bl = min(g * 64u + lane, B - 1u);
             const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);   // the group's block (hrx_lane.h)
             const uint8_t *cptr = in_pm ? a.chars + (size_t)blk0 * a.stride + (size_t)(bl - blk0) * 16u : a.chars + (size_t)bl * a.stride;
@@ -182,6 +219,11 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 const size_t off = (size_t)min(t * 64u + 16u * i, row_cap) * cmul_eff;
                 buf[k * 4u + i] = *reinterpret_cast<const uint4 *>(cptr + off);   // (non-temporal LOADS were tried in round 2: 76.5 vs 75.4 us, dropped)
             }
+        };
+        // request tile q if it exists; tiles are requested in order, so q == total exactly when q opens a new group
+        auto try_issue = [&](const uint32_t q, const uint32_t k) {
+            if (q == total && !ended) next_group();
+            if (q < total) issue(q, k);
         };
         // The pair's FIRST tile travels alone: requested together with the rest, it queues behind the whole chip's opening
         // burst (~48 MiB) and reaches the walker ~10 us into the launch (in-kernel stamps, tools/kbench) instead of ~1.5.
@@ -196,9 +238,8 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             ring_post(ready_off, 1u);
         }
 #pragma unroll
-        for (uint32_t k = 1; k < RT; ++k)
-            if (k < total) issue(k, k);
-        if (RT < total) issue(RT, 0);
+        for (uint32_t k = 1; k < RT; ++k) try_issue(k, k);
+        try_issue(RT, 0);
         for (uint32_t s0 = 0; s0 < total; s0 += RT) {
 #pragma unroll
             for (uint32_t k = 0; k < RT; ++k) {
@@ -223,21 +264,23 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                         *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
                     }
                     ring_post(ready_off, sq + 1u);
-                    if (sq + RT < total) issue(sq + RT, k);
+                    try_issue(sq + RT, k);
                 }
             }
         }
         return;
     }
 
-    for (uint32_t g = g_first; g < a.n_groups; g += g_stride) {
+    for (uint32_t j = 0;; ++j) {
+        const uint32_t g = group_at(j);
+        if (g >= a.n_groups) break;
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
         const bool active = b < B;
         // Lanes beyond the batch (last group only) are EXACT shadows of string B - 1 — same bytes (the loader clamps the same
         // way), same length, same output addresses — so the record / masked stores need no per-lane predicate: every lane of
         // the wave stores, the shadows re-write the last string's values.  Only the status word and the fix-ups are `active`-only.
-        const uint32_t n_raw = g == g_first ? first_len : a.lens[min(b, B - 1u)];
+        const uint32_t n_raw = j == 0u ? first_len : a.lens[min(b, B - 1u)];
         const bool badlen = n_raw > M;
         const uint32_t n = badlen ? M : n_raw;
 
@@ -505,7 +548,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             if (a.stamps && lane == 0) {
                 unsigned long long *o = a.stamps + (size_t)(blockIdx.x * pairs + pair) * 8u;
                 o[0] += tk_wait; o[1] += tk_walk; o[2] += tk_end; o[3] += clock64() - tk_group;
-                if (g == g_first) { o[4] = wall_entry; o[5] = wall_start; }
+                if (j == 0u) { o[4] = wall_entry; o[5] = wall_start; }
                 o[6] = wall_clock64();
             }
 #endif

@@ -139,7 +139,9 @@ def test_planner_picks_the_documented_kernel_per_config():
     cfg = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
     assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pmd_kernel<2> grid=256 waves=6 ")       # <= 2 groups per CU: one walker per def
     assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> ")     # D >= 2: the WIDE table
-    assert cfg.describe_launch(1 << 20, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> grid=256 waves=12 ")
+    d = cfg.describe_launch(1 << 20, layout=1)
+    assert d.startswith("hrx::witness_pm_kernel<2, false, true, false> grid=256 waves=12 ") and d.endswith(" groups=dynamic")   # >= 3 groups per walker pair: drawn from a counter
+    assert "groups=dynamic" not in cfg.describe_launch(65536, layout=1)
     cfg3 = RegexVerifyConfig.configure(1024, _defs(CFG_A + CFG_3), device=None)
     assert cfg3.describe_launch(65536, layout=0).startswith("hrx::witness_pm_kernel<3, false, true, false, true> ")   # string-major D = 3: lane-direct stores
     assert RegexVerifyConfig.configure(1001, _defs(CFG_A + CFG_3), device=None).describe_launch(65536, layout=0).startswith("hrx::witness_kernel<3, false, false> ")
@@ -147,7 +149,7 @@ def test_planner_picks_the_documented_kernel_per_config():
     a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=np.arange(256, dtype=np.uint8), n_substr_pairs=200)
     cfg = RegexVerifyConfig.configure(4096, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)
     d = cfg.describe_launch(65536, layout=3)
-    assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8 ") and "lds=%d" % (128 * 1024 + 4 * (4096 + 16)) in d
+    assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8 ") and "lds=%d" % (128 * 1024 + 4 * (4096 + 128)) in d
     assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_kernel<1, true, true> ")                # string-major: global table
     # beyond 256 states there is no HALF image: global-table walk
     a_txt, sub_txt = synth.random_dfa(300, seed=2)

@@ -440,7 +440,8 @@ def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
     _check_batch_pm(hra, oracle, CFG_123, chars, lens, 704)
 
 
-@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000 | 0x2000000), str(0x400000), str(0x4000000), "0", str(0x8000000), str(0x40000000)],
+@pytest.mark.parametrize("flags", [str(0x80000), str(0x200000 | 0x2000000), str(0x400000), str(0x4000000), "0", str(0x8000000), str(0x40000000),
+                               ],
                          ids=["narrow-table", "wide-table", "half-table", "def-parallel", "planner-default", "no-pair-step", "pair-step"])
 def test_position_major_kernel_on_both_table_formats(hra, oracle, flags, monkeypatch):
     """The position-major path has four table formats (4-byte, WIDE for D >= 2, HALF for big DFAs, PAIR — two bytes per lookup —
@@ -692,6 +693,45 @@ def test_multi_pass_at_a_chip_filling_size_two_blocks(hra, oracle):
     st = _full_check(hra, OracleDefs.from_files(oracle, CFG_D5), cfg, blocks, M, 5)
     assert len(st) == 70000 and (st & np.uint64(0xff) == 0).mean() > 0.9
     _full_check(hra, OracleDefs.from_files(oracle, CFG_D5), cfg, [(base_c[:5000], base_l[:5000])], M, 5, position_major=False)
+
+
+@pytest.mark.parametrize("flags,names", [(0x1000, CFG_1), (0x1000, CFG_A), (0x1000 | 0x400000, CFG_123)], ids=["D1", "D2-wide", "D3-half"])
+def test_dynamic_group_assignment(hra, oracle, flags, names, monkeypatch):
+    """Batches of eight or more long groups per walker pair take their groups from a device counter instead of a fixed stride (the
+    loader draws, walker and finisher follow through an LDS queue).  Forced here from the second group on (kDbgForceDynamicGroups)
+    at 70000 ragged strings — 1094 groups over 1024 pairs, two blocks of the position-major buffers, three tiles per group, one of
+    them partial — and replayed from a HIP graph (the counter is reset by a memset node in front of every launch): every string
+    against the oracle and the MockProver, for the finisher variants and the HALF one."""
+    import torch
+    from halo2_regex_amd import synth
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(flags))
+    M, B = 136, 70000
+    chars, lens = synth.ragged(B, M, seed=23)
+    cfg = _cfg(hra, names, M)
+    assert cfg.describe_launch(B, layout=3).endswith("groups=dynamic")
+    blocks = [(chars[:hra.PM_BLOCK], lens[:hra.PM_BLOCK]), (np.ascontiguousarray(chars[hra.PM_BLOCK:]), lens[hra.PM_BLOCK:])]
+    st = _full_check(hra, OracleDefs.from_files(oracle, names), cfg, blocks, M, len(names))
+    assert (st & np.uint64(0xff) == 0).mean() > 0.9
+    # graph replay: three captured launches, replayed twice, same bytes as an eager launch
+    dev = torch.device("cuda", 0)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    ref = cfg.witness_batch_position_major(d_chars, d_lens)
+    out = cfg.alloc_outputs_position_major(B, dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            for _ in range(3):
+                cfg.witness_batch_position_major(d_chars, d_lens, out=out)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for _ in range(2):
+        for t in out:
+            t.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(out, ref))
 
 
 def test_multi_device_driver_device_resident_shards(hra, oracle):
