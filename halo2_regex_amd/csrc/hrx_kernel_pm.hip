@@ -61,7 +61,13 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
     uint32_t seq = 0;
-    const uint32_t g_first = xcd_slot(blockIdx.x, gridDim.x, (a.debug & kDbgXcdRemap) != 0) * pairs + pair, g_stride = gridDim.x * pairs;
+#if defined(HRX_STAMPS) || defined(HRX_ABLATION)
+    // profiling only (HRX_PACE's high half): rotate which 4-KiB class of every slab an XCD's walkers write
+    const uint32_t wg_rot = (blockIdx.x & ~7u) | ((blockIdx.x + (a.pace_even >> 16)) & 7u);
+#else
+    const uint32_t wg_rot = blockIdx.x;
+#endif
+    const uint32_t g_first = xcd_slot(wg_rot, gridDim.x, (a.debug & kDbgXcdRemap) != 0) * pairs + pair, g_stride = gridDim.x * pairs;
     // j-th group of this pair (j = 0, 1, ..); >= n_groups: there is none.  Static: a fixed stride.  Dynamic (plan_witness_launch:
     // batches of >= 8 long groups per pair): the first group is static, every further one is whatever the pair's LOADER drew from
     // the launch's counter when it got there (it runs ahead of the other two waves) and published in the LDS queue — pairs on
@@ -319,6 +325,14 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             uint4 pend[8];                             // the previous tile's masked rows, not yet stored
             unsigned char *pend_mp = mp;
             bool have_pend = false;
+            // HOLD (HALF table, one def — the random-DFA shape of cfg 5, where the optimistic end mask of hrx_lane.h is wrong for
+            // ~10 % of all masked rows): the masked rows of the last kHold = 3 tiles (all the 256 VGPRs allow) stay in registers, so that a fix-up that arrives
+            // within kHold tiles zeroes them THERE; only what is older was stored already and needs the 2-byte read-modify-writes
+            // at the memory that made the fix-ups 37 % of this launch (0.49 vs 0.31 ms with them skipped).
+            constexpr int kHold = (HALF && D == 1 && !SM) ? 3 : 0;
+            uint4 held[kHold ? kHold : 1][8];
+            uint32_t n_held = 0;
+            unsigned char *const mp_group = mp;
 #pragma unroll
             for (int k = 0; k < 8; ++k) pend[k] = make_uint4(0, 0, 0, 0);
 
@@ -330,8 +344,8 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 const uint32_t t0 = t << 6;
                 const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
 #if defined(HRX_STAMPS) || defined(HRX_ABLATION)
-                if (a.pace_even && !(blockIdx.x & 1u))   // profiling only: hold the walkers of the even workgroups (= even XCDs) back
-                    for (uint32_t i = 0; i < a.pace_even; ++i) __builtin_amdgcn_s_sleep(1);
+                if ((a.pace_even & 0xffffu) && !(blockIdx.x & 1u))   // profiling only: hold the walkers of the even workgroups (= even XCDs) back
+                    for (uint32_t i = 0; i < (a.pace_even & 0xffffu); ++i) __builtin_amdgcn_s_sleep(1);
 #endif
 #ifdef HRX_STAMPS
                 const unsigned long long tk_a = clock64();
@@ -504,19 +518,43 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 } else {
                 // ---------------- reveal masks: lib.rs:598-764 ----------------
                 TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
+                if (a.debug & kDbgSkipFixups) tm.fix = 0;  // profiling only: skip the fix-ups
+                const uint32_t fix_regs = tm.fix;   // held rows: shadow lanes too (they store the same rows to the same addresses as string B - 1)
                 if (!active) tm.fix = 0;   // (tm.mask stays: a shadow lane stores the same masked rows as string B - 1)
+                uint32_t fix_end = t0;     // rows [fix_start, fix_end) were stored already and are fixed at the memory
+                if constexpr (kHold > 0) {
+                    // held[i] = the masked rows of tile t - 1 - i, rows [t0 - 64 (i + 1), t0 - 64 i): zero what lies at or after fix_start
+                    fix_end = t0 - n_held * 64u;
+                    if (fix_regs) {
+#pragma unroll
+                        for (int i = 0; i < kHold; ++i) {
+                            if ((uint32_t)i < n_held) {
+                                const uint32_t base = t0 - 64u * (uint32_t)(i + 1);
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const uint32_t row0 = base + 8u * (uint32_t)k;
+                                    // u16 index of the first row to zero inside this octet: 0 = all of it, >= 8 = none
+                                    const uint32_t keep = tm.fix_start <= row0 ? 0u : min(tm.fix_start - row0, 8u);
+                                    uint32_t w[4] = {held[i][k].x, held[i][k].y, held[i][k].z, held[i][k].w};
+#pragma unroll
+                                    for (uint32_t q = 0; q < 4u; ++q) w[q] = keep > 2u * q + 1u ? w[q] : (keep > 2u * q ? (w[q] & 0xffffu) : 0u);
+                                    held[i][k] = make_uint4(w[0], w[1], w[2], w[3]);
+                                }
+                            }
+                        }
+                    }
+                }
                 // An earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare with real definitions; a
                 // random DFA like cfg 5's takes this path every few tiles, and there each 16-byte piece re-written in a line
-                // that has left L2 is a read-modify-write at the memory: measured 521 vs 357 us with the fix-ups skipped;
-                // a per-lane variant that zeroes whole octets with 16-byte stores was no better — 558 us).
-                uint64_t fixm = __ballot(tm.fix != 0);
-                if (a.debug & kDbgSkipFixups) fixm = 0;  // profiling only: skip the fix-ups
+                // that has left L2 is a read-modify-write at the memory; a per-lane variant that zeroes whole octets with 16-byte
+                // stores was no better).
+                uint64_t fixm = __ballot(tm.fix != 0 && tm.fix_start < fix_end);
                 while (fixm) {
                     const int j = __ffsll((unsigned long long)fixm) - 1;
                     fixm &= fixm - 1;
                     const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
                     const uint32_t bj = b0 + (uint32_t)j;
-                    for (uint32_t r = fs + lane; r < t0; r += 64u)
+                    for (uint32_t r = fs + lane; r < fix_end; r += 64u)
                         a.masked[SM ? (size_t)bj * a.msk_pitch + r : ((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;
                 }
                 // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8]; stored during the next walk ----------------
@@ -524,18 +562,33 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                     const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                              cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
                     const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
+                    if constexpr (kHold > 0) {
+                        // the oldest held tile (t - kHold) leaves now, as a burst (this kernel's walker has the time: the launch is
+                        // memory-bound at 2.4x its chain); the others move up
+                        if (n_held == (uint32_t)kHold && !(a.debug & kDbgSkipMasked)) {
+                            unsigned char *op = mp_group + (size_t)(t - (uint32_t)kHold) * 8u * mstep;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) store16(op + (size_t)k * mstep, held[kHold - 1][k], nt_msk);   // (a held tile is never the last one: all 8 octets exist)
+                        }
+#pragma unroll
+                        for (int i = kHold - 1; i > 0; --i)
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) held[i][k] = held[i - 1][k];
+                        if (n_held < (uint32_t)kHold) ++n_held;
+                    }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
                         uint4 v = make_uint4(0, 0, 0, 0);
                         if (mbyte) v = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);  // lib.rs:752-761
-                        if (D == 1) pend[k] = v;  // leaves during the next tile's walk
+                        if (kHold > 0) held[0][k] = v;
+                        else if (D == 1) pend[k] = v;  // leaves during the next tile's walk
                         else if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked))
                             store16(mp + (size_t)k * mstep, v, nt_msk);  // D >= 2: the walk needs the registers; store now
                     }
                     pend_mp = mp;
                     mp += 8u * mstep;
-                    have_pend = (D == 1);
+                    have_pend = (D == 1) && kHold == 0;
                 }
                 }
 #ifdef HRX_STAMPS
@@ -552,6 +605,19 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 o[6] = wall_clock64();
             }
 #endif
+            if constexpr (kHold > 0) {   // the held tiles, oldest first; only the octets that exist
+                if (!(a.debug & kDbgSkipMasked)) {
+#pragma unroll
+                    for (int i = kHold - 1; i >= 0; --i) {
+                        if ((uint32_t)i < n_held) {
+                            const uint32_t tt = ntiles - 1u - (uint32_t)i;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                if ((tt << 6) + (uint32_t)k * 8u < M) store16(mp_group + ((size_t)tt * 8u + (size_t)k) * mstep, held[i][k], !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)));
+                        }
+                    }
+                }
+            }
             // the last tile's masked rows (only the octets that exist: [ceil(M/8)][B][8])
             if (have_pend && !(a.debug & kDbgSkipMasked)) {
                 const uint32_t t0 = (ntiles - 1u) << 6;
