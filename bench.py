@@ -33,6 +33,7 @@ RESULT_TAG = "HRX_BENCH_RANK_RESULT "
 
 
 def parse_args(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -55,8 +56,11 @@ def parse_args(argv=None):
                     help="buffer layout of include/hrx.h: HRX_LAYOUT_POSITION_MAJOR (input and outputs chunked [pos/k][string][k], "
                     "the coalesced layout) or HRX_LAYOUT_STRING_MAJOR")
     ap.add_argument("--allow-debug-flags", action="store_true", help="tools only: run although HRX_DEBUG_FLAGS is set (recorded in the line's debug_flags)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure the launch's HBM traffic (roofline.traffic)")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # spawned by a bare --gpus N run
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    args.argv = [a for a in argv if a != "--child"]
+    return args
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -150,6 +154,49 @@ def mix_ceiling(dev_index):
     except Exception as e:                                   # a probe must never break the bench line
         sys.stderr.write("mixceil failed: %s\n" % e)
         return None
+
+
+def measured_traffic(argv, dev_index):
+    """HBM bytes per launch of THIS workload on THIS box: two short child runs of this script under `rocprofv3 --pmc`
+    (FETCH_SIZE and WRITE_SIZE in separate passes, eager launches, nothing else), counters corrected as
+    MI355X_MICROARCH.md prescribes (both in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 B: x 2).  The children are
+    separate processes started after the timed region; None if rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    keep = [a for a in argv if a not in ("--no-spread", "--no-verify", "--no-cpu-baseline", "--eager")]
+    for flag in ("--steps", "--warmup", "--gpus"):          # the child runs 3 eager launches on one device
+        while flag in keep:
+            i = keep.index(flag)
+            del keep[i:i + 2]
+    out = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            tmp = tempfile.mkdtemp(prefix="hrx_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", HIP_VISIBLE_DEVICES=str(dev_index))
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "r1", "--", sys.executable, os.path.abspath(__file__)] + keep + \
+                  ["--eager", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-verify", "--no-spread", "--no-pmc"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+            vals = []
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "witness" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            shutil.rmtree(tmp, ignore_errors=True)
+            if r.returncode != 0 or not vals:
+                sys.stderr.write("rocprofv3 --pmc %s pass failed (rc %d): traffic falls back to the committed profile\n" % (counter, r.returncode))
+                return None
+            out[counter] = sum(vals) / len(vals)
+    except Exception as e:                                   # a probe must never break the bench line
+        sys.stderr.write("pmc passes failed: %s\n" % e)
+        return None
+    read, written = out["FETCH_SIZE"] * 1024 * 2, out["WRITE_SIZE"] * 1024
+    return {"read": read, "written": written, "total": read + written,
+            "how": "two rocprofv3 --pmc child passes of this command on this box after the timed region (FETCH_SIZE x 2 KiB: gfx950; WRITE_SIZE KiB), means over the witness kernel's launches"}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -312,6 +359,8 @@ def run_rank(args, rank, world, device_index, barrier):
         torch.cuda.empty_cache()
         if args.config == "regex1" and B == 65536 and M == 1024 and pm:
             res["mix_ceiling"] = mix_ceiling(device_index)
+        if not args.no_pmc:
+            res["traffic"] = measured_traffic(args.argv, device_index)
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(o, names, chars, lens, M)
     return res
@@ -352,7 +401,7 @@ def aggregate(per_rank, args):
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": r0["config"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": (r0.get("traffic") or {}).get("total") or pmc_traffic(args),
                      "kernel": r0["desc"].split(" grid=")[0], "launch": "grid=" + r0["desc"].split(" grid=")[1],
                      "avg_launch_ms": kern_ms,
                      "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D)},
@@ -361,6 +410,7 @@ def aggregate(per_rank, args):
                       "rows_per_s": r["rows"] / r["elapsed_s"], "avg_launch_ms": r["avg_launch_ms"]} for r in per_rank],
         "debug_flags": r0.get("debug_flags"),
     }
+    line["roofline"]["traffic_source"] = r0["traffic"] if r0.get("traffic") else ("profiles/r02_pm_pmc.json (committed rocprofv3 PMC passes of this command)" if line["roofline"]["traffic"] else None)
     if r0.get("verified"):
         line["verified"] = r0["verified"]
     if r0.get("spread"):
