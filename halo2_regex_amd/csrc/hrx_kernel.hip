@@ -8,6 +8,22 @@
 
 namespace hrx {
 
+// Which of the position-major kernel's stores are write-back instead of streaming.  All-streaming output is not the best this
+// memory system does with a launch that writes more than the 256-MB Infinity Cache holds: with about 128 MiB of the records
+// stored write-back (every k-th tile's) the bench line runs at 63-67 us in every process instead of 70 or 78 (DESIGN.md §4.1:
+// same-process and fresh-process A/Bs, tools/nt_mix_sweep.sh) and D = 3 at 65536 x 1024 B goes 0.72 -> 0.84.  Part of that is the
+// cache absorbing lines that the NEXT launch overwrites (the bench re-writes its buffers every step); with outputs rotating over
+// 4-8 buffer sets the policy is neutral (81-83 us either way, tools/rotating_outputs.py), and whoever consumes the rows next
+// finds that share in the cache.  Not for launches whose whole footprint fits the cache (there streaming wins: 36.1 vs 38.0 us
+// at M = 512), nor for the HALF kernel (cfg 5: 0.42 vs 0.43-0.45 ms), nor where k would exceed 8.
+uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li) {
+    if (!(a.layout & 1u) || li.split != 2 || li.half) return 0u;
+    const size_t rec_bytes = (size_t)a.B * a.M * 4u * a.D, msk_bytes = (size_t)a.B * a.M * 2u;
+    if (rec_bytes + msk_bytes < ((size_t)256 << 20)) return 0u;
+    const size_t k = (rec_bytes + ((size_t)128 << 20) - 1) / ((size_t)128 << 20);
+    return k < 2 ? 2u : k <= 8 ? (uint32_t)k : 0u;
+}
+
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.gs = 64;
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);

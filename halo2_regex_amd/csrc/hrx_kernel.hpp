@@ -9,6 +9,8 @@
 
 namespace hrx {
 
+struct LaunchInfo;
+struct WitnessArgs;
 constexpr uint32_t kMaxDefsPerLaunch = 8;   // RegexDefs per config: the status word carries 8 accept bits (include/hrx.h)
 
 struct WitnessArgs {
@@ -37,6 +39,7 @@ struct WitnessArgs {
     // takes the next unclaimed group from a device counter (hrx_kernel_pm.hip); 0 / NULL: groups g_first + j * stride
     uint32_t *group_counter;
     uint32_t group_base, group_first_dyn;
+    uint32_t nt_mix;              // position-major kernels: which stores are write-back instead of streaming (kNtMix*, hrx_kernel_pm.hip)
     uint32_t pace_even;           // profiling only (HRX_PACE, stamps / ablation builds): x 64 idle cycles per tile for the walkers of even workgroups; 0 in the product
     DefConsts dc[kMaxDefsPerLaunch];
 };
@@ -123,6 +126,9 @@ hipError_t launch_witness_pp(const WitnessArgs &a, const LaunchInfo &li, hipStre
 // position-major loader/walker kernel (hrx_kernel_pm.hip): LDS bytes per walker/loader pair.  FIN = the loader also finishes
 // the tiles (reveal masks + masked rows) from a 6-KiB summary the walker hands over; not for the HALF table (a 256-state table
 // leaves no LDS for it) nor for string-major outputs.
+// nt_mix: low byte k: the records of every k-th tile (t % k == k - 1) are stored write-back, 0 = all streaming; bit 8: the masked
+// rows write-back.  plan_nt_mix (hrx_kernel.hip) picks k so that ~128 MiB of a launch's records stay write-back.
+uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li);
 constexpr size_t kPmSummaryBytes = 6144;
 template <bool HALF, bool SM> constexpr bool kPmFinisher = !HALF && !SM;
 constexpr int pm_max_threads(bool half, bool sm) { return (!half && !sm) ? 768 : 512; }

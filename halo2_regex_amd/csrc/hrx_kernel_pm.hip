@@ -109,7 +109,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     if (is_finisher) {
         // ================================ finisher (FIN) ================================
         const size_t q8 = (M + 7u) / 8u;
-        const bool nt_msk = !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
+        const bool nt_msk = !(a.nt_mix & 0x100u) && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
         MaskCarry mc = {0, 0, 0, 0};
         uint32_t b0_f = 0, blk0_f = 0, nb_f = 0;
         bool active_f = false;
@@ -344,8 +344,8 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 const uint32_t t0 = t << 6;
                 const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
 #if defined(HRX_STAMPS) || defined(HRX_ABLATION)
-                if ((a.pace_even & 0xffffu) && !(blockIdx.x & 1u))   // profiling only: hold the walkers of the even workgroups (= even XCDs) back
-                    for (uint32_t i = 0; i < (a.pace_even & 0xffffu); ++i) __builtin_amdgcn_s_sleep(1);
+                if ((a.pace_even & 0xfffu) && !(blockIdx.x & 1u))   // profiling only: hold the walkers of the even workgroups (= even XCDs) back
+                    for (uint32_t i = 0; i < (a.pace_even & 0xfffu); ++i) __builtin_amdgcn_s_sleep(1);
 #endif
 #ifdef HRX_STAMPS
                 const unsigned long long tk_a = clock64();
@@ -367,7 +367,17 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 const bool full = (t0 + 64u < min_n);
                 const bool do_store = !(a.debug & kDbgSkipRecords);
                 // full-line position-major stores stream past L2 (non-temporal); the string-major lane-direct pieces do not (L2 merges them into lines)
-                const bool nt_rec = !SM && !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), nt_msk = !SM && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
+                #if defined(HRX_STAMPS) || defined(HRX_ABLATION)
+                // profiling only (HRX_PACE bits 15 / 14 / 13 / 12): records stored write-back instead of streaming by the walkers of odd
+                // workgroups / of even workgroups / of every workgroup's pairs 0 and 1 / by every walker for every other tile
+                const bool wb_probe = ((a.pace_even & 0x8000u) && (blockIdx.x & 1u)) || ((a.pace_even & 0x4000u) && !(blockIdx.x & 1u)) ||
+                                      ((a.pace_even & 0x2000u) && pair < 2u) || ((a.pace_even & 0x1000u) && (t & 1u));
+#else
+                constexpr bool wb_probe = false;
+#endif
+                const uint32_t wb_k = a.nt_mix & 0xffu;
+                const bool wb_tile = wb_k != 0u && (t % wb_k) == wb_k - 1u;   // the streaming / write-back mix of the records (kNtMixDefault)
+                const bool nt_rec = !SM && !wb_probe && !wb_tile && !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), nt_msk = !SM && !(a.nt_mix & 0x100u) && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
                 const bool pend_store = have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
                 // [ceil(M/4)][D][nb][4]: one def's quads of all strings of the block

@@ -131,6 +131,26 @@ __global__ __launch_bounds__(512) void pairp_k(const uint4 *__restrict__ in, uin
     }
 }
 
+// pair_k with the shipped kernel's store policy: streaming stores, except that the record quads of every other 64-row tile are
+// stored write-back (plan_nt_mix, hrx_kernel.hip: ~128 MiB of a launch's records stay in the cache hierarchy)
+__global__ __launch_bounds__(512) void pairmix_k(const uint4 *__restrict__ in, uint4 *__restrict__ rec, uint4 *__restrict__ msk, unsigned *sink) {
+    const size_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t g = (size_t)blockIdx.x * 4 + (wave & 3), b = g * 64 + lane;
+    typedef unsigned v4 __attribute__((ext_vector_type(4)));
+    if (wave >= 4) {
+        uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll 16
+        for (size_t c = 0; c < M / 16; ++c) { const uint4 v = in[c * B + b]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+        if (acc.x == 0x12345678u) sink[0] = acc.y ^ acc.z ^ acc.w;
+        return;
+    }
+    for (size_t q = 0; q < M / 4; ++q) {
+        if ((q >> 4) & 1) rec[q * B + b] = make_uint4((unsigned)q, 1, 2, 3);
+        else __builtin_nontemporal_store(v4{(unsigned)q, 1, 2, 3}, reinterpret_cast<v4 *>(rec + q * B + b));
+        if (q & 1) __builtin_nontemporal_store(v4{0, 0, 0, (unsigned)q}, reinterpret_cast<v4 *>(msk + (q >> 1) * B + b));
+    }
+}
+
 static bool g_brief = false;
 template <class F> static void timeit(const char *name, F &&launch, const char *key = nullptr) {
     if (g_brief && !key) return;
@@ -194,6 +214,7 @@ int main(int argc, char **argv) {
         timeit("pair: 4 reader + 4 writer waves/CU", [&] { hipLaunchKernelGGL(pair_k, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); }, "pair");
         timeit("pair, merged output array", [&] { hipLaunchKernelGGL(pairv_k<1>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
         timeit("pair, non-temporal stores", [&] { hipLaunchKernelGGL(pairv_k<2>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); }, "pair_nt");
+        timeit("pair, streaming + every other tile's records write-back", [&] { hipLaunchKernelGGL(pairmix_k, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); }, "pair_mix");
         timeit("pair, merged + non-temporal", [&] { hipLaunchKernelGGL(pairv_k<3>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
         timeit("pair, input from L2 (writes only)", [&] { hipLaunchKernelGGL(pairv_k<4>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
         timeit("pair, merged, input from L2", [&] { hipLaunchKernelGGL(pairv_k<5>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
