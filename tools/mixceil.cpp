@@ -195,6 +195,21 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&in, IN_BYTES)); CK(hipMalloc(&rec, REC_BYTES + MSK_BYTES + (64u << 20))); msk = rec + REC_BYTES / 16; /* one allocation: the merged variant uses it as one array */ CK(hipMalloc(&sink, 4)); CK(hipMalloc(&cpy, TOTAL));
     CK(hipMemset(in, 1, IN_BYTES));
     if (!g_brief) printf("bench-line traffic mix without compute: %.1f MB per launch (64 MiB read, 384 MiB written)\n", TOTAL / 1e6);
+    if (argc > 2 && std::string(argv[1]) == "--rotate") {
+        // N sets of (input, records, masked) used in turn: nothing a launch touches is left in the Infinity Cache by the launches before
+        const int nsets = atoi(argv[2]);
+        std::vector<uint4 *> ins(nsets), recs(nsets);
+        for (int k = 0; k < nsets; ++k) { CK(hipMalloc(&ins[k], IN_BYTES)); CK(hipMemset(ins[k], 1, IN_BYTES)); CK(hipMalloc(&recs[k], REC_BYTES + MSK_BYTES)); }
+        int turn = 0;
+        printf("%d buffer sets used in turn (%.1f GB):\n", nsets, nsets * (double)TOTAL / 1e9);
+        for (int round = 0; round < 2; ++round) {
+            timeit("pair, write-back stores", [&] { const int k = turn++ % nsets; hipLaunchKernelGGL(pair_k, dim3(256), dim3(512), 0, 0, ins[k], recs[k], recs[k] + REC_BYTES / 16, sink); });
+            timeit("pair, non-temporal stores", [&] { const int k = turn++ % nsets; hipLaunchKernelGGL(pairv_k<2>, dim3(256), dim3(512), 0, 0, ins[k], recs[k], recs[k] + REC_BYTES / 16, sink); });
+            timeit("pair, streaming + every other tile's records write-back", [&] { const int k = turn++ % nsets; hipLaunchKernelGGL(pairmix_k, dim3(256), dim3(512), 0, 0, ins[k], recs[k], recs[k] + REC_BYTES / 16, sink); });
+            timeit("copy 8192x256 (first set only)", [&] { hipLaunchKernelGGL(copy_k, dim3(8192), dim3(256), 0, 0, (const uint4 *)cpy, cpy + TOTAL / 32, TOTAL / 32); });
+        }
+        return 0;
+    }
     if (sustained) {
         for (int round = 0; round < 2; ++round) {
             series("pair, non-temporal stores", [&] { hipLaunchKernelGGL(pairv_k<2>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
@@ -227,6 +242,14 @@ int main(int argc, char **argv) {
             PP(16, 0); PP(64, 0); PP(256, 0); PP(272, 0); PP(1024, 0); PP(4096, 0); PP(64, 2); PP(256, 2); PP(272, 2); PP(4096, 2);
         }
         timeit("pair, reads only (no writers)", [&] { hipLaunchKernelGGL(pairv_k<16>, dim3(256), dim3(512), 0, 0, in, rec, msk, sink); });
+    }
+    if (g_brief) {   // the same probes over 8 buffer sets used in turn: what HBM alone sustains for this mix (nothing left in the Infinity Cache)
+        const int nsets = 8;
+        std::vector<uint4 *> ins(nsets), recs(nsets);
+        for (int k = 0; k < nsets; ++k) { CK(hipMalloc(&ins[k], IN_BYTES)); CK(hipMemset(ins[k], 1, IN_BYTES)); CK(hipMalloc(&recs[k], REC_BYTES + MSK_BYTES)); }
+        int turn = 0;
+        timeit("", [&] { const int k = turn++ % nsets; hipLaunchKernelGGL(pairv_k<2>, dim3(256), dim3(512), 0, 0, ins[k], recs[k], recs[k] + REC_BYTES / 16, sink); }, "pair_nt_fresh");
+        timeit("", [&] { const int k = turn++ % nsets; hipLaunchKernelGGL(pairmix_k, dim3(256), dim3(512), 0, 0, ins[k], recs[k], recs[k] + REC_BYTES / 16, sink); }, "pair_mix_fresh");
     }
     return 0;
 }
