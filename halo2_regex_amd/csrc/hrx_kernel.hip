@@ -15,10 +15,13 @@ namespace hrx {
 // cache absorbing lines that the NEXT launch overwrites (the bench re-writes its buffers every step); with outputs rotating over
 // 4-8 buffer sets the policy is neutral (81-83 us either way, tools/rotating_outputs.py), and whoever consumes the rows next
 // finds that share in the cache.  Not for launches whose whole footprint fits the cache (there streaming wins: 36.1 vs 38.0 us
-// at M = 512), nor for the HALF kernel (cfg 5: 0.42 vs 0.43-0.45 ms), nor where k would exceed 8.
+// at M = 512), nor for the HALF kernel (cfg 5: 0.42 vs 0.43-0.45 ms), nor where k would exceed 8.  The string-major walker/storer
+// kernel takes the same policy per 64-row block (cfg 2 string-major: 0.65 -> 0.71 of the peak).
 uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li) {
-    if (!(a.layout & 1u) || li.split != 2 || li.half) return 0u;
-    const size_t rec_bytes = (size_t)a.B * a.M * 4u * a.D, msk_bytes = (size_t)a.B * a.M * 2u;
+    const bool pm = (a.layout & 1u) && li.split == 2 && !li.half, sm_split = !(a.layout & 1u) && li.split == 1;   // (the walker/storer kernel streams full lines too)
+    if (!pm && !sm_split) return 0u;
+    const size_t rows = pm ? (size_t)a.M : (size_t)a.rec_pitch;   // string-major: the rows between consecutive strings
+    const size_t rec_bytes = (size_t)a.B * rows * 4u * a.D, msk_bytes = (size_t)a.B * a.M * 2u;
     if (rec_bytes + msk_bytes < ((size_t)256 << 20)) return 0u;
     const size_t k = (rec_bytes + ((size_t)128 << 20) - 1) / ((size_t)128 << 20);
     return k < 2 ? 2u : k <= 8 ? (uint32_t)k : 0u;

@@ -720,10 +720,13 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                     unsigned char *gp = reinterpret_cast<unsigned char *>(a.records + ((size_t)(b0 + js0) * a.rec_pitch + t0) * D + w * 4u);
                     const size_t gstep = (size_t)8u * a.rec_pitch * D * 4u;
                     const uint32_t lim = rows * D / 4u;
+                    // streaming stores, except every k-th 64-row block's records (plan_nt_mix: ~128 MiB of a launch's records write-back)
+                    const uint32_t wb_k = a.nt_mix & 0xffu;
+                    const bool rec_wb = (a.debug & kDbgNoNtStores) || (wb_k != 0u && ((t0 >> 6) % wb_k) == wb_k - 1u);
                     if (!(a.debug & kDbgSkipRecords)) {
 #pragma unroll
                         for (uint32_t it = 0; it < 8u; ++it) {
-                            if (whole || (b0 + it * 8u + js0 < a.B && w < lim)) { if (a.debug & kDbgNoNtStores) *reinterpret_cast<uint4 *>(gp) = v[it]; else store16_nt(gp, v[it]); }   // full 128-byte lines, 8 strings per instruction
+                            if (whole || (b0 + it * 8u + js0 < a.B && w < lim)) { if (rec_wb) *reinterpret_cast<uint4 *>(gp) = v[it]; else store16_nt(gp, v[it]); }   // full 128-byte lines, 8 strings per instruction
                             gp += gstep;
                         }
                     }
