@@ -140,7 +140,7 @@ def mix_ceiling(dev_index):
     the kernel's own address streams (64 MiB read, 384 MiB written in position-major slabs) issued by 4 reader + 4 writer
     waves per CU with nothing else to do, and a plain dwordx4 copy of the same byte count.  Runs after the timed region."""
     exe = os.path.join(ROOT, "tools", "mixceil")
-    if not os.path.exists(exe):
+    if not os.path.exists(exe) or under_profiler():
         return None
     try:
         env = dict(os.environ, HIP_VISIBLE_DEVICES=str(dev_index))
@@ -156,6 +156,12 @@ def mix_ceiling(dev_index):
         return None
 
 
+def under_profiler():
+    """True when this process itself runs under rocprofv3 (its tool library is preloaded): no nested profiler runs then, and no
+    other helper processes either — a process forked from a profiled one must not exec."""
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR"))
+
+
 def measured_traffic(argv, dev_index):
     """HBM bytes per launch of THIS workload on THIS box: two short child runs of this script under `rocprofv3 --pmc`
     (FETCH_SIZE and WRITE_SIZE in separate passes, eager launches, nothing else), counters corrected as
@@ -166,7 +172,7 @@ def measured_traffic(argv, dev_index):
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if not exe:
+    if not exe or under_profiler():
         return None
     keep = [a for a in argv if a not in ("--no-spread", "--no-verify", "--no-cpu-baseline", "--eager")]
     for flag in ("--steps", "--warmup", "--gpus"):          # the child runs 3 eager launches on one device

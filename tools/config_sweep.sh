@@ -1,7 +1,7 @@
 #!/bin/bash
 # One bench line per BASELINE config shape (per-GPU sizes) -> gpurun_out/r02_config_sweep/*.json; copied to profiles/r02_config_sweep/.
 cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r02_config_sweep; rm -rf $O; mkdir -p $O
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-pmc"
 $B                                                                                   > $O/cfg2_regex1_65536x1024.json
 $B --layout string-major                                                             > $O/cfg2_regex1_65536x1024_string_major.json
 $B --batch 131072                                                                    > $O/regex1_131072x1024.json

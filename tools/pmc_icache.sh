@@ -3,7 +3,7 @@
 cd /tmp; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for lib in libhrx.so libhrx_ablation.so; do
   P=gpurun_out/prof_ic_$lib; rm -rf $P; mkdir -p $P
-  HRX_LIB_PATH=$R/halo2_regex_amd/csrc/$lib timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $P -o r1 -- python3 bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline --no-verify --no-spread --allow-debug-flags > $P/log.txt 2>&1; echo "$lib rc=$?"
+  HRX_LIB_PATH=$R/halo2_regex_amd/csrc/$lib timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $P -o r1 -- python3 bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-verify --no-spread --allow-debug-flags > $P/log.txt 2>&1; echo "$lib rc=$?"
   python3 - <<PY
 import csv,collections,glob
 agg=collections.defaultdict(list)
