@@ -98,7 +98,7 @@ struct hrx_ctx {
         uint64_t *d_wide = nullptr;
         uint16_t *d_half = nullptr;
         uint8_t *d_pairtab = nullptr;
-        DevBuf records, status;
+        DevBuf records, status, summary;
     };
     std::vector<GroupDev> groups;
     DevBuf mp_masked;
@@ -357,7 +357,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
         if (g.d_wide) (void)hipFree(g.d_wide);
         if (g.d_half) (void)hipFree(g.d_half);
         if (g.d_pairtab) (void)hipFree(g.d_pairtab);
-        g.records.release(); g.status.release();
+        g.records.release(); g.status.release(); g.summary.release();
     }
     c->mp_masked.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
@@ -396,8 +396,10 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         return fail(HRX_ERR_ARG, "unknown layout");
     // one launch over `set` (a config of up to kMaxDefsPerPass defs, or one group of a larger one) with that set's device images
     auto launch_set = [&](const DefsSet &set, const uint32_t *d_table, const uint64_t *d_wide, const uint16_t *d_half, const uint8_t *d_pairtab,
-                          int lay, uint32_t *rec, uint16_t *msk, uint64_t *stat, size_t rp, size_t mp) -> int {
+                          int lay, uint32_t *rec, uint16_t *msk, uint64_t *stat, size_t rp, size_t mp,
+                          uint32_t rec_D = 0, uint32_t rec_d0 = 0, uint32_t *summary = nullptr) -> int {
         WitnessArgs a{};
+        a.rec_D = rec_D; a.rec_d0 = rec_d0; a.summary = summary;
         a.rec_pitch = (uint32_t)rp; a.msk_pitch = (uint32_t)mp;
         a.layout = (uint32_t)lay;
         a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
@@ -412,9 +414,16 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
 #ifdef HRX_ABLATION
         a.debug = debug_flags_from_env();   // tools/ab_flags.py switches ablations between launches of one process
 #endif
+        // a summary-writing pass is the loader / walker / finisher kernel: no pair-step or def-parallel variant, no HALF table
+        if (summary) a.debug |= kDbgNoPair | kDbgNoDefParallel;
         for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = set.consts[d];
         LaunchInfo li;
         if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+        if (summary && li.half) {   // (a group of one big DFA: walk its 4-byte table out of L2 instead)
+            a.debug |= kDbgForceGlobalTable;
+            if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+        }
+        if (summary && li.split != 2) return fail(HRX_ERR_STATE, "multi-pass: the planner did not pick the position-major loader/walker kernel");
         if (li.dyn) {   // launches that share the counter must not overlap: a launch on another stream waits for the previous one
             if (ctx->scratch_used && ctx->scratch_stream != st) (void)hipStreamSynchronize(ctx->scratch_stream);
             ctx->scratch_stream = st; ctx->scratch_used = true;
@@ -449,18 +458,27 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     if (G > kMaxGroups) return fail(HRX_ERR_BOUNDS, "too many def groups");
     if (ctx->scratch_used && ctx->scratch_stream != st) (void)hipStreamSynchronize(ctx->scratch_stream);
     ctx->scratch_stream = st; ctx->scratch_used = true;
-    const size_t q4 = (M + 3) / 4, q8 = (M + 7) / 8;
-    HIP_TRY(ctx->mp_masked.reserve(q8 * 8 * B * 2));
+    const size_t q4 = (M + 3) / 4, q8 = (M + 7) / 8, ntiles = (M + 63) / 64;
+    const bool summary_mode = (layout & HRX_LAYOUT_POSITION_MAJOR) != 0;   // position-major outputs: the passes write the caller's record planes themselves
+    if (!summary_mode) HIP_TRY(ctx->mp_masked.reserve(q8 * 8 * B * 2));
     CombineArgs ca{};
     for (size_t g = 0; g < G; ++g) {
         const DefsSet &gs = ctx->s.groups[g];
         hrx_ctx::GroupDev &gd = ctx->groups[g];
-        HIP_TRY(gd.records.reserve(q4 * 4 * gs.defs.size() * B * 4));
         HIP_TRY(gd.status.reserve(B * 8));
-        const int rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR),
-                                  (uint32_t *)gd.records.p, (uint16_t *)ctx->mp_masked.p, (uint64_t *)gd.status.p, M, M);
+        int rc;
+        if (summary_mode) {
+            HIP_TRY(gd.summary.reserve(ntiles * 5 * B * 16));
+            rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, layout, records, masked, (uint64_t *)gd.status.p, M, M,
+                            (uint32_t)ctx->s.defs.size(), ctx->s.group_first[g], (uint32_t *)gd.summary.p);
+            ca.gsummary[g] = (const uint32_t *)gd.summary.p;
+        } else {
+            HIP_TRY(gd.records.reserve(q4 * 4 * gs.defs.size() * B * 4));
+            rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR),
+                            (uint32_t *)gd.records.p, (uint16_t *)ctx->mp_masked.p, (uint64_t *)gd.status.p, M, M);
+            ca.grec[g] = (const uint32_t *)gd.records.p;
+        }
         if (rc != HRX_OK) return rc;
-        ca.grec[g] = (const uint32_t *)gd.records.p;
         ca.gstatus[g] = (const uint64_t *)gd.status.p;
         ca.gD[g] = (uint8_t)gs.defs.size();
         ca.gfirst[g] = (uint8_t)ctx->s.group_first[g];
@@ -514,7 +532,7 @@ int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *cha
     return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream, 0, 0, layout);
 }
 
-static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int num_cus, std::string &out) {
+static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int num_cus, std::string &out, bool summary_pass = false) {
     WitnessArgs a{};
     a.layout = (uint32_t)layout; a.B = (uint32_t)B; a.M = (uint32_t)M;
     // the planner only looks at which images exist and how large they are
@@ -526,8 +544,13 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     a.pair_blk_bytes = s.pair.blk_bytes; a.pair_lut_off = s.pair.lut_off;
     a.D = (uint32_t)s.defs.size();
     a.debug = debug_flags_from_env();   // what a context created now would run with (kernel-selection bits only in a release build)
+    if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a summary-writing pass is the loader / walker / finisher kernel)
     LaunchInfo li;
     if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+    if (summary_pass && li.half) {
+        a.debug |= kDbgForceGlobalTable;
+        if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
+    }
     char name[128], line[256];
     const char *tf[2] = {"false", "true"};
     if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
@@ -553,11 +576,11 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
         text = "multi-pass, " + std::to_string(s.groups.size()) + " groups: ";
         for (size_t g = 0; g < s.groups.size(); ++g) {
             std::string one;
-            const int rc = describe_set(s.groups[g], HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR), B, M, num_cus, one);
+            const int rc = describe_set(s.groups[g], HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR), B, M, num_cus, one, (layout & 1) != 0);
             if (rc != HRX_OK) return rc;
             text += "[defs " + std::to_string(s.group_first[g]) + ".." + std::to_string(s.group_first[g] + s.groups[g].defs.size() - 1) + ": " + one + "] ";
         }
-        text += (layout & 1) ? "+ hrx::witness_combine_kernel<false>" : "+ hrx::witness_combine_kernel<true>";
+        text += (layout & 1) ? "+ hrx::witness_combine_summary_kernel" : "+ hrx::witness_combine_kernel<true>";
     }
     std::snprintf(out, cap, "%s", text.c_str());
     return HRX_OK;

@@ -39,6 +39,12 @@ struct WitnessArgs {
     // takes the next unclaimed group from a device counter (hrx_kernel_pm.hip); 0 / NULL: groups g_first + j * stride
     uint32_t *group_counter;
     uint32_t group_base, group_first_dyn;
+    // one pass of a multi-pass config (more than kMaxDefsPerPass defs; position-major outputs): this launch walks defs
+    // rec_d0 .. rec_d0 + D - 1 of a config of rec_D defs and writes their record planes straight into the caller's buffer
+    // ([M/4][rec_D][nb][4]); instead of (meaningless per-group) masked rows its finisher writes the tile summaries the combine
+    // kernel needs — per tile and string 80 bytes: ST / EN bitvectors + one substr-id byte per row, [tile][5][B][16 B]
+    uint32_t rec_D, rec_d0;       // 0 / 0: this launch's defs are the whole config
+    uint32_t *summary;            // NULL: an ordinary launch
     uint32_t nt_mix;              // position-major kernels: which stores are write-back instead of streaming (kNtMix*, hrx_kernel_pm.hip)
     uint32_t pace_even;           // profiling only (HRX_PACE, stamps / ablation builds): x 64 idle cycles per tile for the walkers of even workgroups; 0 in the product
     DefConsts dc[kMaxDefsPerLaunch];
@@ -154,7 +160,8 @@ struct CombineArgs {
     uint32_t *records;
     uint16_t *masked;
     uint64_t *status;
-    const uint32_t *grec[kMaxGroups];
+    const uint32_t *grec[kMaxGroups];      // copy mode: the groups' private records buffers; summary mode: NULL
+    const uint32_t *gsummary[kMaxGroups];  // summary mode (position-major outputs): the groups' tile summaries (WitnessArgs::summary)
     const uint64_t *gstatus[kMaxGroups];
     uint8_t gD[kMaxGroups], gfirst[kMaxGroups];
 };

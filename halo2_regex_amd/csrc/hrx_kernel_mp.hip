@@ -157,10 +157,120 @@ __global__ __launch_bounds__(256) void witness_combine_kernel(const CombineArgs 
     a.status[b] = sw;
 }
 
+// Summary mode (position-major outputs): the passes have written their record planes into the caller's buffer themselves and
+// left, per tile and string, 80 bytes of summary (ST / EN bitvectors of the group's defs + one substr-id byte per row).  The
+// combine reads G x 1.25 + 1 bytes per row and writes the 2 bytes of masked rows: a config of D defs then costs about
+// 4 D + G (1 + 1.25) + 3 bytes per row against 4 D + 3 for a single launch.  Two defs of DIFFERENT groups flagging one row
+// show as overlapping bits here; two defs of one group were caught by that group's own walk (its status word says so).
+__global__ __launch_bounds__(256) void witness_combine_summary_kernel(const CombineArgs a) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t B = a.B, M = a.M;
+    const uint32_t b0 = (blockIdx.x * 4u + wave) * 64u;
+    if (b0 >= B) return;
+    const uint32_t b = b0 + lane;
+    const bool active = b < B;
+    const uint32_t bc = active ? b : B - 1u;
+    const uint32_t n_raw = a.lens[bc];
+    const bool badlen = n_raw > M;
+    const uint32_t n = badlen ? M : n_raw;
+    const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0), bl = bc - blk0;
+    const size_t q8 = (M + 7u) / 8u;
+    const bool in_pm = (a.layout & 2u) != 0;
+    const uint8_t *cptr = in_pm ? a.chars + (size_t)blk0 * a.stride + (size_t)bl * 16u : a.chars + (size_t)bc * a.stride;
+    const size_t cmul = in_pm ? (size_t)nb : (size_t)1;
+    const uint32_t row_cap = (uint32_t)a.stride - 16u;
+    MaskCarry mc = {0, 0, 0, 0};
+    uint32_t sum_prev = 0, ov_row = 0xffffffffu;
+    const uint32_t ntiles = (M + 63u) >> 6;
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const uint32_t t0 = t << 6;
+        uint32_t sidq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sidq[q] = 0;
+        uint64_t st = 0, en1 = 0, ov_st = 0, ov_en = 0;
+        for (uint32_t g = 0; g < a.G; ++g) {
+            const uint4 *sp = reinterpret_cast<const uint4 *>(a.gsummary[g]) + ((size_t)t * 5u * B + bc);
+            const uint4 h = sp[0];
+            const uint64_t gst = (uint64_t)h.x | ((uint64_t)h.y << 32), gen = (uint64_t)h.z | ((uint64_t)h.w << 32);
+            ov_st |= st & gst;
+            ov_en |= en1 & gen;
+            st |= gst;
+            en1 |= gen;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                const uint4 v = sp[(size_t)(i + 1u) * B];
+                sidq[4 * i] += v.x; sidq[4 * i + 1] += v.y; sidq[4 * i + 2] += v.z; sidq[4 * i + 3] += v.w;   // byte sums <= 255 (finalize_defs)
+            }
+        }
+        if (ov_row == 0xffffffffu) {
+            if (ov_st) ov_row = t0 + (uint32_t)ctz64(ov_st);
+            if (ov_en) ov_row = min(ov_row, t0 + (uint32_t)ctz64(ov_en) + 1u);
+        }
+        uint64_t ch = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t x = sidq[q], y = (x << 8) | (q ? (sidq[q - 1] >> 24) : sum_prev);
+            ch |= (uint64_t)nonzero_bytes4(x ^ y) << (4 * q);
+        }
+        sum_prev = sidq[15] >> 24;
+        TileBits tb{st, en1, ch};
+        TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
+        if (!active) tm.fix = 0;
+        uint64_t fixm = __ballot(tm.fix != 0);
+        while (fixm) {   // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare)
+            const int j = __ffsll((unsigned long long)fixm) - 1;
+            fixm &= fixm - 1;
+            const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
+            const uint32_t bj = b0 + (uint32_t)j;
+            for (uint32_t r = fs + lane; r < t0; r += 64u)
+                a.masked[((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;
+        }
+        uint32_t cw[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(t0 + 16u * i, row_cap) * cmul);
+            const bool have = t0 + 16u * i <= row_cap;
+            cw[4 * i] = have ? c.x : 0u; cw[4 * i + 1] = have ? c.y : 0u; cw[4 * i + 2] = have ? c.z : 0u; cw[4 * i + 3] = have ? c.w : 0u;
+        }
+        const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t row8 = t0 + 8u * k;
+            if (row8 < M) {
+                const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (mbyte) v = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);
+                __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4 *>(a.masked + ((size_t)blk0 * q8 + (size_t)(row8 >> 3) * nb + bl) * 8u));
+            }
+        }
+    }
+    if (!active) return;
+    uint64_t sw = 0;
+    bool done = false;
+    if (badlen) { sw = kStatusBadLength; done = true; }
+    uint32_t accept = 0;
+    for (uint32_t g = 0; g < a.G && !done; ++g) {
+        const uint64_t s = a.gstatus[g][b];
+        const uint32_t code = (uint32_t)(s & 0xffu);
+        if (code == kStatusInvalidTransition) {
+            sw = (s & ~0xff00ull) | ((((s >> 8) & 0xffu) + a.gfirst[g]) << 8);
+            done = true;
+        } else if (code == kStatusFlagOverlap) {
+            ov_row = min(ov_row, (uint32_t)(s >> 40));   // two defs of this group flag the same row
+        } else if (code == kStatusOk) {
+            accept |= (uint32_t)((s >> 8) & 0xffu) << a.gfirst[g];
+        }
+    }
+    if (!done) sw = ov_row != 0xffffffffu ? status_overlap(ov_row) : status_ok(accept);
+    a.status[b] = sw;
+}
+
 hipError_t launch_combine(const CombineArgs &a, hipStream_t stream) {
     const uint32_t groups64 = (a.B + 63u) / 64u;
     const dim3 grid((groups64 + 3u) / 4u), block(256);
-    if (a.layout & 1u) hipLaunchKernelGGL(witness_combine_kernel<false>, grid, block, 0, stream, a);
+    if (a.gsummary[0]) hipLaunchKernelGGL(witness_combine_summary_kernel, grid, block, 0, stream, a);
+    else if (a.layout & 1u) hipLaunchKernelGGL(witness_combine_kernel<false>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(witness_combine_kernel<true>, grid, block, 0, stream, a);
     return hipGetLastError();
 }

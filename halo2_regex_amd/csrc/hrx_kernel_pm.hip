@@ -143,6 +143,15 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             }
             ring_post(sum_freed_off, f + 1u);   // (its release fence waits for the reads above)
             lds_store_u32(freed2_off, f + 1u);
+            if (a.summary) {   // a pass of a multi-pass config: the combine kernel forms the sums over all defs (hrx_kernel_mp.hip)
+                if (active_f) {
+                    uint4 *sp = reinterpret_cast<uint4 *>(a.summary) + ((size_t)tf * 5u * B + (b0_f + lane));
+                    sp[0] = s0;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) sp[(size_t)(i + 1u) * B] = make_uint4(sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]);
+                }
+                continue;
+            }
             TileBits tb;
             tb.st = (uint64_t)s0.x | ((uint64_t)s0.y << 32);
             tb.en1 = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
@@ -315,10 +324,12 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
             // SM (string-major outputs from this kernel: D = 3, which the walker/storer kernel's 128-byte string-tiles do not
             // cover): records [B][pitch][D], masked [B][pitch] — same walk, the lane's own strides
+            // a pass of a multi-pass config writes its defs' planes of the caller's [M/4][rec_D][nb][4] buffer (hrx_kernel.hpp)
+            const uint32_t RD = a.rec_D ? a.rec_D : (uint32_t)D;
             unsigned char *rp = SM ? reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * a.rec_pitch * D * 4u
-                                   : reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * D + (bc - blk0)) * 16u;
+                                   : reinterpret_cast<unsigned char *>(a.records) + (((size_t)blk0 * q4 * RD + (size_t)a.rec_d0 * nb) + (bc - blk0)) * 16u;
             // (kDbgFixedLines, profiling only: every quad / octet of a string lands on the first one — same store instructions, no new lines or pages)
-            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u * D : (size_t)nb * 16u * D;  // one quad of rows further: [M/4][D][nb][4]
+            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u * D : (size_t)nb * 16u * RD;  // one quad of rows further: [M/4][D][nb][4]
             unsigned char *mp = SM ? reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * a.msk_pitch * 2u
                                    : reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
             const size_t mstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u : (size_t)nb * 16u;      // 8 rows further: [M/8][nb][8]

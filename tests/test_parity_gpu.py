@@ -655,7 +655,7 @@ def test_more_than_three_regex_defs_multi_pass(hra, oracle, names):
     D = len(names)
     for M in (328, 203):                                       # aligned and unaligned row counts
         cfg = _cfg(hra, names, M)
-        assert cfg.describe_launch(700, layout=3).startswith("multi-pass, ") and "witness_combine_kernel<false>" in cfg.describe_launch(700, layout=3)
+        assert cfg.describe_launch(700, layout=3).startswith("multi-pass, ") and "witness_combine_summary_kernel" in cfg.describe_launch(700, layout=3)
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=31)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=3, stride=chars.shape[1])
         chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
