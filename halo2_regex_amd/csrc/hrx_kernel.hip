@@ -91,15 +91,15 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
         for (; pairs >= 1; --pairs) {
             for (int ns = 4; ns >= 2; --ns) {
-                const size_t lds = a.pair_bytes + (size_t)pairs * (ns * kPpSlotBytes + 16);
+                const size_t lds = a.pair_bytes + (size_t)pairs * pp_pair_bytes((size_t)ns);
                 if (lds > kLdsLimit) continue;
                 out.split = 6; out.gtab = 0; out.wide = 0; out.half = 0;
-                out.waves_per_wg = 2 * pairs;
+                out.waves_per_wg = 3 * pairs;   // walker + loader + finisher
                 out.nslots = ns;
                 out.lds_bytes = lds;
                 const size_t need = ((size_t)a.n_groups + pairs - 1) / pairs;
                 size_t per_cu = kLdsLimit / lds;
-                if (per_cu * (size_t)(2 * pairs) > 8) per_cu = 8 / (size_t)(2 * pairs);
+                if (per_cu * (size_t)(3 * pairs) > 12) per_cu = 12 / (size_t)(3 * pairs);
                 if (per_cu < 1) per_cu = 1;
                 const size_t cap = (size_t)num_cus * per_cu;
                 out.grid = (int)(need < cap ? need : cap);

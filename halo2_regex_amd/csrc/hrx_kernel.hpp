@@ -141,6 +141,7 @@ constexpr int pm_max_threads(bool half, bool sm) { return (!half && !sm) ? 768 :
 constexpr size_t kPmCounterBytes = 128;   // ready / freed / freed2 / sum_ready / sum_freed / gq_ready + the 16-entry group queue
 constexpr size_t pm_pair_bytes(size_t nring, bool half, bool fin) { return nring * 4096 + (half ? 0 : 4096) + (fin ? kPmSummaryBytes : 0) + kPmCounterBytes; }
 constexpr size_t kPpSlotBytes = 8192;   // pair-step kernel: one ring slot = 4 KiB of pair indices + 4 KiB of raw bytes
+constexpr size_t pp_pair_bytes(size_t nring) { return nring * kPpSlotBytes + kPmSummaryBytes + kPmCounterBytes; }   // + the finisher's tile summary + counters
 // LDS bytes per group of the def-parallel kernel: input ring + (D - 1) x (2 summaries of 5 KiB + a 2-KiB status piece) + counters
 constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 128; }
 

@@ -120,18 +120,24 @@ __device__ __forceinline__ TileBits walk_tile_pp(PpLane &L, const uint32_t (&iw)
     return tb;
 }
 
-__global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, const uint32_t nring) {
+// Three waves per group of 64 strings, like witness_pm_kernel: walker (chain, records, error paths, status), loader (input
+// + byte -> class translation) and FINISHER (reveal masks, fix-ups, masked rows from the raw bytes in the ring slot and the
+// 96-byte-per-lane tile summary the walker hands over).  This kernel serves batches that leave walker slots — whole SIMDs —
+// empty, so the third wave costs nothing and takes ~a quarter of the walker's tile time off the string's serial chain.
+__global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, const uint32_t nring) {
     constexpr uint32_t kSlot = (uint32_t)kPpSlotBytes, kRaw = 4096u;   // slot = [pair indices 4 KiB][raw bytes 4 KiB]
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t pairs = blockDim.x >> 7;  // walker waves 0..pairs-1, loader waves pairs..2*pairs-1
-    const bool is_walker = wave < pairs;
-    const uint32_t pair = is_walker ? wave : wave - pairs;
+    const uint32_t pairs = (blockDim.x >> 6) / 3u;  // walker waves 0..pairs-1, loader waves pairs..2*pairs-1, finisher waves 2*pairs..3*pairs-1
+    const bool is_walker = wave < pairs, is_finisher = wave >= 2u * pairs;
+    const uint32_t pair = wave % pairs;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
     const uint32_t tab_bytes = a.pair_bytes, lut = a.pair_lut_off, C = a.pair_classes;
-    const uint32_t ring_base = tab_bytes + pair * (nring * kSlot + 16u);
-    const uint32_t ready_off = ring_base + nring * kSlot, freed_off = ready_off + 4u;
+    const uint32_t ring_base = tab_bytes + pair * (uint32_t)pp_pair_bytes(nring);
+    const uint32_t sum_off = ring_base + nring * kSlot;                                   // the tile summary (kPmSummaryBytes)
+    const uint32_t ready_off = sum_off + (uint32_t)kPmSummaryBytes, freed_off = ready_off + 4u;
+    const uint32_t freed2_off = ready_off + 8u, sum_ready_off = ready_off + 12u, sum_freed_off = ready_off + 16u;
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
     uint32_t seq = 0;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
     uint32_t first_len = M;
     if (is_walker && g_first < a.n_groups) first_len = a.lens[min(g_first * 64u + lane, B - 1u)];
     uint4 first_tile[4];
-    if (!is_walker && g_first < a.n_groups) {
+    if (!is_walker && !is_finisher && g_first < a.n_groups) {
         const bool in_pm0 = (a.layout & 2u) != 0;
         const uint32_t bl = min(g_first * 64u + lane, B - 1u);
         const uint32_t blk0 = (g_first * 64u / kPmBlock) * kPmBlock, nb0 = min(kPmBlock, B - blk0);
@@ -154,10 +160,72 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
         const uint4 *src = reinterpret_cast<const uint4 *>(a.pair_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) dst[i] = src[i];
-        if (is_walker && lane == 0) { lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0); }
+        if (is_walker && lane == 0) {
+            lds_store_u32(ready_off, 0); lds_store_u32(freed_off, 0);
+            lds_store_u32(freed2_off, 0); lds_store_u32(sum_ready_off, 0); lds_store_u32(sum_freed_off, 0);
+        }
     }
     __syncthreads();
 
+    if (is_finisher) {
+        // ================================ finisher ================================
+        const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
+        const size_t q8 = (M + 7u) / 8u;
+        const bool nt_msk = !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
+        uint32_t f = 0;
+        for (uint32_t j = 0; j < my_groups; ++j) {
+            const uint32_t b0 = (g_first + j * g_stride) * 64u, b = b0 + lane;
+            const bool active = b < B;
+            const uint32_t bc = active ? b : B - 1u;     // lanes beyond the batch shadow the last string (same values, same addresses)
+            const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);
+            unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
+            const size_t mstep = (size_t)nb * 16u;
+            MaskCarry mc = {0, 0, 0, 0};
+            for (uint32_t tf = 0; tf < ntiles; ++tf, ++f) {
+                const uint32_t t0 = tf << 6;
+                ring_wait(sum_ready_off, f + 1u);
+                const uint4 s0 = lds_u128(sum_off + lane * 16u), s1 = lds_u128(sum_off + 1024u + lane * 16u);
+                uint32_t sidq[16], cw[16];
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint4 v = lds_u128(sum_off + 2048u + i * 1024u + lane * 16u);
+                    sidq[4 * i] = v.x; sidq[4 * i + 1] = v.y; sidq[4 * i + 2] = v.z; sidq[4 * i + 3] = v.w;
+                    const uint4 c = lds_u128(ring_base + (f % nring) * kSlot + kRaw + i * 1024u + lane * 16u);
+                    cw[4 * i] = c.x; cw[4 * i + 1] = c.y; cw[4 * i + 2] = c.z; cw[4 * i + 3] = c.w;
+                }
+                ring_post(sum_freed_off, f + 1u);   // (its release fence waits for the reads above)
+                lds_store_u32(freed2_off, f + 1u);
+                TileBits tb;
+                tb.st = (uint64_t)s0.x | ((uint64_t)s0.y << 32);
+                tb.en1 = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
+                tb.ch = (uint64_t)s1.x | ((uint64_t)s1.y << 32);
+                const uint32_t n_f = s1.z;
+                // ---------------- reveal masks: lib.rs:598-764 ----------------
+                TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n_f, M), rows_below(t0, n_f));
+                if (a.debug & kDbgPpNoMask) { tm.mask = 0; tm.fix = 0; }
+                if (!active) tm.fix = 0;
+                uint64_t fixm = __ballot(tm.fix != 0);
+                while (fixm) {   // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare with real definitions)
+                    const int jj = __ffsll((unsigned long long)fixm) - 1;
+                    fixm &= fixm - 1;
+                    const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, jj);
+                    const uint32_t bj = b0 + (uint32_t)jj;
+                    for (uint32_t r = fs + lane; r < t0; r += 64u)
+                        a.masked[((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;
+                }
+                // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8] (lib.rs:752-761) ----------------
+                const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (mbyte) v = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);
+                    if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + ((size_t)tf * 8u + (size_t)k) * mstep, v, nt_msk);
+                }
+            }
+        }
+        return;
+    }
     if (!is_walker) {
         // ================================ loader ================================
         // Rolling register prefetch exactly as in witness_pm_kernel (RT tiles ahead, counted vmcnt).  On hand-over the 64
@@ -211,7 +279,10 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
             for (uint32_t k = 0; k < RT; ++k) {
                 const uint32_t sq = s0 + k;
                 if (sq < total && sq != 0u) {
-                    if (sq >= nring) ring_wait(freed_off, sq - nring + 1u);  // the walker is done with this slot
+                    if (sq >= nring) {
+                        ring_wait(freed_off, sq - nring + 1u);     // the walker is done with this slot
+                        ring_wait(freed2_off, sq - nring + 1u);    // ... and the finisher with its raw bytes
+                    }
                     const uint32_t slot = ring_base + (sq % nring) * kSlot;
                     // tile sq was requested RT tiles ago; RT-1 younger tiles (4 loads each) may still be in flight
                     if (sq + RT <= total) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
@@ -241,19 +312,14 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
         L.lo = a.dc[0].first_state * blk8;   // states[0] = first_state_val: lib.rs:807 (byte 3 = 0: no substr id before row 0)
         L.cmp = 0;
         L.mx = L.lo;
-        MaskCarry mc = {0, 0, 0, 0};
         uint32_t dead = 0, err_pos = 0, err_state = 0, err_char = 0;
         uint32_t acc_state = a.dc[0].first_state;  // n == 0
         const uint32_t bc = active ? b : B - 1u;  // idle lanes shadow the last string: they store the same values to the same addresses
         const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);   // the group's block of the position-major buffers
-        const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
+        const size_t q4 = (M + 3u) / 4u;
         unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 + (bc - blk0)) * 16u;
         const size_t rstep = (size_t)nb * 16u;   // one quad of rows further: [M/4][1][nb][4]
-        unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
-        const size_t mstep = (size_t)nb * 16u;   // 8 rows further: [M/8][nb][8]
-        uint4 pend[8];                           // the previous tile's masked rows, not yet stored
-        unsigned char *pend_mp = mp;
-        bool have_pend = false;
+        uint4 pend[8];                           // (the sink's slot for masked rows in flight: unused here, they are the finisher's)
 #pragma unroll
         for (int k = 0; k < 8; ++k) pend[k] = make_uint4(0, 0, 0, 0);
 
@@ -274,7 +340,7 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
             uint32_t odd_dead = 0;
             const bool full = (t0 + 64u < min_n);
             GlobalSink<1, false> sink{rp, (size_t)nb * 16u, rstep, !(a.debug & kDbgSkipRecords), !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)),
-                                      pend, pend_mp, mstep, have_pend && !(a.debug & kDbgSkipMasked), {}};
+                                      pend, rp, rstep, false, {}};
             TileBits tb;
             if (full) tb = walk_tile_pp<true>(L, iw, a, sink, 0, 0, sidq, acc_state, odd_dead);
             else tb = walk_tile_pp<false>(L, iw, a, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, sidq, acc_state, odd_dead);
@@ -303,47 +369,16 @@ __global__ __launch_bounds__(512) void witness_pp_kernel(const WitnessArgs a, co
             }
             // ---------------- accept state when n == M: row n does not exist, s[n] is the live state ----------------
             if (!full && n == t0 + 64u && t + 1 == ntiles) acc_state = lds_u32((L.lo & 0xffffu) * 8u + 4u) & 0xffu;
-            // ---------------- reveal masks: lib.rs:598-764 ----------------
-            TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));
-            if (a.debug & kDbgPpNoMask) { tm.mask = 0; tm.fix = 0; }
-            if (!active) tm.fix = 0;
-            uint64_t fixm = __ballot(tm.fix != 0);
-            while (fixm) {   // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare with real definitions)
-                const int j = __ffsll((unsigned long long)fixm) - 1;
-                fixm &= fixm - 1;
-                const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
-                const uint32_t bj = b0 + (uint32_t)j;
-                for (uint32_t r = fs + lane; r < t0; r += 64u)
-                    a.masked[((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;
-            }
-            // ---------------- masked rows of this tile: 8 x 16 B per string; they leave during the next tile's walk ----------------
+            ring_post(freed_off, seq + 1u);   // done with the slot's pair indices and (slow path) raw bytes; the finisher frees its own view
+            // ---------------- hand the tile over to the finisher wave: bitvectors, substr-id bytes, the string's length ----------------
+            ring_wait(sum_freed_off, seq);   // it has consumed the previous tile's summary (one summary area per pair)
+            typedef __attribute__((address_space(3))) v4u32 lds_v4u32;
+            *(lds_v4u32 *)(uintptr_t)(sum_off + lane * 16u) = v4u32{(uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32)};
+            *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{(uint32_t)tb.ch, (uint32_t)(tb.ch >> 32), n, 0u};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) pend[k] = make_uint4(0, 0, 0, 0);
-            if (__any(tm.mask != 0)) {   // the raw bytes are needed only where a mask bit is set
-                uint32_t cw[16];
-#pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
-                    const uint4 v = lds_u128(slot + kRaw + i * 1024u + lane * 16u);
-                    cw[4 * i] = v.x; cw[4 * i + 1] = v.y; cw[4 * i + 2] = v.z; cw[4 * i + 3] = v.w;
-                }
-                const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
-                    if (mbyte) pend[k] = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);  // lib.rs:752-761
-                }
-            }
-            ring_post(freed_off, seq + 1u);   // done with the slot (indices, and raw bytes of the slow paths / masked rows)
-            pend_mp = mp;
-            mp += 8u * mstep;
-            have_pend = true;
-        }
-        // the last tile's masked rows (only the octets that exist: [ceil(M/8)][B][8])
-        if (have_pend) {
-            const uint32_t t0 = (ntiles - 1u) << 6;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (t0 + (uint32_t)k * 8u < M) store16(pend_mp + (size_t)k * mstep, pend[k], !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)));
+            for (uint32_t i = 0; i < 4u; ++i)
+                *(lds_v4u32 *)(uintptr_t)(sum_off + 2048u + i * 1024u + lane * 16u) = v4u32{sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]};
+            ring_post(sum_ready_off, seq + 1u);
         }
         // ---------------- per-string status ----------------
         if (active) {

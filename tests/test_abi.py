@@ -134,7 +134,7 @@ def test_planner_picks_the_documented_kernel_per_config():
     from halo2_regex_amd import synth
     cfg = RegexVerifyConfig.configure(1024, _defs(CFG_A[:1]), device=None)
     assert cfg.describe_launch(65536, layout=3).startswith("hrx::witness_pm_kernel<1, false, false, false> grid=256 waves=12 ring=4 ")   # a full chip: one byte per lookup; walker + loader + finisher wave per pair
-    assert cfg.describe_launch(32768, layout=3).startswith("hrx::witness_pp_kernel grid=256 waves=4 ")     # walker slots left empty: one def, 18 byte classes -> the pair-step table (76 KiB), two bytes per lookup
+    assert cfg.describe_launch(32768, layout=3).startswith("hrx::witness_pp_kernel grid=256 waves=6 ")     # walker slots left empty: one def, 18 byte classes -> the pair-step table (76 KiB), two bytes per lookup
     assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_split_kernel<1, 32> ")
     cfg = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
     assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pmd_kernel<2> grid=256 waves=6 ")       # <= 2 groups per CU: one walker per def
