@@ -128,10 +128,45 @@ def _load():
         f = getattr(lib, name)
         f.restype = res
         f.argtypes = args
+    if hasattr(lib, "hrx_device_alloc"):      # tools builds only (libhrx_ablation.so: csrc/hrx_alloc.cpp, the placement probes)
+        lib.hrx_device_alloc.restype, lib.hrx_device_alloc.argtypes = i, [i, sz, C.POINTER(vp)]
+        lib.hrx_device_free.restype, lib.hrx_device_free.argtypes = i, [vp]
     return lib
 
 
 lib = _load()
+
+
+class DeviceBuffer:
+    """TOOLS ONLY (needs libhrx_ablation.so): `nbytes` of device memory from csrc/hrx_alloc.cpp — a virtual range over 2-MiB
+    physical chunks, for the placement probes of DESIGN.md §4.4 — exposed through __cuda_array_interface__; freed with the object."""
+
+    def __init__(self, nbytes, device=0):
+        if not hasattr(lib, "hrx_device_alloc"):
+            raise HrxError(HRX_ERR_STATE, "DeviceBuffer needs the tools build: HRX_LIB_PATH=.../libhrx_ablation.so")
+        p = C.c_void_p()
+        _check(lib.hrx_device_alloc(int(device), int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes, self.device = p.value, int(nbytes), int(device)
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+    def tensor(self, dtype=None):
+        """a torch view of the whole buffer (keeps this object alive)"""
+        t = torch.as_tensor(self, device=torch.device("cuda", self.device))
+        return t if dtype is None else t.view(dtype)
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and lib is not None:      # (lib is None while the interpreter shuts down)
+            lib.hrx_device_free(self.ptr)
+            self.ptr = None
+
+
+def device_empty(numel, dtype, device, chunked=False):
+    """torch.empty((numel,), dtype) on `device`; chunked=True (tools only): backed by a DeviceBuffer"""
+    dev = torch.device(device)
+    if not chunked:
+        return torch.empty((int(numel),), dtype=dtype, device=dev)
+    nbytes = max(int(numel) * torch.empty((), dtype=dtype).element_size(), 1)
+    return DeviceBuffer(nbytes, dev.index if dev.index is not None else torch.cuda.current_device()).tensor(dtype)[:numel]
 
 
 def _check(rc):
@@ -372,6 +407,13 @@ def chars_to_position_major(chars):
     """(B, stride) bytes, stride % 16 == 0  ->  flat HRX_LAYOUT_INPUT_POSITION_MAJOR buffer: per block of PM_BLOCK strings
     [stride/16][nb][16], blocks back to back (one block = the plain layout for B <= PM_BLOCK); torch or numpy."""
     B, stride = chars.shape
+    if hasattr(chars, "is_cuda") and chars.is_cuda:       # written block by block into the one output buffer (no second copy of the batch)
+        out = torch.empty((B * stride,), dtype=chars.dtype, device=chars.device)
+        for k0 in range(0, B, PM_BLOCK):
+            c = chars[k0:k0 + PM_BLOCK]
+            nb = c.shape[0]
+            out[k0 * stride:(k0 + nb) * stride].view(stride // 16, nb, 16).copy_(c.reshape(nb, stride // 16, 16).permute(1, 0, 2))
+        return out
     parts = []
     for k0 in range(0, B, PM_BLOCK):
         c = chars[k0:k0 + PM_BLOCK]

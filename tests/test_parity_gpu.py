@@ -715,7 +715,10 @@ def test_dynamic_group_assignment(hra, oracle, flags, names, monkeypatch):
     # graph replay: three captured launches, replayed twice, same bytes as an eager launch
     dev = torch.device("cuda", 0)
     d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
-    ref = cfg.witness_batch_position_major(d_chars, d_lens)
+    ref = cfg.alloc_outputs_position_major(B, dev)
+    for t in ref:
+        t.fill_(-1)          # (cells the contract leaves unspecified — rows of a string whose status is not 0 — keep the fill on both sides)
+    cfg.witness_batch_position_major(d_chars, d_lens, out=ref)
     out = cfg.alloc_outputs_position_major(B, dev)
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=dev)
