@@ -139,7 +139,7 @@ lib = _load()
 
 class DeviceBuffer:
     """TOOLS ONLY (needs libhrx_ablation.so): `nbytes` of device memory from csrc/hrx_alloc.cpp — a virtual range over 2-MiB
-    physical chunks, for the placement probes of DESIGN.md §4.4 — exposed through __cuda_array_interface__; freed with the object."""
+    physical chunks, for the placement probes of DESIGN.md §4.3 — exposed through __cuda_array_interface__; freed with the object."""
 
     def __init__(self, nbytes, device=0):
         if not hasattr(lib, "hrx_device_alloc"):

@@ -113,7 +113,7 @@ void hrx_ctx_destroy(hrx_ctx *ctx);
 int hrx_ctx_device(const hrx_ctx *ctx);
 /* Host-buffer batches (hrx_witness_batch_host, hrx_multi_witness_batch_host) of fewer than `rows` witness rows (B x M)
  * are walked on the calling host thread instead of being staged to the device; default HRX_DEFAULT_HOST_THRESHOLD
- * (the measured crossover, DESIGN.md §4.3); 0 = always the device.  The single-string entry points below always take the
+ * (the measured crossover, DESIGN.md §7c); 0 = always the device.  The single-string entry points below always take the
  * host walk (one GPU lane needs ~50 ns per row, a host core ~3).  Results are identical either way. */
 #define HRX_DEFAULT_HOST_THRESHOLD 32768
 int hrx_ctx_set_host_threshold(hrx_ctx *ctx, size_t rows);
