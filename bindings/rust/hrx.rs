@@ -46,6 +46,9 @@ extern "C" {
     pub fn hrx_witness_batch_device_layout(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, lens: *const u32, b: usize,
                                            m: usize, records: *mut u32, masked: *mut u16, status: *mut u64, stream: *mut c_void) -> c_int;
     pub fn hrx_position_major_sizes(b: usize, m: usize, d: usize, n_records_u32: *mut usize, n_masked_u16: *mut usize);
+    /// placement-aware allocation of the two output buffers of a large position-major batch; release each with hrx_device_free
+    pub fn hrx_alloc_outputs_position_major(ctx: *mut hrx_ctx, b: usize, m: usize, records: *mut *mut u32, masked: *mut *mut u16) -> c_int;
+    pub fn hrx_device_free(ptr: *mut c_void) -> c_int;
     /// device = HRX_DEVICE_NONE (-1): a host-only context (the native small-batch walk; no GPU needed)
     pub fn hrx_device_count(count: *mut c_int) -> c_int;
     pub fn hrx_ctx_device(ctx: *const hrx_ctx) -> c_int;

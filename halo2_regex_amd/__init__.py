@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hrx_defs_push_substr_text", "hrx_defs_push_substr_file", "hrx_defs_push_allstr", "hrx_defs_push_substr",
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
-    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count",
+    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_device_free",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
@@ -98,6 +98,8 @@ def _load():
         "hrx_witness_batch_device_layout": (i, [vp, i, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_describe_launch": (i, [vp, i, sz, sz, i, C.c_char_p, sz]),
+        "hrx_alloc_outputs_position_major": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
+        "hrx_device_free": (i, [vp]),
         "hrx_multi_create": (i, [vp, C.POINTER(i), i, C.POINTER(vp)]),
         "hrx_multi_destroy": (None, [vp]),
         "hrx_multi_num_shards": (i, [vp]),
@@ -128,9 +130,9 @@ def _load():
         f = getattr(lib, name)
         f.restype = res
         f.argtypes = args
-    if hasattr(lib, "hrx_device_alloc"):      # tools builds only (libhrx_ablation.so: csrc/hrx_alloc.cpp, the placement probes)
-        lib.hrx_device_alloc.restype, lib.hrx_device_alloc.argtypes = i, [i, sz, C.POINTER(vp)]
-        lib.hrx_device_free.restype, lib.hrx_device_free.argtypes = i, [vp]
+    if hasattr(lib, "hrx_chunked_alloc"):      # tools builds only (libhrx_ablation.so: csrc/hrx_alloc.cpp, the placement probes)
+        lib.hrx_chunked_alloc.restype, lib.hrx_chunked_alloc.argtypes = i, [i, sz, C.POINTER(vp)]
+        lib.hrx_chunked_free.restype, lib.hrx_chunked_free.argtypes = i, [vp]
     return lib
 
 
@@ -142,10 +144,10 @@ class DeviceBuffer:
     physical chunks, for the placement probes of DESIGN.md §4.3 — exposed through __cuda_array_interface__; freed with the object."""
 
     def __init__(self, nbytes, device=0):
-        if not hasattr(lib, "hrx_device_alloc"):
+        if not hasattr(lib, "hrx_chunked_alloc"):
             raise HrxError(HRX_ERR_STATE, "DeviceBuffer needs the tools build: HRX_LIB_PATH=.../libhrx_ablation.so")
         p = C.c_void_p()
-        _check(lib.hrx_device_alloc(int(device), int(nbytes), C.byref(p)))
+        _check(lib.hrx_chunked_alloc(int(device), int(nbytes), C.byref(p)))
         self.ptr, self.nbytes, self.device = p.value, int(nbytes), int(device)
         self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
 
@@ -156,6 +158,20 @@ class DeviceBuffer:
 
     def __del__(self):
         if getattr(self, "ptr", None) and lib is not None:      # (lib is None while the interpreter shuts down)
+            lib.hrx_chunked_free(self.ptr)
+            self.ptr = None
+
+
+class _LibraryOwned:
+    """device memory handed out by the library (hrx_alloc_outputs_position_major), as a __cuda_array_interface__ object: the
+    torch tensors made from it keep it alive, hrx_device_free runs when the last of them goes"""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, int(nbytes)
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and lib is not None:
             lib.hrx_device_free(self.ptr)
             self.ptr = None
 
@@ -396,6 +412,7 @@ def recommended_pitches(M):
 LAYOUT_STRING_MAJOR, LAYOUT_POSITION_MAJOR, LAYOUT_INPUT_POSITION_MAJOR = 0, 1, 2
 
 
+PLACED_FROM = 1 << 30      # alloc_outputs_position_major: records of this many bytes or more come from hrx_alloc_outputs_position_major
 PM_BLOCK = 65536          # kPmBlock of csrc/hrx_lane.h: position-major buffers are blocked by this many strings
 
 
@@ -597,8 +614,16 @@ class RegexVerifyConfig:
         dev = torch.device("cuda", self.device) if device is None else device
         nr, nm = C.c_size_t(0), C.c_size_t(0)
         lib.hrx_position_major_sizes(B, self.max_chars_size, self.num_defs, C.byref(nr), C.byref(nm))
-        return (torch.empty((nr.value,), dtype=torch.int32, device=dev), torch.empty((nm.value,), dtype=torch.int16, device=dev),
-                torch.empty((B,), dtype=torch.int64, device=dev))
+        st = torch.empty((B,), dtype=torch.int64, device=dev)
+        if nr.value * 4 < PLACED_FROM or dev.index not in (None, self.device):
+            return torch.empty((nr.value,), dtype=torch.int32, device=dev), torch.empty((nm.value,), dtype=torch.int16, device=dev), st
+        # several GB: the library allocates the pair and keeps the masked-row buffer that does not collide with the records
+        pr, pmk = C.c_void_p(), C.c_void_p()
+        _check(lib.hrx_alloc_outputs_position_major(self._ctx, B, self.max_chars_size, C.byref(pr), C.byref(pmk)))
+        d = torch.device("cuda", self.device)
+        rec = torch.as_tensor(_LibraryOwned(pr.value, nr.value * 4), device=d).view(torch.int32)
+        msk = torch.as_tensor(_LibraryOwned(pmk.value, nm.value * 2), device=d).view(torch.int16)
+        return rec, msk, st
 
     def witness_batch_position_major(self, chars, lens, out=None, stream=None, chars_pm_stride=None):
         """Like witness_batch, outputs in HRX_LAYOUT_POSITION_MAJOR (use position_major_to_string_major to view them per

@@ -1,5 +1,5 @@
 // hrx_alloc.cpp — TOOLS ONLY (linked into libhrx_ablation.so, not into libhrx.so; not declared in include/hrx.h):
-// hrx_device_alloc / hrx_device_free, device buffers assembled from 2-MiB physical chunks, for the placement probes
+// hrx_chunked_alloc / hrx_chunked_free, device buffers assembled from 2-MiB physical chunks, for the placement probes
 // (tools/alloc_policy_probe.py, tools/set_probe3.py).
 //
 // Background.  On an MI355X the bandwidth of concurrent write streams depends on where the streams lie in the PHYSICAL
@@ -26,8 +26,8 @@
 
 #include "../../include/hrx.h"
 
-extern "C" int hrx_device_alloc(int device, size_t bytes, void **out);
-extern "C" int hrx_device_free(void *ptr);
+extern "C" int hrx_chunked_alloc(int device, size_t bytes, void **out);
+extern "C" int hrx_chunked_free(void *ptr);
 
 namespace {
 
@@ -52,7 +52,7 @@ void release(void *p, Mapping &m, size_t mapped_chunks) {
 
 }  // namespace
 
-extern "C" int hrx_device_alloc(int device, size_t bytes, void **out) {
+extern "C" int hrx_chunked_alloc(int device, size_t bytes, void **out) {
     if (!out || bytes == 0) return HRX_ERR_ARG;
     *out = nullptr;
     int prev = 0;
@@ -117,7 +117,7 @@ extern "C" int hrx_device_alloc(int device, size_t bytes, void **out) {
     return HRX_OK;
 }
 
-extern "C" int hrx_device_free(void *ptr) {
+extern "C" int hrx_chunked_free(void *ptr) {
     if (!ptr) return HRX_OK;
     Mapping m;
     {

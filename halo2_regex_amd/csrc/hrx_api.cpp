@@ -633,6 +633,48 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
     return HRX_OK;
 }
 
+// Placement-aware allocation of the two output buffers (hrx_place.hip).  Records first; then up to
+// kPlaceCandidates masked-row buffers of the same size, one after the other — each lands a little further from the records —
+// every one measured against the records with the two-stream probe; the fastest is kept, the others are freed.
+constexpr size_t kPlaceFromBytes = (size_t)1 << 30;   // below this the launch's footprint is in the Infinity Cache's reach: plain allocations
+constexpr int kPlaceCandidates = 12;
+int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked) {
+    if (!ctx || !records || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_outputs_position_major: bad argument");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
+    *records = nullptr; *masked = nullptr;
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    size_t nr = 0, nm = 0;
+    const size_t D = ctx->s.defs.size();
+    hrx_position_major_sizes(B, M, D, &nr, &nm);
+    const size_t rec_bytes = nr * 4, msk_bytes = nm * 2;
+    void *rec = nullptr;
+    HIP_TRY(hipMalloc(&rec, rec_bytes));
+    void *cand[kPlaceCandidates] = {nullptr};
+    int n = 0, best = 0;
+    double best_us = -1.0;
+    const int want = rec_bytes >= kPlaceFromBytes ? kPlaceCandidates : 1;
+    for (; n < want; ++n) {
+        if (hipMalloc(&cand[n], msk_bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
+        if (want == 1) break;
+        const double us = hrx::placement_probe_us(rec, rec_bytes, cand[n], msk_bytes, (uint32_t)D, ctx->stream);
+        if (us >= 0 && (best_us < 0 || us < best_us)) { best_us = us; best = n; }
+    }
+    if (want == 1 && cand[0]) n = 1;
+    if (n == 0) { (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_outputs_position_major: out of device memory"); }
+    for (int i = 0; i < n; ++i)
+        if (i != best && cand[i]) (void)hipFree(cand[i]);
+    *records = (uint32_t *)rec;
+    *masked = (uint16_t *)cand[best];
+    return HRX_OK;
+}
+
+int hrx_device_free(void *ptr) {
+    if (!ptr) return HRX_OK;
+    HIP_TRY(hipFree(ptr));
+    return HRX_OK;
+}
+
 void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16) {
     if (records_u32) *records_u32 = (M + 3) / 4 * B * 4 * D;
     if (masked_u16) *masked_u16 = (M + 7) / 8 * B * 8;

@@ -176,6 +176,19 @@ enum { HRX_LAYOUT_STRING_MAJOR = 0, HRX_LAYOUT_POSITION_MAJOR = 1, HRX_LAYOUT_IN
 int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,
                                     size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream);
 void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16);
+/* Allocates the records and masked-row buffers of a position-major batch of B strings x M rows (sizes as
+ * hrx_position_major_sizes) on ctx's device; each is released with hrx_device_free.  Optional — every entry point takes any
+ * device pointer — and for records below 1 GiB just two hipMalloc calls.  From 1 GiB on the call is PLACEMENT-AWARE: two
+ * concurrent write streams run 15 % slower on an MI355X when they lie in the same class of the physical address space
+ * (four classes, chosen by address bits >= 2^33) than when they do not, a launch writes records and masked rows as two such
+ * streams, and buffers allocated one after the other come from one neighbourhood.  So up to 12 candidate masked-row buffers
+ * are allocated in turn, each is measured against the records buffer with a two-stream write of a few hundred microseconds
+ * (both buffers are overwritten), the fastest is kept and the others are freed: 262144 x 2048 B at D = 2 runs at 0.95-1.03 ms
+ * with such a pair against 0.97-1.19 ms (1.18 ms in a fresh process) with two plain allocations (DESIGN.md §4.3,
+ * csrc/hrx_place.hip).  The call synchronises with the context's own stream only.  The reference has no counterpart: its
+ * witness lives in host Vecs. */
+int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked);
+int hrx_device_free(void *ptr);
 /* Which kernel and launch geometry the planner picks for a batch of B strings x M rows in `layout` on a gfx950 device
  * with `num_cus` compute units (MI355X: 256), as text: "hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8
  * ring=1 lds=147520" — the kernel name a profiler will show (bench.py's roofline.kernel).  Host-only: nothing is

@@ -737,6 +737,35 @@ def test_dynamic_group_assignment(hra, oracle, flags, names, monkeypatch):
         assert all(torch.equal(x, y) for x, y in zip(out, ref))
 
 
+def test_placement_aware_output_allocation(hra, oracle):
+    """hrx_alloc_outputs_position_major / hrx_device_free (include/hrx.h): below 1 GiB of records two plain allocations, from 1 GiB
+    on the masked-row buffer is the best of several candidates measured against the records buffer; either way ordinary device
+    memory that a launch fills like any other (here 140000 x 1024 rows at D = 2, 1.07 GiB of records: every string against the oracle)."""
+    import ctypes as C
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    M, B = 1024, 140000
+    cfg = _cfg(hra, CFG_A, M)
+    base_c, base_l = synth.reveal_stress(hra.PM_BLOCK, M - 7, seed=31)
+    blocks = _rolled_blocks(base_c, base_l, 3, last=B - 2 * hra.PM_BLOCK, seed=8)
+    free0 = torch.cuda.mem_get_info()[0]
+    out = cfg.alloc_outputs_position_major(B, dev)
+    assert out[0].numel() * 4 >= hra.PLACED_FROM and out[0].data_ptr() % 16 == 0 and out[1].data_ptr() % 16 == 0
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used < out[0].numel() * 4 + out[1].numel() * 2 + (256 << 20)        # the losing candidates were freed
+    del out
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < (256 << 20)                    # ... and hrx_device_free released the pair
+    st = _full_check(hra, OracleDefs.from_files(oracle, CFG_A), cfg, blocks, M, 2)      # (its launches allocate their outputs the same way)
+    assert len(st) == B
+    pr, pm = C.c_void_p(), C.c_void_p()
+    assert hra.lib.hrx_alloc_outputs_position_major(cfg._ctx, 1000, 64, C.byref(pr), C.byref(pm)) == hra.HRX_OK and pr.value and pm.value
+    assert hra.lib.hrx_device_free(pr) == hra.HRX_OK and hra.lib.hrx_device_free(pm) == hra.HRX_OK and hra.lib.hrx_device_free(None) == hra.HRX_OK
+    assert hra.lib.hrx_alloc_outputs_position_major(cfg._ctx, 0, 64, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_ARG
+    assert hra.lib.hrx_alloc_outputs_position_major(None, 8, 64, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_ARG
+
+
 def test_multi_device_driver_device_resident_shards(hra, oracle):
     """hrx_multi_witness_batch_device: device pointers per shard, one stream per shard, no PCIe copy, no collective — three shards
     on the one device (two position-major blocks' worth of strings in the middle shard), every string against the oracle."""

@@ -36,7 +36,8 @@ for c in range(NC):
     msk = torch.empty(B * M, dtype=torch.int16, device=dev)
     res.append(timeit(msk))
     keep.append(msk)
-    try: keep.append(torch.empty(int(SP * (1 << 30)), dtype=torch.uint8, device=dev))
-    except RuntimeError: break
+    if SP > 0:
+        try: keep.append(torch.empty(int(SP * (1 << 30)), dtype=torch.uint8, device=dev))
+        except RuntimeError: break
 torch.cuda.synchronize()
 print("spacer %.0f GiB, masked-row candidates in allocation order, us per launch (%.1f s in all): " % (SP, time.time() - t0) + " ".join("%.0f" % x for x in res))
