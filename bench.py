@@ -397,7 +397,8 @@ def run_rank(args, rank, world, device_index, barrier):
                                  % (label, D, B, stride, n, M, "uniform noise over the %s%s" % (alphabet, " + planted match" if planted else "")),
                      "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
                      "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of 65536 strings): chars [%d/16][B][16], records "
-                                 "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h)" % stride) if pm else
+                                 "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h); outputs from hrx_alloc_outputs_position_major (placement-aware "
+                                 "from 1 GiB of records on, two plain allocations below)" % stride) if pm else
                                 ("string-major; input stride %d B, records pitch %d rows, masked pitch %d rows" % (stride, rec_pitch, msk_pitch)),
                      "sharding": "by string index, no collective", "launch_mode": launch_mode}
     res["D"], res["rows_per_step"] = D, rows_per_step
