@@ -633,11 +633,13 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
     return HRX_OK;
 }
 
-// Placement-aware allocation of the two output buffers (hrx_place.hip).  Records first; then up to
-// kPlaceCandidates masked-row buffers of the same size, one after the other — each lands a little further from the records —
-// every one measured against the records with the two-stream probe; the fastest is kept, the others are freed.
+// Placement-aware allocation of the two output buffers (hrx_place.hip).  Records first; then masked-row
+// candidates of the same size, one after the other — each lands a little further from the records — every one measured
+// against the records with the two-stream probe.  The first candidate that reaches kPlaceGoodBytesPerUs (two streams that do
+// not collide: 7.0-7.4 TB/s; colliding ones: 6.1-6.4) is taken; failing that, the fastest of kPlaceCandidates.  The rest are freed.
 constexpr size_t kPlaceFromBytes = (size_t)1 << 30;   // below this the launch's footprint is in the Infinity Cache's reach: plain allocations
-constexpr int kPlaceCandidates = 12;
+constexpr int kPlaceCandidates = 24;
+constexpr double kPlaceGoodBytesPerUs = 6.9e6;
 int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked) {
     if (!ctx || !records || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_outputs_position_major: bad argument");
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
@@ -657,8 +659,13 @@ int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t 
     for (; n < want; ++n) {
         if (hipMalloc(&cand[n], msk_bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
         if (want == 1) break;
-        const double us = hrx::placement_probe_us(rec, rec_bytes, cand[n], msk_bytes, (uint32_t)D, ctx->stream);
+        size_t wrote = 0;
+        const double us = hrx::placement_probe_us(rec, rec_bytes, cand[n], msk_bytes, (uint32_t)D, ctx->stream, &wrote);
+#ifdef HRX_ABLATION   // tools/place_trace.py
+        if (std::getenv("HRX_PLACE_TRACE")) std::fprintf(stderr, "placement candidate %d at %p: %.1f us\n", n, cand[n], us);
+#endif
         if (us >= 0 && (best_us < 0 || us < best_us)) { best_us = us; best = n; }
+        if (us > 0 && (double)wrote / us >= kPlaceGoodBytesPerUs) { ++n; break; }
     }
     if (want == 1 && cand[0]) n = 1;
     if (n == 0) { (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_outputs_position_major: out of device memory"); }

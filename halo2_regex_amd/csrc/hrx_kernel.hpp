@@ -135,7 +135,7 @@ hipError_t launch_witness_pp(const WitnessArgs &a, const LaunchInfo &li, hipStre
 // nt_mix: low byte k: the records of every k-th tile (t % k == k - 1) are stored write-back, 0 = all streaming; bit 8: the masked
 // rows write-back.  plan_nt_mix (hrx_kernel.hip) picks k so that ~128 MiB of a launch's records stay write-back.
 // hrx_place.hip: microseconds of a time-aligned two-stream write over a records and a masked-row buffer (both are overwritten)
-double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st);
+double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, size_t *bytes_written);
 uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li);
 constexpr size_t kPmSummaryBytes = 6144;
 template <bool HALF, bool SM> constexpr bool kPmFinisher = !HALF && !SM;

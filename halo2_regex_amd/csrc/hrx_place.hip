@@ -32,13 +32,15 @@ __global__ __launch_bounds__(256) void placement_probe_kernel(unsigned char *rec
 }
 
 // Microseconds for one time-aligned two-stream write over the two (fresh: their contents are overwritten) buffers, best of
-// three; negative on a HIP error.  D: the records hold 4 * D bytes per row against the masked rows' 2.
-double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st) {
+// three; negative on a HIP error.  D: the records hold 4 * D bytes per row against the masked rows' 2.  *bytes_written: what one
+// pass wrote (for a bandwidth figure).
+double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, size_t *bytes_written) {
     uint32_t msk_waves = (uint32_t)((kProbeWaves * 2u) / (4u * D + 2u) + 64u) / 128u * 128u;   // the streams' byte ratio, in units of 128 waves
     msk_waves = std::min(std::max(msk_waves, 128u), 512u);
     const size_t rec_part = rec_bytes / kProbeParts / 4096 * 4096, msk_part = msk_bytes / kProbeParts / 4096 * 4096;
     const size_t steps = std::min<size_t>({(size_t)128, rec_part / ((size_t)(kProbeWaves - msk_waves) << 10), msk_part / ((size_t)msk_waves << 10)});
     if (steps == 0) return -1.0;
+    if (bytes_written) *bytes_written = (size_t)kProbeParts * steps * ((size_t)kProbeWaves << 10);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
     double best = -1.0;
