@@ -48,6 +48,7 @@ extern "C" {
     pub fn hrx_position_major_sizes(b: usize, m: usize, d: usize, n_records_u32: *mut usize, n_masked_u16: *mut usize);
     /// placement-aware allocation of the two output buffers of a large position-major batch; release each with hrx_device_free
     pub fn hrx_alloc_outputs_position_major(ctx: *mut hrx_ctx, b: usize, m: usize, records: *mut *mut u32, masked: *mut *mut u16) -> c_int;
+    pub fn hrx_alloc_output_pair(ctx: *mut hrx_ctx, records_bytes: usize, masked_bytes: usize, records: *mut *mut c_void, masked: *mut *mut c_void) -> c_int;
     pub fn hrx_device_free(ptr: *mut c_void) -> c_int;
     /// device = HRX_DEVICE_NONE (-1): a host-only context (the native small-batch walk; no GPU needed)
     pub fn hrx_device_count(count: *mut c_int) -> c_int;

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hrx_defs_push_substr_text", "hrx_defs_push_substr_file", "hrx_defs_push_allstr", "hrx_defs_push_substr",
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
-    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_device_free",
+    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_device_free",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
@@ -99,6 +99,7 @@ def _load():
         "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_describe_launch": (i, [vp, i, sz, sz, i, C.c_char_p, sz]),
         "hrx_alloc_outputs_position_major": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
+        "hrx_alloc_output_pair": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
         "hrx_device_free": (i, [vp]),
         "hrx_multi_create": (i, [vp, C.POINTER(i), i, C.POINTER(vp)]),
         "hrx_multi_destroy": (None, [vp]),
@@ -605,9 +606,17 @@ class RegexVerifyConfig:
         dev = torch.device("cuda", self.device) if device is None else device
         M, D = self.max_chars_size, self.num_defs
         rp, mp = (recommended_pitches(M)[:2] if pitched else (M, M))
+        st = torch.empty((B,), dtype=torch.int64, device=dev)
+        if B * rp * D * 4 >= PLACED_FROM and dev.index in (None, self.device):     # several GB: a pair that does not collide
+            pr, pmk = C.c_void_p(), C.c_void_p()
+            _check(lib.hrx_alloc_output_pair(self._ctx, B * rp * D * 4, B * mp * 2, C.byref(pr), C.byref(pmk)))
+            d = torch.device("cuda", self.device)
+            rec = torch.as_tensor(_LibraryOwned(pr.value, B * rp * D * 4), device=d).view(torch.int32).view(B, rp, D)[:, :M]
+            msk = torch.as_tensor(_LibraryOwned(pmk.value, B * mp * 2), device=d).view(torch.int16).view(B, mp)[:, :M]
+            return rec, msk, st
         rec = torch.empty((B, rp, D), dtype=torch.int32, device=dev)[:, :M]
         msk = torch.empty((B, mp), dtype=torch.int16, device=dev)[:, :M]
-        return rec, msk, torch.empty((B,), dtype=torch.int64, device=dev)
+        return rec, msk, st
 
     def alloc_outputs_position_major(self, B, device=None):
         """Flat device buffers for HRX_LAYOUT_POSITION_MAJOR: records int32 [ceil(M/4)*B*4*D], masked int16 [ceil(M/8)*B*8]."""

@@ -640,27 +640,24 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
 constexpr size_t kPlaceFromBytes = (size_t)1 << 30;   // below this the launch's footprint is in the Infinity Cache's reach: plain allocations
 constexpr int kPlaceCandidates = 24;
 constexpr double kPlaceGoodBytesPerUs = 6.9e6;
-int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked) {
-    if (!ctx || !records || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_outputs_position_major: bad argument");
+int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_bytes, void **records, void **masked) {
+    if (!ctx || !records || !masked || records_bytes == 0 || masked_bytes == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_pair: bad argument");
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
     *records = nullptr; *masked = nullptr;
     DeviceGuard guard;
     HIP_TRY(guard.set(ctx->device));
-    size_t nr = 0, nm = 0;
     const size_t D = ctx->s.defs.size();
-    hrx_position_major_sizes(B, M, D, &nr, &nm);
-    const size_t rec_bytes = nr * 4, msk_bytes = nm * 2;
     void *rec = nullptr;
-    HIP_TRY(hipMalloc(&rec, rec_bytes));
+    HIP_TRY(hipMalloc(&rec, records_bytes));
     void *cand[kPlaceCandidates] = {nullptr};
     int n = 0, best = 0;
     double best_us = -1.0;
-    const int want = rec_bytes >= kPlaceFromBytes ? kPlaceCandidates : 1;
+    const int want = records_bytes >= kPlaceFromBytes ? kPlaceCandidates : 1;
     for (; n < want; ++n) {
-        if (hipMalloc(&cand[n], msk_bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
+        if (hipMalloc(&cand[n], masked_bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
         if (want == 1) break;
         size_t wrote = 0;
-        const double us = hrx::placement_probe_us(rec, rec_bytes, cand[n], msk_bytes, (uint32_t)D, ctx->stream, &wrote);
+        const double us = hrx::placement_probe_us(rec, records_bytes, cand[n], masked_bytes, (uint32_t)D, ctx->stream, &wrote);
 #ifdef HRX_ABLATION   // tools/place_trace.py
         if (std::getenv("HRX_PLACE_TRACE")) std::fprintf(stderr, "placement candidate %d at %p: %.1f us\n", n, cand[n], us);
 #endif
@@ -668,12 +665,19 @@ int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t 
         if (us > 0 && (double)wrote / us >= kPlaceGoodBytesPerUs) { ++n; break; }
     }
     if (want == 1 && cand[0]) n = 1;
-    if (n == 0) { (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_outputs_position_major: out of device memory"); }
+    if (n == 0) { (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
     for (int i = 0; i < n; ++i)
         if (i != best && cand[i]) (void)hipFree(cand[i]);
-    *records = (uint32_t *)rec;
-    *masked = (uint16_t *)cand[best];
+    *records = rec;
+    *masked = cand[best];
     return HRX_OK;
+}
+
+int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked) {
+    if (!ctx || !records || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_outputs_position_major: bad argument");
+    size_t nr = 0, nm = 0;
+    hrx_position_major_sizes(B, M, ctx->s.defs.size(), &nr, &nm);
+    return hrx_alloc_output_pair(ctx, nr * 4, nm * 2, (void **)records, (void **)masked);
 }
 
 int hrx_device_free(void *ptr) {

@@ -189,6 +189,8 @@ void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32,
  * csrc/hrx_place.hip).  The call synchronises with the context's own stream only.  The reference has no counterpart: its
  * witness lives in host Vecs. */
 int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked);
+/* The same for any pair of output buffers given in bytes (string-major outputs: B * rec_pitch * D * 4 and B * msk_pitch * 2). */
+int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_bytes, void **records, void **masked);
 int hrx_device_free(void *ptr);
 /* Which kernel and launch geometry the planner picks for a batch of B strings x M rows in `layout` on a gfx950 device
  * with `num_cus` compute units (MI355X: 256), as text: "hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8
