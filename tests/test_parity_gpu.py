@@ -764,6 +764,11 @@ def test_placement_aware_output_allocation(hra, oracle):
     assert hra.lib.hrx_device_free(pr) == hra.HRX_OK and hra.lib.hrx_device_free(pm) == hra.HRX_OK and hra.lib.hrx_device_free(None) == hra.HRX_OK
     assert hra.lib.hrx_alloc_outputs_position_major(cfg._ctx, 0, 64, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_ARG
     assert hra.lib.hrx_alloc_outputs_position_major(None, 8, 64, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_ARG
+    # more than the device holds: a loud error, nothing left allocated (records too big; records fit but no masked-row candidate does)
+    free1 = torch.cuda.mem_get_info()[0]
+    assert hra.lib.hrx_alloc_output_pair(cfg._ctx, 1 << 40, 1 << 20, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_HIP and not pr.value and not pm.value
+    assert hra.lib.hrx_alloc_output_pair(cfg._ctx, 2 << 30, 1 << 40, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_HIP and not pr.value and not pm.value
+    assert abs(free1 - torch.cuda.mem_get_info()[0]) < (64 << 20)
 
 
 def test_multi_device_driver_device_resident_shards(hra, oracle):
