@@ -607,7 +607,7 @@ class RegexVerifyConfig:
         M, D = self.max_chars_size, self.num_defs
         rp, mp = (recommended_pitches(M)[:2] if pitched else (M, M))
         st = torch.empty((B,), dtype=torch.int64, device=dev)
-        if B * rp * D * 4 >= PLACED_FROM and dev.index in (None, self.device):     # several GB: a pair that does not collide
+        if B * rp * D * 4 >= PLACED_FROM and dev.index in (None, self.device) and not torch.cuda.is_current_stream_capturing():     # several GB: a pair that does not collide
             pr, pmk = C.c_void_p(), C.c_void_p()
             _check(lib.hrx_alloc_output_pair(self._ctx, B * rp * D * 4, B * mp * 2, C.byref(pr), C.byref(pmk)))
             d = torch.device("cuda", self.device)
@@ -624,7 +624,7 @@ class RegexVerifyConfig:
         nr, nm = C.c_size_t(0), C.c_size_t(0)
         lib.hrx_position_major_sizes(B, self.max_chars_size, self.num_defs, C.byref(nr), C.byref(nm))
         st = torch.empty((B,), dtype=torch.int64, device=dev)
-        if nr.value * 4 < PLACED_FROM or dev.index not in (None, self.device):
+        if nr.value * 4 < PLACED_FROM or dev.index not in (None, self.device) or torch.cuda.is_current_stream_capturing():     # (the search allocates and measures: not inside a stream capture)
             return torch.empty((nr.value,), dtype=torch.int32, device=dev), torch.empty((nm.value,), dtype=torch.int16, device=dev), st
         # several GB: the library allocates the pair and keeps the masked-row buffer that does not collide with the records
         pr, pmk = C.c_void_p(), C.c_void_p()

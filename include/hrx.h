@@ -184,10 +184,10 @@ void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32,
  * streams, and buffers allocated one after the other come from one neighbourhood.  So candidate masked-row buffers are
  * allocated in turn (at most 24), each is measured against the records buffer with a two-stream write of a few hundred
  * microseconds (both buffers are overwritten); the first that does not collide — failing that, the fastest — is kept and
- * the others are freed: 262144 x 2048 B at D = 2 runs at 0.95-1.03 ms
- * with such a pair against 0.97-1.19 ms (1.18 ms in a fresh process) with two plain allocations (DESIGN.md §4.3,
- * csrc/hrx_place.hip).  The call synchronises with the context's own stream only.  The reference has no counterpart: its
- * witness lives in host Vecs. */
+ * the others are freed: 262144 x 2048 B at D = 2 runs at 0.97-1.03 ms with such a pair against 0.97-1.19 ms (1.12-1.19 ms in
+ * a fresh process) with two plain allocations (csrc/hrx_place.hip).  The call allocates, launches on the
+ * context's own stream and waits for it: not inside a stream capture.  The reference has no counterpart: its witness lives
+ * in host Vecs. */
 int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked);
 /* The same for any pair of output buffers given in bytes (string-major outputs: B * rec_pitch * D * 4 and B * msk_pitch * 2). */
 int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_bytes, void **records, void **masked);
