@@ -505,14 +505,24 @@ def _random_defs(rng, D, big=False):
     return out
 
 
-@pytest.mark.parametrize("seed", list(range(16)) + [100, 101, 102, 103, 104, 105])
+def _fuzz_seeds():
+    """the suite's seeds, plus ranges named in HRX_FUZZ_EXTRA ("16:400,106:200") for a soak run (profiles/r02_soak.txt)"""
+    seeds = list(range(16)) + [100, 101, 102, 103, 104, 105]
+    for part in os.environ.get("HRX_FUZZ_EXTRA", "").split(","):
+        if ":" in part:
+            a, b = part.split(":")
+            seeds += [x for x in range(int(a), int(b)) if x not in seeds]
+    return seeds
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
 def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
     """Seeded fuzz: random DFAs (partial ones included: status 1 must carry the reference's state/char), 1-3 defs (overlapping
     flags -> status 2), random M incl. odd values, ragged lengths incl. 0 and > M, bytes outside the alphabets; the
     string-major and the position-major kernels against the oracle, bit for bit."""
     import torch
     rng = np.random.default_rng(1000 + seed)
-    big = seed >= 100                                                        # one big DFA: the HALF-table / global-table kernels
+    big = 100 <= seed < 10000                                                # one big DFA: the HALF-table / global-table kernels (soak seeds >= 10000: small again)
     D = 1 if big else int(rng.integers(1, 4))
     defs_t = _random_defs(rng, D, big)
     M = int(rng.choice([5, 31, 64, 100, 129, 256, 321, 520, 777]))
