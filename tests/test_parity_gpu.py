@@ -507,7 +507,7 @@ def _random_defs(rng, D, big=False):
 
 def _fuzz_seeds():
     """the suite's seeds, plus ranges named in HRX_FUZZ_EXTRA ("16:400,106:200") for a soak run (profiles/r02_soak.txt)"""
-    seeds = list(range(16)) + [100, 101, 102, 103, 104, 105]
+    seeds = list(range(16)) + [100, 101, 102, 103, 104, 105] + [20000, 20001, 20002, 20003, 20004, 20005]
     for part in os.environ.get("HRX_FUZZ_EXTRA", "").split(","):
         if ":" in part:
             a, b = part.split(":")
@@ -517,13 +517,13 @@ def _fuzz_seeds():
 
 @pytest.mark.parametrize("seed", _fuzz_seeds())
 def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
-    """Seeded fuzz: random DFAs (partial ones included: status 1 must carry the reference's state/char), 1-3 defs (overlapping
-    flags -> status 2), random M incl. odd values, ragged lengths incl. 0 and > M, bytes outside the alphabets; the
+    """Seeded fuzz: random DFAs (partial ones included: status 1 must carry the reference's state/char), 1-3 defs — 4-7 for the
+    seeds from 20000 on: the multi-pass path — (overlapping flags -> status 2), random M incl. odd values, ragged lengths incl. 0 and > M, bytes outside the alphabets; the
     string-major and the position-major kernels against the oracle, bit for bit."""
     import torch
     rng = np.random.default_rng(1000 + seed)
     big = 100 <= seed < 10000                                                # one big DFA: the HALF-table / global-table kernels (soak seeds >= 10000: small again)
-    D = 1 if big else int(rng.integers(1, 4))
+    D = 1 if big else (int(rng.integers(4, 8)) if seed >= 20000 else int(rng.integers(1, 4)))     # seeds >= 20000: more defs than one launch walks (passes + combine)
     defs_t = _random_defs(rng, D, big)
     M = int(rng.choice([5, 31, 64, 100, 129, 256, 321, 520, 777]))
     B = int(rng.choice([1, 63, 64, 65, 200, 333, 500]))
