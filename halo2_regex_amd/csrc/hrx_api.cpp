@@ -4,10 +4,13 @@
 // below the context's threshold — a GPU launch cannot beat a host core on ~1000 rows.
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -76,6 +79,9 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct hrx_place_arena;
+static void arena_retire(hrx_place_arena *a);
+
 struct hrx_ctx {
     DefsSet s;  // private copy: the ctx outlives / is independent of the hrx_defs it was made from
     int device = 0;          // HRX_DEVICE_NONE: no device, host walk only
@@ -110,6 +116,12 @@ struct hrx_ctx {
     // host) for the stream that used the scratch last.  No events: these calls must stay legal inside a stream capture.
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
+    // placement-aware output allocation (hrx_alloc_output_pair): tunables read once at creation, the last call's report
+    bool place_enabled = true, place_trace = false;
+    int place_max_steps = 48;
+    hrx_place_report last_place{};
+    struct hrx_place_arena *arena_rec = nullptr, *arena_msk = nullptr;   // bench-sized outputs: the measured arena pair requests are carved from
+    hrx_place_report arena_report{};
 #ifdef HRX_STAMPS
     DevBuf stamps;                  // tools-only build: 8 u64 per walker pair of the position-major kernel (hrx_kernel_pm.hip)
 #endif
@@ -298,6 +310,10 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     c->debug = debug_flags_from_env();
+    // tuning knobs of the placement search: HRX_PLACE=0 switches it off, HRX_PLACE_MAX_STEPS bounds the walk, HRX_PLACE_TRACE=1 prints every measured step to stderr
+    if (const char *v = std::getenv("HRX_PLACE")) c->place_enabled = std::atoi(v) != 0;
+    if (const char *v = std::getenv("HRX_PLACE_TRACE")) c->place_trace = std::atoi(v) != 0;
+    if (const char *v = std::getenv("HRX_PLACE_MAX_STEPS")) { const int n = std::atoi(v); if (n >= 1 && n <= 256) c->place_max_steps = n; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_group_counter, 64);
     if (e == hipSuccess) e = hipMemset(c->d_group_counter, 0, 64);
@@ -361,6 +377,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     }
     c->mp_masked.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
+    arena_retire(c->arena_rec); arena_retire(c->arena_msk);   // released now, or with their last sub-buffer
 #ifdef HRX_STAMPS
     c->stamps.release();
 #endif
@@ -425,7 +442,10 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         }
         if (summary && li.split != 2) return fail(HRX_ERR_STATE, "multi-pass: the planner did not pick the position-major loader/walker kernel");
         if (li.dyn) {   // launches that share the counter must not overlap: a launch on another stream waits for the previous one
-            if (ctx->scratch_used && ctx->scratch_stream != st) (void)hipStreamSynchronize(ctx->scratch_stream);
+            if (ctx->scratch_used && ctx->scratch_stream != st && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(HRX_ERR_STATE, "the context's launch scratch is in use on another stream and that stream cannot be waited for here (stream capture?): one context serves one stream / graph at a time");
+            }
             ctx->scratch_stream = st; ctx->scratch_used = true;
             const uint32_t slots = (uint32_t)li.grid * (uint32_t)(li.waves_per_wg / ((a.layout & 1u) && !li.half ? 3 : 2));
             HIP_TRY(hipMemsetAsync(ctx->d_group_counter, 0, 4, st));
@@ -456,7 +476,10 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     // on another stream first waits for the previous combine.
     const size_t G = ctx->s.groups.size();
     if (G > kMaxGroups) return fail(HRX_ERR_BOUNDS, "too many def groups");
-    if (ctx->scratch_used && ctx->scratch_stream != st) (void)hipStreamSynchronize(ctx->scratch_stream);
+    if (ctx->scratch_used && ctx->scratch_stream != st && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(HRX_ERR_STATE, "the context's group buffers are in use on another stream and that stream cannot be waited for here (stream capture?): one context serves one stream / graph at a time");
+    }
     ctx->scratch_stream = st; ctx->scratch_used = true;
     const size_t q4 = (M + 3) / 4, q8 = (M + 7) / 8, ntiles = (M + 63) / 64;
     const bool summary_mode = (layout & HRX_LAYOUT_POSITION_MAJOR) != 0;   // position-major outputs: the passes write the caller's record planes themselves
@@ -633,43 +656,195 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
     return HRX_OK;
 }
 
-// Placement-aware allocation of the two output buffers (hrx_place.hip).  Records first; then masked-row
-// candidates of the same size, one after the other — each lands a little further from the records — every one measured
-// against the records with the two-stream probe.  The first candidate that reaches kPlaceGoodBytesPerUs (two streams that do
-// not collide: 7.0-7.4 TB/s; colliding ones: 6.1-6.4) is taken; failing that, the fastest of kPlaceCandidates.  The rest are freed.
-constexpr size_t kPlaceFromBytes = (size_t)1 << 30;   // below this the launch's footprint is in the Infinity Cache's reach: plain allocations
-constexpr int kPlaceCandidates = 24;
-constexpr double kPlaceGoodBytesPerUs = 6.9e6;
+// Placement-aware allocation of the two output buffers (hrx_place.hip).
+//
+// Device memory is handed out top-down, so whatever a process allocates next lands right below what it allocated last — in
+// the same class of the physical address space, where the launch's two write streams collide.  The search WALKS down the
+// device memory instead and measures, with the two-stream probe, what lies there against where the records are:
+//   * records >= kPlaceDirectFrom (1 GiB): masked-row candidates are allocated one after the other, each is measured against
+//     the records buffer itself, and a rejected candidate stays allocated as the spacer that pushes the next one further
+//     (round 2's scheme, now bounded by a budget and a relative acceptance rule);
+//   * smaller records (the bench line's 256 MiB): buffers of that size live in the reach of the 256-MB Infinity Cache — a
+//     probe over them measures the cache — and the driver's buddy allocator puts small blocks into whatever hole is highest,
+//     not below the previous allocation.  They are therefore carved out of ARENAS: two 2-GiB blocks per context, one for
+//     records and one for masked rows, the second found by walking 2-GiB blocks down the memory and measuring each, whole,
+//     against the first (2 GiB per probe pass: the HBM regime).  Later requests are served from the same measured pair until
+//     it is full; hrx_device_free returns a sub-buffer to its arena, and an arena is released when its last sub-buffer is
+//     (and the context has moved on to another pair or is gone).
+// Reference time: the same probe over two parts of ONE block (the records arena, or the records buffer): what two streams in
+// one neighbourhood cost on this box.  A candidate is accepted when it is faster than that by kPlaceMargin — no absolute
+// threshold (round 2's 6.9 TB/s did not hold on every box); failing that the fastest measured candidate is kept.  Spacers and
+// rejected candidates are freed before the call returns.  The walk never takes more than kPlaceBudgetFrac of the free memory.
+constexpr size_t kPlaceFromBytes = (size_t)128 << 20;    // below this the whole launch lives in the Infinity Cache: plain allocations
+constexpr size_t kPlaceDirectFrom = (size_t)1 << 30;
+constexpr size_t kPlaceArenaBytes = (size_t)2 << 30, kPlaceArenaAlign = (size_t)2 << 20;
+constexpr double kPlaceMargin = 0.98, kPlaceBudgetFrac = 0.70;
+
+struct hrx_place_arena {
+    void *base = nullptr;
+    size_t bytes = 0, used = 0;
+    int live = 0;            // sub-buffers handed out and not yet freed
+    bool retired = false;    // no context serves requests from it any more: released with its last sub-buffer
+};
+static std::mutex g_arena_mu;
+static std::map<uintptr_t, hrx_place_arena *> g_arena_of;   // sub-buffer -> arena (hrx_device_free has no context argument)
+
+static void *arena_take(hrx_place_arena *a, size_t bytes) {
+    const size_t need = (bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
+    if (!a || a->used + need > a->bytes) return nullptr;
+    void *p = (unsigned char *)a->base + a->used;
+    a->used += need;
+    ++a->live;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    g_arena_of[(uintptr_t)p] = a;
+    return p;
+}
+static void arena_retire(hrx_place_arena *a) {
+    if (!a) return;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    a->retired = true;
+    if (a->live == 0) { (void)hipFree(a->base); delete a; }
+}
+// true if ptr was a sub-buffer of an arena (and has been returned to it)
+static bool arena_release(void *ptr) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arena_of.find((uintptr_t)ptr);
+    if (it == g_arena_of.end()) return false;
+    hrx_place_arena *a = it->second;
+    g_arena_of.erase(it);
+    if (--a->live == 0) {
+        if (a->retired) { (void)hipFree(a->base); delete a; }
+        else a->used = 0;      // empty again: the measured pair is reused from the start
+    }
+    return true;
+}
+
+static void place_trace(const hrx_ctx *ctx, const char *fmt, ...) {
+    if (!ctx->place_trace) return;
+    va_list ap;
+    va_start(ap, fmt);
+    std::vfprintf(stderr, fmt, ap);
+    va_end(ap);
+}
+
+// The walk.  A: the block everything is measured against (a_bytes), cand_bytes: the size of the blocks to walk with.  Returns the
+// kept candidate (NULL: none could be allocated); everything else it allocated is freed.
+static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes, hrx_place_report &rep) {
+    const uint32_t D = (uint32_t)ctx->s.defs.size();
+    unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);   // 16 bytes of the context's 64-byte scratch word area
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
+    rep.searched = 1;
+    {   // the reference: both streams inside ONE block, in the launch's byte ratio (4 D : 2)
+        const size_t a_rec = a_bytes / (4 * D + 2) * (4 * D) / 4096 * 4096;
+        rep.ref_us = hrx::placement_probe_us(A, a_rec, (unsigned char *)A + a_rec, a_bytes - a_rec, D, ctx->stream, clk, nullptr);
+    }
+    std::vector<void *> spacers;       // rejected candidates: they are what pushes the next candidate further down
+    void *best = nullptr;
+    size_t spent = 0;
+    double best_us = -1.0;
+    for (int i = 0; i < ctx->place_max_steps && spent + cand_bytes <= budget; ++i) {
+        void *cand = nullptr;
+        if (hipMalloc(&cand, cand_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        spent += cand_bytes;
+        rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
+        const double us = hrx::placement_probe_us(A, a_bytes, cand, cand_bytes, D, ctx->stream, clk, &rep.probe_bytes);
+        place_trace(ctx, "hrx placement: step %d candidate %p: %.1f us, reference %.1f us\n", i, cand, us, rep.ref_us);
+        ++rep.steps;
+        if (i == 0) rep.first_us = us;
+        const bool better = us >= 0 && (best_us < 0 || us < best_us);
+        void *loser = better ? best : cand;
+        if (better) { best = cand; best_us = us; rep.chosen_step = i; }
+        if (loser) spacers.push_back(loser);
+        if (us >= 0 && rep.ref_us > 0 && us <= kPlaceMargin * rep.ref_us) { rep.accepted = 1; break; }
+    }
+    for (void *p : spacers) (void)hipFree(p);
+    rep.best_us = best_us;
+    place_trace(ctx, "hrx placement: kept step %d (%.1f us vs reference %.1f us, %s), %d steps\n", rep.chosen_step, best_us, rep.ref_us,
+                rep.accepted ? "accepted" : "fastest measured", rep.steps);
+    return best;
+}
+
 int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_bytes, void **records, void **masked) {
     if (!ctx || !records || !masked || records_bytes == 0 || masked_bytes == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_pair: bad argument");
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
     *records = nullptr; *masked = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
     DeviceGuard guard;
     HIP_TRY(guard.set(ctx->device));
-    const size_t D = ctx->s.defs.size();
-    void *rec = nullptr;
-    HIP_TRY(hipMalloc(&rec, records_bytes));
-    void *cand[kPlaceCandidates] = {nullptr};
-    int n = 0, best = 0;
-    double best_us = -1.0;
-    const int want = records_bytes >= kPlaceFromBytes ? kPlaceCandidates : 1;
-    for (; n < want; ++n) {
-        if (hipMalloc(&cand[n], masked_bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
-        if (want == 1) break;
-        size_t wrote = 0;
-        const double us = hrx::placement_probe_us(rec, records_bytes, cand[n], masked_bytes, (uint32_t)D, ctx->stream, &wrote);
-#ifdef HRX_ABLATION   // tools/place_trace.py
-        if (std::getenv("HRX_PLACE_TRACE")) std::fprintf(stderr, "placement candidate %d at %p: %.1f us\n", n, cand[n], us);
-#endif
-        if (us >= 0 && (best_us < 0 || us < best_us)) { best_us = us; best = n; }
-        if (us > 0 && (double)wrote / us >= kPlaceGoodBytesPerUs) { ++n; break; }
+    const auto t_begin = std::chrono::steady_clock::now();
+    hrx_place_report rep{};
+    auto done = [&](void *r, void *m) -> int {
+        *records = r; *masked = m;
+        rep.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        ctx->last_place = rep;
+        return HRX_OK;
+    };
+    auto plain = [&]() -> int {
+        void *r = nullptr, *m = nullptr;
+        if (hipMalloc(&r, records_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
+        if (hipMalloc(&m, masked_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(r); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
+        return done(r, m);
+    };
+    if (records_bytes < kPlaceFromBytes || !ctx->place_enabled) return plain();
+    if (records_bytes >= kPlaceDirectFrom) {
+        // ---- large outputs: candidates measured against the records buffer itself
+        void *rec = nullptr;
+        if (hipMalloc(&rec, records_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
+        void *best = place_walk(ctx, rec, records_bytes, masked_bytes, rep);
+        if (!best && hipMalloc(&best, masked_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
+        return done(rec, best);
     }
-    if (want == 1 && cand[0]) n = 1;
-    if (n == 0) { (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
-    for (int i = 0; i < n; ++i)
-        if (i != best && cand[i]) (void)hipFree(cand[i]);
-    *records = rec;
-    *masked = cand[best];
+    // ---- bench-sized outputs: sub-buffers of the context's measured arena pair
+    if (records_bytes > kPlaceArenaBytes || masked_bytes > kPlaceArenaBytes) return plain();
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (ctx->arena_rec && ctx->arena_msk) {
+            const size_t r_need = (records_bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
+            const size_t m_need = (masked_bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
+            if (ctx->arena_rec->used + r_need <= ctx->arena_rec->bytes && ctx->arena_msk->used + m_need <= ctx->arena_msk->bytes) {
+                void *r = arena_take(ctx->arena_rec, records_bytes), *m = arena_take(ctx->arena_msk, masked_bytes);
+                if (attempt == 0) { rep = ctx->arena_report; rep.searched = 2; }   // served from the pair an earlier call measured
+                return done(r, m);
+            }
+            arena_retire(ctx->arena_rec); arena_retire(ctx->arena_msk);     // full: a new pair
+            ctx->arena_rec = ctx->arena_msk = nullptr;
+        }
+        void *A = nullptr;
+        if (hipMalloc(&A, kPlaceArenaBytes) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+        void *X = place_walk(ctx, A, kPlaceArenaBytes, kPlaceArenaBytes, rep);
+        if (!X) { (void)hipFree(A); rep = hrx_place_report{}; return plain(); }
+        ctx->arena_rec = new hrx_place_arena(); ctx->arena_rec->base = A; ctx->arena_rec->bytes = kPlaceArenaBytes;
+        ctx->arena_msk = new hrx_place_arena(); ctx->arena_msk->base = X; ctx->arena_msk->bytes = kPlaceArenaBytes;
+        ctx->arena_report = rep;
+    }
+    return plain();
+}
+
+int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out) {
+    if (!ctx || !out) return fail(HRX_ERR_ARG, "NULL argument");
+    *out = ctx->last_place;
+    return HRX_OK;
+}
+
+int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, uint16_t *masked, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
+    if (B == 0) return HRX_OK;
+    if (!chars || !records || !masked) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)records & 15) || ((uintptr_t)masked & 15))
+        return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    // the store policy the planner gives the real launch of this shape
+    WitnessArgs a{};
+    a.layout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)ctx->s.defs.size();
+    LaunchInfo li{};
+    li.split = 2;
+    const uint32_t nt_mix = plan_nt_mix(a, li);
+    HIP_TRY(launch_traffic_pass(chars, stride, B, M, a.D, records, masked, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream));
     return HRX_OK;
 }
 
@@ -682,6 +857,7 @@ int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t 
 
 int hrx_device_free(void *ptr) {
     if (!ptr) return HRX_OK;
+    if (arena_release(ptr)) return HRX_OK;   // a sub-buffer of a measured arena pair (hrx_alloc_output_pair)
     HIP_TRY(hipFree(ptr));
     return HRX_OK;
 }
@@ -791,6 +967,7 @@ void hrx_multi_destroy(hrx_multi *m) {
 
 int hrx_multi_num_shards(const hrx_multi *m) { return m ? (int)m->ctxs.size() : 0; }
 int hrx_multi_shard_device(const hrx_multi *m, int shard) { return m && shard >= 0 && shard < (int)m->ctxs.size() ? m->ctxs[(size_t)shard]->device : HRX_DEVICE_NONE; }
+void *hrx_multi_shard_stream(const hrx_multi *m, int shard) { return m && shard >= 0 && shard < (int)m->ctxs.size() ? (void *)m->ctxs[(size_t)shard]->stream : nullptr; }
 
 int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                                  uint32_t *records, uint16_t *masked, uint64_t *status) {

@@ -134,8 +134,11 @@ hipError_t launch_witness_pp(const WitnessArgs &a, const LaunchInfo &li, hipStre
 // leaves no LDS for it) nor for string-major outputs.
 // nt_mix: low byte k: the records of every k-th tile (t % k == k - 1) are stored write-back, 0 = all streaming; bit 8: the masked
 // rows write-back.  plan_nt_mix (hrx_kernel.hip) picks k so that ~128 MiB of a launch's records stay write-back.
-// hrx_place.hip: microseconds of a time-aligned two-stream write over a records and a masked-row buffer (both are overwritten)
-double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, size_t *bytes_written);
+// hrx_place.hip: microseconds (device clock) of a time-aligned two-stream write over two regions (both are overwritten); clk: 16 bytes of device scratch
+double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, unsigned long long *clk, size_t *bytes_written);
+// hrx_place.hip: the memory traffic of one position-major witness launch of this shape and nothing else (roofline diagnostics)
+hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
+                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream);
 uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li);
 constexpr size_t kPmSummaryBytes = 6144;
 template <bool HALF, bool SM> constexpr bool kPmFinisher = !HALF && !SM;

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
         const uint4 *src = WIDE ? reinterpret_cast<const uint4 *>(a.wide_image)
                                 : HALF ? reinterpret_cast<const uint4 *>(a.half_image) : reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        // (Batching these loads — several per thread in flight before their LDS writes — was tried twice and is SLOWER: the walkers' first
+        // row moves from 3.7 to 4.8 us after the launch, 81.5 -> 82.1 us per step; profiles/r03_probes/ab_staging.txt.)
         if (!GTAB)
             for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) dst[i] = src[i];
         if (is_walker && lane == 0) {

@@ -1,13 +1,18 @@
-// hrx_place.hip — placement of the two output streams of a large position-major batch (hrx_alloc_outputs_position_major,
-// include/hrx.h): the measuring half.  DESIGN.md §4.3.
+// hrx_place.hip — the measuring half of the placement-aware output allocator (hrx_alloc_output_pair, include/hrx.h;
+// DESIGN.md §4.3) and the no-compute traffic pass behind the roofline diagnostics (hrx_traffic_pass_device).
 //
 // On an MI355X two concurrent write streams run at 5.5-6.4 TB/s together when both lie in the same CLASS of the physical
 // address space and at 7.0-7.4 TB/s when they lie in different ones (four classes, selected by address bits >= 2^33; the
-// first 64 GiB of a contiguous allocation are one class: tools/region_map2d.cpp, profiles/r02_probes/placement/region_map2d.txt).
+// first 64 GiB of a contiguous allocation are one class: profiles/r02_probes/placement/region_map2d.txt).
 // A witness launch writes two such streams, records and masked rows, part k of the one while part k of the other; buffers
 // allocated one after the other — what any process does — come from one neighbourhood, i.e. one class.  User space cannot see
-// physical addresses, but it can MEASURE: this kernel writes the two buffers the way a launch does (time-aligned parts, the
-// streams' byte ratio, 1-KiB pieces per wave), and the allocator keeps the masked-row candidate that measures fastest.
+// physical addresses, but it can MEASURE: the probe kernel writes two regions the way a launch does (time-aligned parts, the
+// streams' byte ratio, 1-KiB pieces per wave) and the allocator keeps the masked-row candidate whose neighbourhood measures
+// fastest against the records' neighbourhood.
+//
+// The probe times ITSELF (s_memrealtime, the 100-MHz clock every CU shares: earliest wave start to latest wave end), so that a
+// profiler that serialises and instruments dispatches (rocprofv3 --kernel-trace) cannot blur the sub-millisecond
+// differences the search ranks candidates by — round 2's event-timed probe mis-ranked under a kernel trace.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -20,7 +25,8 @@ constexpr uint32_t kProbeWaves = 1024;   // 256 workgroups of 4 waves
 constexpr uint32_t kProbeParts = 16;
 
 __global__ __launch_bounds__(256) void placement_probe_kernel(unsigned char *rec, size_t rec_part, unsigned char *msk, size_t msk_part,
-                                                              uint32_t msk_waves, uint32_t steps) {
+                                                              uint32_t msk_waves, uint32_t steps, unsigned long long *clk) {
+    const unsigned long long t0 = wall_clock64();
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const bool on_msk = wave < msk_waves;
     const uint32_t w = on_msk ? wave : wave - msk_waves, nw = on_msk ? msk_waves : kProbeWaves - msk_waves;
@@ -29,33 +35,97 @@ __global__ __launch_bounds__(256) void placement_probe_kernel(unsigned char *rec
     const uint4 v = make_uint4(0, 0, 0, 0);
     for (uint32_t k = 0; k < kProbeParts; ++k)
         for (uint32_t s = 0; s < steps; ++s) store16_nt(base + k * part + s * window, v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been accepted by the memory system
+    if (lane == 0u) {
+        atomicMin(clk, t0);
+        atomicMax(clk + 1, wall_clock64());
+    }
 }
 
-// Microseconds for one time-aligned two-stream write over the two (fresh: their contents are overwritten) buffers, best of
-// three; negative on a HIP error.  D: the records hold 4 * D bytes per row against the masked rows' 2.  *bytes_written: what one
-// pass wrote (for a bandwidth figure).
-double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, size_t *bytes_written) {
+// Microseconds (device clock) for one time-aligned two-stream write over the two regions (their contents are overwritten):
+// median of three passes after a warm-up pass; negative on a HIP error.  D: the records hold 4 * D bytes per row against the
+// masked rows' 2.  `clk`: 16 bytes of device scratch.  *bytes_written: what one pass wrote.
+double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, unsigned long long *clk, size_t *bytes_written) {
     uint32_t msk_waves = (uint32_t)((kProbeWaves * 2u) / (4u * D + 2u) + 64u) / 128u * 128u;   // the streams' byte ratio, in units of 128 waves
     msk_waves = std::min(std::max(msk_waves, 128u), 512u);
     const size_t rec_part = rec_bytes / kProbeParts / 4096 * 4096, msk_part = msk_bytes / kProbeParts / 4096 * 4096;
     const size_t steps = std::min<size_t>({(size_t)128, rec_part / ((size_t)(kProbeWaves - msk_waves) << 10), msk_part / ((size_t)msk_waves << 10)});
-    if (steps == 0) return -1.0;
+    if (steps == 0 || !clk) return -1.0;
     if (bytes_written) *bytes_written = (size_t)kProbeParts * steps * ((size_t)kProbeWaves << 10);
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
-    double best = -1.0;
-    for (int r = 0; r < 3; ++r) {
-        (void)hipEventRecord(e0, st);
+    double us[4];
+    for (int r = 0; r < 4; ++r) {
+        if (hipMemsetAsync(clk, 0xff, 8, st) != hipSuccess || hipMemsetAsync(clk + 1, 0, 8, st) != hipSuccess) return -1.0;
         hipLaunchKernelGGL(placement_probe_kernel, dim3(kProbeWaves / 4), dim3(256), 0, st, (unsigned char *)rec, rec_part, (unsigned char *)msk, msk_part,
-                           msk_waves, (uint32_t)steps);
-        (void)hipEventRecord(e1, st);
-        float ms = 0;
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best = -1.0; break; }
-        if (r && (best < 0 || ms * 1e3 < best)) best = ms * 1e3;
+                           msk_waves, (uint32_t)steps, clk);
+        unsigned long long h[2] = {0, 0};
+        if (hipMemcpyAsync(h, clk, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1.0;
+        us[r] = h[1] > h[0] ? (double)(h[1] - h[0]) * 0.01 : -1.0;   // 100 MHz
+        if (us[r] < 0) return -1.0;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return best;
+    std::sort(us + 1, us + 4);   // (pass 0 is the warm-up)
+    return us[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// No-compute traffic pass: the memory traffic of ONE position-major witness launch of this shape — the input read in the
+// loader's 16-byte-per-lane chunks, D record planes and the masked rows written in the walker's / finisher's 1-KiB runs at the
+// launch's own addresses, with the launch's store policy (plan_nt_mix) — and no DFA work at all.  Like the kernel: one
+// workgroup per CU, four reader and four writer waves, one string per lane, groups of 64 strings strided over the writers.
+// What this takes is the box's ceiling for the launch's byte mix on these very buffers (bench.py: roofline.mix_ceiling).
+// ---------------------------------------------------------------------------------------------
+struct TrafficArgs {
+    const unsigned char *chars;
+    uint64_t stride;
+    uint32_t B, M, D;
+    unsigned char *records, *masked;
+    uint32_t nt_mix;
+    uint32_t *sink;
+};
+
+__global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_groups = (a.B + 63u) / 64u;
+    const size_t q4 = (a.M + 3u) / 4u, q8 = (a.M + 7u) / 8u;
+    for (uint32_t g = blockIdx.x * 4u + (wave & 3u); g < n_groups; g += gridDim.x * 4u) {
+        const uint32_t b = min(g * 64u + lane, a.B - 1u);
+        const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0), bl = b - blk0;
+        if (wave >= 4u) {   // reader: every 16-byte chunk of the string
+            const unsigned char *cp = a.chars + (size_t)blk0 * a.stride + (size_t)bl * 16u;
+            uint4 acc = make_uint4(0, 0, 0, 0);
+            const uint32_t nchunk = (uint32_t)(a.stride / 16u);
+#pragma unroll 8
+            for (uint32_t c = 0; c < nchunk; ++c) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(cp + (size_t)c * nb * 16u);
+                acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+            }
+            if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) a.sink[0] = acc.z ^ acc.w;
+            continue;
+        }
+        unsigned char *rp = a.records + ((size_t)blk0 * q4 * a.D + bl) * 16u;
+        unsigned char *mp = a.masked + ((size_t)blk0 * q8 + bl) * 16u;
+        const uint32_t wb_k = a.nt_mix & 0xffu;
+        for (uint32_t q = 0; q < (uint32_t)q4; ++q) {
+            const uint32_t t = q >> 4;
+            const bool wb = wb_k != 0u && (t % wb_k) == wb_k - 1u;
+            const uint4 v = make_uint4(q, 1, 2, 3);
+            for (uint32_t d = 0; d < a.D; ++d) {
+                unsigned char *p = rp + ((size_t)q * a.D + d) * nb * 16u;
+                if (wb) *reinterpret_cast<uint4 *>(p) = v;
+                else store16_nt(p, v);
+            }
+            if ((q & 1u) && (q >> 1) < (uint32_t)q8) store16_nt(mp + (size_t)(q >> 1) * nb * 16u, make_uint4(0, 0, 0, q));
+        }
+        if ((q4 & 1u) && (q4 >> 1) < q8) store16_nt(mp + (size_t)(q4 >> 1) * nb * 16u, make_uint4(0, 0, 0, 0));   // odd number of quads: the last octet
+    }
+}
+
+hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
+                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream) {
+    TrafficArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink};
+    const size_t n_groups = (B + 63) / 64, need = (n_groups + 3) / 4;
+    const int grid = (int)std::min<size_t>(need, (size_t)num_cus);
+    hipLaunchKernelGGL(traffic_pass_kernel, dim3(grid < 1 ? 1 : grid), dim3(512), 0, stream, a);
+    return hipGetLastError();
 }
 
 }  // namespace hrx
