@@ -56,6 +56,12 @@ def parse_args(argv=None):
                     help="buffer layout of include/hrx.h: HRX_LAYOUT_POSITION_MAJOR (input and outputs chunked [pos/k][string][k], "
                     "the coalesced layout) or HRX_LAYOUT_STRING_MAJOR")
     ap.add_argument("--allow-debug-flags", action="store_true", help="tools only: run although HRX_DEBUG_FLAGS is set (recorded in the line's debug_flags)")
+    ap.add_argument("--sets", type=int, default=8, help="input / output buffer sets the timed steps rotate over (1: every step re-processes one batch into one set of "
+                    "buffers, which leaves part of the traffic in the 256-MB Infinity Cache)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: --batch strings PER GPU; strong: --batch strings IN TOTAL, sharded by "
+                    "string index over the ranks (hrx_shard_range) — the BASELINE multi-GPU configs: --config headers3 --batch 262144 --len 32768 --rows 32768, "
+                    "--config dfa256 --batch 1048576 --len 4096 --rows 4096")
+    ap.add_argument("--verify-all-ranks", action="store_true", help="every rank compares its own timed buffers with the oracle (default: rank 0)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure the launch's HBM traffic (roofline.traffic)")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # spawned by a bare --gpus N run
     args = ap.parse_args(argv)
@@ -66,10 +72,17 @@ def parse_args(argv=None):
 # ----------------------------------------------------------------------------------------------------------------
 # checker / baseline legs (the oracle is never on the product path)
 # ----------------------------------------------------------------------------------------------------------------
-def oracle_handle(names):
+def oracle_handle(names, allow_build=True):
+    """the oracle (test infrastructure): None when its library is missing / stale and must not be built here (under a profiler
+    no helper process may be started)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import OracleDefs, load_oracle
-    return OracleDefs(load_oracle(), names)
+    import oracle_lib
+    if not allow_build:
+        so = os.path.join(ROOT, "oracle", "_build", "libhrx_oracle.so")
+        src = os.path.join(ROOT, "oracle", "hrx_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            return None
+    return oracle_lib.OracleDefs(oracle_lib.load_oracle(), names)
 
 
 def cpu_baseline(o, names, chars, lens, M, budget_s=8.0):
@@ -111,28 +124,37 @@ def cpu_baseline(o, names, chars, lens, M, budget_s=8.0):
     return res
 
 
-def verify_timed_buffers(o, hra, out, chars, lens, M, D, pm, nstr):
-    """Bit-exact comparison of the buffers the TIMED launches wrote with the oracle's rows for the first nstr strings
-    (all host cores): the bench line then carries proof that the timed kernel did the work."""
+def verify_timed_buffers(o, hra, sets, shift, chars, lens, M, D, pm, dev):
+    """Bit-exact comparison of EVERY buffer set the timed launches wrote with the oracle's rows for every string (position-major:
+    every string of the first block of 65536): the oracle walks the batch once on all host cores, its rows are uploaded, and set k
+    — the batch rotated by k * shift strings — is compared on the device with the rows rotated the same way."""
     import numpy as np
+    import torch
     cores = os.cpu_count() or 1
-    orec, omsk, ost = o.witness_batch(chars[:nstr], lens[:nstr], M, threads=cores)
-    rec, msk, st = out
-    if pm:
-        # the first block of the position-major buffers holds strings 0 .. min(B, 65536) - 1
-        nb = min(len(lens), hra.PM_BLOCK)
-        q4, q8 = (M + 3) // 4, (M + 7) // 8
-        r = rec[:q4 * D * nb * 4].reshape(q4, D, nb, 4)[:, :, :nstr].permute(2, 0, 3, 1).reshape(nstr, -1, D)[:, :M]
-        m = msk[:q8 * nb * 8].reshape(q8, nb, 8)[:, :nstr].permute(1, 0, 2).reshape(nstr, -1)[:, :M]
-    else:
-        r, m = rec[:nstr], msk[:nstr]
-    g_rec = r.cpu().numpy().view(np.uint32)
-    g_msk = m.cpu().numpy().view(np.uint16)
-    g_st = st[:nstr].cpu().numpy().view(np.uint64)
-    ok = (ost & np.uint64(0xff)) == 0
-    exact = bool(np.array_equal(g_st, ost) and np.array_equal(g_rec[ok], orec[ok]) and np.array_equal(g_msk[ok], omsk[ok]))
-    return {"strings": int(nstr), "rows": int(lens[:nstr].sum()), "bit_exact": exact,
-            "against": "oracle/hrx_oracle.c (%d threads) on the first %d strings of the timed output buffers: status words, records and masked rows" % (cores, nstr)}
+    B = len(lens)
+    nstr = min(B, hra.PM_BLOCK) if pm else B
+    orec, omsk, ost = o.witness_batch(chars, lens, M, threads=cores)
+    ok = torch.from_numpy(((ost & np.uint64(0xff)) == 0)).to(dev)
+    d_orec = torch.from_numpy(orec.view(np.int32)).to(dev)
+    d_omsk = torch.from_numpy(omsk.view(np.int16)).to(dev)
+    d_ost = torch.from_numpy(ost.view(np.int64)).to(dev)
+    exact, rows = True, 0
+    for k, (_, _, (rec, msk, st)) in enumerate(sets):
+        if pm:
+            # the first block of the position-major buffers holds strings 0 .. nstr - 1
+            q4, q8 = (M + 3) // 4, (M + 7) // 8
+            r = rec[:q4 * D * nstr * 4].reshape(q4, D, nstr, 4).permute(2, 0, 3, 1).reshape(nstr, -1, D)[:, :M]
+            m = msk[:q8 * nstr * 8].reshape(q8, nstr, 8).permute(1, 0, 2).reshape(nstr, -1)[:, :M]
+        else:
+            r, m = rec, msk
+        idx = (torch.arange(nstr, device=dev) - k * shift) % B      # string j of set k is string (j - k shift) mod B of the batch
+        okk = ok[idx]
+        exact = exact and bool(torch.equal(st[:nstr], d_ost[idx])) and bool(torch.equal(r[okk], d_orec[idx][okk])) and bool(torch.equal(m[okk], d_omsk[idx][okk]))
+        rows += int(lens[idx.cpu().numpy()].sum())
+        del idx, okk
+    return {"strings": int(nstr) * len(sets), "strings_per_set": int(nstr), "buffer_sets": len(sets), "rows": rows, "bit_exact": exact,
+            "against": "oracle/hrx_oracle.c (%d threads): status words, records and masked rows of every string%s of every buffer set the timed steps wrote"
+                       % (cores, "" if nstr == B else " of the first position-major block")}
 
 
 def mix_ceiling(dev_index):
@@ -143,7 +165,7 @@ def mix_ceiling(dev_index):
     if not os.path.exists(exe) or under_profiler():
         return None
     try:
-        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(dev_index))
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=physical_device(dev_index))
         txt = subprocess.run([exe, "--brief"], capture_output=True, text=True, timeout=120, env=env).stdout
         res = {}
         for line in txt.splitlines():
@@ -175,7 +197,7 @@ def measured_traffic(argv, dev_index):
     if not exe or under_profiler():
         return None
     keep = [a for a in argv if a not in ("--no-spread", "--no-verify", "--no-cpu-baseline", "--eager")]
-    for flag in ("--steps", "--warmup", "--gpus"):          # the child runs 3 eager launches on one device
+    for flag in ("--steps", "--warmup", "--gpus", "--sets"):          # the child runs 3 eager launches on one device, one buffer set
         while flag in keep:
             i = keep.index(flag)
             del keep[i:i + 2]
@@ -183,9 +205,9 @@ def measured_traffic(argv, dev_index):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             tmp = tempfile.mkdtemp(prefix="hrx_pmc_", dir="/tmp")
-            env = dict(os.environ, TMPDIR="/tmp", HIP_VISIBLE_DEVICES=str(dev_index))
+            env = dict(os.environ, TMPDIR="/tmp", HIP_VISIBLE_DEVICES=physical_device(dev_index))
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "r1", "--", sys.executable, os.path.abspath(__file__)] + keep + \
-                  ["--eager", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-verify", "--no-spread", "--no-pmc"]
+                  ["--eager", "--steps", "3", "--warmup", "1", "--sets", "1", "--no-cpu-baseline", "--no-verify", "--no-spread", "--no-pmc"]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
             vals = []
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
@@ -242,8 +264,46 @@ def workload(args):
     return names, label, alphabet, gen, planted
 
 
+def pin_to_device_numa_node(device_index):
+    """Best effort, before any GPU call: run this rank on the host cores next to its GPU (the launch loop and the graph upload
+    then do not cross sockets).  HIP enumerates devices in PCI bus order; the render nodes under /sys/class/drm carry the NUMA
+    node of each AMD GPU.  Silently does nothing where the topology cannot be read."""
+    try:
+        import glob
+        gpus = []
+        for d in glob.glob("/sys/class/drm/renderD*/device"):
+            if open(os.path.join(d, "vendor")).read().strip() == "0x1002":
+                gpus.append((os.path.basename(os.path.realpath(d)), int(open(os.path.join(d, "numa_node")).read())))
+        gpus.sort()
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        idx = int(vis.split(",")[device_index]) if vis else device_index
+        node = gpus[idx][1]
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        pass
+    return None
+
+
+def pick_sets(args, footprint_bytes):
+    """How many input / output buffer sets the timed steps rotate over (--sets; default 8): with fewer than ~2 GB touched between two
+    uses of a buffer the 256-MB Infinity Cache is part of the measurement.  Capped so that all sets fit 48 GiB."""
+    n = max(1, args.sets)
+    while n > 1 and n * footprint_bytes > (48 << 30):
+        n -= 1
+    return n
+
+
 def run_rank(args, rank, world, device_index, barrier):
     """Everything one rank does; returns its result dict (rank 0's carries the line's descriptive fields)."""
+    numa = pin_to_device_numa_node(device_index)
     import numpy as np
     import torch
     import halo2_regex_amd as hra
@@ -251,11 +311,20 @@ def run_rank(args, rank, world, device_index, barrier):
     dbg = os.environ.get("HRX_DEBUG_FLAGS", "")
     if dbg.strip() not in ("", "0", "0x0") and not args.allow_debug_flags:
         raise SystemExit("bench.py refuses to run with HRX_DEBUG_FLAGS=%r set: the timed kernel must be the one the planner picks" % dbg)
+    default_lib = os.path.join(ROOT, "halo2_regex_amd", "csrc", "libhrx.so")
+    if os.path.realpath(hra.LIB_PATH) != os.path.realpath(default_lib) and not args.allow_debug_flags:
+        raise SystemExit("bench.py refuses to run with HRX_LIB_PATH=%r: the timed library must be the release build %s" % (hra.LIB_PATH, default_lib))
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     names, label, alphabet, gen, planted = workload(args)
     D = len(names)
-    M, n, B = args.rows, args.n, args.batch
+    M, n = args.rows, args.n
+    if args.scaling == "strong":      # the job is --batch strings in total, sharded by string index (hrx_shard_range)
+        b_begin, B = hra.shard_range(args.batch, world, rank)
+        if B == 0:
+            raise SystemExit("rank %d: empty shard (--batch %d over %d ranks)" % (rank, args.batch, world))
+    else:
+        b_begin, B = rank * args.batch, args.batch
     pm = args.layout == "position-major"
     rec_pitch, msk_pitch, rec_stride = hra.recommended_pitches(M)
     if args.dense or pm:
@@ -264,18 +333,41 @@ def run_rank(args, rank, world, device_index, barrier):
     defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in names]
     cfg = hra.RegexVerifyConfig.configure(M, defs, device=device_index)
 
-    # this rank's shard of the (world * B)-string job: independent strings, seeded per rank
-    chars, lens = gen(B, n, seed=rank, stride=stride)
-    d_chars = torch.from_numpy(chars).to(dev)
-    d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    # this rank's shard of the job: independent strings, seeded per rank (strong scaling: per shard start)
+    chars, lens = gen(B, n, seed=rank if args.scaling == "weak" else 7919 * b_begin + world, stride=stride)
+    d_lens0 = torch.from_numpy(lens.astype(np.int32)).to(dev)
     rows_per_step = int(lens.sum())
+    d_chars0 = torch.from_numpy(chars).to(dev)
+    q4, q8 = (M + 3) // 4, (M + 7) // 8
+    foot = B * stride + B * rec_pitch * 4 * D + B * msk_pitch * 2
+    nsets = pick_sets(args, foot)
+    # Buffer set k holds the same strings rotated by k * shift places (another arrangement of the same batch at other addresses:
+    # generating 8 x 64 MiB of planted text on the host would take longer than everything else in this script); its oracle rows
+    # are the rotated oracle rows of set 0.
+    shift = (B // nsets + 37) % B if nsets > 1 else 0
+    sets, placement = [], []
+    for r in range(world):        # one rank at a time: the placement search times memory traffic
+        if r == rank:
+            for k in range(nsets):
+                c_k = d_chars0 if k == 0 else torch.roll(d_chars0, shifts=k * shift, dims=0)
+                l_k = d_lens0 if k == 0 else torch.roll(d_lens0, shifts=k * shift, dims=0)
+                if pm:
+                    c_k = hra.chars_to_position_major(c_k)       # [stride/16][B][16]: done once, outside the timed region
+                    out = cfg.alloc_outputs_position_major(B, dev)
+                else:
+                    c_k = c_k.contiguous()
+                    out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
+                rep = cfg.last_placement_report() if out[0].numel() * 4 >= hra.PLACED_FROM else {"searched": 0}
+                placement.append(rep)
+                sets.append((c_k, l_k, out))
+            torch.cuda.synchronize()
+        if world > 1:
+            barrier()
+    del d_chars0
     if pm:
-        d_chars = hra.chars_to_position_major(d_chars)       # [stride/16][B][16]: done once, outside the timed region
-        out = cfg.alloc_outputs_position_major(B, dev)
-        step = lambda: cfg.witness_batch_position_major(d_chars, d_lens, out=out, chars_pm_stride=stride)
+        launch = lambda i: cfg.witness_batch_position_major(sets[i % nsets][0], sets[i % nsets][1], out=sets[i % nsets][2], chars_pm_stride=stride)
     else:
-        out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
-        step = lambda: cfg.witness_batch(d_chars, d_lens, out=out)
+        launch = lambda i: cfg.witness_batch(sets[i % nsets][0], sets[i % nsets][1], out=sets[i % nsets][2])
 
     def sync_barrier():
         torch.cuda.synchronize()
@@ -285,14 +377,8 @@ def run_rank(args, rank, world, device_index, barrier):
     # the kernel and geometry the planner picks for this shape on this device (what rocprofv3 will list)
     desc = cfg.describe_launch(B, layout=3 if pm else 0, num_cus=torch.cuda.get_device_properties(dev).multi_processor_count)
 
-    for _ in range(args.warmup):
-        step()
-    sync_barrier()
-    # The K timed steps are K kernel launches.  They are recorded once into a HIP graph (stream capture of the very same
-    # step() calls) and the graph is replayed inside the timed region, so that a slow host thread cannot turn the
-    # measurement into a launch-rate test (one launch is ~80 us of device time); --eager launches them one by one.
-    run_steps, launch_mode = None, "eager"
-    if not args.eager:
+    def graph_of(fn, count):
+        """`count` calls of fn(i) recorded once into a HIP graph (stream capture of the very same calls); None if capture fails"""
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -300,23 +386,53 @@ def run_rank(args, rank, world, device_index, barrier):
             with torch.cuda.stream(side):
                 # thread_local: the RCCL watchdog thread of a multi-GPU run may poll events while this thread captures
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    for _ in range(args.steps):
-                        step()
+                    for i in range(count):
+                        fn(i)
             torch.cuda.current_stream(dev).wait_stream(side)
-            for _ in range(2):                             # untimed replays: graph upload, caches, clocks
-                g.replay()
-            torch.cuda.synchronize()
-            run_steps, launch_mode = g.replay, "hipGraph of %d kernel nodes" % args.steps
-        except Exception as e:                              # capture unsupported: fall back to plain launches
+            return g
+        except Exception as e:                              # capture unsupported: the caller falls back to plain launches
             sys.stderr.write("graph capture failed (%s): eager launches\n" % e)
             torch.cuda.synchronize()
+            return None
+
+    def timed_replays(run, reps, count):
+        per = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record()
+            torch.cuda.synchronize()
+            per.append(e0.elapsed_time(e1) / count)
+        return per
+
+    for i in range(args.warmup):
+        launch(i)
+    sync_barrier()
+    # The K timed steps are K kernel launches, step i over buffer set i % nsets.  They are recorded once into a HIP graph and the
+    # graph is replayed inside the timed region, so that a slow host thread cannot turn the measurement into a launch-rate test
+    # (one launch is ~80 us of device time); --eager launches them one by one.
+    run_steps, launch_mode = None, "eager"
+    if not args.eager:
+        g = graph_of(launch, args.steps)
+        if g is not None:
+            # untimed replays of the same graph, ~100 launches: graph upload, and the memory system's own warm-up — a kernel trace of this
+            # script shows the launches of a replay that follows a pause or other kernels taking 92 -> 84 us over its first twenty
+            # (profiles/r03_probes/trace_replays.txt); W = 5 eager steps do not cover that
+            untimed = max(2, -(-100 // args.steps))
+            for _ in range(untimed):
+                g.replay()
+            torch.cuda.synchronize()
+            run_steps, launch_mode = g.replay, "hipGraph of %d kernel nodes (after %d untimed replays of it)" % (args.steps, untimed)
     if run_steps is None:
         def run_steps():
-            for _ in range(args.steps):
-                step()   # launched on torch's current stream, where the events sit
-    # poison the outputs: what the verification reads afterwards was written by the timed launches
-    for t in out[:2]:
-        t.fill_(-1)
+            for i in range(args.steps):
+                launch(i)   # launched on torch's current stream, where the events sit
+    # poison the outputs: what the verification reads afterwards was written by the timed launches.  Status words entirely; records and
+    # masked rows at one element per 64 KiB — filling the 3 GB of buffers outright would leave the memory system (256 MB of dirty lines in
+    # the Infinity Cache, everything written once more) in a state no steady series of launches ever sees, right before the timed region.
+    for _, _, out in sets:
+        out[0].view(-1)[::16384].fill_(-1)
+        out[1].view(-1)[::32768].fill_(-1)
+        out[2].fill_(-1)
     sync_barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -328,89 +444,93 @@ def run_rank(args, rank, world, device_index, barrier):
     barrier()
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch duration, HIP events on the launch stream
 
-    # sanity: every string of the timed workload finished with status 0
-    st = out[2].cpu().numpy().view(np.uint64)
-    assert ((st & np.uint64(0xff)) == 0).all(), "status != ok in the bench workload"
+    # sanity: every string of every buffer set the timed steps wrote finished with status 0
+    written = min(nsets, args.steps)
+    for k in range(written):
+        st = sets[k][2][2].cpu().numpy().view(np.uint64)
+        assert ((st & np.uint64(0xff)) == 0).all(), "status != ok in the bench workload (buffer set %d)" % k
 
     res = {"rank": rank, "device": device_index, "rows": rows_per_step * args.steps, "elapsed_s": elapsed, "avg_launch_ms": kern_ms,
-           "debug_flags": dbg or None}
+           "debug_flags": dbg or None, "numa_node": numa, "strings": B, "shard_begin": b_begin}
+    profiled = under_profiler()
+    o = None
+    if (not args.no_verify and (rank == 0 or args.verify_all_ranks)) or (rank == 0 and not args.no_cpu_baseline):
+        o = oracle_handle(names, allow_build=not profiled)
+    if not args.no_verify and (rank == 0 or args.verify_all_ranks):
+        if o is None:
+            res["verified"] = {"bit_exact": None, "skipped": "under a profiler and the oracle library is not built: no helper process may be started here"}
+        else:
+            res["verified"] = verify_timed_buffers(o, hra, sets[:written], shift, chars, lens, M, D, pm, dev)
+            if not res["verified"]["bit_exact"]:
+                raise SystemExit("bench.py: the timed output buffers differ from the oracle")
     if rank != 0:
         return res
 
-    o = None
-    if not args.no_verify or not args.no_cpu_baseline:
-        o = oracle_handle(names)
-    if not args.no_verify:
-        res["verified"] = verify_timed_buffers(o, hra, out, chars, lens, M, D, pm, min(B, 16384))
-        if not res["verified"]["bit_exact"]:
-            raise SystemExit("bench.py: the timed output buffers differ from the oracle")
     # spread: R more replays of the same K steps, each timed by its own event pair (after the contract's timed region)
     if not args.no_spread:
-        per = []
-        reps = max(5, min(200, int(0.25 / max(kern_ms * args.steps * 1e-3, 1e-6))))
-        for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); run_steps(); e1.record()
-            torch.cuda.synchronize()
-            per.append(e0.elapsed_time(e1) / args.steps)
+        reps = max(5, min(100, int(0.25 / max(kern_ms * args.steps * 1e-3, 1e-6))))
+        per = timed_replays(run_steps, reps, args.steps)
         res["spread"] = {"replays": reps, "steps_per_replay": args.steps, "ms_per_step_median": statistics.median(per),
                          "ms_per_step_min": min(per), "ms_per_step_max": max(per)}
-    # The timed steps re-process ONE batch into ONE set of output buffers (the contract's step), so from the second launch on the
-    # 256-MB Infinity Cache holds part of what a launch reads and overwrites.  The complementary figure: the same launches over
-    # NSETS input / output sets used in turn — nothing a launch touches was touched by the previous NSETS - 1 launches.
+    # The complementary figure: the same K launches re-processing ONE batch into ONE set of buffers (round 1 and 2's step).  From the
+    # second launch on the 256-MB Infinity Cache holds part of what a launch reads and overwrites — not an HBM figure.
+    if not args.no_spread and world == 1 and nsets > 1:
+        try:
+            one = lambda i: launch(0)
+            g1 = graph_of(one, args.steps) if not args.eager else None
+            run1 = g1.replay if g1 is not None else (lambda: [one(i) for i in range(args.steps)])
+            run1(); torch.cuda.synchronize()
+            per = timed_replays(run1, 5, args.steps)
+            res["one_buffer_set"] = {"ms_per_step_median": statistics.median(per), "ms_per_step_min": min(per), "ms_per_step_max": max(per)}
+            del g1
+        except Exception as e:                                   # a probe must never break the bench line
+            sys.stderr.write("one-buffer-set probe failed: %s\n" % e)
+    # No-compute ceiling on THESE buffers (after the verification: it overwrites the outputs): hrx_traffic_pass_device moves the bytes
+    # of one launch — same addresses, same instructions, same store policy — and does no DFA work.
     if not args.no_spread and world == 1 and pm:
         try:
-            nsets = 8
-            foot = B * stride + sum(t.numel() * t.element_size() for t in out)
-            if nsets * foot <= (24 << 30):
-                sets = [(d_chars, out)]
-                for k in range(1, nsets):
-                    c2, _ = gen(B, n, seed=1000 + k, stride=stride)
-                    sets.append((hra.chars_to_position_major(torch.from_numpy(c2).to(dev)), cfg.alloc_outputs_position_major(B, dev)))
-                rot = lambda i: cfg.witness_batch_position_major(sets[i % nsets][0], d_lens, out=sets[i % nsets][1], chars_pm_stride=stride)
-                for i in range(2 * nsets):
-                    rot(i)
-                torch.cuda.synchronize()
-                kk = max(nsets, min(200, args.steps) // nsets * nsets)
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.stream(side):
-                    with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
-                        for i in range(kk):
-                            rot(i)
-                torch.cuda.current_stream(dev).wait_stream(side)
-                g2.replay()
-                torch.cuda.synchronize()
-                per = []
-                for _ in range(3):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(); g2.replay(); e1.record()
-                    torch.cuda.synchronize()
-                    per.append(e0.elapsed_time(e1) / kk)
-                res["fresh_buffers"] = {"sets": nsets, "ms_per_step_median": statistics.median(per), "ms_per_step_min": min(per), "ms_per_step_max": max(per)}
-                del sets, g2
-        except Exception as e:                                   # a probe must never break the bench line
-            sys.stderr.write("fresh-buffer probe failed: %s\n" % e)
+            tp = lambda i: cfg.traffic_pass(sets[i % nsets][0], B, sets[i % nsets][2], stride)
+            gt = graph_of(tp, args.steps) if not args.eager else None
+            runt = gt.replay if gt is not None else (lambda: [tp(i) for i in range(args.steps)])
+            runt(); torch.cuda.synchronize()
+            per = timed_replays(runt, 5, args.steps)
+            mc = {"rotating_us": statistics.median(per) * 1e3}
+            if nsets > 1:
+                tp1 = lambda i: cfg.traffic_pass(sets[0][0], B, sets[0][2], stride)
+                gt1 = graph_of(tp1, args.steps) if not args.eager else None
+                runt1 = gt1.replay if gt1 is not None else (lambda: [tp1(i) for i in range(args.steps)])
+                runt1(); torch.cuda.synchronize()
+                mc["one_set_us"] = statistics.median(timed_replays(runt1, 5, args.steps)) * 1e3
+                del gt1
+            res["traffic_pass"] = mc
+            del gt
+        except Exception as e:
+            sys.stderr.write("traffic-pass probe failed: %s\n" % e)
     res["desc"] = desc
+    res["placement"] = placement
+    res["library"] = os.path.realpath(hra.LIB_PATH)
+    res["nsets"] = nsets
     res["config"] = {"workload": "%s DFA (D=%d), %d x %d-byte strings per GPU (n=%d chars, M=%d witness rows), %s"
                                  % (label, D, B, stride, n, M, "uniform noise over the %s%s" % (alphabet, " + planted match" if planted else "")),
                      "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
                      "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of 65536 strings): chars [%d/16][B][16], records "
                                  "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h); outputs from hrx_alloc_outputs_position_major (placement-aware "
-                                 "from 1 GiB of records on, two plain allocations below)" % stride) if pm else
+                                 "from 128 MiB of records on, two plain allocations below)" % stride) if pm else
                                 ("string-major; input stride %d B, records pitch %d rows, masked pitch %d rows" % (stride, rec_pitch, msk_pitch)),
+                     "buffer_sets": "%d input / output buffer sets, step i runs on set i %% %d (set k = the batch rotated by %d k strings): nothing a launch touches "
+                                    "was touched by the previous %d launches, so the 256-MB Infinity Cache holds none of it" % (nsets, nsets, shift, nsets - 1)
+                                    if nsets > 1 else "one buffer set, re-processed every step",
                      "sharding": "by string index, no collective", "launch_mode": launch_mode}
     res["D"], res["rows_per_step"] = D, rows_per_step
     if world == 1:
-        del d_chars
+        del sets
         torch.cuda.empty_cache()
         if args.config == "regex1" and B == 65536 and M == 1024 and pm:
             res["mix_ceiling"] = mix_ceiling(device_index)
         if not args.no_pmc:
             res["traffic"] = measured_traffic(args.argv, device_index)
-        if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(o, names, chars, lens, M)
+    if not args.no_cpu_baseline and o is not None:
+        res["cpu_baseline"] = cpu_baseline(o, names, chars, lens, M)
     return res
 
 
@@ -443,51 +563,67 @@ def aggregate(per_rank, args):
     algo_bytes = BYTES_PER_ROW(D) * r0["rows_per_step"]
     kern_ms = r0["avg_launch_ms"]
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    nsets = r0.get("nsets", 1)
     line = {
         "metric": "DFA witness rows/sec", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "scaling": getattr(args, "scaling", "weak"), "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": r0["config"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": (r0.get("traffic") or {}).get("total") or pmc_traffic(args),
                      "kernel": r0["desc"].split(" grid=")[0], "launch": "grid=" + r0["desc"].split(" grid=")[1],
                      "avg_launch_ms": kern_ms,
-                     "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D)},
+                     "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D),
+                     "regime": ("the K timed steps rotate over %d input / output buffer sets: every byte a launch moves comes from / goes to HBM" % nsets) if nsets > 1
+                               else "the K timed steps re-process one batch into one set of buffers (part of the traffic stays in the 256-MB Infinity Cache)"},
         "ranks_seen": world,
-        "per_rank": [{"rank": r["rank"], "device": r["device"], "rows": r["rows"], "elapsed_s": r["elapsed_s"],
-                      "rows_per_s": r["rows"] / r["elapsed_s"], "avg_launch_ms": r["avg_launch_ms"]} for r in per_rank],
+        "per_rank": [dict({"rank": r["rank"], "device": r["device"], "rows": r["rows"], "elapsed_s": r["elapsed_s"],
+                           "rows_per_s": r["rows"] / r["elapsed_s"], "avg_launch_ms": r["avg_launch_ms"]},
+                          **({"strings": r["strings"], "shard_begin": r["shard_begin"]} if "strings" in r else {}),
+                          **({"verified": r["verified"]["bit_exact"]} if r.get("verified") and r["rank"] != 0 else {})) for r in per_rank],
         "debug_flags": r0.get("debug_flags"),
     }
+    if r0.get("library"):
+        line["library"] = r0["library"]
     line["roofline"]["traffic_source"] = r0["traffic"] if r0.get("traffic") else ("profiles/r02_pm_pmc.json (committed rocprofv3 PMC passes of this command)" if line["roofline"]["traffic"] else None)
     if r0.get("verified"):
         line["verified"] = r0["verified"]
     if r0.get("spread"):
         line["spread"] = r0["spread"]
-    if r0.get("fresh_buffers"):
-        fb = r0["fresh_buffers"]
-        fb_gbs = algo_bytes / (fb["ms_per_step_median"] * 1e-3) / 1e9
-        line["roofline"]["fresh_buffers"] = dict(fb, achieved=fb_gbs, frac=fb_gbs / HBM_PEAK_GBS,
-                                                 what="the same launches over %d input / output buffer sets used in turn (nothing a launch touches is left in the 256-MB "
-                                                      "Infinity Cache by the previous launches); the timed steps above re-process one batch into one set of buffers" % fb["sets"])
+    if r0.get("placement"):
+        pl = r0["placement"]
+        srch = [p for p in pl if p.get("searched")]
+        line["roofline"]["placement"] = {
+            "sets_searched": len(srch), "sets_accepted": sum(1 for p in srch if p.get("accepted")),
+            "steps": [p.get("steps") for p in srch], "chosen_step": [p.get("chosen_step") for p in srch],
+            "ref_us": [round(p.get("ref_us", 0), 1) for p in srch], "first_us": [round(p.get("first_us", 0), 1) for p in srch],
+            "best_us": [round(p.get("best_us", 0), 1) for p in srch], "search_ms": [round(p.get("search_ms", 0), 1) for p in srch],
+            "what": "hrx_alloc_outputs_position_major per buffer set: two-stream probe times (device clock) of the same-neighbourhood reference, the first candidate "
+                    "(= two plain allocations) and the kept masked-row buffer; accepted = kept one >= 6 % faster than the reference (DESIGN.md §4.3)"}
+    if r0.get("one_buffer_set"):
+        ob = r0["one_buffer_set"]
+        gbs = algo_bytes / (ob["ms_per_step_median"] * 1e-3) / 1e9
+        line["roofline"]["one_buffer_set"] = dict(ob, achieved=gbs, frac=gbs / HBM_PEAK_GBS,
+                                                  what="the same K launches re-processing ONE batch into ONE set of buffers (rounds 1-2's step): from the second launch on "
+                                                       "the 256-MB Infinity Cache holds part of what a launch reads and overwrites — not an HBM figure")
+    tp = r0.get("traffic_pass")
     mc = r0.get("mix_ceiling")
-    if mc:
-        # the kernel's traffic mix with no compute, measured on this box after the timed region (tools/mixceil.cpp)
-        same = {k: v for k, v in mc.items() if not k.endswith("_fresh")}
-        fresh = {k: v for k, v in mc.items() if k.endswith("_fresh")}
-        best = min(same.values())
-        line["roofline"]["mix_ceiling"] = {"us_per_launch": same, "best_us": best, "best_gbs": algo_bytes / (best * 1e-6) / 1e9,
-                                           "kernel_over_best": kern_ms * 1e3 / best,
-                                           "what": "tools/mixceil --brief: the same 64 MiB read + 384 MiB written per launch, no DFA work: "
-                                                   "copy = plain dwordx4 copy of the byte count; pair / pair_nt / pair_mix = the kernel's position-major slabs "
-                                                   "from 4 reader + 4 writer waves per CU with write-back / streaming stores / the shipped mix (streaming, every other "
-                                                   "tile's records write-back); like the timed steps, these probes re-write one set of buffers"}
-        if fresh:
-            fbest = min(fresh.values())
-            line["roofline"]["mix_ceiling"]["fresh_buffers"] = {
-                "us_per_launch": fresh, "best_us": fbest, "best_gbs": algo_bytes / (fbest * 1e-6) / 1e9,
-                "what": "the pair probes over 8 buffer sets used in turn: what HBM alone sustains for this traffic mix"}
-            if line["roofline"].get("fresh_buffers"):
-                line["roofline"]["fresh_buffers"]["kernel_over_best_probe"] = line["roofline"]["fresh_buffers"]["ms_per_step_median"] * 1e3 / fbest
+    if tp or mc:
+        ceil = {}
+        if tp:
+            ceil["traffic_pass_us"] = tp["rotating_us"]
+            ceil["traffic_pass_gbs"] = algo_bytes / (tp["rotating_us"] * 1e-6) / 1e9
+            ceil["kernel_over_best_probe"] = kern_ms * 1e3 / tp["rotating_us"]
+            ceil["what"] = ("hrx_traffic_pass_device over the SAME buffer sets in the same rotation, replayed as the same kind of graph: the bytes of one launch — "
+                            "same addresses, same 16-byte-per-lane instructions, same store policy, 4 reader + 4 writer waves per CU — with no DFA work")
+            if "one_set_us" in tp:
+                ceil["one_set_us"] = tp["one_set_us"]
+                if r0.get("one_buffer_set"):
+                    ceil["one_set_kernel_over_probe"] = r0["one_buffer_set"]["ms_per_step_median"] * 1e3 / tp["one_set_us"]
+        if mc:
+            ceil["mixceil"] = {"us_per_launch": mc, "what": "tools/mixceil --brief, a separate process with its own plain allocations: copy = plain dwordx4 copy of the "
+                               "byte count; pair* = the bench line's slabs with write-back / streaming / mixed stores, one buffer set; *_fresh = over 8 buffer sets in turn"}
+        line["roofline"]["mix_ceiling"] = ceil
     if r0.get("cpu_baseline"):
         line["cpu_baseline"] = r0["cpu_baseline"]
     return line
@@ -510,33 +646,65 @@ def free_port():
     return p
 
 
-def spawn_children(args, argv):
-    """Bare `python bench.py --gpus N`: N fresh child processes, one per device.  This (parent) process never touches a GPU."""
+def physical_device(dev_index):
+    """HIP_VISIBLE_DEVICES value that selects logical device `dev_index` of THIS process in a child (the parent may itself be restricted)"""
+    vis = os.environ.get("HIP_VISIBLE_DEVICES")
+    if vis:
+        ids = [v.strip() for v in vis.split(",") if v.strip()]
+        if dev_index < len(ids):
+            return ids[dev_index]
+    return str(dev_index)
+
+
+def spawn_children(args, argv, timeout_s=3600):
+    """Bare `python bench.py --gpus N`: N fresh child processes, one per device.  This (parent) process never touches a GPU.  The children
+    are polled: the first one that fails (or the overall timeout) takes its siblings down instead of leaving them in a rendezvous."""
+    import tempfile
     devs = os.environ.get("HRX_BENCH_DEVICES")
     devices = [int(x) for x in devs.split(",")] if devs else list(range(args.gpus))
-    port = free_port()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, HRX_BENCH_RANK=str(r), HRX_BENCH_WORLD=str(args.gpus), HRX_BENCH_PORT=str(port),
-                   HRX_BENCH_DEVICE=str(devices[r % len(devices)]))
-        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-            env.pop(k, None)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--child"], env=env, stdout=subprocess.PIPE, text=True))
-    results, failed = [], False
-    for r, p in enumerate(procs):
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            sys.stderr.write("bench.py: rank %d exited with %d\n" % (r, p.returncode))
-            failed = True
+    procs, outs = [], []
+    for attempt in range(3):      # (free_port() closes its socket before the children bind: retry on the rare lost race)
+        port = free_port()
+        procs, outs = [], []
+        for r in range(args.gpus):
+            env = dict(os.environ, HRX_BENCH_RANK=str(r), HRX_BENCH_WORLD=str(args.gpus), HRX_BENCH_PORT=str(port),
+                       HRX_BENCH_DEVICE=str(devices[r % len(devices)]))
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            f = tempfile.TemporaryFile(mode="w+")
+            outs.append(f)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--child"], env=env, stdout=f, text=True))
+        deadline, failed = time.time() + timeout_s, None
+        while any(p.poll() is None for p in procs):
+            bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad or time.time() > deadline:
+                failed = bad[0] if bad else -1
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                for p in procs:
+                    p.wait()
+                break
+            time.sleep(0.05)
+        if failed is None and all(p.returncode == 0 for p in procs):
+            break
+        codes = [p.returncode for p in procs]
+        if failed == -1:
+            sys.stderr.write("bench.py: timed out after %d s; children killed\n" % timeout_s)
+            raise SystemExit(1)
+        if attempt < 2 and any(c == 75 for c in codes):     # EX_TEMPFAIL: the rendezvous port was taken
             continue
-        lines = [l for l in out.splitlines() if l.startswith(RESULT_TAG)]
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        raise SystemExit(1)
+    results = []
+    for r, f in enumerate(outs):
+        f.seek(0)
+        lines = [l for l in f.read().splitlines() if l.startswith(RESULT_TAG)]
+        f.close()
         if not lines:
             sys.stderr.write("bench.py: rank %d reported nothing\n" % r)
-            failed = True
-            continue
+            raise SystemExit(1)
         results.append(json.loads(lines[-1][len(RESULT_TAG):]))
-    if failed or len(results) != args.gpus:
-        raise SystemExit(1)
     return aggregate(results, args)
 
 
@@ -563,7 +731,13 @@ def main(argv=None):
         # ---- one of the N children of a bare --gpus N run: gloo over 127.0.0.1 for the barrier, result over the pipe
         import torch.distributed as dist
         rank, world = int(os.environ["HRX_BENCH_RANK"]), int(os.environ["HRX_BENCH_WORLD"])
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["HRX_BENCH_PORT"], rank=rank, world_size=world)
+        import datetime
+        try:
+            dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["HRX_BENCH_PORT"], rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=120))
+        except Exception as e:          # rank 0 could not bind the port the parent picked (taken in between): the parent retries with another
+            sys.stderr.write("bench.py child %d: rendezvous failed: %s\n" % (rank, e))
+            raise SystemExit(75)
         res = run_rank(args, rank, world, int(os.environ["HRX_BENCH_DEVICE"]), dist.barrier)
         print(RESULT_TAG + json.dumps(res), flush=True)
         dist.barrier()

@@ -7,6 +7,12 @@ use std::ffi::{c_char, c_int, c_void, CStr};
 #[repr(C)] pub struct hrx_defs { _p: [u8; 0] }
 #[repr(C)] pub struct hrx_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct hrx_multi { _p: [u8; 0] }
+#[repr(C)] #[derive(Default, Clone, Copy)]
+pub struct hrx_place_report {
+    pub searched: c_int, pub steps: c_int, pub accepted: c_int, pub chosen_step: c_int,
+    pub ref_us: f64, pub first_us: f64, pub best_us: f64,
+    pub probe_bytes: usize, pub peak_candidate_bytes: usize, pub search_ms: f64,
+}
 
 pub const HRX_DEVICE_NONE: c_int = -1;
 pub const HRX_MAX_DEFS: usize = 32;   // RegexDefs per config (more than three are walked in passes)
@@ -37,6 +43,8 @@ extern "C" {
     /// its own stream, asynchronous; hrx_multi_synchronize waits.  No PCIe traffic, no collective.
     pub fn hrx_multi_num_shards(m: *const hrx_multi) -> c_int;
     pub fn hrx_multi_shard_device(m: *const hrx_multi, shard: c_int) -> c_int;
+    /// the shard's private hipStream_t: make it wait on an event behind whatever produced the shard's inputs
+    pub fn hrx_multi_shard_stream(m: *const hrx_multi, shard: c_int) -> *mut c_void;
     pub fn hrx_multi_witness_batch_device(m: *mut hrx_multi, layout: c_int, chars: *const *const u8, stride: usize, lens: *const *const u32,
                                           counts: *const usize, max_chars_size: usize, records: *const *mut u32, masked: *const *mut u16,
                                           status: *const *mut u64) -> c_int;
@@ -50,6 +58,11 @@ extern "C" {
     pub fn hrx_alloc_outputs_position_major(ctx: *mut hrx_ctx, b: usize, m: usize, records: *mut *mut u32, masked: *mut *mut u16) -> c_int;
     pub fn hrx_alloc_output_pair(ctx: *mut hrx_ctx, records_bytes: usize, masked_bytes: usize, records: *mut *mut c_void, masked: *mut *mut c_void) -> c_int;
     pub fn hrx_device_free(ptr: *mut c_void) -> c_int;
+    /// what the context's last placement-aware allocation did (steps measured, reference / first / kept probe times, memory held)
+    pub fn hrx_alloc_last_report(ctx: *const hrx_ctx, out: *mut hrx_place_report) -> c_int;
+    /// roofline diagnostic: the memory traffic of one position-major launch over these buffers, no DFA work (overwrites the outputs)
+    pub fn hrx_traffic_pass_device(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, m: usize, records: *mut u32,
+                                   masked: *mut u16, stream: *mut c_void) -> c_int;
     /// device = HRX_DEVICE_NONE (-1): a host-only context (the native small-batch walk; no GPU needed)
     pub fn hrx_device_count(count: *mut c_int) -> c_int;
     pub fn hrx_ctx_device(ctx: *const hrx_ctx) -> c_int;

@@ -30,11 +30,11 @@ ABI_SYMBOLS = [
     "hrx_defs_push_substr_text", "hrx_defs_push_substr_file", "hrx_defs_push_allstr", "hrx_defs_push_substr",
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
-    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_device_free",
+    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_device_free",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
-    "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_shard_device", "hrx_multi_witness_batch_host",
+    "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_shard_device", "hrx_multi_shard_stream", "hrx_multi_witness_batch_host",
     "hrx_multi_witness_batch_device", "hrx_multi_synchronize",
     "hrx_witness_batch_host",
     "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
@@ -50,6 +50,12 @@ _u8p = C.POINTER(C.c_uint8)
 
 class _RegexPartC(C.Structure):      # hrx_regex_part of include/hrx.h
     _fields_ = [("regex_def", C.c_char_p), ("regex_len", C.c_size_t), ("is_public", C.c_int), ("max_size", C.c_size_t)]
+
+
+class _PlaceReportC(C.Structure):    # hrx_place_report of include/hrx.h
+    _fields_ = [("searched", C.c_int), ("steps", C.c_int), ("accepted", C.c_int), ("chosen_step", C.c_int),
+                ("ref_us", C.c_double), ("first_us", C.c_double), ("best_us", C.c_double), ("probe_bytes", C.c_size_t),
+                ("peak_candidate_bytes", C.c_size_t), ("search_ms", C.c_double)]
 
 
 class HrxError(RuntimeError):
@@ -101,10 +107,13 @@ def _load():
         "hrx_alloc_outputs_position_major": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
         "hrx_alloc_output_pair": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
         "hrx_device_free": (i, [vp]),
+        "hrx_alloc_last_report": (i, [vp, C.POINTER(_PlaceReportC)]),
+        "hrx_traffic_pass_device": (i, [vp, vp, sz, sz, sz, vp, vp, vp]),
         "hrx_multi_create": (i, [vp, C.POINTER(i), i, C.POINTER(vp)]),
         "hrx_multi_destroy": (None, [vp]),
         "hrx_multi_num_shards": (i, [vp]),
         "hrx_multi_shard_device": (i, [vp, i]),
+        "hrx_multi_shard_stream": (vp, [vp, i]),
         "hrx_multi_witness_batch_device": (i, [vp, i, C.POINTER(vp), sz, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "hrx_multi_synchronize": (i, [vp]),
         "hrx_multi_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
@@ -413,7 +422,7 @@ def recommended_pitches(M):
 LAYOUT_STRING_MAJOR, LAYOUT_POSITION_MAJOR, LAYOUT_INPUT_POSITION_MAJOR = 0, 1, 2
 
 
-PLACED_FROM = 1 << 30      # alloc_outputs_position_major: records of this many bytes or more come from hrx_alloc_outputs_position_major
+PLACED_FROM = 128 << 20    # alloc_outputs*: records of this many bytes or more come from the library's placement-aware allocator (kPlaceFromBytes)
 PM_BLOCK = 65536          # kPmBlock of csrc/hrx_lane.h: position-major buffers are blocked by this many strings
 
 
@@ -634,6 +643,19 @@ class RegexVerifyConfig:
         msk = torch.as_tensor(_LibraryOwned(pmk.value, nm.value * 2), device=d).view(torch.int16)
         return rec, msk, st
 
+    def last_placement_report(self):
+        """hrx_alloc_last_report: what the last placement-aware allocation of this config's context did (a dict)."""
+        r = _PlaceReportC()
+        _check(lib.hrx_alloc_last_report(self._need_ctx(), C.byref(r)))
+        return {k: getattr(r, k) for k, _ in _PlaceReportC._fields_}
+
+    def traffic_pass(self, chars_pm, B, out, chars_pm_stride, stream=None):
+        """hrx_traffic_pass_device: the memory traffic of one position-major launch over these buffers, no DFA work; OVERWRITES out."""
+        rec, msk, _ = out
+        s = torch.cuda.current_stream(chars_pm.device) if stream is None else stream
+        _check(lib.hrx_traffic_pass_device(self._need_device(chars_pm, rec, msk), chars_pm.data_ptr(), int(chars_pm_stride), int(B), self.max_chars_size,
+                                           rec.data_ptr(), msk.data_ptr(), s.cuda_stream))
+
     def witness_batch_position_major(self, chars, lens, out=None, stream=None, chars_pm_stride=None):
         """Like witness_batch, outputs in HRX_LAYOUT_POSITION_MAJOR (use position_major_to_string_major to view them per
         string).  chars: (B, stride) string-major, or — with chars_pm_stride=stride — the flat position-major buffer made by
@@ -738,21 +760,42 @@ class MultiDevice:
     def witness_batch_device(self, shards, layout=LAYOUT_POSITION_MAJOR | LAYOUT_INPUT_POSITION_MAJOR, chars_stride=None):
         """hrx_multi_witness_batch_device: `shards` = one (chars, lens, (records, masked, status)) per shard, CUDA tensors on
         that shard's device (outputs as made by alloc_outputs_position_major / alloc_outputs on that device).  Asynchronous:
-        one kernel per shard on the shard's own stream; synchronize() waits for all.  No PCIe traffic, no collective."""
+        one kernel per shard on the shard's own stream; synchronize() waits for all.  No PCIe traffic, no collective.
+        Every shard's stream first waits for what torch's current stream of that device has been given so far (the kernels
+        that produced the inputs).  chars_stride: the per-string capacity in bytes; required for flat position-major
+        inputs unless it follows from the buffer sizes (numel(chars) / numel(lens), the same for every shard)."""
         n = self.num_shards
         assert len(shards) == n
         vpa, sza = C.c_void_p * n, C.c_size_t * n
         chars, lens, recs, msks, sts, counts = vpa(), vpa(), vpa(), vpa(), vpa(), sza()
-        stride = None
+        strides = set()
         for r, (c, l, (rec, msk, st)) in enumerate(shards):
             for t in (c, l, rec, msk, st):
                 if t.numel() and t.device.index != self.shard_device(r):
                     raise HrxError(HRX_ERR_ARG, "shard %d: tensor on %s, shard lives on cuda:%d" % (r, t.device, self.shard_device(r)))
             chars[r], lens[r], recs[r], msks[r], sts[r], counts[r] = c.data_ptr(), l.data_ptr(), rec.data_ptr(), msk.data_ptr(), st.data_ptr(), l.numel()
             if chars_stride is None and l.numel():
-                stride = c.stride(0) if c.dim() == 2 else stride
-        stride = int(chars_stride) if chars_stride is not None else stride
-        _check(lib.hrx_multi_witness_batch_device(self._h, layout, chars, stride or 16, lens, counts, self._cfg.max_chars_size, recs, msks, sts))
+                if c.dim() == 2 and not (layout & LAYOUT_INPUT_POSITION_MAJOR):
+                    strides.add(int(c.stride(0)))
+                elif c.numel() % l.numel() == 0:
+                    strides.add(c.numel() // l.numel())
+                else:
+                    raise HrxError(HRX_ERR_ARG, "shard %d: chars_stride not given and numel(chars) is not a multiple of numel(lens)" % r)
+        if chars_stride is not None:
+            stride = int(chars_stride)
+        elif len(strides) == 1:
+            stride = strides.pop()
+        elif not strides:
+            stride = 16      # every shard is empty: nothing is launched
+        else:
+            raise HrxError(HRX_ERR_ARG, "chars_stride not given and the shards' buffers imply different strides: %s" % sorted(strides))
+        if stride % 16 or stride < 16:
+            raise HrxError(HRX_ERR_ARG, "chars stride %d: must be a multiple of 16 bytes, >= 16" % stride)
+        for r in range(n):     # order each shard's private stream behind the producer of its inputs
+            if counts[r]:
+                d = self.shard_device(r)
+                torch.cuda.ExternalStream(lib.hrx_multi_shard_stream(self._h, r), device=torch.device("cuda", d)).wait_stream(torch.cuda.current_stream(d))
+        _check(lib.hrx_multi_witness_batch_device(self._h, layout, chars, stride, lens, counts, self._cfg.max_chars_size, recs, msks, sts))
 
     def synchronize(self):
         _check(lib.hrx_multi_synchronize(self._h))

@@ -93,6 +93,7 @@ struct hrx_ctx {
     uint64_t *d_wide = nullptr;
     uint16_t *d_half = nullptr;
     uint8_t *d_pairtab = nullptr;
+    uint8_t *d_bytetab = nullptr;
     std::vector<uint16_t *> d_pair;
     std::vector<uint8_t *> d_member;
     std::mutex mu;
@@ -104,6 +105,7 @@ struct hrx_ctx {
         uint64_t *d_wide = nullptr;
         uint16_t *d_half = nullptr;
         uint8_t *d_pairtab = nullptr;
+        uint8_t *d_bytetab = nullptr;
         DevBuf records, status, summary;
     };
     std::vector<GroupDev> groups;
@@ -128,6 +130,13 @@ struct hrx_ctx {
 };
 
 // device copies of one DefsSet's kernel-side images
+static hipError_t upload_blob(const std::vector<uint8_t> &v, uint8_t *&d) {
+    if (v.empty()) return hipSuccess;
+    hipError_t e = hipMalloc((void **)&d, v.size());
+    if (e == hipSuccess) e = hipMemcpy(d, v.data(), v.size(), hipMemcpyHostToDevice);
+    return e;
+}
+
 static hipError_t upload_images(const DefsSet &s, uint32_t *&d_table, uint64_t *&d_wide, uint16_t *&d_half, uint8_t *&d_pairtab) {
     hipError_t e = hipMalloc((void **)&d_table, s.table_image.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(d_table, s.table_image.data(), s.table_image.size() * 4, hipMemcpyHostToDevice);
@@ -320,10 +329,13 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
 
     if (c->s.groups.empty()) {
         if (e == hipSuccess) e = upload_images(c->s, c->d_table, c->d_wide, c->d_half, c->d_pairtab);
+        if (e == hipSuccess) e = upload_blob(c->s.byte.image, c->d_bytetab);
     } else {   // multi-pass: the kernels only ever see a group's images
         c->groups.resize(c->s.groups.size());
-        for (size_t g = 0; e == hipSuccess && g < c->s.groups.size(); ++g)
+        for (size_t g = 0; e == hipSuccess && g < c->s.groups.size(); ++g) {
             e = upload_images(c->s.groups[g], c->groups[g].d_table, c->groups[g].d_wide, c->groups[g].d_half, c->groups[g].d_pairtab);
+            if (e == hipSuccess) e = upload_blob(c->s.groups[g].byte.image, c->groups[g].d_bytetab);
+        }
     }
     for (size_t d = 0; e == hipSuccess && d < c->s.pair_tags.size(); ++d) {
         uint16_t *p = nullptr;
@@ -368,11 +380,13 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_half) (void)hipFree(c->d_half);
     if (c->d_pairtab) (void)hipFree(c->d_pairtab);
+    if (c->d_bytetab) (void)hipFree(c->d_bytetab);
     for (auto &g : c->groups) {
         if (g.d_table) (void)hipFree(g.d_table);
         if (g.d_wide) (void)hipFree(g.d_wide);
         if (g.d_half) (void)hipFree(g.d_half);
         if (g.d_pairtab) (void)hipFree(g.d_pairtab);
+        if (g.d_bytetab) (void)hipFree(g.d_bytetab);
         g.records.release(); g.status.release(); g.summary.release();
     }
     c->mp_masked.release();
@@ -413,7 +427,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         return fail(HRX_ERR_ARG, "unknown layout");
     // one launch over `set` (a config of up to kMaxDefsPerPass defs, or one group of a larger one) with that set's device images
     auto launch_set = [&](const DefsSet &set, const uint32_t *d_table, const uint64_t *d_wide, const uint16_t *d_half, const uint8_t *d_pairtab,
-                          int lay, uint32_t *rec, uint16_t *msk, uint64_t *stat, size_t rp, size_t mp,
+                          const uint8_t *d_bytetab, int lay, uint32_t *rec, uint16_t *msk, uint64_t *stat, size_t rp, size_t mp,
                           uint32_t rec_D = 0, uint32_t rec_d0 = 0, uint32_t *summary = nullptr) -> int {
         WitnessArgs a{};
         a.rec_D = rec_D; a.rec_d0 = rec_d0; a.summary = summary;
@@ -426,6 +440,8 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         a.half_image = d_half; a.half_bytes = (uint32_t)(set.half_image.size() * 2);
         a.pair_image = d_pairtab; a.pair_bytes = set.pair.bytes; a.pair_classes = set.pair.n_classes;
         a.pair_blk_bytes = set.pair.blk_bytes; a.pair_lut_off = set.pair.lut_off;
+        a.byte_image = d_bytetab; a.byte_bytes = set.byte.bytes; a.byte_ptab_off = set.byte.ptab_off; a.byte_mul_a4 = set.byte.mul_a * 4; a.byte_mul_b4 = set.byte.mul_b * 4;
+        a.byte_dead = set.byte.dead;
         a.D = (uint32_t)set.defs.size();
         a.debug = ctx->debug;
 #ifdef HRX_ABLATION
@@ -470,7 +486,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         return HRX_OK;
     };
     if (ctx->s.groups.empty())
-        return launch_set(ctx->s, ctx->d_table, ctx->d_wide, ctx->d_half, ctx->d_pairtab, layout, records, masked, status, rec_pitch, msk_pitch);
+        return launch_set(ctx->s, ctx->d_table, ctx->d_wide, ctx->d_half, ctx->d_pairtab, ctx->d_bytetab, layout, records, masked, status, rec_pitch, msk_pitch);
     // ---- more than kMaxDefsPerPass defs: one ordinary launch per group into its private position-major buffers, then the
     // combine kernel (hrx_kernel_mp.hip) writes the caller's buffers.  The group buffers belong to the context: a launch
     // on another stream first waits for the previous combine.
@@ -492,12 +508,12 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         int rc;
         if (summary_mode) {
             HIP_TRY(gd.summary.reserve(ntiles * 5 * B * 16));
-            rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, layout, records, masked, (uint64_t *)gd.status.p, M, M,
+            rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, gd.d_bytetab, layout, records, masked, (uint64_t *)gd.status.p, M, M,
                             (uint32_t)ctx->s.defs.size(), ctx->s.group_first[g], (uint32_t *)gd.summary.p);
             ca.gsummary[g] = (const uint32_t *)gd.summary.p;
         } else {
             HIP_TRY(gd.records.reserve(q4 * 4 * gs.defs.size() * B * 4));
-            rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR),
+            rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, gd.d_bytetab, HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR),
                             (uint32_t *)gd.records.p, (uint16_t *)ctx->mp_masked.p, (uint64_t *)gd.status.p, M, M);
             ca.grec[g] = (const uint32_t *)gd.records.p;
         }
@@ -565,6 +581,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     a.half_bytes = (uint32_t)(s.half_image.size() * 2);
     a.pair_image = s.pair.image.empty() ? nullptr : s.pair.image.data(); a.pair_bytes = s.pair.bytes; a.pair_classes = s.pair.n_classes;
     a.pair_blk_bytes = s.pair.blk_bytes; a.pair_lut_off = s.pair.lut_off;
+    a.byte_image = s.byte.image.empty() ? nullptr : s.byte.image.data(); a.byte_bytes = s.byte.bytes; a.byte_dead = s.byte.dead;
     a.D = (uint32_t)s.defs.size();
     a.debug = debug_flags_from_env();   // what a context created now would run with (kernel-selection bits only in a release build)
     if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a summary-writing pass is the loader / walker / finisher kernel)
@@ -578,6 +595,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     const char *tf[2] = {"false", "true"};
     if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
     else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u>", a.D);
+    else if (li.split == 2 && li.byte) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, false, false, false, false, true>", a.D);
     else if (li.split == 2) std::snprintf(name, sizeof name, (layout & 1) ? "hrx::witness_pm_kernel<%u, %s, %s, %s>" : "hrx::witness_pm_kernel<%u, %s, %s, %s, true>", a.D, tf[li.gtab], tf[li.wide], tf[li.half]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u>", a.D, 32u / a.D);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);

@@ -155,6 +155,68 @@ static void build_pair_table(DefsSet &s) {
     s.pair = std::move(p);
 }
 
+// BYTE image (hrx_lane.h) of def 0 from its dense 4-byte table and its (state, next) -> tag matrix.
+// The tags go into a 4096-slot table addressed by an ARITHMETIC perfect hash of the pair: slot = (state * A + next * B) & 4095
+// with (A, B) searched so that no two tagged pairs share a slot; a lookup reads the slot of ANY pair and takes the tag only if
+// the slot's key is the pair.  No (A, B) within the search budget (hundreds of tagged pairs): no BYTE image — the HALF table
+// serves the def.
+static void build_byte_table(DefsSet &s) {
+    s.byte = ByteTable();
+    if (s.defs.size() != 1) return;
+    const DefConsts &c = s.consts[0];
+    const uint32_t L = (uint32_t)s.defs[0].allstr.largest_state_val, S = L + 1;
+    const uint32_t *T = s.table_image.data() + (size_t)c.row_base * 256;
+    bool total = true;
+    for (uint32_t st = 0; st < S && total; ++st)
+        for (int ch = 0; ch < 256 && total; ++ch) total = T[st * 256 + ch] < c.dead_entry;
+    const uint32_t rows = S + (total ? 0u : 1u);
+    if (rows > 256) return;
+    ByteTable b;
+    b.n_rows = rows;
+    b.dead = total ? kByteNoDead : S;
+    const std::vector<uint16_t> &pt = s.pair_tags[0];   // [(L+1)^2]
+    std::vector<uint32_t> keys;                          // state << 8 | next of every tagged pair
+    for (uint32_t cur = 0; cur < S; ++cur)
+        for (uint32_t nx = 0; nx < S; ++nx)
+            if (pt[(size_t)cur * S + nx]) keys.push_back(cur << 8 | nx);
+    std::vector<uint32_t> seen(kByteSlots, 0xffffffffu);
+    uint32_t A = 0, B = 0, stamp = 0;
+    bool found = keys.empty();
+    if (found) { A = 1; B = 1; }
+    // deterministic search: odd B, any A, in a fixed pseudo-random order
+    uint64_t x = 0x9e3779b97f4a7c15ull;
+    for (uint32_t tries = 0; !found && tries < 200000; ++tries, ++stamp) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const uint32_t a = (uint32_t)(x >> 20) & 0xfffu, bb = ((uint32_t)(x >> 40) & 0xfffu) | 1u;
+        bool ok = true;
+        for (uint32_t k : keys) {
+            const uint32_t slot = ((k >> 8) * a + (k & 0xffu) * bb) & (kByteSlots - 1);
+            if (seen[slot] == stamp) { ok = false; break; }
+            seen[slot] = stamp;
+        }
+        if (ok) { A = a; B = bb; found = true; }
+    }
+    if (!found) return;
+    b.mul_a = A; b.mul_b = B;
+    b.ptab_off = (rows * 256 + kByteSlots * 4 - 1) & ~(kByteSlots * 4 - 1);   // 16-KiB aligned: slot address = (hash & 0x3ffc) | ptab_off, one v_and_or_b32
+    b.bytes = b.ptab_off + kByteSlots * 4;
+    b.image.assign(b.bytes, 0);
+    for (uint32_t st = 0; st < rows; ++st)
+        for (int ch = 0; ch < 256; ++ch) {
+            uint32_t nx = b.dead;
+            if (st < S) {
+                const uint32_t e = T[st * 256 + ch];
+                if (e < c.dead_entry) nx = (e >> kNextShift) - c.row_base;
+            }
+            b.image[(size_t)st * 256 + ch] = (uint8_t)nx;   // (total: every entry is a real state; partial: dead = S <= 255)
+        }
+    std::vector<uint32_t> slot(kByteSlots, 0xffffu);      // key 0xffff: empty (no pair has state 0xff AND next 0xff tagged... see below)
+    for (uint32_t k : keys) slot[((k >> 8) * A + (k & 0xffu) * B) & (kByteSlots - 1)] = k | (uint32_t)pt[(size_t)(k >> 8) * S + (k & 0xffu)] << 16;
+    // an empty slot must not look like the pair (0xff, 0xff): give empty slots the tag 0 (already) — a key match then yields tag 0, which is what an untagged pair has
+    std::memcpy(&b.image[b.ptab_off], slot.data(), (size_t)kByteSlots * 4);
+    s.byte = std::move(b);
+}
+
 int finalize_defs(DefsSet &s, std::string &err) {
     if (s.finalized) return HRX_OK;
     if (s.defs.empty()) { err = "no RegexDefs pushed"; return HRX_ERR_STATE; }
@@ -270,6 +332,7 @@ int finalize_defs(DefsSet &s, std::string &err) {
         }
     }
     build_pair_table(s);
+    if (!passes) build_byte_table(s);
     // more defs than one launch walks: consecutive groups, each finalized as a DefsSet of its own
     s.groups.clear();
     s.group_first.clear();

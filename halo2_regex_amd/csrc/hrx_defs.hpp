@@ -67,6 +67,18 @@ struct PairTable {
     std::vector<uint8_t> image; // the exact LDS image
 };
 
+// BYTE table (hrx_lane.h; position-major kernel, one def of at most 256 table rows): a 1-byte next-state table on the walk's
+// dependent chain — 64 KiB for a 256-state x 256-symbol DFA where the HALF table takes 128 — and the substring tag of a
+// transition, which is a function of the PAIR (state, next), in a perfect-hash table off the chain.
+struct ByteTable {
+    uint32_t n_rows = 0;      // real states (+ one absorbing dead row if the DFA is partial)
+    uint32_t dead = 0x100;    // row number of the dead row; 0x100: the DFA is total, there is none
+    uint32_t ptab_off = 0;    // LDS byte offset of u32 ptab[kByteSlots]: low 16 bits the pair state << 8 | next (0xffff: empty), high 16 bits its 10-bit tag
+    uint32_t mul_a = 0, mul_b = 0;   // slot of pair (state, next) = (state * mul_a + next * mul_b) & (kByteSlots - 1): collision-free over the tagged pairs
+    uint32_t bytes = 0;       // size of the LDS image, a multiple of 16
+    std::vector<uint8_t> image;
+};
+
 constexpr size_t kMaxDefs = 32;          // RegexDefs per config: the status word's accept mask (bits 8..39, include/hrx.h)
 constexpr size_t kMaxDefsPerPass = 3;    // defs one kernel launch walks side by side (the kernels are instantiated for D = 1..3)
 
@@ -91,6 +103,9 @@ struct DefsSet {
     // PAIR image (hrx_lane.h): empty unless there is exactly one def with <= kPairMaxClasses byte classes, <= 254 real
     // states and a table of at most kPairMaxBytes
     PairTable pair;
+    // BYTE image (hrx_lane.h): empty unless there is exactly one def whose real states (+ a dead row if it is partial) fit 256
+    // rows and whose tagged (state, next) pairs fit the displacement table
+    ByteTable byte;
     std::vector<DefConsts> consts;
     // (cur,next) -> {sid, is_start(cur), is_end(next)} per def, for the states-in entry points (lib.rs:825-888)
     std::vector<std::vector<uint16_t>> pair_tags;  // [(largest+1)^2], entry = tag bits as in the fused table

@@ -33,6 +33,7 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     out.gtab = 0;
     out.wide = 0;
     out.half = 0;
+    out.byte = 0;
     out.dyn = 0;
     // DFAs whose fused table leaves no room for the per-wave LDS areas are walked out of global memory (L2-resident)
     const size_t min_stage = (a.layout & 1u) ? pm_pair_bytes(2, false, true) : wave_stage_bytes((int)a.D, 16);
@@ -52,6 +53,33 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     const uint32_t table_bytes_saved = a.table_bytes;
     struct Restore { WitnessArgs &a; uint32_t v; ~Restore() { a.table_bytes = v; } } restore{a, table_bytes_saved};
     if (out.gtab) a.table_bytes = 0;  // for the LDS budgeting below only; restored on return
+    if ((a.layout & 1u) && a.D == 1 && a.byte_image && !(a.debug & (kDbgNoByte | kDbgForceHalf)) &&
+        ((out.gtab && !(a.debug & kDbgForceGlobalTable)) || (a.debug & kDbgForceByte))) {
+        // ---- loader / walker / finisher kernel on the BYTE table (1-byte next states + the pair tags off the chain): one def of up
+        // to 256 states whose 4-byte table does not fit LDS (cfg 5).  Half the HALF table's LDS, which buys what that variant
+        // lacks: a finisher wave and a ring of more than one slot (its walker spent 46 % of its cycles in the tile-end work).
+        int pairs = 4;
+        while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        for (; pairs >= 1; --pairs) {
+            for (int ns = 4; ns >= 2; --ns) {
+                const size_t lds = a.byte_bytes + (size_t)pairs * pm_pair_bytes((size_t)ns, false, true);
+                if (lds > kLdsLimit) continue;
+                out.split = 2; out.gtab = 0; out.wide = 0; out.half = 0; out.byte = 1;
+                out.waves_per_wg = 3 * pairs;
+                out.nslots = ns;
+                out.lds_bytes = lds;
+                const size_t need = ((size_t)a.n_groups + pairs - 1) / pairs;
+                size_t per_cu = kLdsLimit / lds;
+                if (per_cu * (size_t)(3 * pairs) > 12) per_cu = 12 / (size_t)(3 * pairs);
+                if (per_cu < 1) per_cu = 1;
+                const size_t cap = (size_t)num_cus * per_cu;
+                out.grid = (int)(need < cap ? need : cap);
+                if (out.grid < 1) out.grid = 1;
+                out.dyn = want_dyn(out.grid, pairs);
+                return true;
+            }
+        }
+    }
     if ((a.layout & 1u) && a.half_image && ((out.gtab && !(a.debug & kDbgForceGlobalTable)) || (a.debug & kDbgForceHalf))) {
         // ---- loader/walker kernel on the HALF table (2-byte entries): DFAs of up to 256 states whose 4-byte table does not
         // fit LDS (cfg 5: 256 x 256 -> 128 KiB) stay LDS-resident instead of being walked out of L2 (kDbgForceHalf forces it)

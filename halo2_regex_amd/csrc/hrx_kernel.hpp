@@ -28,6 +28,8 @@ struct WitnessArgs {
     const uint64_t *wide_image;   // device copy of DefsSet::wide_image (same byte size as table_image), or NULL
     const uint16_t *half_image;   // device copy of DefsSet::half_image (the exact LDS image, half_bytes long), or NULL
     uint32_t half_bytes;
+    const uint8_t *byte_image;    // device copy of DefsSet::byte.image (the exact LDS image: next-state bytes, disp, pair slots), or NULL
+    uint32_t byte_bytes, byte_ptab_off, byte_mul_a4, byte_mul_b4, byte_dead;   // (mul_a * 4, mul_b * 4: byte offsets of the pair slots)
     const uint8_t *pair_image;    // device copy of DefsSet::pair.image (the exact LDS image: blocks + class LUT), or NULL
     uint32_t pair_bytes, pair_classes, pair_blk_bytes, pair_lut_off;
     uint32_t n_groups;            // ceil(B / gs), set by plan_witness_launch
@@ -75,12 +77,15 @@ enum : uint32_t {
     kDbgPpNoMask = HRX_ABL(0x400u),            // ablation, pair-step kernel: no reveal-mask work at the tile end
     kDbgSkipFixups = HRX_ABL(0x800000u),       // ablation: no end-mask fix-ups
     kDbgFixedLines = HRX_ABL(0x1000000u),      // ablation: every quad / octet of a string is stored onto its first one
+    kDbgFixToDummy = HRX_ABL(0x4000u),         // ablation: the end-mask repairs are stored onto the string's first octets (same instructions, no read-modify-write at the memory)
     kDbgForceOneWave = 0x10000u,      // string-major: the one-wave kernel instead of the walker/storer kernel
     kDbgGroups32 = 0x20000u,          // one-wave kernel: 32 strings per wave
     kDbgForceGlobalTable = 0x40000u,  // walk the fused table out of global memory even if it fits LDS
     kDbgForceNarrow = 0x80000u,       // position-major kernel: 4-byte table even where the planner picks WIDE
     kDbgForceWide = 0x200000u,        // position-major kernel: WIDE table also at D = 1
     kDbgForceHalf = 0x400000u,        // position-major kernel: HALF table even if the 4-byte one fits LDS
+    kDbgForceByte = 0x2000u,          // position-major kernel, one def: BYTE table even if the 4-byte one fits LDS
+    kDbgNoByte = 0x8000u,             // position-major kernel: never the BYTE table (the HALF table where the 4-byte one does not fit)
     kDbgNoDefParallel = 0x2000000u,   // position-major: never the def-parallel kernel
     kDbgForceDefParallel = 0x4000000u,// position-major, D >= 2, WIDE table: the def-parallel kernel whatever the batch size (tests)
     kDbgNoPair = 0x8000000u,          // position-major, D = 1: never the pair-step kernel (hrx_kernel_pp.hip)
@@ -91,7 +96,7 @@ enum : uint32_t {
     kDbgForceHost = 0x10000000u,      // host-buffer entry points: always the native host walk (hrx_host_walk.cpp)
     kDbgNoHost = 0x20000000u,         // host-buffer entry points: never the native host walk
     // every bit that merely selects a kernel (the only ones a release build honours)
-    kDbgForceMask = kDbgForceOneWave | kDbgGroups32 | kDbgForceGlobalTable | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf |
+    kDbgForceMask = kDbgForceOneWave | kDbgGroups32 | kDbgForceGlobalTable | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf | kDbgForceByte | kDbgNoByte |
                     kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForcePair | kDbgXcdRemap | kDbgNoDynamicGroups | kDbgForceDynamicGroups | kDbgForceHost | kDbgNoHost,
 #ifdef HRX_ABLATION
     kDbgHonoured = 0xffffffffu,
@@ -112,6 +117,7 @@ struct LaunchInfo {
     int gtab;          // 1: fused table read from global memory (too large for LDS)
     int wide;          // 1: position-major kernel on the WIDE table (hrx_lane.h)
     int half;          // 1: position-major kernel on the HALF table (hrx_lane.h)
+    int byte;          // 1: position-major kernel on the BYTE table (hrx_lane.h): walker + loader + finisher
     int grid;
     int dyn;           // 1: dynamic group assignment (position-major loader/walker kernel, >= 8 long groups per walker pair)
     size_t lds_bytes;

@@ -32,8 +32,9 @@ namespace hrx {
 // disturbs the loader's counted vmcnt waits.  The walker keeps the chain, the records and their stores, the error paths and
 // the status word.  Three waves per SIMD: 168 VGPRs each (the loader runs 8 instead of 12 tiles ahead).
 // =============================================================================================
-template <int D, bool GTAB, bool WIDE, bool HALF = false, bool SM = false>
+template <int D, bool GTAB, bool WIDE, bool HALF = false, bool SM = false, bool BYTE = false>
 __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(const WitnessArgs a, const uint32_t nring) {
+    static_assert(!BYTE || (D == 1 && !GTAB && !WIDE && !HALF && !SM), "the BYTE table serves one def, position-major outputs");
     constexpr bool FIN = kPmFinisher<HALF, SM>;
 #ifdef HRX_STAMPS
     const unsigned long long wall_entry = wall_clock64();   // 100 MHz, the same clock on every CU
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     // ring + the walker's 4-KiB scratch (HALF: none, its slow path re-walks out of registers) + FIN: the 6-KiB tile summary
     // + counters (hrx_kernel.hpp pm_pair_bytes: the planner budgets the same bytes)
     const uint32_t pair_bytes = (uint32_t)pm_pair_bytes(nring, HALF, FIN);
-    const uint32_t tab_bytes = GTAB ? 0u : HALF ? a.half_bytes : a.table_bytes;
+    const uint32_t tab_bytes = GTAB ? 0u : BYTE ? a.byte_bytes : HALF ? a.half_bytes : a.table_bytes;
     const uint32_t ring_base = tab_bytes + pair * pair_bytes;
     const uint32_t scratch_off = ring_base + nring * kPmTileBytes;
     const uint32_t sum_off = scratch_off + (HALF ? 0u : kPmTileBytes);
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     }
     {
         const uint4 *src = WIDE ? reinterpret_cast<const uint4 *>(a.wide_image)
+                                : BYTE ? reinterpret_cast<const uint4 *>(a.byte_image)
                                 : HALF ? reinterpret_cast<const uint4 *>(a.half_image) : reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         // (Batching these loads — several per thread in flight before their LDS writes — was tried twice and is SLOWER: the walkers' first
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             LaneRegs<D> L;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                L.e[d] = HALF ? a.dc[d].half_row_base + a.dc[d].first_state : a.dc[d].first_entry;  // states[d][0] = first_state_val: lib.rs:807
+                L.e[d] = BYTE ? a.dc[d].first_state : HALF ? a.dc[d].half_row_base + a.dc[d].first_state : a.dc[d].first_entry;  // states[d][0] = first_state_val: lib.rs:807
                 L.mx[d] = 0;
             }
             L.sid_prev = 0;
@@ -414,6 +416,9 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                         }
                         hb &= 0x80808080u;
                     }
+                } else if constexpr (BYTE) {
+                    if (full) tb = walk_tile_pm_byte<true>(L, cq, a, sink, 0, 0, t0, sidq, acc_state);
+                    else tb = walk_tile_pm_byte<false>(L, cq, a, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state);
                 } else if (full)
                     tb = walk_tile_pm<D, true, GTAB, HALF>(L, cq, a, sink, 0, 0, t0, sidq, acc_state);
                 else
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                     // WIDE: the dead row absorbs, so the last real chain word tells; a byte >= 128 has no column and was
                     // walked through its masked alias, so such a tile is re-walked as well
                     const bool hit = WIDE ? ((L.mx[d] & kWideRowMask) == a.dc[d].dead_entry || hb != 0)
+                                          : BYTE ? L.mx[d] >= a.byte_dead
                                           : HALF ? L.mx[d] >= kHalfDead : L.mx[d] >= a.dc[d].dead_entry;
                     if (!((dead >> d) & 1u) && hit) newly |= 1u << d;
                 }
@@ -478,13 +484,16 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                                 if (WIDE) {
                                     nx = c < 128u ? lds_u32((e & kWideRowMask) | (c << 3)) : a.dc[d].dead_entry;
                                     bad = (nx & kWideRowMask) == a.dc[d].dead_entry;
+                                } else if (BYTE) {
+                                    nx = lds_u8((e << 8) | c);
+                                    bad = nx >= a.byte_dead;
                                 } else {
                                     nx = table_at<GTAB>(a, (e & ~kTagMask) | (c << 2));
                                     bad = nx >= a.dc[d].dead_entry;
                                 }
                                 if (bad) {
                                     err_pos[d] = t0 + p;
-                                    err_state[d] = (WIDE ? ((e >> kWideRowShift) & 0xffu) : (e >> kNextShift)) - a.dc[d].row_base;
+                                    err_state[d] = BYTE ? e : (WIDE ? ((e >> kWideRowShift) & 0xffu) : (e >> kNextShift)) - a.dc[d].row_base;
                                     err_char[d] = c;
                                     found = true;
                                     break;
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 if (!full && n == t0 + 64u && t + 1 == ntiles) {  // n == M: row n does not exist, s[n] is the live state
 #pragma unroll
                     for (int d = 0; d < D; ++d)
-                        acc_state[d] = HALF ? (L.e[d] & 0xffu) - a.dc[d].half_row_base
+                        acc_state[d] = BYTE ? L.e[d] : HALF ? (L.e[d] & 0xffu) - a.dc[d].half_row_base
                                             : (WIDE ? ((L.e[d] >> kWideRowShift) & 0xffu) : (L.e[d] >> kNextShift)) - a.dc[d].row_base;
                 }
                 if constexpr (FIN) {
@@ -577,8 +586,10 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                     fixm &= fixm - 1;
                     const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
                     const uint32_t bj = b0 + (uint32_t)j;
-                    for (uint32_t r = fs + lane; r < fix_end; r += 64u)
-                        a.masked[SM ? (size_t)bj * a.msk_pitch + r : ((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;
+                    for (uint32_t r = fs + lane; r < fix_end; r += 64u) {
+                        const uint32_t rr = (a.debug & kDbgFixToDummy) ? (r & 63u) : r;
+                        a.masked[SM ? (size_t)bj * a.msk_pitch + rr : ((size_t)blk0 * q8 + (size_t)(rr >> 3) * nb + (bj - blk0)) * 8u + (rr & 7u)] = 0;
+                    }
                 }
                 // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8]; stored during the next walk ----------------
                 {
@@ -672,9 +683,9 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     }
 }
 
-template <int D, bool GTAB, bool WIDE = false, bool HALF = false, bool SM = false>
+template <int D, bool GTAB, bool WIDE = false, bool HALF = false, bool SM = false, bool BYTE = false>
 static hipError_t launch_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto k = witness_pm_kernel<D, GTAB, WIDE, HALF, SM>;
+    auto k = witness_pm_kernel<D, GTAB, WIDE, HALF, SM, BYTE>;
     static std::atomic<size_t> granted[64];  // per device: the attribute is set on the current device's function
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -689,6 +700,7 @@ hipError_t launch_witness_pm(const WitnessArgs &a, const LaunchInfo &li, hipStre
         if (a.D != 3 || li.half || li.gtab) return hipErrorInvalidValue;
         return li.wide ? launch_pm<3, false, true, false, true>(a, li, stream) : launch_pm<3, false, false, false, true>(a, li, stream);
     }
+    if (li.byte) return a.D == 1 ? launch_pm<1, false, false, false, false, true>(a, li, stream) : hipErrorInvalidValue;
     if (li.half) return a.D == 1 ? launch_pm<1, false, false, true>(a, li, stream) : a.D == 2 ? launch_pm<2, false, false, true>(a, li, stream) : launch_pm<3, false, false, true>(a, li, stream);
     if (li.wide) return a.D == 1 ? launch_pm<1, false, true>(a, li, stream) : a.D == 2 ? launch_pm<2, false, true>(a, li, stream) : launch_pm<3, false, true>(a, li, stream);
     if (li.gtab) return a.D == 1 ? launch_pm<1, true>(a, li, stream) : a.D == 2 ? launch_pm<2, true>(a, li, stream) : launch_pm<3, true>(a, li, stream);

@@ -20,8 +20,6 @@
 
 namespace hrx {
 
-typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
-__device__ __forceinline__ uint32_t lds_u8(uint32_t off) { return *(lds_cu8 *)(uintptr_t)off; }
 // next lookup address = (chain word's low 16 bits) * 8 + pair index: the whole VALU part of the dependent chain
 __device__ __forceinline__ uint32_t pp_addr(uint32_t lo, uint32_t idx) {
     uint32_t r;

@@ -58,6 +58,19 @@ constexpr uint32_t kHalfMaxSid = 62;
 HRX_HD uint32_t half_addr(uint32_t row, uint32_t c) { return ((c >> 7) << 16) | (row << 8) | ((c & 127u) << 1); }
 HRX_HD uint32_t half_image_bytes(uint32_t rows) { return kHalfUpperBase + rows * 256u; }
 
+// BYTE table (position-major kernel; ONE def of at most 256 table rows — cfg 5's 256-state x 256-symbol DFA): the HALF table's
+// 128 KiB leave 32 KiB of LDS, one ring slot per walker and no room for a finisher wave, and in-kernel stamps showed that
+// walker spending 46 % of its cycles in the tile-end work (reveal masks, held rows, repairs, masked-row stores).  Here the
+// dependent chain reads a 1-byte next-state table — entry (row, c) at LDS byte address row << 8 | c, 64 KiB for 256 rows, one
+// v_lshl_or_b32 + one ds_read_u8 per row — and the substring tag of a row, which is a function of the PAIR (state, next)
+// (lib.rs:831-840, 861-866, 874-879), comes off the chain from a perfect-hash table: 4096 u32 slots {state << 8 | next (0xffff:
+// empty), tag << 16} at slot (state * A + next * B) & 4095, with (A, B) searched at finalize time so that the tagged pairs do
+// not collide; the tag counts only if the slot's key is the row's pair.  One more LDS read per row (a row-displacement table
+// with its u16 disp[state] took two: 162 cycles per row against the HALF walk's 113), software-pipelined two rows deep, not on
+// the chain.  Rows: the real states, then one absorbing dead row if the DFA is partial (lib.rs:817).
+constexpr uint32_t kByteNoDead = 0x100u;
+constexpr uint32_t kByteSlots = 4096u;
+
 // PAIR table (position-major kernel hrx_kernel_pp.hip; one def, at most kPairMaxClasses byte-equivalence classes): one
 // dependent lookup per TWO input bytes.  Bytes are mapped to classes first (class LUT, value = class * 8); block s holds
 // the n_classes^2 entries of state s (real states, then one absorbing dead block), entry (a, b) = the walk from s over a

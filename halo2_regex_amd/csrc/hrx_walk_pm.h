@@ -184,6 +184,80 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
 }
 
 // ---------------------------------------------------------------------------------------------
+// BYTE-table walk (hrx_lane.h; one def).  Per row two LDS reads, neither of which waits for the other:
+//   iteration p:  next-state byte of row p  (the dependent chain: address = state << 8 | byte),
+//                 pair slot of row p - 1    (address ((state * A4 + next * B4) & 0x3ffc) | ptab_off, both known since the previous iteration),
+//   and in their shadow the record / flag / id work of row p - 2, whose slot arrived an iteration ago.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+__device__ __forceinline__ uint32_t lds_u8(uint32_t off) { return *(lds_cu8 *)(uintptr_t)off; }
+
+template <bool FULL, class Sink>
+__device__ __forceinline__ TileBits walk_tile_pm_byte(LaneRegs<1> &L, const uint4 (&cq)[4], const WitnessArgs &a, Sink &sink, int rem, int mrem,
+                                                      uint32_t t0, uint32_t (&sidq)[16], uint32_t (&acc_state)[1]) {
+    uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
+    uint32_t rbuf[4];
+    const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
+                             cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
+    const uint32_t A4 = a.byte_mul_a4, B4 = a.byte_mul_b4, ptab = a.byte_ptab_off;
+    uint32_t cur = L.e[0];                  // state at the row whose chain lookup is issued next
+    uint32_t s1 = 0, n1 = 0;                // row p - 1: its state and its next state
+    uint32_t k2 = 0, pe2 = 0xffffu;         // row p - 2: its pair key (state << 8 | next) and its pair slot
+
+    auto post = [&](const int p, const uint32_t key, const uint32_t pe) {
+        uint32_t state = key >> 8;
+        uint32_t tag = ((pe & 0xffffu) == key) ? (pe >> 16) : 0u;   // the slot holds this pair: (state, next) is tagged
+        if (!FULL) {
+            if (p >= rem) tag = 0;                                   // padding rows: their lookups ran on stand-in states (lib.rs:404-418)
+            if (p > rem) state = a.dc[0].dummy_state;                // lib.rs:413
+            if (p >= mrem) tag &= ~kTagEnd;
+            if (p == rem) acc_state[0] = state;                      // the state at row n (lib.rs:437-457)
+        }
+        rbuf[p & 3] = state | (tag << 16);
+        if ((p & 3) == 3) sink.quad(0, p, FULL, mrem, make_uint4(rbuf[0], rbuf[1], rbuf[2], rbuf[3]));
+        const uint32_t sid = tag & 0xffu;
+        st[p >> 5] |= ((tag >> 8) & 1u) << (p & 31);
+        en1[p >> 5] |= ((tag >> 9) & 1u) << (p & 31);
+        ch[p >> 5] |= (sid != L.sid_prev ? 1u : 0u) << (p & 31);
+        L.sid_prev = sid;
+        if (Sink::kSidq) sidq[p >> 2] |= sid << (8 * (p & 3));
+        sink.row(p);
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sidq[i] = 0;
+#pragma unroll
+    for (int p = 0; p < 66; ++p) {
+        uint32_t raw_n = 0, raw_pe = 0xffffu;
+        if (p < 64) {
+            const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
+            raw_n = lds_u8((cur << 8) | c);                          // delta(state, byte): lib.rs:810
+        }
+        if (p >= 1 && p < 65) raw_pe = lds_u32(((__umul24(s1, A4) + __umul24(n1, B4)) & ((kByteSlots - 1u) << 2)) | ptab);
+        if (p >= 2) {
+            post(p - 2, k2, pe2);
+            asm volatile("" : "+v"(st[(p - 2) >> 5]), "+v"(en1[(p - 2) >> 5]), "+v"(ch[(p - 2) >> 5]), "+v"(L.sid_prev));
+            if (Sink::kSidq) asm volatile("" : "+v"(sidq[(p - 2) >> 2]));
+            if (!FULL) asm volatile("" : "+v"(acc_state[0]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        k2 = (s1 << 8) | n1; pe2 = raw_pe;
+        if (p < 64) {
+            const uint32_t nxt = (FULL || p < rem) ? raw_n : 0u;    // rows >= n: any valid row; post() writes the dummy state and no tag
+            L.mx[0] = max(L.mx[0], nxt);                              // reaching the dead row = an undefined transition (lib.rs:817)
+            asm volatile("" : "+v"(L.mx[0]));
+            s1 = cur; n1 = nxt;
+            cur = nxt;
+        }
+    }
+    L.e[0] = cur;
+    TileBits tb;
+    tb.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
+    tb.en1 = (uint64_t)en1[0] | ((uint64_t)en1[1] << 32);
+    tb.ch = (uint64_t)ch[0] | ((uint64_t)ch[1] << 32);
+    return tb;
+}
+
+// ---------------------------------------------------------------------------------------------
 // WIDE-table walk (hrx_lane.h): one ds_read_b64 per row and def returns the chain word AND the finished record, so a
 // row costs, beyond the lookups,  v_add3 (per-row sums of substr ids and flag counts over the defs, straight from the
 // chain words) + v_bfe (substr id) + 2 shifts + 2 v_alignbit (start / end bit into the tile bitvectors) +

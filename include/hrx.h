@@ -102,7 +102,11 @@ size_t hrx_table_endpoint_rows(const hrx_defs *defs, size_t def, uint64_t *rows3
 
 int hrx_device_count(int *count);
 /* Uploads the tables to `device` and creates a stream.  The handle may be shared by clones of a
- * RegexVerifyConfig (lib.rs:96 derives Clone); device work of one ctx is serialised internally.  Every entry point
+ * RegexVerifyConfig (lib.rs:96 derives Clone); device work of one ctx is serialised internally.  A context owns device
+ * scratch that some launches use (the group counter of multi-round batches, the group buffers of configs of more than three
+ * defs): it serves ONE stream or captured graph at a time — a launch on another stream first waits on the host for the stream
+ * that used the scratch last (HRX_ERR_STATE if that wait is impossible, e.g. inside a stream capture), and a captured graph
+ * must not be replayed concurrently with other launches of the same context; use one context per concurrent stream.  Every entry point
  * leaves the caller's current HIP device as it found it.
  * device = HRX_DEVICE_NONE: a host-only context (no HIP call is made): the single-string entry points and
  * hrx_witness_batch_host run the native host walk, device-pointer entry points return HRX_ERR_HIP.
@@ -178,19 +182,49 @@ int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *cha
 void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16);
 /* Allocates the records and masked-row buffers of a position-major batch of B strings x M rows (sizes as
  * hrx_position_major_sizes) on ctx's device; each is released with hrx_device_free.  Optional — every entry point takes any
- * device pointer — and for records below 1 GiB just two hipMalloc calls.  From 1 GiB on the call is PLACEMENT-AWARE: two
- * concurrent write streams run 15 % slower on an MI355X when they lie in the same class of the physical address space
- * (four classes, chosen by address bits >= 2^33) than when they do not, a launch writes records and masked rows as two such
- * streams, and buffers allocated one after the other come from one neighbourhood.  So candidate masked-row buffers are
- * allocated in turn (at most 24), each is measured against the records buffer with a two-stream write of a few hundred
- * microseconds (both buffers are overwritten); the first that does not collide — failing that, the fastest — is kept and
- * the others are freed: 262144 x 2048 B at D = 2 runs at 0.97-1.03 ms with such a pair against 0.97-1.19 ms (1.12-1.19 ms in
- * a fresh process) with two plain allocations (csrc/hrx_place.hip).  The call allocates, launches on the
- * context's own stream and waits for it: not inside a stream capture.  The reference has no counterpart: its witness lives
- * in host Vecs. */
+ * device pointer — and for records below 128 MiB (a launch that lives in the 256-MB Infinity Cache) just two hipMalloc calls.
+ * From there on the call is PLACEMENT-AWARE: two concurrent write streams run ~15 % slower on an MI355X when they lie in the
+ * same class of the physical address space (four classes, chosen by address bits >= 2^33) than when they do not, a launch
+ * writes records and masked rows as two such streams, and buffers allocated one after the other come from one neighbourhood.
+ * So the call walks down the device memory — block after block, each measured against the records with a two-stream write of
+ * a few hundred microseconds that times itself on the device clock (robust under a profiler); the reference is the same probe
+ * inside ONE block, a candidate faster than that is taken, failing that the fastest measured, and everything else is freed
+ * before the call returns; the walk never holds more than 70 % of the device memory that was free.
+ *   records >= 1 GiB: the blocks are the masked-row candidates themselves, measured against the records buffer itself.
+ *   records <  1 GiB: such buffers are carved out of two 2-GiB ARENAS per context (one for records, one for masked rows; a
+ *     probe over buffers that fit the Infinity Cache would measure the cache, and the driver puts small blocks into any hole):
+ *     the first such call finds the pair, later calls are served from it until it is full (then a new pair is found);
+ *     hrx_device_free returns a sub-buffer to its arena and an arena is released with its last sub-buffer once the context
+ *     has moved on or is destroyed.  A context therefore holds up to 4 GiB for its small output buffers.
+ * 262144 x 2048 B at D = 2 runs at 0.97-1.03 ms with such a pair against 1.12-1.19 ms in a fresh process with two plain
+ * allocations (csrc/hrx_place.hip).  The call takes the context's lock, launches on the context's own stream
+ * and waits for it: not inside a stream capture.  Environment, read by hrx_ctx_create: HRX_PLACE=0 (plain allocations),
+ * HRX_PLACE_MAX_STEPS, HRX_PLACE_TRACE=1.  The reference has no counterpart: its witness lives in host Vecs. */
 int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked);
 /* The same for any pair of output buffers given in bytes (string-major outputs: B * rec_pitch * D * 4 and B * msk_pitch * 2). */
 int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_bytes, void **records, void **masked);
+/* What the context's last hrx_alloc_output_pair / hrx_alloc_outputs_position_major call did. */
+typedef struct hrx_place_report {
+    int searched;                /* 0: two plain allocations (small buffers, HRX_PLACE=0, or no memory to walk with); 1: this call walked;
+                                    2: served from the arena pair an earlier call measured (the numbers below are that walk's) */
+    int steps;                   /* candidates measured */
+    int accepted;                /* 1: the kept candidate beat the same-neighbourhood reference by the margin; 0: the fastest measured */
+    int chosen_step;
+    double ref_us;               /* the reference: both probe streams inside one neighbourhood (device clock) */
+    double first_us, best_us;    /* the first candidate (what two plain allocations would have been) and the kept one */
+    size_t probe_bytes;          /* bytes one probe pass writes */
+    size_t peak_candidate_bytes; /* most memory the walk held at once: rejected candidates stay allocated, as the spacers that push the
+                                    next candidate further, until the walk ends */
+    double search_ms;            /* host time of the whole call */
+} hrx_place_report;
+int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out);
+/* Roofline diagnostic: the memory traffic of ONE position-major witness launch of B strings x M rows of this context's
+ * config (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR) and nothing else — the input read in 16-byte chunks
+ * per lane, every record plane and the masked rows written at the launch's own addresses with the launch's store policy, by
+ * four reader and four writer waves per CU — no DFA work.  OVERWRITES records and masked with junk.  What it takes is this
+ * box's ceiling for the launch's byte mix on these very buffers (bench.py: roofline.mix_ceiling).  Asynchronous on `stream`. */
+int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records,
+                            uint16_t *masked, void *stream);
 int hrx_device_free(void *ptr);
 /* Which kernel and launch geometry the planner picks for a batch of B strings x M rows in `layout` on a gfx950 device
  * with `num_cus` compute units (MI355X: 256), as text: "hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8
@@ -242,7 +276,12 @@ int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stri
  * inputs already sit in each device's HBM.  Shard r = counts[r] strings whose buffers chars[r], lens[r], records[r],
  * masked[r], status[r] are DEVICE pointers on the device of shard r (hrx_multi_shard_device), in `layout` (one of the
  * hrx_witness_batch_device_layout layouts, each shard a complete array of its own strings).  One kernel per shard is
- * enqueued on the shard's own stream — asynchronous; hrx_multi_synchronize waits for all of them.  No collective. */
+ * enqueued on the shard's own stream — asynchronous; hrx_multi_synchronize waits for all of them.  No collective.
+ * ORDERING: the shard streams are the contexts' private non-blocking streams; nothing orders them against the stream that
+ * produced a shard's inputs.  The inputs must be complete before the call, or the caller makes the shard stream
+ * (hrx_multi_shard_stream, a hipStream_t) wait on an event recorded behind the producer; the outputs are complete after
+ * hrx_multi_synchronize (or behind an event recorded on the shard stream). */
+void *hrx_multi_shard_stream(const hrx_multi *m, int shard);
 int hrx_multi_witness_batch_device(hrx_multi *m, int layout, const uint8_t *const *chars, size_t stride, const uint32_t *const *lens,
                                    const size_t *counts, size_t M, uint32_t *const *records, uint16_t *const *masked,
                                    uint64_t *const *status);

@@ -167,6 +167,36 @@ long sim_check_half_image(void *p) {
     return n;
 }
 
+// BYTE image (1-byte next states + the pair tags in a perfect-hash table, hrx_lane.h) against the 4-byte fused table: every
+// (state, byte) — the kernel's lookups restated: next = image[state << 8 | byte], slot = ptab[(state * A + next * B) & 4095],
+// tag = slot.key == (state << 8 | next) ? slot.tag : 0.  Returns the number of entries compared, -1 without a BYTE image, -2 - index on a mismatch.
+long sim_check_byte_image(void *p) {
+    const DefsSet &s = *(DefsSet *)p;
+    if (s.byte.image.empty()) return -1;
+    const DefConsts &c = s.consts[0];
+    const ByteTable &b = s.byte;
+    if (b.ptab_off % (kByteSlots * 4) || b.ptab_off + kByteSlots * 4 != b.bytes) return -2;
+    long n = 0;
+    for (uint32_t st = 0; st < b.n_rows; ++st)
+        for (uint32_t ch = 0; ch < 256; ++ch, ++n) {
+            const uint32_t nx = b.image[(size_t)st << 8 | ch];
+            uint32_t slot;
+            std::memcpy(&slot, &b.image[b.ptab_off + (((st * b.mul_a + nx * b.mul_b) & (kByteSlots - 1)) << 2)], 4);
+            const uint32_t tag = (slot & 0xffffu) == (st << 8 | nx) ? slot >> 16 : 0u;
+            if (st == b.dead) {                                   // the absorbing dead row (partial DFAs only)
+                if (nx != b.dead || tag) return -2 - n;
+                continue;
+            }
+            const uint32_t e4 = s.table_image[(size_t)(c.row_base + st) * 256 + ch];
+            if ((e4 & ~kTagMask) == c.dead_entry) {
+                if (nx != b.dead || b.dead == kByteNoDead) return -2 - n;
+                continue;
+            }
+            if (nx != (e4 >> kNextShift) - c.row_base || tag != (e4 & kTagMask)) return -2 - n;
+        }
+    return n;
+}
+
 // direct access to the scan primitives for property tests
 uint64_t sim_fill_up(uint64_t set, uint64_t rst, uint32_t cin) { return fill_up(set, rst, cin); }
 uint64_t sim_fill_down(uint64_t set, uint64_t rst, uint32_t cin) { return fill_down(set, rst, cin); }

@@ -129,7 +129,7 @@ def test_compute_fails_loudly_without_a_device():
         cfg.witness_batch_host(np.zeros((1, 16), np.uint8), np.zeros(1, np.uint32))
 
 
-def test_planner_picks_the_documented_kernel_per_config():
+def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     """hrx_describe_launch (host-only): which kernel and table format serve which shape on a 256-CU MI355X."""
     from halo2_regex_amd import synth
     cfg = RegexVerifyConfig.configure(1024, _defs(CFG_A[:1]), device=None)
@@ -149,7 +149,12 @@ def test_planner_picks_the_documented_kernel_per_config():
     a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=np.arange(256, dtype=np.uint8), n_substr_pairs=200)
     cfg = RegexVerifyConfig.configure(4096, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)
     d = cfg.describe_launch(65536, layout=3)
+    # ... one def: the BYTE table (64 KiB of next-state bytes + the pair tags off the chain) leaves room for a finisher wave and a ring of 3 slots
+    assert d.startswith("hrx::witness_pm_kernel<1, false, false, false, false, true> grid=256 waves=12 ring=2 ")
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", str(0x8000))          # kDbgNoByte: the 128-KiB HALF table, walker + loader only
+    d = cfg.describe_launch(65536, layout=3)
     assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8 ") and "lds=%d" % (128 * 1024 + 4 * (4096 + 128)) in d
+    monkeypatch.delenv("HRX_DEBUG_FLAGS")
     assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_kernel<1, true, true> ")                # string-major: global table
     # beyond 256 states there is no HALF image: global-table walk
     a_txt, sub_txt = synth.random_dfa(300, seed=2)

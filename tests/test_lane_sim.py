@@ -30,6 +30,8 @@ def sim():
     lib.sim_finalize.argtypes = [C.c_void_p]
     lib.sim_check_half_image.argtypes = [C.c_void_p]
     lib.sim_check_half_image.restype = C.c_long
+    lib.sim_check_byte_image.argtypes = [C.c_void_p]
+    lib.sim_check_byte_image.restype = C.c_long
     lib.sim_witness_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sim_witness_batch_w.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
@@ -176,3 +178,21 @@ def test_half_table_image_equals_the_fused_table(sim):
     assert sim.sim_check_half_image(SimDefs(sim, [(a_txt.encode(), [sub_txt.encode()])]).h) == 256 * 256
     a_txt, sub_txt = synth.random_dfa(300, seed=5, alphabet=allb[:64], n_substr_pairs=50)
     assert sim.sim_check_half_image(SimDefs(sim, [(a_txt.encode(), [sub_txt.encode()])]).h) == -1
+
+
+def test_byte_table_image_equals_the_fused_table(sim):
+    """The BYTE image (1-byte next-state table on the chain + the (state, next) pair tags in a perfect-hash table off it; one
+    def of at most 256 table rows, cfg 5) carries exactly the transitions, substr ids and start/end flags of the 4-byte fused
+    table: total DFAs have no dead row, partial ones one more row than states; two defs or more than 256 rows: no image."""
+    for cfg, rows in ((CFG_1, 29 + 1), (CFG_3, 20 + 1)):                        # (98-symbol alphabets: partial over the 256 byte values -> + the dead row)
+        assert sim.sim_check_byte_image(SimDefs(sim, cfg).h) == rows * 256
+    allb = np.arange(256, dtype=np.uint8)
+    a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=200)
+    assert sim.sim_check_byte_image(SimDefs(sim, [(a_txt.encode(), [sub_txt.encode()])]).h) == 256 * 256          # total: 256 rows
+    a_txt, sub_txt = synth.random_dfa(255, seed=3, total=False, alphabet=allb, n_substr_pairs=250)
+    assert sim.sim_check_byte_image(SimDefs(sim, [(a_txt.encode(), [sub_txt.encode()])]).h) == 256 * 256          # partial: 255 states + the dead row
+    a_txt, sub_txt = synth.random_dfa(255, seed=3, total=False, alphabet=allb, n_substr_pairs=900)
+    assert sim.sim_check_byte_image(SimDefs(sim, [(a_txt.encode(), [sub_txt.encode()])]).h) == -1                 # too many tagged pairs for a collision-free hash: the HALF table serves it
+    a_txt, sub_txt = synth.random_dfa(256, seed=4, total=False, alphabet=allb, n_substr_pairs=50)
+    assert sim.sim_check_byte_image(SimDefs(sim, [(a_txt.encode(), [sub_txt.encode()])]).h) == -1                 # partial with 256 states: no row left for the dead state
+    assert sim.sim_check_byte_image(SimDefs(sim, CFG_A).h) == -1                                                  # two defs

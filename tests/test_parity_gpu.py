@@ -386,20 +386,24 @@ def test_cfg5_shape_256_state_dense_dfa_4096_byte_strings(hra, oracle):
     _full_check(hra, o, cfg, [(chars, lens)], M, 1, position_major=False)
 
 
-def test_half_table_kernel_on_dfas_of_up_to_256_states(hra, oracle):
-    """DFAs of 141..256 states: the 4-byte fused table does not fit LDS next to the input rings, the 2-byte HALF table does
-    (position-major kernel).  Total and partial DFAs (undefined transitions -> status 1 with the reference's state/char),
-    ragged lengths, bytes outside the alphabet."""
+@pytest.mark.parametrize("flags", [0, 0x8000], ids=["byte-table", "half-table"])
+def test_half_table_kernel_on_dfas_of_up_to_256_states(hra, oracle, flags, monkeypatch):
+    """DFAs of 141..256 states: the 4-byte fused table does not fit LDS next to the input rings.  One def takes the BYTE table
+    (1-byte next states on the chain, the pair tags off it: walker + loader + finisher), kDbgNoByte the 2-byte HALF table
+    (walker + loader).  Total and partial DFAs (undefined transitions -> status 1 with the reference's state/char; 255 partial
+    states fill the BYTE table's 256 rows), ragged lengths, bytes outside the alphabet."""
     import torch
     from halo2_regex_amd import synth
     dev = torch.device("cuda", 0)
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(flags))
     for nstates, total, seed, alpha in ((200, False, 7, synth.ALPHABET98), (256, True, 2, np.arange(256, dtype=np.uint8)),
-                                        (160, False, 9, np.arange(256, dtype=np.uint8))):
+                                        (160, False, 9, np.arange(256, dtype=np.uint8)), (255, False, 11, np.arange(256, dtype=np.uint8))):
         allstr, sub = synth.random_dfa(nstates, seed=seed, total=total, alphabet=alpha, n_substr_pairs=120)
         defs = [hra.RegexDefs(hra.AllstrRegexDef(allstr), [hra.SubstrRegexDef(sub)])]
         M = 328
         cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
         assert cfg.table_bytes() == (nstates + 2) * 1024
+        assert ("witness_pm_kernel<1, false, false, true>" if flags else "witness_pm_kernel<1, false, false, false, false, true>") in cfg.describe_launch(700, layout=1)
         o = OracleDefs(oracle, [(allstr, [sub])])
         chars, lens = synth.ragged(700, M, seed=nstates, planted=False, alphabet=alpha)
         if len(alpha) < 256:
@@ -441,8 +445,8 @@ def test_global_table_variant_on_the_reference_dfas(hra, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("flags", [str(0x80000), str(0x200000 | 0x2000000), str(0x400000), str(0x4000000), "0", str(0x8000000), str(0x40000000),
-                               ],
-                         ids=["narrow-table", "wide-table", "half-table", "def-parallel", "planner-default", "no-pair-step", "pair-step"])
+                               str(0x2000 | 0x8000000)],
+                         ids=["narrow-table", "wide-table", "half-table", "def-parallel", "planner-default", "no-pair-step", "pair-step", "byte-table"])
 def test_position_major_kernel_on_both_table_formats(hra, oracle, flags, monkeypatch):
     """The position-major path has four table formats (4-byte, WIDE for D >= 2, HALF for big DFAs, PAIR — two bytes per lookup —
     for one def with few byte classes: the planner's default at D = 1) and, for D >= 2 batches that leave walker slots empty,
@@ -705,7 +709,8 @@ def test_multi_pass_at_a_chip_filling_size_two_blocks(hra, oracle):
     _full_check(hra, OracleDefs.from_files(oracle, CFG_D5), cfg, [(base_c[:5000], base_l[:5000])], M, 5, position_major=False)
 
 
-@pytest.mark.parametrize("flags,names", [(0x1000, CFG_1), (0x1000, CFG_A), (0x1000 | 0x400000, CFG_123)], ids=["D1", "D2-wide", "D3-half"])
+@pytest.mark.parametrize("flags,names", [(0x1000, CFG_1), (0x1000, CFG_A), (0x1000 | 0x400000, CFG_123), (0x1000 | 0x2000 | 0x8000000, CFG_1)],
+                         ids=["D1", "D2-wide", "D3-half", "D1-byte"])
 def test_dynamic_group_assignment(hra, oracle, flags, names, monkeypatch):
     """Batches of eight or more long groups per walker pair take their groups from a device counter instead of a fixed stride (the
     loader draws, walker and finisher follow through an LDS queue).  Forced here from the second group on (kDbgForceDynamicGroups)
@@ -763,7 +768,10 @@ def test_placement_aware_output_allocation(hra, oracle):
     out = cfg.alloc_outputs_position_major(B, dev)
     assert out[0].numel() * 4 >= hra.PLACED_FROM and out[0].data_ptr() % 16 == 0 and out[1].data_ptr() % 16 == 0
     used = free0 - torch.cuda.mem_get_info()[0]
-    assert used < out[0].numel() * 4 + out[1].numel() * 2 + (256 << 20)        # the losing candidates were freed
+    assert used < out[0].numel() * 4 + out[1].numel() * 2 + (256 << 20)        # the losing candidates and the spacers were freed
+    rep = cfg.last_placement_report()
+    assert rep["searched"] == 1 and rep["steps"] >= 1 and rep["ref_us"] > 0 and rep["best_us"] > 0 and rep["best_us"] <= rep["first_us"]
+    assert out[1].numel() * 2 <= rep["peak_candidate_bytes"] <= 0.70 * free0   # bounded: never more than 70 % of the free memory
     del out
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < (256 << 20)                    # ... and hrx_device_free released the pair
@@ -772,6 +780,7 @@ def test_placement_aware_output_allocation(hra, oracle):
     pr, pm = C.c_void_p(), C.c_void_p()
     assert hra.lib.hrx_alloc_outputs_position_major(cfg._ctx, 1000, 64, C.byref(pr), C.byref(pm)) == hra.HRX_OK and pr.value and pm.value
     assert hra.lib.hrx_device_free(pr) == hra.HRX_OK and hra.lib.hrx_device_free(pm) == hra.HRX_OK and hra.lib.hrx_device_free(None) == hra.HRX_OK
+    assert cfg.last_placement_report()["searched"] == 0                          # a launch that lives in the Infinity Cache: two plain allocations
     assert hra.lib.hrx_alloc_outputs_position_major(cfg._ctx, 0, 64, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_ARG
     assert hra.lib.hrx_alloc_outputs_position_major(None, 8, 64, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_ARG
     # more than the device holds: a loud error, nothing left allocated (records too big; records fit but no masked-row candidate does)
@@ -779,6 +788,62 @@ def test_placement_aware_output_allocation(hra, oracle):
     assert hra.lib.hrx_alloc_output_pair(cfg._ctx, 1 << 40, 1 << 20, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_HIP and not pr.value and not pm.value
     assert hra.lib.hrx_alloc_output_pair(cfg._ctx, 2 << 30, 1 << 40, C.byref(pr), C.byref(pm)) == hra.HRX_ERR_HIP and not pr.value and not pm.value
     assert abs(free1 - torch.cuda.mem_get_info()[0]) < (64 << 20)
+
+
+def test_placement_search_for_bench_sized_buffers_uses_measured_arenas(hra, oracle, monkeypatch):
+    """Records below 1 GiB (the bench line: 256 MiB of records, 128 MiB of masked rows) are carved out of a measured pair of 2-GiB
+    arenas — a probe over buffers that fit the Infinity Cache would measure the cache: the first call walks (never more than 70 %
+    of the free memory), later calls are served from the same pair, a full pair is replaced, hrx_device_free returns sub-buffers
+    and the arenas go with the context, and the buffers are ordinary memory (one launch against the oracle, every string).
+    HRX_PLACE=0 (read at context creation) turns the search off."""
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    M, B = 1024, 65536
+    cfg = _cfg(hra, CFG_1, M)
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    outs = [cfg.alloc_outputs_position_major(B, dev)]
+    rep = cfg.last_placement_report()
+    nrec, nmsk = outs[0][0].numel() * 4, outs[0][1].numel() * 2
+    assert nrec == 256 << 20 and rep["searched"] == 1 and rep["steps"] >= 1 and rep["ref_us"] > 0 and 0 < rep["best_us"] <= rep["first_us"]
+    assert (2 << 30) <= rep["peak_candidate_bytes"] <= 0.70 * free0 and rep["probe_bytes"] >= 1 << 30
+    assert free0 - torch.cuda.mem_get_info()[0] < (4 << 30) + (256 << 20)            # the pair of arenas, nothing else
+    for k in range(7):                                                                # 8 x 256 MiB fill the records arena exactly
+        outs.append(cfg.alloc_outputs_position_major(B, dev))
+        assert cfg.last_placement_report()["searched"] == 2
+    ptrs = sorted(o[0].data_ptr() for o in outs)
+    assert all(b - a == nrec for a, b in zip(ptrs, ptrs[1:]))                         # back to back inside one 2-GiB block
+    assert free0 - torch.cuda.mem_get_info()[0] < (4 << 30) + (256 << 20)
+    outs.append(cfg.alloc_outputs_position_major(B, dev))                             # the pair is full: a new one is measured
+    assert cfg.last_placement_report()["searched"] == 1
+    chars, lens = synth.reveal_stress(B, M - 1, seed=5)
+    d_c, d_l = hra.chars_to_position_major(torch.from_numpy(chars).to(dev)), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    rec, msk, st = cfg.witness_batch_position_major(d_c, d_l, out=outs[3], chars_pm_stride=chars.shape[1])
+    torch.cuda.synchronize()
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_1).witness_batch(chars, lens, M, threads=os.cpu_count() or 8)
+    r2, m2 = hra.position_major_to_string_major(rec, msk, B, M, 1)
+    ok = torch.from_numpy((ost & np.uint64(0xff)) == 0).to(dev)
+    assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+    assert torch.equal(r2[ok], torch.from_numpy(orec.view(np.int32)).to(dev)[ok]) and torch.equal(m2[ok], torch.from_numpy(omsk.view(np.int16)).to(dev)[ok])
+    # hrx_traffic_pass_device: the launch's memory traffic with no DFA work — it overwrites these outputs (with junk) and nothing else
+    before = [o[0][:4096].clone() for o in outs]
+    cfg.traffic_pass(d_c, B, outs[3], chars.shape[1])
+    torch.cuda.synchronize()
+    r3, _ = hra.position_major_to_string_major(outs[3][0], outs[3][1], B, M, 1)
+    assert not torch.equal(r3[ok], torch.from_numpy(orec.view(np.int32)).to(dev)[ok])
+    assert all(torch.equal(o[0][:4096], b) for k, (o, b) in enumerate(zip(outs, before)) if k != 3)
+    del outs, rec, msk, st, r2, m2, r3, d_c, d_l, ok, before
+    del cfg                                                                           # the context goes: its arenas are released
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()       # (the test's own tensors sit in torch's caching allocator)
+    assert free0 - torch.cuda.mem_get_info()[0] < (256 << 20)
+    monkeypatch.setenv("HRX_PLACE", "0")
+    cfg0 = _cfg(hra, CFG_1, M + 8)
+    out = cfg0.alloc_outputs_position_major(B, dev)
+    assert cfg0.last_placement_report()["searched"] == 0 and out[0].numel() * 4 == (M + 8) * B * 4
 
 
 def test_multi_device_driver_device_resident_shards(hra, oracle):
@@ -805,7 +870,11 @@ def test_multi_device_driver_device_resident_shards(hra, oracle):
             else:
                 shards.append((d_c, d_l, cfg.alloc_outputs(c, dev)))
         if layout_pm:
-            multi.witness_batch_device(shards, chars_stride=chars.shape[1])
+            # chars_stride omitted: it follows from the buffer sizes (never a silent fallback); shards that disagree are refused
+            bad = [(shards[0][0][:-16], shards[0][1], shards[0][2])] + shards[1:]
+            with pytest.raises(hra.HrxError):
+                multi.witness_batch_device(bad)
+            multi.witness_batch_device(shards)
         else:
             multi.witness_batch_device(shards, layout=hra.LAYOUT_STRING_MAJOR)
         multi.synchronize()
@@ -966,6 +1035,6 @@ def test_full_size_cfg5_dfa256_131072_strings_of_4096_bytes(hra, oracle):
     n, M = 4095, 4096
     base_c, base_l = synth.noise(hra.PM_BLOCK, n, seed=2, alphabet=allb, stride=4096)
     cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
-    assert "witness_pm_kernel<1, false, false, true>" in cfg.describe_launch(131072, layout=3)
+    assert "witness_pm_kernel<1, false, false, false, false, true>" in cfg.describe_launch(131072, layout=3)     # the BYTE table: walker + loader + finisher
     st = _full_check(hra, OracleDefs(oracle, [(allstr, [sub])]), cfg, _rolled_blocks(base_c, base_l, 2, seed=5), M, 1)
     assert (st & np.uint64(0xff) == 0).all()
