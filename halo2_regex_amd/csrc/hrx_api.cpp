@@ -476,7 +476,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
 #endif
 #ifdef HRX_STAMPS
         if (li.split == 2) {
-            const size_t bytes = (size_t)li.grid * 8 * 8 * 8;
+            const size_t bytes = (size_t)li.grid * 8 * 16 * 8;   // 16 u64 per walker pair (8 walker + 8 finisher stamps), up to 8 pairs per workgroup
             if (ctx->stamps.cap < bytes) { HIP_TRY(ctx->stamps.reserve(bytes)); }
             HIP_TRY(hipMemsetAsync(ctx->stamps.p, 0, bytes, st));
             a.stamps = (unsigned long long *)ctx->stamps.p;

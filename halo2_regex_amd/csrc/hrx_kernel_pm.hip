@@ -120,6 +120,19 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
         unsigned char *mp_f = nullptr;
         size_t mstep_f = 0;
         uint32_t f = 0;
+        // HOLD (BYTE table — the random-DFA shape of cfg 5, where the optimistic end mask of hrx_lane.h is wrong for ~10 % of all masked
+        // rows): the masked rows of the last kHoldF tiles stay in the finisher's registers, so that a fix-up that arrives within
+        // kHoldF tiles zeroes them THERE; only what is older was stored already and is repaired at the memory (2-byte scattered stores).
+        // Two tiles: a third takes the kernel past the 168 VGPRs three waves per SIMD leave each (8 spills, 0.36 -> 0.41 ms).
+        #ifndef HRX_HOLDF
+#define HRX_HOLDF 2
+#endif
+        constexpr int kHoldF = BYTE ? HRX_HOLDF : 0;
+        uint4 held[kHoldF ? kHoldF : 1][8];
+        uint32_t n_held = 0;
+#ifdef HRX_STAMPS
+        unsigned long long fk_wait = 0, fk_work = 0;
+#endif
         for (uint32_t j = 0;; ++j) {
           const uint32_t gf = group_at(j);
           if (gf >= a.n_groups) break;
@@ -134,8 +147,16 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 mp_f = reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0_f * q8 + (bc - blk0_f)) * 16u;
                 mstep_f = (a.debug & kDbgFixedLines) ? (size_t)0 : (size_t)nb_f * 16u;
                 mc = MaskCarry{0, 0, 0, 0};
+                n_held = 0;
             }
+#ifdef HRX_STAMPS
+            const unsigned long long fk_a = clock64();
+#endif
             ring_wait(sum_ready_off, f + 1u);
+#ifdef HRX_STAMPS
+            const unsigned long long fk_b = clock64();
+            fk_wait += fk_b - fk_a;
+#endif
             const uint4 s0 = lds_u128(sum_off + lane * 16u), s1 = lds_u128(sum_off + 1024u + lane * 16u);
             uint32_t sidq[16], cw[16];
 #pragma unroll
@@ -163,29 +184,91 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             const uint32_t n_f = s1.z;          // the string's length (<= M; the walker clamps bad lengths)
             // ---------------- reveal masks: lib.rs:598-764 ----------------
             TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n_f, M), rows_below(t0, n_f));
+            if (a.debug & kDbgSkipFixups) tm.fix = 0;
+            const uint32_t fix_regs = tm.fix;   // held rows: shadow lanes too (they store the same rows to the same addresses as string B - 1)
             if (!active_f) tm.fix = 0;
-            uint64_t fixm = __ballot(tm.fix != 0);
-            if (a.debug & kDbgSkipFixups) fixm = 0;
+            uint32_t fix_end = t0;     // rows [fix_start, fix_end) were stored already and are fixed at the memory
+            if constexpr (kHoldF > 0) {
+                // held[i] = the masked rows of tile tf - 1 - i, rows [t0 - 64 (i + 1), t0 - 64 i): zero what lies at or after fix_start
+                fix_end = t0 - n_held * 64u;
+                if (fix_regs) {
+#pragma unroll
+                    for (int i = 0; i < kHoldF; ++i) {
+                        if ((uint32_t)i < n_held) {
+                            const uint32_t base = t0 - 64u * (uint32_t)(i + 1);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const uint32_t row0 = base + 8u * (uint32_t)k;
+                                // u16 index of the first row to zero inside this octet: 0 = all of it, >= 8 = none
+                                const uint32_t keep = tm.fix_start <= row0 ? 0u : min(tm.fix_start - row0, 8u);
+                                uint32_t w[4] = {held[i][k].x, held[i][k].y, held[i][k].z, held[i][k].w};
+#pragma unroll
+                                for (uint32_t q = 0; q < 4u; ++q) w[q] = keep > 2u * q + 1u ? w[q] : (keep > 2u * q ? (w[q] & 0xffffu) : 0u);
+                                held[i][k] = make_uint4(w[0], w[1], w[2], w[3]);
+                            }
+                        }
+                    }
+                }
+            }
+            uint64_t fixm = __ballot(tm.fix != 0 && tm.fix_start < fix_end);
             while (fixm) {   // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows (rare with real definitions)
                 const int j = __ffsll((unsigned long long)fixm) - 1;
                 fixm &= fixm - 1;
                 const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
                 const uint32_t bj = b0_f + (uint32_t)j;
-                for (uint32_t r = fs + lane; r < t0; r += 64u)
-                    a.masked[((size_t)blk0_f * q8 + (size_t)(r >> 3) * nb_f + (bj - blk0_f)) * 8u + (r & 7u)] = 0;
+                for (uint32_t r = fs + lane; r < fix_end; r += 64u) {
+                    const uint32_t rr = (a.debug & kDbgFixToDummy) ? (r & 63u) : r;
+                    a.masked[((size_t)blk0_f * q8 + (size_t)(rr >> 3) * nb_f + (bj - blk0_f)) * 8u + (rr & 7u)] = 0;
+                }
             }
             // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8] (lib.rs:752-761) ----------------
             const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
             unsigned char *mp = mp_f + (size_t)tf * 8u * mstep_f;
+            if constexpr (kHoldF > 0) {
+                // the oldest held tile (tf - kHoldF) leaves now; the others move up
+                if (n_held == (uint32_t)kHoldF && !(a.debug & kDbgSkipMasked)) {
+                    unsigned char *op = mp_f + (size_t)(tf - (uint32_t)kHoldF) * 8u * mstep_f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) store16(op + (size_t)k * mstep_f, held[kHoldF - 1][k], nt_msk);   // (a held tile is never the last one: all 8 octets exist)
+                }
+#pragma unroll
+                for (int i = kHoldF - 1; i > 0; --i)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) held[i][k] = held[i - 1][k];
+                if (n_held < (uint32_t)kHoldF) ++n_held;
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (mbyte) v = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);
-                if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_msk);
+                if (kHoldF > 0) held[0][k] = v;
+                else if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_msk);
             }
+            if constexpr (kHoldF > 0) {
+                if (tf + 1u == ntiles && !(a.debug & kDbgSkipMasked)) {   // the group's last tile: the held tiles leave, oldest first; only the octets that exist
+#pragma unroll
+                    for (int i = kHoldF - 1; i >= 0; --i) {
+                        if ((uint32_t)i < n_held) {
+                            const uint32_t tt = ntiles - 1u - (uint32_t)i;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                if ((tt << 6) + (uint32_t)k * 8u < M) store16(mp_f + ((size_t)tt * 8u + (size_t)k) * mstep_f, held[i][k], nt_msk);
+                        }
+                    }
+                }
+            }
+#ifdef HRX_STAMPS
+            fk_work += clock64() - fk_b;
+#endif
           }
         }
+#ifdef HRX_STAMPS
+        if (a.stamps && lane == 0) {
+            unsigned long long *o = a.stamps + (size_t)(blockIdx.x * pairs + pair) * 16u + 8u;
+            o[0] += fk_wait; o[1] += fk_work;
+        }
+#endif
         return;
     }
     if (!is_walker) {
@@ -633,7 +716,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             }
 #ifdef HRX_STAMPS
             if (a.stamps && lane == 0) {
-                unsigned long long *o = a.stamps + (size_t)(blockIdx.x * pairs + pair) * 8u;
+                unsigned long long *o = a.stamps + (size_t)(blockIdx.x * pairs + pair) * 16u;
                 o[0] += tk_wait; o[1] += tk_walk; o[2] += tk_end; o[3] += clock64() - tk_group;
                 if (j == 0u) { o[4] = wall_entry; o[5] = wall_start; }
                 o[6] = wall_clock64();

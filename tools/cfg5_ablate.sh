@@ -1,5 +1,5 @@
 #!/bin/bash
-# cfg 5 (256-state DFA, HALF table): what the end-mask repairs cost and whether write-back masked rows absorb them (profiling only; `make ablation`)
+# cfg 5 (256-state DFA): ablations of the BYTE-table kernel (profiling only; `make ablation`)
 cd "$(dirname "$0")/.." || exit 1
 L=$PWD/halo2_regex_amd/csrc/libhrx_ablation.so
 B="python3 bench.py --config dfa256 --len 4096 --rows 4096 --batch 65536 --sets 1 --steps 20 --warmup 3 --no-verify --no-cpu-baseline --no-pmc --no-spread --allow-debug-flags"
@@ -7,8 +7,11 @@ run() { echo -n "$1: "; env HRX_LIB_PATH=$L $2 $B 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ms/step %.4f frac %.3f' % (d['ms_per_step'], d['roofline']['frac']))"; }
 for i in 1 2; do
-run "shipped                    " "HRX_DEBUG_FLAGS=0"
-run "fix-ups skipped            " "HRX_DEBUG_FLAGS=0x800000"
-run "records skipped            " "HRX_DEBUG_FLAGS=1"
-run "HALF kernel                " "HRX_DEBUG_FLAGS=0x8000"
+run "shipped                              " "HRX_DEBUG_FLAGS=0"
+run "fix-ups skipped                      " "HRX_DEBUG_FLAGS=0x800000"
+run "fix-ups + masked stores skipped      " "HRX_DEBUG_FLAGS=0x800002"
+run "records skipped                      " "HRX_DEBUG_FLAGS=1"
+run "all three skipped (chain + hand-over)" "HRX_DEBUG_FLAGS=0x800003"
+run "HALF kernel                          " "HRX_DEBUG_FLAGS=0x8000"
+run "HALF kernel, all three skipped       " "HRX_DEBUG_FLAGS=0x808003"
 done

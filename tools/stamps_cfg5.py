@@ -31,10 +31,10 @@ e1.record()
 torch.cuda.synchronize()
 print("%.1f us per launch (events; eager launches, stamps build)" % (e0.elapsed_time(e1) * 1e3 / 10))
 npairs = 1024
-buf = (C.c_ulonglong * (npairs * 8))()
+buf = (C.c_ulonglong * (npairs * 16))()
 hra.lib.hrx_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_size_t]
-assert hra.lib.hrx_debug_read_stamps(cfg._ctx, buf, npairs * 8) == 0
-s = np.frombuffer(buf, dtype=np.uint64).reshape(npairs, 8).astype(np.int64)
+assert hra.lib.hrx_debug_read_stamps(cfg._ctx, buf, npairs * 16) == 0
+s = np.frombuffer(buf, dtype=np.uint64).reshape(npairs, 16).astype(np.int64)
 wait, walk, end, grp, w_entry, w_start, w_end = (s[:, i] for i in range(7))
 t0 = w_entry.min()
 us = lambda x: (x - t0) * 0.01
@@ -43,3 +43,4 @@ print("start walking (us): " + pct(us(w_start)) + "   walker done: " + pct(us(w_
 nt = (n + 63) // 64
 print("walker cycles per TILE: input wait %.0f  walk (incl. record stores) %.0f  tile end (masks, repairs, masked rows) %.0f  total %.0f" %
       (wait.mean() / nt, walk.mean() / nt, end.mean() / nt, grp.mean() / nt))
+print("finisher cycles per TILE: waiting for the walker's summary %.0f  work (masks, repairs, masked rows) %.0f" % (s[:, 8].mean() / nt, s[:, 9].mean() / nt))

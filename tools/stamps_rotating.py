@@ -35,10 +35,10 @@ e1.record()
 torch.cuda.synchronize()
 print("%d launches over %d sets: %.2f us per launch (events; eager launches, stamps build)" % (launches, nsets, e0.elapsed_time(e1) * 1e3 / launches))
 npairs = 1024
-buf = (C.c_ulonglong * (npairs * 8))()
+buf = (C.c_ulonglong * (npairs * 16))()
 hra.lib.hrx_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_size_t]
-assert hra.lib.hrx_debug_read_stamps(cfg._ctx, buf, npairs * 8) == 0
-s = np.frombuffer(buf, dtype=np.uint64).reshape(npairs, 8).astype(np.int64)
+assert hra.lib.hrx_debug_read_stamps(cfg._ctx, buf, npairs * 16) == 0
+s = np.frombuffer(buf, dtype=np.uint64).reshape(npairs, 16).astype(np.int64)
 wait, walk, end, grp, w_entry, w_start, w_end = (s[:, i] for i in range(7))
 t0 = w_entry.min()
 us = lambda x: (x - t0) * 0.01
