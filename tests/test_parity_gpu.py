@@ -907,6 +907,31 @@ def test_bench_runs_bare_with_two_ranks_on_one_device():
     assert line["verified"]["bit_exact"] is True and line["debug_flags"] is None
 
 
+def test_bench_strong_scaling_shards_one_job_over_the_ranks():
+    """`python3 bench.py --gpus 2 --scaling strong --config headers3`: --batch strings IN TOTAL, sharded by string index over the ranks
+    (hrx_shard_range; BASELINE configs[3] is such a job: 262144 strings over 8 GPUs), every rank verifies its own shard against the
+    oracle; both ranks on device 0 here.  With one rank the strong and the weak line are the same job."""
+    import json
+    import subprocess
+    import sys
+    from oracle_lib import ROOT
+    env = dict(os.environ, HRX_BENCH_DEVICES="0,0")
+    env.pop("HRX_DEBUG_FLAGS", None)
+    common = ["--steps", "6", "--warmup", "2", "--config", "headers3", "--batch", "6000", "--len", "2000", "--rows", "2048", "--sets", "2",
+              "--no-cpu-baseline", "--no-spread", "--no-pmc"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--verify-all-ranks"] + common,
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and [r["strings"] for r in line["per_rank"]] == [3000, 3000]
+    assert [r["shard_begin"] for r in line["per_rank"]] == [0, 3000] and line["per_rank"][1]["verified"] is True and line["verified"]["bit_exact"] is True
+    assert sum(r["rows"] for r in line["per_rank"]) == 6 * 6000 * 2000
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scaling", "strong"] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    l1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert l1["per_rank"][0]["strings"] == 6000 and l1["per_rank"][0]["rows"] == 6 * 6000 * 2000 and l1["verified"]["bit_exact"] is True
+
+
 def test_invalid_bytes_bad_lengths_and_overlap_status(hra, oracle):
     from halo2_regex_amd import synth
     chars, lens = synth.ragged(257, 300, seed=3)
