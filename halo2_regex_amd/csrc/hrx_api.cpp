@@ -111,6 +111,9 @@ struct hrx_ctx {
     };
     std::vector<GroupDev> groups;
     DevBuf mp_masked;
+    DevBuf spec_cls, spec_ends, spec_fail, spec_init, spec_vstatus, spec_vinfo, spec_work;
+    bool spec_qabs_ready = false;
+    uint32_t spec_qabs[kMaxDefsPerPass][8];   // chunked launches (hrx_kernel_spec.hip)
     // dynamic group assignment (hrx_kernel_pm.hip): a device counter, zeroed on the launch's stream right before the launch
     // (a memset node when the launches are captured into a HIP graph: replay-safe)
     uint32_t *d_group_counter = nullptr;
@@ -391,6 +394,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
         g.records.release(); g.status.release(); g.summary.release();
     }
     c->mp_masked.release();
+    c->spec_cls.release(); c->spec_ends.release(); c->spec_fail.release(); c->spec_init.release(); c->spec_vstatus.release(); c->spec_vinfo.release(); c->spec_work.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
     arena_retire(c->arena_rec); arena_retire(c->arena_msk);   // released now, or with their last sub-buffer
 #ifdef HRX_STAMPS
@@ -427,6 +431,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         layout != (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR))
         return fail(HRX_ERR_ARG, "unknown layout");
     // one launch over `set` (a config of up to kMaxDefsPerPass defs, or one group of a larger one) with that set's device images
+    const uint16_t *const *d_pair_tags = ctx->s.groups.empty() && !ctx->d_pair.empty() ? ctx->d_pair.data() : nullptr;
     auto launch_set = [&](const DefsSet &set, const uint32_t *d_table, const uint64_t *d_wide, const uint16_t *d_half, const uint8_t *d_pairtab,
                           const uint8_t *d_bytetab, int lay, uint32_t *rec, uint16_t *msk, uint64_t *stat, size_t rp, size_t mp,
                           uint32_t rec_D = 0, uint32_t rec_d0 = 0, uint32_t *summary = nullptr) -> int {
@@ -458,6 +463,67 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
             if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
         }
         if (summary && li.split != 2) return fail(HRX_ERR_STATE, "multi-pass: the planner did not pick the position-major loader/walker kernel");
+        SpecArgs sp{};
+        if (li.spec_tiles) {
+            // ---- chunked launch (hrx_kernel_spec.hip): scout + compose find every chunk's start state, the walk below runs over the
+            // chunks, the stitch launch behind it settles what crosses the chunk borders.  Context scratch, like the group buffers.
+            if (ctx->scratch_used && ctx->scratch_stream != st && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(HRX_ERR_STATE, "the context's chunk scratch is in use on another stream and that stream cannot be waited for here (stream capture?): one context serves one stream / graph at a time");
+            }
+            ctx->scratch_stream = st; ctx->scratch_used = true;
+            const uint32_t C = (uint32_t)li.spec_chunks, Dn = a.D, G = a.n_groups;
+            const size_t Bpad = (size_t)G * 64;
+            uint32_t smax = 4;
+            for (uint32_t d = 0; d < Dn; ++d) smax = std::max<uint32_t>(smax, (uint32_t)set.defs[d].allstr.largest_state_val + 1);
+            smax = (smax + 3u) & ~3u;
+            HIP_TRY(ctx->spec_cls.reserve((size_t)C * Dn * smax * Bpad));
+            HIP_TRY(ctx->spec_ends.reserve((size_t)C * Dn * 8 * Bpad * 2));
+            HIP_TRY(ctx->spec_fail.reserve((size_t)C * Dn * Bpad));
+            HIP_TRY(ctx->spec_init.reserve((size_t)C * B * Dn * 4));
+            HIP_TRY(ctx->spec_vstatus.reserve((size_t)C * B * 8));
+            HIP_TRY(ctx->spec_vinfo.reserve((size_t)C * B * 8));
+            HIP_TRY(ctx->spec_work.reserve(16 + (size_t)C * B * 8));
+            sp.chars = chars; sp.stride = stride; sp.lens = lens; sp.B = (uint32_t)B; sp.M = (uint32_t)M; sp.D = Dn;
+            sp.C = C; sp.tiles_per_chunk = (uint32_t)li.spec_tiles; sp.n_groups = G;
+            sp.table_image = d_table; sp.table_bytes = a.table_bytes;
+            sp.smax = smax;
+            for (uint32_t d = 0; d < Dn; ++d) {
+                sp.dc[d] = set.consts[d];
+                sp.n_states[d] = (uint32_t)set.defs[d].allstr.largest_state_val + 1;
+                sp.pair_tags[d] = d_pair_tags ? d_pair_tags[d] : nullptr;
+            }
+            if (!ctx->spec_qabs_ready) {     // quasi-absorbing states (hrx_kernel_spec.hip), once per context: from the defs' dense tables
+                std::memset(ctx->spec_qabs, 0, sizeof ctx->spec_qabs);
+                for (uint32_t d = 0; d < Dn; ++d) {
+                    const uint32_t S = sp.n_states[d], *T = set.table_image.data() + (size_t)set.consts[d].row_base * 256;
+                    bool undefined_everywhere[256];
+                    for (uint32_t c = 0; c < 256; ++c) {
+                        undefined_everywhere[c] = true;
+                        for (uint32_t t = 0; t < S && undefined_everywhere[c]; ++t) undefined_everywhere[c] = T[(size_t)t * 256 + c] >= set.consts[d].dead_entry;
+                    }
+                    for (uint32_t t = 0; t < S && t < 256; ++t) {
+                        bool q = true;
+                        for (uint32_t c = 0; c < 256 && q; ++c) {
+                            const uint32_t e = T[(size_t)t * 256 + c];
+                            q = e >= set.consts[d].dead_entry ? undefined_everywhere[c] : (e >> kNextShift) - set.consts[d].row_base == t;
+                        }
+                        if (q) ctx->spec_qabs[d][t >> 5] |= 1u << (t & 31);
+                    }
+                }
+                ctx->spec_qabs_ready = true;
+            }
+            std::memcpy(sp.qabs, ctx->spec_qabs, sizeof sp.qabs);
+            sp.cls = (uint8_t *)ctx->spec_cls.p; sp.ends = (uint16_t *)ctx->spec_ends.p; sp.fail = (uint8_t *)ctx->spec_fail.p;
+            sp.init = (uint32_t *)ctx->spec_init.p; sp.vinfo = (const uint2 *)ctx->spec_vinfo.p; sp.vstatus = (const uint64_t *)ctx->spec_vstatus.p;
+            sp.status = stat; sp.records = rec; sp.masked = msk;
+            sp.work_count = (uint32_t *)ctx->spec_work.p; sp.work = (uint2 *)((unsigned char *)ctx->spec_work.p + 16); sp.work_cap = (uint32_t)(C * B);
+            HIP_TRY(launch_spec_scout(sp, ctx->num_cus, st));
+            HIP_TRY(launch_spec_compose(sp, st));
+            a.vs_init = sp.init; a.vs_chunks = C; a.vs_tiles = (uint32_t)li.spec_tiles; a.vs_groups = G;
+            a.vs_status = (uint64_t *)ctx->spec_vstatus.p; a.vs_info = (uint2 *)ctx->spec_vinfo.p;
+            a.n_groups = G * C;
+        }
         if (li.dyn) {   // launches that share the counter must not overlap: a launch on another stream waits for the previous one
             if (ctx->scratch_used && ctx->scratch_stream != st && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) {
                 (void)hipGetLastError();
@@ -484,6 +550,9 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         }
 #endif
         HIP_TRY(launch_witness(a, li, st));
+        if (li.spec_tiles) {
+            HIP_TRY(launch_spec_stitch(sp, ctx->num_cus, st));
+        }
         return HRX_OK;
     };
     if (ctx->s.groups.empty())
@@ -602,6 +671,10 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
     std::snprintf(line, sizeof line, "%s grid=%d waves=%d ring=%d lds=%zu%s", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes, li.dyn ? " groups=dynamic" : "");
     out = line;
+    if (li.spec_tiles) {
+        std::snprintf(line, sizeof line, " chunked=%dx%d tiles: hrx::spec_scout_kernel + hrx::spec_compose_kernel before, hrx::spec_stitch_kernel behind", li.spec_chunks, li.spec_tiles);
+        out += line;
+    }
     return HRX_OK;
 }
 

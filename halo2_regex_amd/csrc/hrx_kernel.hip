@@ -27,14 +27,23 @@ uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li) {
     return k < 2 ? 2u : k <= 8 ? (uint32_t)k : 0u;
 }
 
+static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &out);
+
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.gs = 64;
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
+    return plan_witness_launch_groups(a, num_cus, out);
+}
+
+// (a.n_groups given: the chunked launch plans the walk over n_groups x chunks virtual groups)
+static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     out.gtab = 0;
     out.wide = 0;
     out.half = 0;
     out.byte = 0;
     out.dyn = 0;
+    out.spec_tiles = 0;
+    out.spec_chunks = 0;
     // DFAs whose fused table leaves no room for the per-wave LDS areas are walked out of global memory (L2-resident)
     const size_t min_stage = (a.layout & 1u) ? pm_pair_bytes(2, false, true) : wave_stage_bytes((int)a.D, 16);
     if (a.table_bytes + min_stage > kLdsLimit || (a.debug & kDbgForceGlobalTable)) out.gtab = 1;
@@ -50,6 +59,39 @@ bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
         if (a.debug & kDbgForceDynamicGroups) return (size_t)a.n_groups > slots ? 1 : 0;
         return ((size_t)a.n_groups >= 8 * slots && (a.M + 63u) / 64u >= 32u) ? 1 : 0;
     };
+    // ---- CHUNKED launch (hrx_kernel_spec.hip): a batch of at most one group per CU runs for as long as one string's dependent chain
+    // (n x 29-50 ns) with three quarters of the walker slots empty.  Cut every string into chunks of 16 tiles, find the chunks' start
+    // states (scout + compose) and walk the chunks as groups of their own: the chip is full again.  From two groups per CU on the
+    // sequential kernels are bound by the memory system anyway (32768 x 32768 B: 1.3 ms of traffic against 0.95 ms of chain).
+    if ((a.layout & 3u) == 3u && !out.gtab && !a.summary && !a.vs_init && !(a.debug & (kDbgNoSpec | kDbgForceHalf | kDbgForceByte | kDbgForceGlobalTable | kDbgForcePair | kDbgForceDefParallel))) {
+        const uint32_t ntiles = (a.M + 63u) / 64u;
+        uint32_t tpc = 0;
+        if (a.debug & kDbgForceSpec) {
+            tpc = 4;
+            while (tpc <= kSpecMaxChunkTiles && (ntiles % tpc != 0u || ntiles / tpc > kSpecMaxChunks)) tpc *= 2;
+            if (tpc > kSpecMaxChunkTiles || ntiles / tpc < 2u) tpc = 0;
+        } else if ((size_t)a.n_groups <= (size_t)num_cus && ntiles >= 64u) {
+            tpc = 16;
+            while (tpc <= kSpecMaxChunkTiles && (ntiles % tpc != 0u || ntiles / tpc > kSpecMaxChunks)) tpc *= 2;
+            if (tpc > kSpecMaxChunkTiles) tpc = 0;
+        }
+        if (tpc && a.B <= kPmBlock && a.M % 64u == 0u) {
+            WitnessArgs v = a;
+            v.n_groups = a.n_groups * (ntiles / tpc);
+            v.vs_init = reinterpret_cast<const uint32_t *>(&v);   // (any non-null value: the walk over the chunks is planned, not launched)
+            v.debug = (a.debug & ~kDbgForceSpec) | kDbgNoPair | kDbgNoDefParallel | kDbgNoSpec;
+            LaunchInfo li;
+            const uint32_t real_groups = a.n_groups;
+            if (plan_witness_launch_groups(v, num_cus, li) && li.split == 2 && !li.half && !li.byte && !li.gtab) {
+                out = li;
+                out.spec_tiles = (int)tpc;
+                out.spec_chunks = (int)(ntiles / tpc);
+                a.gs = 64;
+                a.n_groups = real_groups;
+                return true;
+            }
+        }
+    }
     const uint32_t table_bytes_saved = a.table_bytes;
     struct Restore { WitnessArgs &a; uint32_t v; ~Restore() { a.table_bytes = v; } } restore{a, table_bytes_saved};
     if (out.gtab) a.table_bytes = 0;  // for the LDS budgeting below only; restored on return

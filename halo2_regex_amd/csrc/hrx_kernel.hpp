@@ -47,6 +47,11 @@ struct WitnessArgs {
     // kernel needs — per tile and string 80 bytes: ST / EN bitvectors + one substr-id byte per row, [tile][5][B][16 B]
     uint32_t rec_D, rec_d0;       // 0 / 0: this launch's defs are the whole config
     uint32_t *summary;            // NULL: an ordinary launch
+    // chunked launch of the loader / walker / finisher kernel (hrx_kernel_spec.hip): NULL / 0 in an ordinary launch
+    const uint32_t *vs_init;      // [chunk][B][D]: state | substr id of the transition into the chunk's first row << 16 | its end flag << 24
+    uint32_t vs_chunks, vs_tiles, vs_groups;   // chunks per string, tiles per chunk, REAL groups (n_groups = vs_groups * vs_chunks)
+    uint64_t *vs_status;          // [chunk][B]: every chunk's status word
+    uint2 *vs_info;               // [chunk][B]: pend | fwd << 1 | sm << 2 | dec << 3, pend_start (hrx_lane.h TileMasks)
     uint32_t nt_mix;              // position-major kernels: which stores are write-back instead of streaming (kNtMix*, hrx_kernel_pm.hip)
     uint32_t pace_even;           // profiling only (HRX_PACE, stamps / ablation builds): x 64 idle cycles per tile for the walkers of even workgroups; 0 in the product
     DefConsts dc[kMaxDefsPerLaunch];
@@ -93,11 +98,14 @@ enum : uint32_t {
     kDbgNoDynamicGroups = 0x1u << 11,  // position-major kernel: static group assignment whatever the batch size
     kDbgForceDynamicGroups = 0x1u << 12,   // ... dynamic from two groups per walker and any row count (tests)
     kDbgXcdRemap = 0x100000u,         // position-major kernels: every XCD walks a CONTIGUOUS eighth of the groups (hrx_device.h xcd_slot; measured 1.5 % slower, off by default)
+    kDbgForceSpec = 0x80u,            // position-major: the chunked launch (hrx_kernel_spec.hip) whatever the batch size, chunks of 4 tiles (tests)
+    kDbgNoSpec = 0x80000000u,         // position-major: never the chunked launch
     kDbgForceHost = 0x10000000u,      // host-buffer entry points: always the native host walk (hrx_host_walk.cpp)
     kDbgNoHost = 0x20000000u,         // host-buffer entry points: never the native host walk
     // every bit that merely selects a kernel (the only ones a release build honours)
     kDbgForceMask = kDbgForceOneWave | kDbgGroups32 | kDbgForceGlobalTable | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf | kDbgForceByte | kDbgNoByte |
-                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForcePair | kDbgXcdRemap | kDbgNoDynamicGroups | kDbgForceDynamicGroups | kDbgForceHost | kDbgNoHost,
+                    kDbgNoDefParallel | kDbgForceDefParallel | kDbgNoPair | kDbgForcePair | kDbgXcdRemap | kDbgNoDynamicGroups | kDbgForceDynamicGroups | kDbgForceHost | kDbgNoHost |
+                    kDbgForceSpec | kDbgNoSpec,
 #ifdef HRX_ABLATION
     kDbgHonoured = 0xffffffffu,
 #else
@@ -120,6 +128,8 @@ struct LaunchInfo {
     int byte;          // 1: position-major kernel on the BYTE table (hrx_lane.h): walker + loader + finisher
     int grid;
     int dyn;           // 1: dynamic group assignment (position-major loader/walker kernel, >= 8 long groups per walker pair)
+    int spec_tiles;    // > 0: CHUNKED launch (hrx_kernel_spec.hip): tiles per chunk; the geometry above is that of the walk over the chunks
+    int spec_chunks;   // chunks per string
     size_t lds_bytes;
 };
 
@@ -178,6 +188,42 @@ struct CombineArgs {
     uint8_t gD[kMaxGroups], gfirst[kMaxGroups];
 };
 hipError_t launch_combine(const CombineArgs &a, hipStream_t stream);
+
+// CHUNKED walk (hrx_kernel_spec.hip): scout -> compose -> the loader / walker / finisher kernel over chunks (WitnessArgs::vs_*) -> stitch
+constexpr uint32_t kSpecMaxChunks = 32, kSpecMaxChunkTiles = 64;
+struct SpecArgs {
+    const uint8_t *chars;
+    uint64_t stride;
+    const uint32_t *lens;
+    uint32_t B, M, D;
+    uint32_t C, tiles_per_chunk, n_groups;   // chunks per string, 64-row tiles per chunk, REAL groups of 64 strings
+    const uint32_t *table_image;             // the narrow fused table (global copy; the scout stages it into LDS)
+    uint32_t table_bytes;
+    DefConsts dc[kMaxDefsPerLaunch];
+    uint32_t n_states[kMaxDefsPerLaunch];    // real states per def (largest + 1)
+    uint32_t qabs[kMaxDefsPerPass][8];       // bit s: real state s is quasi-absorbing — every byte keeps it where it is, except bytes that NO real state
+                                             // of the def has a transition for (those send it to the dead row, like everybody else)
+    uint32_t smax;                           // >= every n_states
+    const uint16_t *pair_tags[kMaxDefsPerLaunch];   // device (state, next) -> tag tables (hrx_defs.hpp pair_tags)
+    // scratch, all [chunk][def][..][n_groups * 64]: which survivor each start state became; the survivors' states after the chunk and
+    // before its last byte; 1 = more than kSpecSlots survivors
+    uint8_t *cls;
+    uint16_t *ends;
+    uint8_t *fail;
+    uint32_t *init;                          // [chunk][B][D] -> WitnessArgs::vs_init
+    const uint2 *vinfo;                      // [chunk][B] <- WitnessArgs::vs_info
+    const uint64_t *vstatus;                 // [chunk][B] <- WitnessArgs::vs_status
+    uint64_t *status;
+    const uint32_t *records;
+    uint16_t *masked;
+    // chunks whose reveal-mask assumptions were wrong, found by the stitch launch, recomputed by the repair launch (one wave each)
+    uint32_t *work_count;                    // [1], zeroed in front of the stitch launch
+    uint2 *work;                             // [work_cap]: string, chunk | true start_mask before it << 8 | true end_mask of its last row << 9
+    uint32_t work_cap;
+};
+hipError_t launch_spec_scout(const SpecArgs &a, int num_cus, hipStream_t stream);
+hipError_t launch_spec_compose(const SpecArgs &a, hipStream_t stream);
+hipError_t launch_spec_stitch(const SpecArgs &a, int num_cus, hipStream_t stream);
 
 // states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])
 hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,

@@ -61,6 +61,14 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     const bool dyn = a.group_counter != nullptr;
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
+    // CHUNKED launch (hrx_kernel_spec.hip): every string is cut into vs_chunks pieces of vs_tiles tiles and each piece is walked as a
+    // group of its own — virtual group vg = chunk * vs_groups + real group, chunk-major, so that the chip still writes one compact
+    // slab at a time — from the state, previous substr id and end flag the scout / compose launches found for its first row
+    // (a.vs_init).  Everything below works on absolute rows, so n, M, padding, the accept state and the error rows keep their meaning.
+    const bool vs = FIN && a.vs_init != nullptr;
+    const uint32_t gt = vs ? a.vs_tiles : ntiles;                     // tiles per (virtual) group
+    auto vg_real = [&](const uint32_t vg) -> uint32_t { return vs ? vg % a.vs_groups : vg; };
+    auto vg_tile0 = [&](const uint32_t vg) -> uint32_t { return vs ? (vg / a.vs_groups) * a.vs_tiles : 0u; };
     uint32_t seq = 0;
 #if defined(HRX_STAMPS) || defined(HRX_ABLATION)
     // profiling only (HRX_PACE's high half): rotate which 4-KiB class of every slab an XCD's walkers write
@@ -81,17 +89,18 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     // The loaders request their pair's first input tile BEFORE the table is staged: the HBM round trip (~2 us) then runs
     // under the staging instead of after it.
     uint32_t first_len = M;   // ... and the walkers their first group's lengths
-    if (is_walker && g_first < a.n_groups) first_len = a.lens[min(g_first * 64u + lane, B - 1u)];
+    if (is_walker && g_first < a.n_groups) first_len = a.lens[min(vg_real(g_first) * 64u + lane, B - 1u)];
     uint4 first_tile[4];
     if (!is_walker && !is_finisher && g_first < a.n_groups) {
         const bool in_pm0 = (a.layout & 2u) != 0;
-        const uint32_t bl = min(g_first * 64u + lane, B - 1u);
-        const uint32_t blk0 = (g_first * 64u / kPmBlock) * kPmBlock, nb0 = min(kPmBlock, B - blk0);   // this group's block (hrx_lane.h)
+        const uint32_t gr0 = vg_real(g_first), tr0 = vg_tile0(g_first) * 64u;
+        const uint32_t bl = min(gr0 * 64u + lane, B - 1u);
+        const uint32_t blk0 = (gr0 * 64u / kPmBlock) * kPmBlock, nb0 = min(kPmBlock, B - blk0);   // this group's block (hrx_lane.h)
         const uint8_t *cptr = in_pm0 ? a.chars + (size_t)blk0 * a.stride + (size_t)(bl - blk0) * 16u : a.chars + (size_t)bl * a.stride;
         const uint32_t row_cap0 = (uint32_t)a.stride - 16u;
         const size_t cmul0 = (a.debug & kDbgInputFromL2) ? (size_t)0 : in_pm0 ? (size_t)nb0 : (size_t)1;
 #pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i) first_tile[i] = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(16u * i, row_cap0) * cmul0);
+        for (uint32_t i = 0; i < 4u; ++i) first_tile[i] = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(tr0 + 16u * i, row_cap0) * cmul0);
     }
     {
         const uint4 *src = WIDE ? reinterpret_cast<const uint4 *>(a.wide_image)
@@ -134,11 +143,13 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
         unsigned long long fk_wait = 0, fk_work = 0;
 #endif
         for (uint32_t j = 0;; ++j) {
-          const uint32_t gf = group_at(j);
-          if (gf >= a.n_groups) break;
-          for (uint32_t tf = 0; tf < ntiles; ++tf, ++f) {
+          const uint32_t vgf = group_at(j);
+          if (vgf >= a.n_groups) break;
+          const uint32_t gf = vg_real(vgf), tf0 = vg_tile0(vgf);
+          uint32_t vs_fwd = 0, vs_dec = 0;   // chunked launch: has the chunk a forward event; what its first deciding tile says about the rows before it
+          for (uint32_t tf = tf0; tf < tf0 + gt; ++tf, ++f) {
             const uint32_t t0 = tf << 6;
-            if (tf == 0u) {   // a new group: this lane's string
+            if (tf == tf0) {   // a new group: this lane's string
                 b0_f = gf * 64u;
                 const uint32_t b = b0_f + lane;
                 active_f = b < B;
@@ -182,8 +193,15 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             tb.en1 = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
             tb.ch = (uint64_t)s1.x | ((uint64_t)s1.y << 32);
             const uint32_t n_f = s1.z;          // the string's length (<= M; the walker clamps bad lengths)
+            if (vs && tf == tf0) mc.en = s1.w;  // a chunk: the is_end flag that lands on its first row (from the row before it)
             // ---------------- reveal masks: lib.rs:598-764 ----------------
             TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n_f, M), rows_below(t0, n_f));
+            if (vs) {
+                vs_fwd |= tm.fwd;
+                if (vs_dec == 0u) vs_dec = tm.dec;
+                if (tf + 1u == tf0 + gt && active_f)    // the chunk's last tile: what the stitch launch needs to know about it (hrx_kernel_spec.hip)
+                    a.vs_info[(size_t)(vgf / a.vs_groups) * B + (b0_f + lane)] = make_uint2(mc.pend | vs_fwd << 1 | mc.sm << 2 | vs_dec << 3, mc.pend_start);
+            }
             if (a.debug & kDbgSkipFixups) tm.fix = 0;
             const uint32_t fix_regs = tm.fix;   // held rows: shadow lanes too (they store the same rows to the same addresses as string B - 1)
             if (!active_f) tm.fix = 0;
@@ -246,11 +264,11 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 else if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_msk);
             }
             if constexpr (kHoldF > 0) {
-                if (tf + 1u == ntiles && !(a.debug & kDbgSkipMasked)) {   // the group's last tile: the held tiles leave, oldest first; only the octets that exist
+                if (tf + 1u == tf0 + gt && !(a.debug & kDbgSkipMasked)) {   // the group's last tile: the held tiles leave, oldest first; only the octets that exist
 #pragma unroll
                     for (int i = kHoldF - 1; i >= 0; --i) {
                         if ((uint32_t)i < n_held) {
-                            const uint32_t tt = ntiles - 1u - (uint32_t)i;
+                            const uint32_t tt = tf0 + gt - 1u - (uint32_t)i;
 #pragma unroll
                             for (int k = 0; k < 8; ++k)
                                 if ((tt << 6) + (uint32_t)k * 8u < M) store16(mp_f + ((size_t)tt * 8u + (size_t)k) * mstep_f, held[i][k], nt_msk);
@@ -290,7 +308,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
         // assignment draws it from the launch's counter (lane 0, value broadcast) — the compiler waits for every load in flight
         // before it reads the result, which the RT tiles already in registers cover — and publishes it, or the end mark,
         // to the walker and the finisher through the LDS queue.
-        uint32_t total = g_first < a.n_groups ? ntiles : 0u, known = 1u, issue_g = g_first;
+        uint32_t total = g_first < a.n_groups ? gt : 0u, known = 1u, issue_g = g_first;
         bool ended = total == 0u;
         auto next_group = [&]() {
             uint32_t g;
@@ -305,12 +323,12 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 lds_store_u32(gq_off + (known & 15u) * 4u, g);
                 ring_post(gq_ready_off, known);
             }
-            if (g < a.n_groups) { issue_g = g; total += ntiles; ++known; }
+            if (g < a.n_groups) { issue_g = g; total += gt; ++known; }
             else ended = true;
         };
         uint4 buf[RT * 4u];
         auto issue = [&](const uint32_t q, const uint32_t k) {  // tile q of the pair's sequence (a tile of group issue_g) -> register tile k
-            const uint32_t g = issue_g, t = q % ntiles;
+            const uint32_t g = vg_real(issue_g), t = vg_tile0(issue_g) + q % gt;
             const uint32_t bl = min(g * 64u + lane, B - 1u);
             const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);   // the group's block (hrx_lane.h)
             const uint8_t *cptr = in_pm ? a.chars + (size_t)blk0 * a.stride + (size_t)(bl - blk0) * 16u : a.chars + (size_t)bl * a.stride;
@@ -374,8 +392,9 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     }
 
     for (uint32_t j = 0;; ++j) {
-        const uint32_t g = group_at(j);
-        if (g >= a.n_groups) break;
+        const uint32_t vg = group_at(j);
+        if (vg >= a.n_groups) break;
+        const uint32_t g = vg_real(vg), tile0 = vg_tile0(vg), chunk = vs ? vg / a.vs_groups : 0u;
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
         const bool active = b < B;
@@ -397,6 +416,20 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             }
             L.sid_prev = 0;
             L.ov_row = 0xffffffffu;
+            uint32_t vs_en = 0;   // chunked launch: the is_end flag landing on the chunk's first row
+            if (vs) {
+                // a chunk starts from what the scout / compose launches found for its first row: per def the state, and the substr id and
+                // end flag of the transition INTO that row (hrx_kernel_spec.hip)
+                const uint32_t *ip = a.vs_init + ((size_t)chunk * B + min(b, B - 1u)) * D;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const uint32_t w = ip[d];
+                    const uint32_t row = a.dc[d].row_base + (w & 0xffffu);
+                    L.e[d] = WIDE ? row << kWideRowShift : row << kNextShift;
+                    L.sid_prev += (w >> 16) & 0xffu;
+                    vs_en |= (w >> 24) & 1u;
+                }
+            }
             MaskCarry mc = {0, 0, 0, 0};
             uint32_t dead = 0, accept = 0;
             uint32_t err_pos[D], err_state[D], err_char[D], acc_state[D];
@@ -420,6 +453,8 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             unsigned char *mp = SM ? reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * a.msk_pitch * 2u
                                    : reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
             const size_t mstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u : (size_t)nb * 16u;      // 8 rows further: [M/8][nb][8]
+            rp += (size_t)tile0 * 16u * rstep;         // (a chunk: its first quad / octet)
+            mp += (size_t)tile0 * 8u * mstep;
             uint4 pend[8];                             // the previous tile's masked rows, not yet stored
             unsigned char *pend_mp = mp;
             bool have_pend = false;
@@ -438,7 +473,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             unsigned long long tk_wait = 0, tk_walk = 0, tk_end = 0;
             const unsigned long long tk_group = clock64(), wall_start = wall_clock64();
 #endif
-            for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
+            for (uint32_t t = tile0; t < tile0 + gt; ++t, ++seq) {
                 const uint32_t t0 = t << 6;
                 const uint32_t slot = ring_base + (seq % nring) * kPmTileBytes;
 #if defined(HRX_STAMPS) || defined(HRX_ABLATION)
@@ -625,7 +660,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                     ring_wait(sum_freed_off, seq);   // it has consumed the previous tile's summary (one summary area per pair)
                     typedef __attribute__((address_space(3))) v4u32 lds_v4u32;
                     *(lds_v4u32 *)(uintptr_t)(sum_off + lane * 16u) = v4u32{(uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32)};
-                    *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{(uint32_t)tb.ch, (uint32_t)(tb.ch >> 32), n, 0u};
+                    *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{(uint32_t)tb.ch, (uint32_t)(tb.ch >> 32), n, vs_en};
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i)
                         *(lds_v4u32 *)(uintptr_t)(sum_off + 2048u + i * 1024u + lane * 16u) = v4u32{sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]};
@@ -760,7 +795,8 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 } else {
                     sw = status_ok(accept);
                 }
-                a.status[b] = sw;
+                if (vs) a.vs_status[(size_t)chunk * B + b] = sw;   // a chunk's view of its string; the stitch launch merges them
+                else a.status[b] = sw;
             }
         }
     }

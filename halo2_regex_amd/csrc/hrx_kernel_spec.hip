@@ -1,0 +1,409 @@
+// hrx_kernel_spec.hip — CHUNKED walk for batches that leave most walker slots empty.
+//
+// derive_states is strictly sequential per string (src/lib.rs:808-819): a batch of fewer strings than the chip has lanes runs
+// for as long as ONE string's dependent chain, n x ~50 ns (8192 x 32768-byte strings: 0.94 ms with the pair-step table, a
+// quarter of the memory system's rate).  What lets a string be cut: a DFA forgets.  Started from ALL of its states on the same
+// bytes, the walks merge within a few dozen bytes into a handful of survivors — for the reference's definitions two: the state
+// every "ordinary" history leads to and the absorbing accept state behind a finished match (the case that defeats a plain
+// warm-up from the start state: no warm-up reaches "already matched").  So:
+//
+//   scout    every (string, chunk, def): walk the chunk's first kSpecPrefix bytes from every real state, keep the (at most
+//            kSpecSlots) distinct survivors and which survivor each start state became, then walk only the survivors to the
+//            chunk's end; no rows are written — a chunk costs ~S x 32 + 2 x (chunk - 32) table lookups, several independent
+//            chains per lane.
+//   compose  one thread per (string, def): from first_state, chunk by chunk, the state at every chunk's first row (a table
+//            lookup per chunk) and the substr id / end flag of the transition into it.  A chunk whose start states did not
+//            merge into kSpecSlots survivors is simply walked here, sequentially — correct for any DFA, fast for forgetful ones.
+//   walk     the ordinary loader / walker / finisher kernel (hrx_kernel_pm.hip) over chunks as virtual groups: B x C "strings"
+//            fill the chip, the launch is bound by the memory system again.  Rows are final except for what crosses a
+//            chunk's borders in the reveal-mask scans (lib.rs:598-714): a chunk assumes no open span at its first row
+//            (start_mask carry 0) and, as everywhere, end_mask = 1 for rows after its last backward event.
+//   stitch   one thread per string: the true carries from the chunks' one-word summaries ("last event wins": a chunk with a
+//            forward event fixes the carry out of it, one without passes it on; the first deciding tile of a later chunk
+//            tells the end mask of the rows before it); a chunk whose assumption was wrong has its masked rows recomputed
+//            from its finished records and the input bytes (rare with real definitions: a revealed substring must straddle a
+//            chunk border); the chunks' status words merge (lowest chunk's undefined transition, lowest overlap row, the accept
+//            state of the chunk that holds row n).
+#include <hip/hip_runtime.h>
+
+#include "hrx_device.h"
+
+namespace hrx {
+
+constexpr uint32_t kSpecPrefix = 32;   // bytes every real state is walked over before the survivors are taken
+constexpr uint32_t kSpecSlots = 4;     // survivors per (string, chunk, def); more: the compose launch walks that chunk itself
+
+// ---------------------------------------------------------------------------------------------
+// scout: lane = (chunk, string); the narrow fused table in LDS
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t Bpad = a.n_groups * 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rows = a.tiles_per_chunk * 64u;
+    const uint32_t row_cap = (uint32_t)a.stride - 16u;
+    for (uint32_t vw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); vw < a.n_groups * a.C; vw += gridDim.x * (blockDim.x >> 6)) {
+        const uint32_t k = vw / a.n_groups, g = vw % a.n_groups;
+        const uint32_t b = g * 64u + lane, bc = min(b, a.B - 1u);
+        const uint32_t r0 = k * rows;
+        const uint32_t n = min(a.lens[bc], a.M);
+        // nothing of this chunk matters if no string of the wave reaches it (rows >= n are padding: lib.rs:404-418)
+        if (__ballot(n > r0) == 0ull) continue;
+        const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
+        const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(bc - blk0) * 16u;   // position-major input: 16-byte piece i at + i * nb * 16
+        auto piece = [&](const uint32_t i) -> uint4 {   // bytes [r0 + 16 i, r0 + 16 i + 16) of the string (clamped inside its stride)
+            return *reinterpret_cast<const uint4 *>(cptr + (size_t)min(r0 + 16u * i, row_cap) * nb);
+        };
+        const uint4 p0 = piece(0), p1 = piece(1);
+        const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        for (uint32_t d = 0; d < a.D; ++d) {
+            const uint32_t S = a.n_states[d], base = a.dc[d].row_base;
+            uint32_t slot[kSpecSlots];
+#pragma unroll
+            for (uint32_t j = 0; j < kSpecSlots; ++j) slot[j] = 0xffffffffu;
+            uint32_t K = 0, fail = 0;
+            uint8_t *cls = a.cls + ((size_t)(k * a.D + d) * a.smax) * Bpad + b;
+            // ---- the prefix: every real state over the chunk's first kSpecPrefix bytes, four independent chains at a time
+            // (chunk 0 starts in first_state: one candidate)
+            const uint32_t s_begin = k == 0u ? a.dc[d].first_state : 0u, s_end = k == 0u ? s_begin + 1u : S;
+            for (uint32_t s0 = s_begin; s0 < s_end; s0 += 4u) {
+                uint32_t e[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) e[j] = (base + min(s0 + j, S - 1u)) << kNextShift;
+#pragma unroll
+                for (uint32_t i = 0; i < kSpecPrefix; ++i) {
+                    const uint32_t c4 = ((pw[i >> 2] >> (8u * (i & 3u))) & 0xffu) << 2;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) e[j] = lds_u32((e[j] & ~kTagMask) | c4);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    if (s0 + j < s_end) {
+                        const uint32_t v = e[j] & ~kTagMask;
+                        uint32_t idx = 0xffu;
+#pragma unroll
+                        for (uint32_t q = 0; q < kSpecSlots; ++q) if (idx == 0xffu && slot[q] == v) idx = q;
+                        if (idx == 0xffu) {
+                            if (K < kSpecSlots) {
+#pragma unroll
+                                for (uint32_t q = 0; q < kSpecSlots; ++q) if (q == K) slot[q] = v;
+                                idx = K++;
+                            } else {
+                                fail = 1; idx = 0;
+                            }
+                        }
+                        if (b < a.B) cls[(size_t)(s0 + j) * Bpad] = (uint8_t)idx;
+                    }
+                }
+            }
+            // ---- the survivors to the chunk's end.  A QUASI-ABSORBING survivor (hrx_kernel.hpp SpecArgs::qabs: every byte keeps it where it is
+            // or — only bytes NO state has a transition for — kills it: the accept state behind a finished match) is not walked: it ends
+            // where it started unless a walked survivor died, and then it died at the same byte.  The walked ones go first; as many
+            // chains as the wave's busiest lane has of them (at least one: somebody has to see such a byte).
+            uint32_t walk[kSpecSlots], idle[kSpecSlots], nw = 0, ni = 0;      // slot numbers in walking order
+#pragma unroll
+            for (uint32_t j = 0; j < kSpecSlots; ++j) { walk[j] = 0; idle[j] = 0; }
+#pragma unroll
+            for (uint32_t j = 0; j < kSpecSlots; ++j) {
+                if (j < K) {
+                    const uint32_t stt = (slot[j] >> kNextShift) - base;
+                    const bool q = stt < S && ((a.qabs[d][stt >> 5] >> (stt & 31u)) & 1u);
+#pragma unroll
+                    for (uint32_t t = 0; t < kSpecSlots; ++t) {
+                        if (q && t == ni) idle[t] = j;
+                        if (!q && t == nw) walk[t] = j;
+                    }
+                    if (q) ++ni; else ++nw;
+                }
+            }
+            if (nw == 0u && K > 0u) { walk[0] = idle[0]; nw = 1; }           // (slot idle[0] is then walked AND derived: the same result)
+            uint32_t Kw = nw;
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) Kw = max(Kw, (uint32_t)__shfl_xor((int)Kw, sft, 64));
+            uint32_t e[kSpecSlots], em1[kSpecSlots];
+#pragma unroll
+            for (uint32_t j = 0; j < kSpecSlots; ++j) {
+                uint32_t v = base << kNextShift;
+#pragma unroll
+                for (uint32_t t = 0; t < kSpecSlots; ++t) if (j < nw && walk[j] == t && slot[t] != 0xffffffffu) v = slot[t];
+                e[j] = v; em1[j] = v;
+            }
+            const uint32_t npieces = rows / 16u;
+            uint4 cur = piece(kSpecPrefix / 16u), nxt = piece(min(kSpecPrefix / 16u + 1u, npieces - 1u));
+            for (uint32_t i = kSpecPrefix / 16u; i < npieces; ++i) {
+                const uint4 nn = piece(min(i + 2u, npieces - 1u));      // two pieces ahead of the chains
+                const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (uint32_t q = 0; q < 16u; ++q) {
+                    const uint32_t c4 = ((w[q >> 2] >> (8u * (q & 3u))) & 0xffu) << 2;
+                    if (q == 15u) {
+#pragma unroll
+                        for (uint32_t j = 0; j < kSpecSlots; ++j) em1[j] = e[j];    // the state BEFORE the piece's last byte (kept for the chunk's last piece)
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < kSpecSlots; ++j)
+                        if (j < Kw) e[j] = lds_u32((e[j] & ~kTagMask) | c4);
+                }
+                cur = nxt; nxt = nn;
+            }
+            if (b < a.B) {
+                uint16_t *ends = a.ends + ((size_t)(k * a.D + d) * 2u * kSpecSlots) * Bpad + b;
+                const uint32_t dead_row = S + 1u;
+                // did a walked survivor die, and had it died before the chunk's last byte already?
+                bool died = false, died_m1 = false;
+#pragma unroll
+                for (uint32_t j = 0; j < kSpecSlots; ++j) {
+                    if (j < nw) {
+                        died = died || (e[j] >> kNextShift) - base == dead_row;
+                        died_m1 = died_m1 || (em1[j] >> kNextShift) - base == dead_row;
+                    }
+                }
+#pragma unroll
+                for (uint32_t t = 0; t < kSpecSlots; ++t) {          // slot t: walked as chain j, or derived
+                    uint32_t end = (slot[t] >> kNextShift) - base, endm1 = end;
+                    bool walked = false;
+#pragma unroll
+                    for (uint32_t j = 0; j < kSpecSlots; ++j)
+                        if (j < nw && walk[j] == t) { end = (e[j] >> kNextShift) - base; endm1 = (em1[j] >> kNextShift) - base; walked = true; }
+                    if (!walked) { if (died) end = dead_row; if (died_m1) endm1 = dead_row; }
+                    if (t < K) {
+                        ends[(size_t)t * Bpad] = (uint16_t)end;
+                        ends[(size_t)(kSpecSlots + t) * Bpad] = (uint16_t)endm1;
+                    }
+                }
+                a.fail[(size_t)(k * a.D + d) * Bpad + b] = (uint8_t)fail;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compose: thread = (string, def)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spec_compose_kernel(const SpecArgs a) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = idx % (a.n_groups * 64u), d = idx / (a.n_groups * 64u);
+    if (idx == 0u) a.work_count[0] = 0u;     // the repair list of this launch (stitch appends, repair reads): zeroed here, two launches ahead
+    if (b >= a.B || d >= a.D) return;
+    const uint32_t Bpad = a.n_groups * 64u, rows = a.tiles_per_chunk * 64u;
+    const uint32_t S = a.n_states[d], base = a.dc[d].row_base;
+    const uint32_t n = min(a.lens[b], a.M);
+    const uint32_t dead = S + 1u;             // table rows: real states 0 .. S - 1, the dummy row S, the dead row S + 1
+    const uint32_t *T = a.table_image + (size_t)base * 256u;
+    const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
+    const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(b - blk0) * 16u;
+    uint32_t s = a.dc[d].first_state, prev = 0xffffffffu;
+    // what chunk k's step needs besides the start state — its fail flag and the survivors' 2 x kSpecSlots states — is loaded a chunk
+    // ahead, so that one dependent load per chunk (which survivor the start state became) is the thread's whole chain
+    auto load_chunk = [&](const uint32_t k, uint32_t &fl, uint32_t (&en)[2u * kSpecSlots]) {
+        const size_t at = (size_t)(k * a.D + d);
+        fl = a.fail[at * Bpad + b];
+        const uint16_t *ends = a.ends + (at * 2u * kSpecSlots) * Bpad + b;
+#pragma unroll
+        for (uint32_t j = 0; j < 2u * kSpecSlots; ++j) en[j] = ends[(size_t)j * Bpad];
+    };
+    uint32_t fl_n = 0, en_n[2u * kSpecSlots];
+    load_chunk(0, fl_n, en_n);
+    for (uint32_t k = 0; k < a.C; ++k) {
+        const uint32_t r0 = k * rows;
+        uint32_t tag = 0;
+        if (prev < S && s < S && r0 <= n) tag = a.pair_tags[d][(size_t)prev * S + s];     // (prev, s): the transition into the chunk's first row
+        // rows beyond n hold the dummy state (table row S: lib.rs:413); row n itself holds s[n]
+        a.init[((size_t)k * a.B + b) * a.D + d] = (r0 > n ? S : s) | (tag & 0xffu) << 16 | ((tag >> 9) & 1u) << 24;
+        const uint32_t fl = fl_n;
+        uint32_t en[2u * kSpecSlots];
+#pragma unroll
+        for (uint32_t j = 0; j < 2u * kSpecSlots; ++j) en[j] = en_n[j];
+        if (k + 1u < a.C) load_chunk(k + 1u, fl_n, en_n);
+        if (r0 + rows > n) { prev = 0xffffffffu; continue; }   // the string ends in this chunk: every later chunk is padding (its start state is never looked at)
+        if (s >= S) { prev = s; continue; }                    // dead (an undefined transition further up, lib.rs:817): absorbing
+        if (!fl) {
+            const uint32_t q = a.cls[(((size_t)(k * a.D + d)) * a.smax + s) * Bpad + b];
+            prev = en[kSpecSlots]; s = en[0];
+#pragma unroll
+            for (uint32_t j = 1; j < kSpecSlots; ++j) if (q == j) { prev = en[kSpecSlots + j]; s = en[j]; }
+        } else {
+            // the chunk's start states did not merge into kSpecSlots survivors: walk it here (any DFA stays correct)
+            for (uint32_t r = r0; r < r0 + rows; ++r) {
+                const uint32_t c = cptr[(size_t)(r >> 4) * nb * 16u + (r & 15u)];
+                prev = s;
+                const uint32_t e = T[s * 256u + c];
+                s = (e >> kNextShift) - base;
+                if (s >= S) { s = dead; break; }
+            }
+        }
+        if (s >= S) s = dead;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stitch: thread = string
+// ---------------------------------------------------------------------------------------------
+// Work item of the repair launch: chunk `k` of string `b` with the TRUE start_mask before its first row and the true end_mask of its
+// last row.
+struct SpecWork { uint32_t b, k_sm_em; };
+
+// repair: one WAVE per work item, lanes = rows.  The masked rows of rows [r0, r1) of string b are recomputed from its finished
+// records and the input bytes — App. A.3 (lib.rs:598-764) with the two "last event wins" scans as wave ballots + carry chains
+// (hrx_lane.h fill_up / fill_down), 64 rows per step.
+__global__ __launch_bounds__(64) void spec_repair_kernel(const SpecArgs a) {
+    __shared__ uint64_t smbits[kSpecMaxChunkTiles];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = min(a.work_count[0], a.work_cap);
+    const SpecWork *work = reinterpret_cast<const SpecWork *>(a.work);
+    const uint32_t rows = a.tiles_per_chunk * 64u, D = a.D;
+    for (uint32_t wi = blockIdx.x; wi < count; wi += gridDim.x) {
+        const uint32_t b = work[wi].b, k = work[wi].k_sm_em & 0xffu;
+        uint32_t sm = (work[wi].k_sm_em >> 8) & 1u;
+        const uint32_t em_last = (work[wi].k_sm_em >> 9) & 1u;
+        const uint32_t r0 = k * rows, r1 = min(r0 + rows, a.M), steps = (r1 - r0) / 64u;
+        const uint32_t n = min(a.lens[b], a.M);
+        const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0), bl = b - blk0;
+        const size_t q4 = (a.M + 3u) / 4u, q8 = (a.M + 7u) / 8u;
+        const uint32_t *rec = a.records + (size_t)blk0 * q4 * D * 4u;
+        uint16_t *msk = a.masked + (size_t)blk0 * q8 * 8u;
+        const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)bl * 16u;
+        // row r: sid = sum of the defs' substr ids, st = any start_enable, en1 = any end_enable (= EN[r + 1], lib.rs:501-519); zeros beyond M
+        auto row = [&](const uint32_t r, uint32_t &sid, uint32_t &st, uint32_t &en1) {
+            sid = 0; st = 0; en1 = 0;
+            if (r >= a.M) return;
+            for (uint32_t d = 0; d < D; ++d) {
+                const uint32_t w = rec[(((size_t)(r >> 2) * D + d) * nb + bl) * 4u + (r & 3u)];
+                sid += (w >> 16) & 0xffu; st |= (w >> 24) & 1u; en1 |= (w >> 25) & 1u;
+            }
+        };
+        // ---- forward: start_mask (lib.rs:598-645)
+        uint32_t c_sid = 0, c_en = 0, t_st;
+        if (r0 > 0u) row(r0 - 1u, c_sid, t_st, c_en);       // the row before the chunk (every lane loads the same word)
+        for (uint32_t s = 0; s < steps; ++s) {
+            uint32_t sid, st, en1;
+            row(r0 + s * 64u + lane, sid, st, en1);
+            uint32_t sidp = (uint32_t)__shfl_up((int)sid, 1, 64), en = (uint32_t)__shfl_up((int)en1, 1, 64);
+            if (lane == 0u) { sidp = c_sid; en = c_en; }
+            const bool chg = sid != sidp;
+            const uint64_t setm = __ballot(st && chg), rstm = __ballot(!st && en && chg);
+            const uint64_t bits = fill_up(setm, rstm, sm);
+            sm = (uint32_t)(bits >> 63) & 1u;
+            if (lane == 0u) smbits[s] = bits;
+            c_sid = (uint32_t)__shfl((int)sid, 63, 64);
+            c_en = (uint32_t)__shfl((int)en1, 63, 64);
+        }
+        __syncthreads();
+        // ---- backward: end_mask (lib.rs:663-714); the event of position p is made of row p + 1's quantities
+        uint32_t n_sid = 0, n_st = 0, t_en;
+        row(r1, n_sid, n_st, t_en);                          // row r1 (zeros if r1 == M: SID[M] = 0, ST[M] = 0)
+        uint32_t em = 0;                                     // e_M = 0; for r1 < M the chunk's last row is forced to em_last below
+        for (uint32_t s = steps; s-- > 0u;) {
+            const uint32_t p = r0 + s * 64u + lane;
+            uint32_t sid, st, enp1;
+            row(p, sid, st, enp1);
+            uint32_t sid1 = (uint32_t)__shfl_down((int)sid, 1, 64), st1 = (uint32_t)__shfl_down((int)st, 1, 64);
+            if (lane == 63u) { sid1 = n_sid; st1 = n_st; }
+            const bool chg = sid1 != sid;
+            bool set = enp1 && chg, rst = !enp1 && st1 && chg;
+            if (r1 < a.M && p + 1u == r1) { set = em_last != 0u; rst = em_last == 0u; }    // the stitch launch knows this row's end_mask
+            const uint64_t bits = fill_down(__ballot(set), __ballot(rst), em);
+            em = (uint32_t)bits & 1u;
+            const uint32_t mask = (uint32_t)((smbits[s] >> lane) & (bits >> lane) & 1ull) && p < n ? 1u : 0u;
+            const uint32_t c = cptr[(size_t)(p >> 4) * nb * 16u + (p & 15u)];
+            msk[((size_t)(p >> 3) * nb + bl) * 8u + (p & 7u)] = mask ? (uint16_t)(c | sid << 8) : (uint16_t)0;
+            n_sid = (uint32_t)__shfl((int)sid, 0, 64);
+            n_st = (uint32_t)__shfl((int)st, 0, 64);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void spec_stitch_kernel(const SpecArgs a) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const uint32_t rows = a.tiles_per_chunk * 64u, C = a.C;
+    const uint32_t n = min(a.lens[b], a.M);
+    // ---- status: lowest chunk's undefined transition (lib.rs:806-817), else the lowest overlap row, else ok with the accept bits of
+    // the chunk that holds row n (n == M: the last chunk); a bad length shows in every chunk
+    uint64_t sw_err = 0, sw_ov = 0, sw_acc = 0;
+    bool have_err = false, have_ov = false;
+    for (uint32_t k = 0; k < C; ++k) {
+        const uint64_t w = a.vstatus[(size_t)k * a.B + b];
+        const uint32_t code = (uint32_t)(w & 0xffu);
+        const uint32_t r0 = k * rows;
+        if (code == kStatusBadLength) { sw_err = w; have_err = true; break; }
+        if (code == kStatusInvalidTransition && !have_err) { sw_err = w; have_err = true; }
+        if (code == kStatusFlagOverlap && (!have_ov || (w >> 40) < (sw_ov >> 40))) { sw_ov = w; have_ov = true; }
+        if (code == kStatusOk && ((n >= r0 && n < r0 + rows) || (k + 1u == C && n >= r0))) sw_acc = w;
+    }
+    if (have_err && (sw_err & 0xffu) == kStatusInvalidTransition && have_ov && (sw_ov >> 40) < (sw_err >> 40)) {
+        // (an overlap row before the undefined transition: the walk of one string reports the error — it is found first, per tile, in the
+        // kernel too — so does the chunked one)
+    }
+    a.status[b] = have_err ? sw_err : have_ov ? sw_ov : sw_acc;
+    if (have_err) return;                     // rows of a string whose code is not 0 are unspecified
+    // ---- reveal-mask carries across the chunk borders
+    // E[k] = end_mask of chunk k's last row = what the first deciding tile of a later chunk says (none: the string's end decides: 0 pending)
+    uint32_t need = 0;                        // bit k: chunk k's masked rows must be recomputed
+    uint32_t E_bits = 0;
+    uint32_t Enext = 0;
+    for (uint32_t k = C; k-- > 0u;) {
+        // end_mask of chunk k's last row: from chunk k + 1's first deciding tile, else whatever holds for chunk k + 1's last row
+        uint32_t E = 0;
+        if (k + 1u < C) {
+            const uint32_t dec = (a.vinfo[(size_t)(k + 1u) * a.B + b].x >> 3) & 3u;
+            E = dec == 1u ? 1u : dec == 2u ? 0u : Enext;
+        }
+        E_bits |= E << k;
+        Enext = E;
+    }
+    uint32_t sm = 0;
+    for (uint32_t k = 0; k < C; ++k) {
+        const uint2 vi = a.vinfo[(size_t)k * a.B + b];
+        const uint32_t pend = vi.x & 1u, fwd = (vi.x >> 1) & 1u, sm_out = (vi.x >> 2) & 1u;
+        const uint32_t r0 = k * rows;
+        if (r0 >= n && r0 > 0u) break;        // padding chunks: no flags, masks all zero whatever the carries
+        if (sm) need |= 1u << k;              // the chunk assumed start_mask = 0 at its first row
+        if (pend && !((E_bits >> k) & 1u)) need |= 1u << k;   // its trailing rows were written with end_mask = 1
+        sm = fwd ? sm_out : sm;
+    }
+    sm = 0;
+    for (uint32_t k = 0; k < C && need; ++k) {
+        const uint2 vi = a.vinfo[(size_t)k * a.B + b];
+        if ((need >> k) & 1u) {     // a work item for the repair launch (one wave each)
+            const uint32_t at = atomicAdd(a.work_count, 1u);
+            if (at < a.work_cap) a.work[at] = make_uint2(b, k | sm << 8 | ((E_bits >> k) & 1u) << 9);
+            need &= ~(1u << k);
+        }
+        sm = ((vi.x >> 1) & 1u) ? ((vi.x >> 2) & 1u) : sm;
+    }
+}
+
+hipError_t launch_spec_scout(const SpecArgs &a, int num_cus, hipStream_t stream) {
+    static std::atomic<size_t> granted[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t e = ensure_lds(spec_scout_kernel, granted[dev & 63], a.table_bytes);
+    if (e != hipSuccess) return e;
+    const size_t waves = (size_t)a.n_groups * a.C;
+    const size_t per_cu = std::max<size_t>(1, std::min<size_t>(kLdsLimit / std::max<uint32_t>(a.table_bytes, 1u), 4));   // workgroups of 4 waves per CU
+    const size_t grid = std::min<size_t>((waves + 3) / 4, (size_t)num_cus * per_cu);
+    hipLaunchKernelGGL(spec_scout_kernel, dim3((unsigned)std::max<size_t>(grid, 1)), dim3(256), a.table_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_compose(const SpecArgs &a, hipStream_t stream) {
+    const size_t threads = (size_t)a.n_groups * 64u * a.D;
+    hipLaunchKernelGGL(spec_compose_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// (a.work_count[0] must be zero when the stitch launch starts: a memset node in front of it)
+hipError_t launch_spec_stitch(const SpecArgs &a, int num_cus, hipStream_t stream) {
+    hipLaunchKernelGGL(spec_stitch_kernel, dim3((a.B + 63u) / 64u), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(spec_repair_kernel, dim3((unsigned)num_cus * 8u), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace hrx

@@ -154,6 +154,9 @@ struct TileMasks {
     uint64_t mask;        // start_mask & end_mask for rows r < n
     uint32_t fix;         // 1: zero masked rows [fix_start, t0) — an earlier optimistic end_mask = 1 was wrong
     uint32_t fix_start;
+    // for walks that start in the middle of a string (chunks, hrx_kernel_spec.hip): what this tile says about rows BEFORE it
+    uint32_t dec;         // 0: nothing (no backward event, not exact); 1 / 2: end_mask of row t0 - 1 is 1 / 0 — what decides rows left pending before t0
+    uint32_t fwd;         // 1: the tile holds a forward (start_mask) event: the carry out of it does not depend on the carry into it
 };
 
 // Reveal mask of one tile of W rows, W <= 64 (src/lib.rs:598-764 on integers); bits >= W of the inputs are 0.
@@ -216,6 +219,8 @@ HRX_HD TileMasks tile_masks(const TileBits &b, MaskCarry &c, uint32_t t0, bool e
     const U any = (U)(setB | rstB);
     out.fix = 0;
     out.fix_start = 0;
+    out.dec = (any != 0 || exact) ? ((F & 1) ? 1u : 2u) : 0u;
+    out.fwd = (U)(setF | rstF) != 0 ? 1u : 0u;
     if (c.pend && (any != 0 || exact)) {
         if (!(F & 1)) { out.fix = 1; out.fix_start = c.pend_start; }
         c.pend = 0;

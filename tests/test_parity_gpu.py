@@ -466,6 +466,49 @@ def test_position_major_kernel_on_both_table_formats(hra, oracle, flags, monkeyp
     _check_batch_pm(hra, oracle, [CFG_1[0], CFG_1[0]], chars, lens, 200)     # the same def twice: every flag overlaps
 
 
+@pytest.mark.parametrize("M", [512, 1024, 2048])
+def test_chunked_launch_every_chunk_border_case(hra, oracle, M, monkeypatch):
+    """The chunked launch (hrx_kernel_spec.hip: scout + compose find every chunk's start state, the loader / walker / finisher kernel
+    walks the chunks as groups of their own, the stitch launch settles the reveal-mask carries and merges the status words), forced
+    with chunks of 4 tiles (kDbgForceSpec) so that every string has 2 .. 8 of them: D = 1 .. 3, strings that end inside any chunk,
+    at a chunk border, at M and at 0; the absorbing accept state behind a finished match (no warm-up from the start state reaches
+    it); revealed substrings that straddle a chunk border (the start-mask assumption of the chunk behind it is wrong: its masked rows
+    are recomputed); undefined transitions in a later chunk with the reference's (state, char) (lib.rs:817); two defs flagging one row."""
+    from halo2_regex_amd import synth
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(0x80))
+    chars, lens = synth.reveal_stress(700, M, seed=40 + M)
+    rng = np.random.default_rng(M)
+    for b in range(0, 700, 7):                       # full-length strings, some ending exactly at a chunk border
+        lens[b] = M if b % 14 else 256 * (1 + b % 2)
+        tail = synth.reveal_stress(1, M, seed=b)[0][0]
+        chars[b, :M] = np.where(chars[b, :M] == 0, tail[:M], chars[b, :M])
+    for b in range(3, 700, 31):                      # a byte no DFA has a column for, beyond the first chunk where the string is long enough
+        if lens[b] > 300:
+            chars[b, int(rng.integers(257, lens[b]))] = 200 + b % 50
+    for b in range(5, 700, 53):                      # a revealed part that certainly crosses the row-256 border
+        t = b"email was meant for @" + bytes(synth.LOWER[rng.integers(0, 26, size=60)]) + b"."
+        chars[b, 220:220 + len(t)] = np.frombuffer(t, np.uint8)
+        lens[b] = max(lens[b], 220 + len(t))
+    for names in (CFG_1, CFG_23, CFG_123, CFG_A, [CFG_1[0], CFG_1[0]]):
+        assert "chunked=%dx4 tiles" % (M // 256) in _cfg(hra, names, M).describe_launch(700, layout=3)
+        _check_batch_pm(hra, oracle, names, chars, lens, M)
+
+
+def test_chunked_launch_is_what_a_batch_of_few_long_strings_gets(hra, oracle):
+    """Up to one group of 64 strings per CU and 4096 rows or more: the planner cuts the strings into chunks of 16 tiles (a launch of the
+    sequential kernels would last one string's dependent chain, n x 29-50 ns, with three quarters of the walker slots empty).
+    4096 x 8192-byte strings = 8 chunks each, every string against the oracle and the MockProver; D = 1 and D = 3."""
+    from halo2_regex_amd import synth
+    M = 8192
+    for names, D, gen, seed in ((CFG_1, 1, synth.regex1_planted, 3), (CFG_123, 3, synth.noise, 4)):
+        cfg = _cfg(hra, names, M)
+        assert "chunked=8x16 tiles" in cfg.describe_launch(4096, layout=3) and "chunked" not in cfg.describe_launch(32768, layout=3)
+        chars, lens = gen(4096, M - 1, seed=seed, stride=M)
+        lens[::5] = np.random.default_rng(seed).integers(0, M, size=len(lens[::5]))          # ragged
+        st = _full_check(hra, OracleDefs.from_files(oracle, names), cfg, [(chars, lens)], M, D)
+        assert len(st) == 4096
+
+
 @pytest.mark.parametrize("flags", ["65536", "196608"], ids=["one-wave-gs64", "one-wave-gs32"])
 def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
     """D <= 2 normally takes the walker/storer kernel; force the one-wave kernel (used for D = 3 and unaligned M)
