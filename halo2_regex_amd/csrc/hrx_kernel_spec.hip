@@ -324,59 +324,66 @@ __global__ __launch_bounds__(64) void spec_stitch_kernel(const SpecArgs a) {
     if (b >= a.B) return;
     const uint32_t rows = a.tiles_per_chunk * 64u, C = a.C;
     const uint32_t n = min(a.lens[b], a.M);
+    // every chunk's two summary words, all loads in flight at once (a thread's chunks are 8 B x B apart: a loop that waited for each
+    // word took 32 us for 32 chunks)
+    uint2 vi[kSpecMaxChunks];
+    uint64_t vst[kSpecMaxChunks];
+#pragma unroll
+    for (uint32_t k = 0; k < kSpecMaxChunks; ++k) {
+        vi[k] = make_uint2(0, 0); vst[k] = 0;
+        if (k < C) { vi[k] = a.vinfo[(size_t)k * a.B + b]; vst[k] = a.vstatus[(size_t)k * a.B + b]; }
+    }
     // ---- status: lowest chunk's undefined transition (lib.rs:806-817), else the lowest overlap row, else ok with the accept bits of
     // the chunk that holds row n (n == M: the last chunk); a bad length shows in every chunk
     uint64_t sw_err = 0, sw_ov = 0, sw_acc = 0;
     bool have_err = false, have_ov = false;
-    for (uint32_t k = 0; k < C; ++k) {
-        const uint64_t w = a.vstatus[(size_t)k * a.B + b];
-        const uint32_t code = (uint32_t)(w & 0xffu);
-        const uint32_t r0 = k * rows;
-        if (code == kStatusBadLength) { sw_err = w; have_err = true; break; }
-        if (code == kStatusInvalidTransition && !have_err) { sw_err = w; have_err = true; }
-        if (code == kStatusFlagOverlap && (!have_ov || (w >> 40) < (sw_ov >> 40))) { sw_ov = w; have_ov = true; }
-        if (code == kStatusOk && ((n >= r0 && n < r0 + rows) || (k + 1u == C && n >= r0))) sw_acc = w;
-    }
-    if (have_err && (sw_err & 0xffu) == kStatusInvalidTransition && have_ov && (sw_ov >> 40) < (sw_err >> 40)) {
-        // (an overlap row before the undefined transition: the walk of one string reports the error — it is found first, per tile, in the
-        // kernel too — so does the chunked one)
+#pragma unroll
+    for (uint32_t k = 0; k < kSpecMaxChunks; ++k) {
+        if (k < C) {
+            const uint64_t w = vst[k];
+            const uint32_t code = (uint32_t)(w & 0xffu);
+            const uint32_t r0 = k * rows;
+            if ((code == kStatusBadLength || code == kStatusInvalidTransition) && !have_err) { sw_err = w; have_err = true; }
+            if (code == kStatusFlagOverlap && (!have_ov || (w >> 40) < (sw_ov >> 40))) { sw_ov = w; have_ov = true; }
+            if (code == kStatusOk && ((n >= r0 && n < r0 + rows) || (k + 1u == C && n >= r0))) sw_acc = w;
+        }
     }
     a.status[b] = have_err ? sw_err : have_ov ? sw_ov : sw_acc;
     if (have_err) return;                     // rows of a string whose code is not 0 are unspecified
     // ---- reveal-mask carries across the chunk borders
-    // E[k] = end_mask of chunk k's last row = what the first deciding tile of a later chunk says (none: the string's end decides: 0 pending)
-    uint32_t need = 0;                        // bit k: chunk k's masked rows must be recomputed
-    uint32_t E_bits = 0;
-    uint32_t Enext = 0;
-    for (uint32_t k = C; k-- > 0u;) {
-        // end_mask of chunk k's last row: from chunk k + 1's first deciding tile, else whatever holds for chunk k + 1's last row
-        uint32_t E = 0;
-        if (k + 1u < C) {
-            const uint32_t dec = (a.vinfo[(size_t)(k + 1u) * a.B + b].x >> 3) & 3u;
-            E = dec == 1u ? 1u : dec == 2u ? 0u : Enext;
+    // E[k] = end_mask of chunk k's last row = what the first deciding tile of a later chunk says
+    uint32_t E_bits = 0, Enext = 0;
+#pragma unroll
+    for (uint32_t kk = 0; kk < kSpecMaxChunks; ++kk) {
+        const uint32_t k = kSpecMaxChunks - 1u - kk;
+        if (k < C) {
+            uint32_t E = 0;
+            if (k + 1u < C) {
+                const uint32_t dec = (vi[(k + 1u) % kSpecMaxChunks].x >> 3) & 3u;
+                E = dec == 1u ? 1u : dec == 2u ? 0u : Enext;
+            }
+            E_bits |= E << k;
+            Enext = E;
         }
-        E_bits |= E << k;
-        Enext = E;
     }
     uint32_t sm = 0;
-    for (uint32_t k = 0; k < C; ++k) {
-        const uint2 vi = a.vinfo[(size_t)k * a.B + b];
-        const uint32_t pend = vi.x & 1u, fwd = (vi.x >> 1) & 1u, sm_out = (vi.x >> 2) & 1u;
-        const uint32_t r0 = k * rows;
-        if (r0 >= n && r0 > 0u) break;        // padding chunks: no flags, masks all zero whatever the carries
-        if (sm) need |= 1u << k;              // the chunk assumed start_mask = 0 at its first row
-        if (pend && !((E_bits >> k) & 1u)) need |= 1u << k;   // its trailing rows were written with end_mask = 1
-        sm = fwd ? sm_out : sm;
-    }
-    sm = 0;
-    for (uint32_t k = 0; k < C && need; ++k) {
-        const uint2 vi = a.vinfo[(size_t)k * a.B + b];
-        if ((need >> k) & 1u) {     // a work item for the repair launch (one wave each)
-            const uint32_t at = atomicAdd(a.work_count, 1u);
-            if (at < a.work_cap) a.work[at] = make_uint2(b, k | sm << 8 | ((E_bits >> k) & 1u) << 9);
-            need &= ~(1u << k);
+    bool live = true;
+#pragma unroll
+    for (uint32_t k = 0; k < kSpecMaxChunks; ++k) {
+        if (k < C && live) {
+            const uint32_t pend = vi[k].x & 1u, fwd = (vi[k].x >> 1) & 1u, sm_out = (vi[k].x >> 2) & 1u;
+            const uint32_t r0 = k * rows;
+            if (r0 >= n && r0 > 0u) { live = false; }        // padding chunks: no flags, masks all zero whatever the carries
+            else {
+                // the chunk assumed start_mask = 0 at its first row / wrote its trailing rows with end_mask = 1: a work item for the repair
+                // launch (one wave each) with the true values
+                if (sm || (pend && !((E_bits >> k) & 1u))) {
+                    const uint32_t at = atomicAdd(a.work_count, 1u);
+                    if (at < a.work_cap) a.work[at] = make_uint2(b, k | sm << 8 | ((E_bits >> k) & 1u) << 9);
+                }
+                sm = fwd ? sm_out : sm;
+            }
         }
-        sm = ((vi.x >> 1) & 1u) ? ((vi.x >> 2) & 1u) : sm;
     }
 }
 
