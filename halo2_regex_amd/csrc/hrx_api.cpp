@@ -478,7 +478,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
             for (uint32_t d = 0; d < Dn; ++d) smax = std::max<uint32_t>(smax, (uint32_t)set.defs[d].allstr.largest_state_val + 1);
             smax = (smax + 3u) & ~3u;
             HIP_TRY(ctx->spec_cls.reserve((size_t)C * Dn * smax * Bpad));
-            HIP_TRY(ctx->spec_ends.reserve((size_t)C * Dn * 8 * Bpad * 2));
+            HIP_TRY(ctx->spec_ends.reserve((size_t)C * Dn * 24 * Bpad * 2));   // 3 x kSpecKeys u16 per (chunk, def, string)
             HIP_TRY(ctx->spec_fail.reserve((size_t)C * Dn * Bpad));
             HIP_TRY(ctx->spec_init.reserve((size_t)C * B * Dn * 4));
             HIP_TRY(ctx->spec_vstatus.reserve((size_t)C * B * 8));

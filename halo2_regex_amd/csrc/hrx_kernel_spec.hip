@@ -30,8 +30,12 @@
 
 namespace hrx {
 
-constexpr uint32_t kSpecPrefix = 32;   // bytes every real state is walked over before the survivors are taken
-constexpr uint32_t kSpecSlots = 4;     // survivors per (string, chunk, def); more: the compose launch walks that chunk itself
+// The prefix in two stages: every real state over kSpecStageA bytes (the walks merge fast: 29 states -> at most 7 after 8 bytes of the
+// reference's and the header definitions, profiles/r03_probes/convergence.txt) — the distinct states reached are the chunk's KEYS —
+// then only the keys over the rest of the prefix, then the distinct survivors of that to the chunk's end.
+constexpr uint32_t kSpecStageA = 8, kSpecPrefix = 32;
+constexpr uint32_t kSpecKeys = 8;      // distinct states after stage A per (string, chunk, def); more: the compose launch walks that chunk itself
+constexpr uint32_t kSpecSlots = 4;     // survivors walked to the chunk's end; more: likewise
 
 // ---------------------------------------------------------------------------------------------
 // scout: lane = (chunk, string); the narrow fused table in LDS
@@ -63,20 +67,19 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
         const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
         for (uint32_t d = 0; d < a.D; ++d) {
             const uint32_t S = a.n_states[d], base = a.dc[d].row_base;
-            uint32_t slot[kSpecSlots];
+            uint32_t key[kSpecKeys], NK = 0, fail = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < kSpecSlots; ++j) slot[j] = 0xffffffffu;
-            uint32_t K = 0, fail = 0;
+            for (uint32_t j = 0; j < kSpecKeys; ++j) key[j] = 0xffffffffu;
             uint8_t *cls = a.cls + ((size_t)(k * a.D + d) * a.smax) * Bpad + b;
-            // ---- the prefix: every real state over the chunk's first kSpecPrefix bytes, four independent chains at a time
-            // (chunk 0 starts in first_state: one candidate)
+            // ---- stage A: every real state over the chunk's first kSpecStageA bytes, four independent chains at a time; cls[s] = the
+            // state reached (chunk 0 starts in first_state: one candidate)
             const uint32_t s_begin = k == 0u ? a.dc[d].first_state : 0u, s_end = k == 0u ? s_begin + 1u : S;
             for (uint32_t s0 = s_begin; s0 < s_end; s0 += 4u) {
                 uint32_t e[4];
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; ++j) e[j] = (base + min(s0 + j, S - 1u)) << kNextShift;
 #pragma unroll
-                for (uint32_t i = 0; i < kSpecPrefix; ++i) {
+                for (uint32_t i = 0; i < kSpecStageA; ++i) {
                     const uint32_t c4 = ((pw[i >> 2] >> (8u * (i & 3u))) & 0xffu) << 2;
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j) e[j] = lds_u32((e[j] & ~kTagMask) | c4);
@@ -85,20 +88,62 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
                 for (uint32_t j = 0; j < 4u; ++j) {
                     if (s0 + j < s_end) {
                         const uint32_t v = e[j] & ~kTagMask;
-                        uint32_t idx = 0xffu;
+                        bool have = false;
 #pragma unroll
-                        for (uint32_t q = 0; q < kSpecSlots; ++q) if (idx == 0xffu && slot[q] == v) idx = q;
-                        if (idx == 0xffu) {
-                            if (K < kSpecSlots) {
+                        for (uint32_t q = 0; q < kSpecKeys; ++q) have = have || key[q] == v;
+                        if (!have) {
+                            if (NK < kSpecKeys) {
 #pragma unroll
-                                for (uint32_t q = 0; q < kSpecSlots; ++q) if (q == K) slot[q] = v;
-                                idx = K++;
+                                for (uint32_t q = 0; q < kSpecKeys; ++q) if (q == NK) key[q] = v;
+                                ++NK;
                             } else {
-                                fail = 1; idx = 0;
+                                fail = 1;
                             }
                         }
-                        if (b < a.B) cls[(size_t)(s0 + j) * Bpad] = (uint8_t)idx;
+                        if (b < a.B) cls[(size_t)(s0 + j) * Bpad] = (uint8_t)((v >> kNextShift) - base);
                     }
+                }
+            }
+            // ---- stage B: the keys over the rest of the prefix (as many groups of four chains as the wave's busiest lane has keys), then
+            // their distinct survivors: slot[] and, per key, which slot it became
+            uint32_t NKw = NK;
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) NKw = max(NKw, (uint32_t)__shfl_xor((int)NKw, sft, 64));
+            uint32_t kb[kSpecKeys];
+#pragma unroll
+            for (uint32_t j = 0; j < kSpecKeys; ++j) kb[j] = key[j] == 0xffffffffu ? (base << kNextShift) : key[j];
+#pragma unroll
+            for (uint32_t h = 0; h < kSpecKeys; h += 4u) {
+                if (h < NKw) {
+#pragma unroll
+                    for (uint32_t i = kSpecStageA; i < kSpecPrefix; ++i) {
+                        const uint32_t c4 = ((pw[i >> 2] >> (8u * (i & 3u))) & 0xffu) << 2;
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; ++j) kb[h + j] = lds_u32((kb[h + j] & ~kTagMask) | c4);
+                    }
+                }
+            }
+            uint32_t slot[kSpecSlots], kslot[kSpecKeys], K = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kSpecSlots; ++j) slot[j] = 0xffffffffu;
+#pragma unroll
+            for (uint32_t j = 0; j < kSpecKeys; ++j) {
+                kslot[j] = 0;
+                if (j < NK) {
+                    const uint32_t v = kb[j] & ~kTagMask;
+                    uint32_t idx = 0xffu;
+#pragma unroll
+                    for (uint32_t q = 0; q < kSpecSlots; ++q) if (idx == 0xffu && slot[q] == v) idx = q;
+                    if (idx == 0xffu) {
+                        if (K < kSpecSlots) {
+#pragma unroll
+                            for (uint32_t q = 0; q < kSpecSlots; ++q) if (q == K) slot[q] = v;
+                            idx = K++;
+                        } else {
+                            fail = 1; idx = 0;
+                        }
+                    }
+                    kslot[j] = idx;
                 }
             }
             // ---- the survivors to the chunk's end.  A QUASI-ABSORBING survivor (hrx_kernel.hpp SpecArgs::qabs: every byte keeps it where it is
@@ -152,7 +197,8 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
                 cur = nxt; nxt = nn;
             }
             if (b < a.B) {
-                uint16_t *ends = a.ends + ((size_t)(k * a.D + d) * 2u * kSpecSlots) * Bpad + b;
+                // per KEY (a state reached after stage A): the key itself, where it is at the chunk's end and before the chunk's last byte
+                uint16_t *ends = a.ends + ((size_t)(k * a.D + d) * 3u * kSpecKeys) * Bpad + b;
                 const uint32_t dead_row = S + 1u;
                 // did a walked survivor die, and had it died before the chunk's last byte already?
                 bool died = false, died_m1 = false;
@@ -163,6 +209,7 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
                         died_m1 = died_m1 || (em1[j] >> kNextShift) - base == dead_row;
                     }
                 }
+                uint32_t s_end_v[kSpecSlots], s_endm1_v[kSpecSlots];
 #pragma unroll
                 for (uint32_t t = 0; t < kSpecSlots; ++t) {          // slot t: walked as chain j, or derived
                     uint32_t end = (slot[t] >> kNextShift) - base, endm1 = end;
@@ -171,10 +218,16 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
                     for (uint32_t j = 0; j < kSpecSlots; ++j)
                         if (j < nw && walk[j] == t) { end = (e[j] >> kNextShift) - base; endm1 = (em1[j] >> kNextShift) - base; walked = true; }
                     if (!walked) { if (died) end = dead_row; if (died_m1) endm1 = dead_row; }
-                    if (t < K) {
-                        ends[(size_t)t * Bpad] = (uint16_t)end;
-                        ends[(size_t)(kSpecSlots + t) * Bpad] = (uint16_t)endm1;
-                    }
+                    s_end_v[t] = end; s_endm1_v[t] = endm1;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < kSpecKeys; ++j) {
+                    uint32_t end = 0, endm1 = 0;
+#pragma unroll
+                    for (uint32_t t = 0; t < kSpecSlots; ++t) if (kslot[j] == t) { end = s_end_v[t]; endm1 = s_endm1_v[t]; }
+                    ends[(size_t)j * Bpad] = j < NK ? (uint16_t)((key[j] >> kNextShift) - base) : (uint16_t)0xffffu;
+                    ends[(size_t)(kSpecKeys + j) * Bpad] = (uint16_t)end;
+                    ends[(size_t)(2u * kSpecKeys + j) * Bpad] = (uint16_t)endm1;
                 }
                 a.fail[(size_t)(k * a.D + d) * Bpad + b] = (uint8_t)fail;
             }
@@ -200,14 +253,14 @@ __global__ __launch_bounds__(256) void spec_compose_kernel(const SpecArgs a) {
     uint32_t s = a.dc[d].first_state, prev = 0xffffffffu;
     // what chunk k's step needs besides the start state — its fail flag and the survivors' 2 x kSpecSlots states — is loaded a chunk
     // ahead, so that one dependent load per chunk (which survivor the start state became) is the thread's whole chain
-    auto load_chunk = [&](const uint32_t k, uint32_t &fl, uint32_t (&en)[2u * kSpecSlots]) {
+    auto load_chunk = [&](const uint32_t k, uint32_t &fl, uint32_t (&en)[3u * kSpecKeys]) {
         const size_t at = (size_t)(k * a.D + d);
         fl = a.fail[at * Bpad + b];
-        const uint16_t *ends = a.ends + (at * 2u * kSpecSlots) * Bpad + b;
+        const uint16_t *ends = a.ends + (at * 3u * kSpecKeys) * Bpad + b;
 #pragma unroll
-        for (uint32_t j = 0; j < 2u * kSpecSlots; ++j) en[j] = ends[(size_t)j * Bpad];
+        for (uint32_t j = 0; j < 3u * kSpecKeys; ++j) en[j] = ends[(size_t)j * Bpad];
     };
-    uint32_t fl_n = 0, en_n[2u * kSpecSlots];
+    uint32_t fl_n = 0, en_n[3u * kSpecKeys];
     load_chunk(0, fl_n, en_n);
     for (uint32_t k = 0; k < a.C; ++k) {
         const uint32_t r0 = k * rows;
@@ -216,17 +269,18 @@ __global__ __launch_bounds__(256) void spec_compose_kernel(const SpecArgs a) {
         // rows beyond n hold the dummy state (table row S: lib.rs:413); row n itself holds s[n]
         a.init[((size_t)k * a.B + b) * a.D + d] = (r0 > n ? S : s) | (tag & 0xffu) << 16 | ((tag >> 9) & 1u) << 24;
         const uint32_t fl = fl_n;
-        uint32_t en[2u * kSpecSlots];
+        uint32_t en[3u * kSpecKeys];
 #pragma unroll
-        for (uint32_t j = 0; j < 2u * kSpecSlots; ++j) en[j] = en_n[j];
+        for (uint32_t j = 0; j < 3u * kSpecKeys; ++j) en[j] = en_n[j];
         if (k + 1u < a.C) load_chunk(k + 1u, fl_n, en_n);
         if (r0 + rows > n) { prev = 0xffffffffu; continue; }   // the string ends in this chunk: every later chunk is padding (its start state is never looked at)
         if (s >= S) { prev = s; continue; }                    // dead (an undefined transition further up, lib.rs:817): absorbing
         if (!fl) {
-            const uint32_t q = a.cls[(((size_t)(k * a.D + d)) * a.smax + s) * Bpad + b];
-            prev = en[kSpecSlots]; s = en[0];
+            const uint32_t v = a.cls[(((size_t)(k * a.D + d)) * a.smax + s) * Bpad + b];   // the state after stage A: one of the chunk's keys
+            uint32_t ns = dead, np = dead;
 #pragma unroll
-            for (uint32_t j = 1; j < kSpecSlots; ++j) if (q == j) { prev = en[kSpecSlots + j]; s = en[j]; }
+            for (uint32_t j = 0; j < kSpecKeys; ++j) if (en[j] == v) { ns = en[kSpecKeys + j]; np = en[2u * kSpecKeys + j]; }
+            s = ns; prev = np;
         } else {
             // the chunk's start states did not merge into kSpecSlots survivors: walk it here (any DFA stays correct)
             for (uint32_t r = r0; r < r0 + rows; ++r) {
