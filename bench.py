@@ -430,8 +430,12 @@ def run_rank(args, rank, world, device_index, barrier):
     # masked rows at one element per 64 KiB — filling the 3 GB of buffers outright would leave the memory system (256 MB of dirty lines in
     # the Infinity Cache, everything written once more) in a state no steady series of launches ever sees, right before the timed region.
     for _, _, out in sets:
-        out[0].view(-1)[::16384].fill_(-1)
-        out[1].view(-1)[::32768].fill_(-1)
+        if pm:
+            out[0].view(-1)[::16384].fill_(-1)
+            out[1].view(-1)[::32768].fill_(-1)
+        else:                                  # (string-major outputs are pitched views: every 64th row of every string)
+            out[0][:, ::64].fill_(-1)
+            out[1][:, ::64].fill_(-1)
         out[2].fill_(-1)
     sync_barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -111,6 +111,7 @@ struct hrx_ctx {
     };
     std::vector<GroupDev> groups;
     DevBuf mp_masked;
+    DevBuf tp_records, tp_masked;   // string-major callers served by the position-major path + transpose_pm_to_sm_kernel (hrx_kernel_tp.hip)
     DevBuf spec_cls, spec_ends, spec_fail, spec_init, spec_vstatus, spec_vinfo, spec_work;
     bool spec_qabs_ready = false;
     uint32_t spec_qabs[kMaxDefsPerPass][8];   // chunked launches (hrx_kernel_spec.hip)
@@ -394,6 +395,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
         g.records.release(); g.status.release(); g.summary.release();
     }
     c->mp_masked.release();
+    c->tp_records.release(); c->tp_masked.release();
     c->spec_cls.release(); c->spec_ends.release(); c->spec_fail.release(); c->spec_init.release(); c->spec_vstatus.release(); c->spec_vinfo.release(); c->spec_work.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
     arena_retire(c->arena_rec); arena_retire(c->arena_msk);   // released now, or with their last sub-buffer
@@ -555,8 +557,28 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         }
         return HRX_OK;
     };
-    if (ctx->s.groups.empty())
+    if (ctx->s.groups.empty()) {
+        // string-major outputs of a DFA whose 4-byte table does not fit LDS (cfg 5): the string-major kernels would walk it out of global
+        // memory (0.21 of peak); the BYTE / HALF table kernels are position-major — run them into context scratch and turn the rows around
+        if (layout == HRX_LAYOUT_STRING_MAJOR && M % 8 == 0 &&
+            (!ctx->s.byte.image.empty() || !ctx->s.half_image.empty()) && ctx->s.table_image.size() * 4 + wave_stage_bytes((int)ctx->s.defs.size(), 16) > kLdsLimit) {
+            if (ctx->scratch_used && ctx->scratch_stream != st && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(HRX_ERR_STATE, "the context's transpose scratch is in use on another stream and that stream cannot be waited for here (stream capture?): one context serves one stream / graph at a time");
+            }
+            ctx->scratch_stream = st; ctx->scratch_used = true;
+            const size_t q4 = (M + 3) / 4, q8 = (M + 7) / 8, D = ctx->s.defs.size();
+            HIP_TRY(ctx->tp_records.reserve(q4 * 4 * D * B * 4));
+            HIP_TRY(ctx->tp_masked.reserve(q8 * 8 * B * 2));
+            const int rc = launch_set(ctx->s, ctx->d_table, ctx->d_wide, ctx->d_half, ctx->d_pairtab, ctx->d_bytetab, HRX_LAYOUT_POSITION_MAJOR,
+                                      (uint32_t *)ctx->tp_records.p, (uint16_t *)ctx->tp_masked.p, status, M, M);
+            if (rc != HRX_OK) return rc;
+            TransposeArgs ta{(const uint32_t *)ctx->tp_records.p, (const uint16_t *)ctx->tp_masked.p, (uint32_t)B, (uint32_t)M, (uint32_t)D, records, masked, (uint32_t)rec_pitch, (uint32_t)msk_pitch};
+            HIP_TRY(launch_transpose(ta, st));
+            return HRX_OK;
+        }
         return launch_set(ctx->s, ctx->d_table, ctx->d_wide, ctx->d_half, ctx->d_pairtab, ctx->d_bytetab, layout, records, masked, status, rec_pitch, msk_pitch);
+    }
     // ---- more than kMaxDefsPerPass defs: one ordinary launch per group into its private position-major buffers, then the
     // combine kernel (hrx_kernel_mp.hip) writes the caller's buffers.  The group buffers belong to the context: a launch
     // on another stream first waits for the previous combine.
@@ -568,6 +590,18 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     }
     ctx->scratch_stream = st; ctx->scratch_used = true;
     const size_t q4 = (M + 3) / 4, q8 = (M + 7) / 8, ntiles = (M + 63) / 64;
+    // string-major outputs (rows in multiples of 8): the passes and the combine run position-major into context scratch and
+    // transpose_pm_to_sm_kernel turns the rows around (hrx_kernel_tp.hip: 3.7 -> ~1 ms at D = 5, 65536 x 1024 rows); other row counts keep the
+    // copy-mode combine (per-lane 4-byte stores)
+    const bool via_tp = !(layout & HRX_LAYOUT_POSITION_MAJOR) && M % 8 == 0;
+    uint32_t *const caller_records = records;
+    uint16_t *const caller_masked = masked;
+    if (via_tp) {
+        HIP_TRY(ctx->tp_records.reserve(q4 * 4 * ctx->s.defs.size() * B * 4));
+        HIP_TRY(ctx->tp_masked.reserve(q8 * 8 * B * 2));
+        records = (uint32_t *)ctx->tp_records.p; masked = (uint16_t *)ctx->tp_masked.p;
+        layout = HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR);
+    }
     const bool summary_mode = (layout & HRX_LAYOUT_POSITION_MAJOR) != 0;   // position-major outputs: the passes write the caller's record planes themselves
     if (!summary_mode) HIP_TRY(ctx->mp_masked.reserve(q8 * 8 * B * 2));
     CombineArgs ca{};
@@ -597,6 +631,10 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     ca.rec_pitch = (uint32_t)rec_pitch; ca.msk_pitch = (uint32_t)msk_pitch;
     ca.records = records; ca.masked = masked; ca.status = status;
     HIP_TRY(launch_combine(ca, st));
+    if (via_tp) {
+        TransposeArgs ta{records, masked, (uint32_t)B, (uint32_t)M, (uint32_t)ctx->s.defs.size(), caller_records, caller_masked, (uint32_t)rec_pitch, (uint32_t)msk_pitch};
+        HIP_TRY(launch_transpose(ta, st));
+    }
     return HRX_OK;
 }
 
@@ -685,17 +723,23 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
     const DefsSet &s = defs->s;
     std::string text;
     if (s.groups.empty()) {
-        const int rc = describe_set(s, layout, B, M, num_cus, text);
+        const bool via_tp = layout == HRX_LAYOUT_STRING_MAJOR && M % 8 == 0 &&
+                            (!s.byte.image.empty() || !s.half_image.empty()) && s.table_image.size() * 4 + wave_stage_bytes((int)s.defs.size(), 16) > kLdsLimit;
+        const int rc = describe_set(s, via_tp ? HRX_LAYOUT_POSITION_MAJOR : layout, B, M, num_cus, text);
         if (rc != HRX_OK) return rc;
+        if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
     } else {   // one launch per group of defs (position-major, the caller's input layout), then the combine kernel
         text = "multi-pass, " + std::to_string(s.groups.size()) + " groups: ";
         for (size_t g = 0; g < s.groups.size(); ++g) {
             std::string one;
-            const int rc = describe_set(s.groups[g], HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR), B, M, num_cus, one, (layout & 1) != 0);
+            const bool tp = !(layout & 1) && M % 8 == 0;
+            const int rc = describe_set(s.groups[g], HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR), B, M, num_cus, one, (layout & 1) != 0 || tp);
             if (rc != HRX_OK) return rc;
             text += "[defs " + std::to_string(s.group_first[g]) + ".." + std::to_string(s.group_first[g] + s.groups[g].defs.size() - 1) + ": " + one + "] ";
         }
-        text += (layout & 1) ? "+ hrx::witness_combine_summary_kernel" : "+ hrx::witness_combine_kernel<true>";
+        const bool via_tp = !(layout & 1) && M % 8 == 0;
+        text += (layout & 1) || via_tp ? "+ hrx::witness_combine_summary_kernel" : "+ hrx::witness_combine_kernel<true>";
+        if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
     }
     std::snprintf(out, cap, "%s", text.c_str());
     return HRX_OK;

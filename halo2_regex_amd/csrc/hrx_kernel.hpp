@@ -225,6 +225,17 @@ hipError_t launch_spec_scout(const SpecArgs &a, int num_cus, hipStream_t stream)
 hipError_t launch_spec_compose(const SpecArgs &a, hipStream_t stream);
 hipError_t launch_spec_stitch(const SpecArgs &a, int num_cus, hipStream_t stream);
 
+// position-major -> string-major (hrx_kernel_tp.hip): string-major callers served by the position-major path
+struct TransposeArgs {
+    const uint32_t *records_pm;     // [ceil(M/4)][D][nb][4], blocked by kPmBlock strings
+    const uint16_t *masked_pm;      // [ceil(M/8)][nb][8]
+    uint32_t B, M, D;
+    uint32_t *records;              // [B][rec_pitch][D]
+    uint16_t *masked;               // [B][msk_pitch]
+    uint32_t rec_pitch, msk_pitch;  // rows, multiples of 8
+};
+hipError_t launch_transpose(const TransposeArgs &a, hipStream_t stream);
+
 // states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])
 hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,
                             const uint32_t *n_states, uint16_t *tags, hipStream_t stream);

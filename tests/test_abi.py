@@ -155,7 +155,10 @@ def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     d = cfg.describe_launch(65536, layout=3)
     assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8 ") and "lds=%d" % (128 * 1024 + 4 * (4096 + 128)) in d
     monkeypatch.delenv("HRX_DEBUG_FLAGS")
-    assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_kernel<1, true, true> ")                # string-major: global table
+    # string-major outputs: the same position-major kernel into context scratch + the transpose kernel (rows in multiples of 8; else the one-wave global-table walk)
+    d = cfg.describe_launch(65536, layout=0)
+    assert d.startswith("hrx::witness_pm_kernel<1, false, false, false, false, true> ") and d.endswith("+ hrx::transpose_pm_to_sm_kernel")
+    assert RegexVerifyConfig.configure(4097, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None).describe_launch(65536, layout=0).startswith("hrx::witness_kernel<1, false, true> ")
     # beyond 256 states there is no HALF image: global-table walk
     a_txt, sub_txt = synth.random_dfa(300, seed=2)
     cfg = RegexVerifyConfig.configure(1024, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)

@@ -3,9 +3,9 @@
 # (kernel trace + stats in one pass; FETCH_SIZE / WRITE_SIZE in their own passes; copy what is cited into profiles/)
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; tag=$1; shift; P=$R/gpurun_out/prof_$tag; rm -rf $P; mkdir -p $P; cd $R
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -o r1 -- python3 bench.py --no-cpu-baseline --no-pmc "$@" > $P/kt.log 2>&1; echo kt rc=$?
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch -o r1 -- python3 bench.py --eager --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-spread --no-pmc "$@" > $P/fetch.log 2>&1; echo fetch rc=$?
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write -o r1 -- python3 bench.py --eager --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-spread --no-pmc "$@" > $P/write.log 2>&1; echo write rc=$?
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -o r1 -- python3 bench.py --no-cpu-baseline --no-pmc --no-spread "$@" > $P/kt.log 2>&1; echo kt rc=$?
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch -o r1 -- python3 bench.py --eager --steps 3 --warmup 1 --sets 1 --no-cpu-baseline --no-verify --no-spread --no-pmc "$@" > $P/fetch.log 2>&1; echo fetch rc=$?
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write -o r1 -- python3 bench.py --eager --steps 3 --warmup 1 --sets 1 --no-cpu-baseline --no-verify --no-spread --no-pmc "$@" > $P/write.log 2>&1; echo write rc=$?
 python3 tools/summarize_prof.py $P $R/gpurun_out/$tag > /dev/null && echo summarized
 python3 - <<PY
 import json

@@ -35,6 +35,14 @@ for name in ("fetch", "write", "sq"):
     for k, v in agg.items():
         out["pmc_per_launch"][k] = sum(v) / len(v)
     out["kernel"] = kern
+    # every kernel of the library (a chunked launch is scout + compose + walk + stitch + repair; string-major via the transpose kernel)
+    by = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if "hrx::" in r["Kernel_Name"] and "placement_probe" not in r["Kernel_Name"] and "traffic_pass" not in r["Kernel_Name"]:
+            by[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for kn, cs in by.items():
+        for c, v in cs.items():
+            out.setdefault("pmc_by_kernel", {}).setdefault(kn, {})[c] = sum(v) / len(v)
 p = out["pmc_per_launch"]
 if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
     out["hbm_bytes_per_launch"] = {
