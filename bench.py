@@ -427,12 +427,12 @@ def run_rank(args, rank, world, device_index, barrier):
             for i in range(args.steps):
                 launch(i)   # launched on torch's current stream, where the events sit
     # poison the outputs: what the verification reads afterwards was written by the timed launches.  Status words entirely; records and
-    # masked rows at one element per 64 KiB — filling the 3 GB of buffers outright would leave the memory system (256 MB of dirty lines in
+    # masked rows at one element per ~64 KiB — filling the 3 GB of buffers outright would leave the memory system (256 MB of dirty lines in
     # the Infinity Cache, everything written once more) in a state no steady series of launches ever sees, right before the timed region.
     for _, _, out in sets:
-        if pm:
-            out[0].view(-1)[::16384].fill_(-1)
-            out[1].view(-1)[::32768].fill_(-1)
+        if pm:                                 # (prime strides: every string and every row position gets its share of the spots)
+            out[0].view(-1)[::16411].fill_(-1)
+            out[1].view(-1)[::32771].fill_(-1)
         else:                                  # (string-major outputs are pitched views: every 64th row of every string)
             out[0][:, ::64].fill_(-1)
             out[1][:, ::64].fill_(-1)
@@ -600,10 +600,10 @@ def aggregate(per_rank, args):
         line["roofline"]["placement"] = {
             "sets_searched": len(srch), "sets_accepted": sum(1 for p in srch if p.get("accepted")),
             "steps": [p.get("steps") for p in srch], "chosen_step": [p.get("chosen_step") for p in srch],
-            "ref_us": [round(p.get("ref_us", 0), 1) for p in srch], "first_us": [round(p.get("first_us", 0), 1) for p in srch],
-            "best_us": [round(p.get("best_us", 0), 1) for p in srch], "search_ms": [round(p.get("search_ms", 0), 1) for p in srch],
-            "what": "hrx_alloc_outputs_position_major per buffer set: two-stream probe times (device clock) of the same-neighbourhood reference, the first candidate "
-                    "(= two plain allocations) and the kept masked-row buffer; accepted = kept one >= 6 % faster than the reference (DESIGN.md §4.3)"}
+            "ref_gbs": [round(p.get("ref_gbs", 0)) for p in srch], "first_gbs": [round(p.get("first_gbs", 0)) for p in srch],
+            "best_gbs": [round(p.get("best_gbs", 0)) for p in srch], "search_ms": [round(p.get("search_ms", 0), 1) for p in srch],
+            "what": "hrx_alloc_outputs_position_major per buffer set: two-stream probe rates (GB/s written, device clock) of the same-block reference, the first candidate "
+                    "(= two plain allocations) and the kept masked-row buffer; accepted = kept one >= 10 % above the reference (DESIGN.md §4.3)"}
     if r0.get("one_buffer_set"):
         ob = r0["one_buffer_set"]
         gbs = algo_bytes / (ob["ms_per_step_median"] * 1e-3) / 1e9

@@ -11,6 +11,7 @@ use std::ffi::{c_char, c_int, c_void, CStr};
 pub struct hrx_place_report {
     pub searched: c_int, pub steps: c_int, pub accepted: c_int, pub chosen_step: c_int,
     pub ref_us: f64, pub first_us: f64, pub best_us: f64,
+    pub ref_gbs: f64, pub first_gbs: f64, pub best_gbs: f64,
     pub probe_bytes: usize, pub peak_candidate_bytes: usize, pub search_ms: f64,
 }
 

@@ -54,7 +54,8 @@ class _RegexPartC(C.Structure):      # hrx_regex_part of include/hrx.h
 
 class _PlaceReportC(C.Structure):    # hrx_place_report of include/hrx.h
     _fields_ = [("searched", C.c_int), ("steps", C.c_int), ("accepted", C.c_int), ("chosen_step", C.c_int),
-                ("ref_us", C.c_double), ("first_us", C.c_double), ("best_us", C.c_double), ("probe_bytes", C.c_size_t),
+                ("ref_us", C.c_double), ("first_us", C.c_double), ("best_us", C.c_double),
+                ("ref_gbs", C.c_double), ("first_gbs", C.c_double), ("best_gbs", C.c_double), ("probe_bytes", C.c_size_t),
                 ("peak_candidate_bytes", C.c_size_t), ("search_ms", C.c_double)]
 
 

@@ -283,6 +283,12 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
     return true;
 }
 
+__global__ void zero_u32_kernel(uint32_t *p) { *p = 0u; }
+hipError_t launch_zero_u32(uint32_t *p, hipStream_t stream) {
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
     if (li.split == 6) return launch_witness_pp(a, li, stream);
     if (li.split == 5) return launch_witness_pmd(a, li, stream);

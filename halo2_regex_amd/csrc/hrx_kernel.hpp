@@ -140,6 +140,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // Picks the launch geometry for `a` on a device with `num_cus` CUs; returns false if nothing fits.
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out);
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
+hipError_t launch_zero_u32(uint32_t *p, hipStream_t stream);   // *p = 0 as a kernel node (hrx_kernel.hip)
 // the two kernel translation units behind launch_witness: li.split == 2 -> hrx_kernel_pm.hip, else hrx_kernel_sm.hip
 hipError_t launch_witness_pm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 hipError_t launch_witness_sm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);

@@ -188,7 +188,7 @@ void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32,
  * writes records and masked rows as two such streams, and buffers allocated one after the other come from one neighbourhood.
  * So the call walks down the device memory — block after block, each measured against the records with a two-stream write of
  * a few hundred microseconds that times itself on the device clock (robust under a profiler); the reference is the same probe
- * inside ONE block, a candidate faster than that is taken, failing that the fastest measured, and everything else is freed
+ * inside ONE block, a candidate that writes 10 % more bytes per time than that is taken, failing that the fastest measured, and everything else is freed
  * before the call returns; the walk never holds more than 70 % of the device memory that was free.
  *   records >= 1 GiB: the blocks are the masked-row candidates themselves, measured against the records buffer itself.
  *   records <  1 GiB: such buffers are carved out of two 2-GiB ARENAS per context (one for records, one for masked rows; a
@@ -212,6 +212,8 @@ typedef struct hrx_place_report {
     int chosen_step;
     double ref_us;               /* the reference: both probe streams inside one neighbourhood (device clock) */
     double first_us, best_us;    /* the first candidate (what two plain allocations would have been) and the kept one */
+    double ref_gbs, first_gbs, best_gbs;   /* the same three as bytes written per time (GB/s): what acceptance compares — the reference pass
+                                    writes fewer bytes than a candidate pass; accepted = best_gbs >= 1.10 ref_gbs */
     size_t probe_bytes;          /* bytes one probe pass writes */
     size_t peak_candidate_bytes; /* most memory the walk held at once: rejected candidates stay allocated, as the spacers that push the
                                     next candidate further, until the walk ends */

@@ -770,29 +770,33 @@ def test_dynamic_group_assignment(hra, oracle, flags, names, monkeypatch):
     blocks = [(chars[:hra.PM_BLOCK], lens[:hra.PM_BLOCK]), (np.ascontiguousarray(chars[hra.PM_BLOCK:]), lens[hra.PM_BLOCK:])]
     st = _full_check(hra, OracleDefs.from_files(oracle, names), cfg, blocks, M, len(names))
     assert (st & np.uint64(0xff) == 0).mean() > 0.9
-    # graph replay: three captured launches, replayed twice, same bytes as an eager launch
+    # graph replay: four captured launches INTO FOUR DIFFERENT OUTPUT SETS, replayed three times, every set the same bytes as an eager launch
+    # (with one set a launch that skipped its dynamic groups goes unnoticed behind the launches around it: round 3 found the counter's
+    # reset — then a memset node — executing out of order with the kernel nodes from the second replay on)
     dev = torch.device("cuda", 0)
     d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
     ref = cfg.alloc_outputs_position_major(B, dev)
     for t in ref:
         t.fill_(-1)          # (cells the contract leaves unspecified — rows of a string whose status is not 0 — keep the fill on both sides)
     cfg.witness_batch_position_major(d_chars, d_lens, out=ref)
-    out = cfg.alloc_outputs_position_major(B, dev)
+    outs = [cfg.alloc_outputs_position_major(B, dev) for _ in range(4)]
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-            for _ in range(3):
+            for out in outs:
                 cfg.witness_batch_position_major(d_chars, d_lens, out=out)
     torch.cuda.current_stream(dev).wait_stream(side)
-    for _ in range(2):
-        for t in out:
-            t.fill_(-1)
+    for _ in range(3):
+        for out in outs:
+            for t in out:
+                t.fill_(-1)
         g.replay()
         torch.cuda.synchronize()
-        assert all(torch.equal(x, y) for x, y in zip(out, ref))
+        for out in outs:
+            assert all(torch.equal(x, y) for x, y in zip(out, ref))
 
 
 def test_placement_aware_output_allocation(hra, oracle):

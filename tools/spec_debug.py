@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Debug aid for the chunked launch: forced chunks of 4 tiles on a small batch, first differing row per string against the oracle."""
 import os, sys
-os.environ["HRX_DEBUG_FLAGS"] = str(0x80 | 0x20000000)
+os.environ["HRX_DEBUG_FLAGS"] = str(int(os.environ.get("SPEC_FLAGS", "0x80"), 0) | 0x20000000)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
