@@ -397,7 +397,10 @@ __global__ __launch_bounds__(64) void spec_stitch_kernel(const SpecArgs a) {
             const uint64_t w = vst[k];
             const uint32_t code = (uint32_t)(w & 0xffu);
             const uint32_t r0 = k * rows;
-            if ((code == kStatusBadLength || code == kStatusInvalidTransition) && !have_err) { sw_err = w; have_err = true; }
+            // the reference walks the defs one after the other (lib.rs:806): the lowest DEF with an undefined transition anywhere wins,
+            // at its first position — the first chunk that reports that def (a chunk reports its own lowest def)
+            if (code == kStatusBadLength && !have_err) { sw_err = w; have_err = true; }
+            if (code == kStatusInvalidTransition && (!have_err || ((sw_err & 0xffu) == kStatusInvalidTransition && ((w >> 8) & 0xffu) < ((sw_err >> 8) & 0xffu)))) { sw_err = w; have_err = true; }
             if (code == kStatusFlagOverlap && (!have_ov || (w >> 40) < (sw_ov >> 40))) { sw_ov = w; have_ov = true; }
             if (code == kStatusOk && ((n >= r0 && n < r0 + rows) || (k + 1u == C && n >= r0))) sw_acc = w;
         }

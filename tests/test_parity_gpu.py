@@ -607,6 +607,46 @@ def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
         assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
 
 
+@pytest.mark.parametrize("seed", list(range(300, 316)))
+def test_fuzz_chunked_launch_on_random_definitions(hra, oracle, seed, monkeypatch):
+    """Seeded fuzz of the chunked launch (forced, chunks of 4 tiles): random DFAs — partial ones included, and random transition
+    functions need not forget their start state: chunks whose start states do not merge into the scout's bounds are walked by the
+    compose launch — 1-3 defs, 2-8 chunks per string, ragged lengths incl. 0, M and > M, bytes outside the alphabets, flag overlap;
+    against the oracle, bit for bit."""
+    import torch
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(0x80))
+    rng = np.random.default_rng(5000 + seed)
+    D = int(rng.integers(1, 4))
+    defs_t = _random_defs(rng, D, False)
+    M = int(rng.choice([512, 768, 1024, 1280, 2048]))
+    B = int(rng.choice([1, 64, 65, 200, 333]))
+    stride = M
+    common = defs_t[0][2]
+    for _, _, a in defs_t[1:]:
+        common = np.intersect1d(common, a)
+    alpha = np.unique(np.concatenate([a for _, _, a in defs_t]))
+    pool = common if len(common) >= 2 else alpha
+    chars = pool[rng.integers(0, len(pool), size=(B, stride))].astype(np.uint8)
+    lens = rng.integers(0, M + 1, size=B).astype(np.uint32)
+    lens[rng.random(B) < 0.3] = M
+    lens[rng.random(B) < 0.1] = 256 * int(rng.integers(1, M // 256 + 1))   # ends exactly at a chunk border
+    lens[rng.random(B) < 0.03] = M + 3                                      # BadLength
+    for b in np.nonzero(rng.random(B) < 0.1)[0]:                            # a byte no def has a column for
+        chars[b, int(rng.integers(0, stride))] = 0
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs, _ in defs_t]
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    assert "chunked=" in cfg.describe_launch(B, layout=3) or cfg.table_bytes() > 100 * 1024     # (tables that leave no LDS for the rings are walked out of global memory, unchunked)
+    orec, omsk, ost = OracleDefs(oracle, [(a, subs) for a, subs, _ in defs_t]).witness_batch(chars, lens, M)
+    ok = (ost & np.uint64(0xff)) == 0
+    dev = torch.device("cuda", 0)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    rec, msk, st = cfg.witness_batch_position_major(hra.chars_to_position_major(d_chars), d_lens, chars_pm_stride=stride)
+    torch.cuda.synchronize()
+    r1, m1 = hra.position_major_to_string_major(rec, msk, B, M, D)
+    assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+    assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
+
+
 def test_three_defs_every_kernel_agrees_at_a_chip_filling_size(hra, oracle, monkeypatch):
     """D = 3, 16384 x 1024-byte strings (one group per CU): the def-parallel kernel (the planner's choice), the regular
     position-major kernel, its narrow-table build and the string-major path must produce the same bytes, and every string
