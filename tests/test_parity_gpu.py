@@ -607,7 +607,17 @@ def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
         assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
 
 
-@pytest.mark.parametrize("seed", list(range(300, 316)))
+def _spec_fuzz_seeds():
+    """the suite's seeds, plus a range named in HRX_FUZZ_SPEC_EXTRA ("1000:1400") for a soak run (profiles/r03_soak.txt)"""
+    seeds = list(range(300, 316))
+    part = os.environ.get("HRX_FUZZ_SPEC_EXTRA", "")
+    if ":" in part:
+        a, b = part.split(":")
+        seeds += list(range(int(a), int(b)))
+    return seeds
+
+
+@pytest.mark.parametrize("seed", _spec_fuzz_seeds())
 def test_fuzz_chunked_launch_on_random_definitions(hra, oracle, seed, monkeypatch):
     """Seeded fuzz of the chunked launch (forced, chunks of 4 tiles): random DFAs — partial ones included, and random transition
     functions need not forget their start state: chunks whose start states do not merge into the scout's bounds are walked by the
