@@ -162,6 +162,9 @@ __global__ __launch_bounds__(256) void witness_combine_kernel(const CombineArgs 
 // combine reads G x 1.25 + 1 bytes per row and writes the 2 bytes of masked rows: a config of D defs then costs about
 // 4 D + G (1 + 1.25) + 3 bytes per row against 4 D + 3 for a single launch.  Two defs of DIFFERENT groups flagging one row
 // show as overlapping bits here; two defs of one group were caught by that group's own walk (its status word says so).
+// GP > 0: exactly GP groups, and the NEXT tile's loads (5 GP summary pieces + 4 input pieces per lane) are in flight while a tile is
+// processed — without that every tile waited a full memory round trip: 290 us for 65536 x 2048 rows at D = 5 (0.74 GB: 2.5 TB/s).
+template <int GP>
 __global__ __launch_bounds__(256) void witness_combine_summary_kernel(const CombineArgs a) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t B = a.B, M = a.M;
@@ -183,13 +186,53 @@ __global__ __launch_bounds__(256) void witness_combine_summary_kernel(const Comb
     uint32_t sum_prev = 0, ov_row = 0xffffffffu;
     const uint32_t ntiles = (M + 63u) >> 6;
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    constexpr int GPn = GP > 0 ? GP : 1;
+    uint4 pre_s[GPn][5], pre_c[4];
+    auto prefetch = [&](const uint32_t t) {
+        if constexpr (GP > 0) {
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const uint4 *sp = reinterpret_cast<const uint4 *>(a.gsummary[g]) + ((size_t)t * 5u * B + bc);
+#pragma unroll
+                for (uint32_t i = 0; i < 5u; ++i) pre_s[g][i] = sp[(size_t)i * B];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) pre_c[i] = *reinterpret_cast<const uint4 *>(cptr + (size_t)min((t << 6) + 16u * i, row_cap) * cmul);
+        }
+    };
+    if (ntiles) prefetch(0);
     for (uint32_t t = 0; t < ntiles; ++t) {
         const uint32_t t0 = t << 6;
         uint32_t sidq[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) sidq[q] = 0;
         uint64_t st = 0, en1 = 0, ov_st = 0, ov_en = 0;
-        for (uint32_t g = 0; g < a.G; ++g) {
+        uint4 cur_c[4];
+        if constexpr (GP > 0) {
+            uint4 cur_s[GPn][5];
+#pragma unroll
+            for (int g = 0; g < GP; ++g)
+#pragma unroll
+                for (uint32_t i = 0; i < 5u; ++i) cur_s[g][i] = pre_s[g][i];
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) cur_c[i] = pre_c[i];
+            if (t + 1u < ntiles) prefetch(t + 1u);
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const uint4 h = cur_s[g][0];
+                const uint64_t gst = (uint64_t)h.x | ((uint64_t)h.y << 32), gen = (uint64_t)h.z | ((uint64_t)h.w << 32);
+                ov_st |= st & gst;
+                ov_en |= en1 & gen;
+                st |= gst;
+                en1 |= gen;
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint4 v = cur_s[g][i + 1u];
+                    sidq[4 * i] += v.x; sidq[4 * i + 1] += v.y; sidq[4 * i + 2] += v.z; sidq[4 * i + 3] += v.w;
+                }
+            }
+        }
+        for (uint32_t g = 0; GP == 0 && g < a.G; ++g) {
             const uint4 *sp = reinterpret_cast<const uint4 *>(a.gsummary[g]) + ((size_t)t * 5u * B + bc);
             const uint4 h = sp[0];
             const uint64_t gst = (uint64_t)h.x | ((uint64_t)h.y << 32), gen = (uint64_t)h.z | ((uint64_t)h.w << 32);
@@ -229,7 +272,9 @@ __global__ __launch_bounds__(256) void witness_combine_summary_kernel(const Comb
         uint32_t cw[16];
 #pragma unroll
         for (uint32_t i = 0; i < 4u; ++i) {
-            const uint4 c = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(t0 + 16u * i, row_cap) * cmul);
+            uint4 c;
+            if constexpr (GP > 0) c = cur_c[i];
+            else c = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(t0 + 16u * i, row_cap) * cmul);
             const bool have = t0 + 16u * i <= row_cap;
             cw[4 * i] = have ? c.x : 0u; cw[4 * i + 1] = have ? c.y : 0u; cw[4 * i + 2] = have ? c.z : 0u; cw[4 * i + 3] = have ? c.w : 0u;
         }
@@ -269,7 +314,12 @@ __global__ __launch_bounds__(256) void witness_combine_summary_kernel(const Comb
 hipError_t launch_combine(const CombineArgs &a, hipStream_t stream) {
     const uint32_t groups64 = (a.B + 63u) / 64u;
     const dim3 grid((groups64 + 3u) / 4u), block(256);
-    if (a.gsummary[0]) hipLaunchKernelGGL(witness_combine_summary_kernel, grid, block, 0, stream, a);
+    if (a.gsummary[0]) {
+        if (a.G == 2) hipLaunchKernelGGL(witness_combine_summary_kernel<2>, grid, block, 0, stream, a);
+        else if (a.G == 3) hipLaunchKernelGGL(witness_combine_summary_kernel<3>, grid, block, 0, stream, a);
+        else if (a.G == 4) hipLaunchKernelGGL(witness_combine_summary_kernel<4>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(witness_combine_summary_kernel<0>, grid, block, 0, stream, a);
+    }
     else if (a.layout & 1u) hipLaunchKernelGGL(witness_combine_kernel<false>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(witness_combine_kernel<true>, grid, block, 0, stream, a);
     return hipGetLastError();
