@@ -478,10 +478,9 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
             const size_t Bpad = (size_t)G * 64;
             uint32_t smax = 4;
             for (uint32_t d = 0; d < Dn; ++d) smax = std::max<uint32_t>(smax, (uint32_t)set.defs[d].allstr.largest_state_val + 1);
-            smax = (smax + 3u) & ~3u;
-            HIP_TRY(ctx->spec_cls.reserve((size_t)C * Dn * smax * Bpad));
-            HIP_TRY(ctx->spec_ends.reserve((size_t)C * Dn * 24 * Bpad * 2));   // 3 x kSpecKeys u16 per (chunk, def, string)
-            HIP_TRY(ctx->spec_fail.reserve((size_t)C * Dn * Bpad));
+            smax = (smax + 15u) & ~15u;
+            const uint32_t row_bytes = smax + 32u;
+            HIP_TRY(ctx->spec_cls.reserve((size_t)C * Dn * Bpad * row_bytes));   // one row per (chunk, def, string)
             HIP_TRY(ctx->spec_init.reserve((size_t)C * B * Dn * 4));
             HIP_TRY(ctx->spec_vstatus.reserve((size_t)C * B * 8));
             HIP_TRY(ctx->spec_vinfo.reserve((size_t)C * B * 8));
@@ -516,7 +515,10 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
                 ctx->spec_qabs_ready = true;
             }
             std::memcpy(sp.qabs, ctx->spec_qabs, sizeof sp.qabs);
-            sp.cls = (uint8_t *)ctx->spec_cls.p; sp.ends = (uint16_t *)ctx->spec_ends.p; sp.fail = (uint8_t *)ctx->spec_fail.p;
+            sp.rows = (uint8_t *)ctx->spec_cls.p; sp.row_bytes = row_bytes;
+#ifdef HRX_ABLATION
+            if (const char *v = std::getenv("HRX_SPEC_DBG")) sp.dbg = (uint32_t)std::strtoul(v, nullptr, 0);
+#endif
             sp.init = (uint32_t *)ctx->spec_init.p; sp.vinfo = (const uint2 *)ctx->spec_vinfo.p; sp.vstatus = (const uint64_t *)ctx->spec_vstatus.p;
             sp.status = stat; sp.records = rec; sp.masked = msk;
             sp.work_count = (uint32_t *)ctx->spec_work.p; sp.work = (uint2 *)((unsigned char *)ctx->spec_work.p + 16); sp.work_cap = (uint32_t)(C * B);

@@ -76,7 +76,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
             if (tpc > kSpecMaxChunkTiles) tpc = 0;
         }
         for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d)
-            if (a.dc[d].n_rows > 256u) tpc = 0;          // (the scout keeps states as bytes)
+            if (a.dc[d].n_rows > 255u) tpc = 0;          // (the scout keeps states as bytes, 0xff = none)
         if (tpc && a.B <= kPmBlock && a.M % 64u == 0u) {
             WitnessArgs v = a;
             v.n_groups = a.n_groups * (ntiles / tpc);

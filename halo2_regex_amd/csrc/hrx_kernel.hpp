@@ -206,11 +206,11 @@ struct SpecArgs {
                                              // of the def has a transition for (those send it to the dead row, like everybody else)
     uint32_t smax;                           // >= every n_states
     const uint16_t *pair_tags[kMaxDefsPerLaunch];   // device (state, next) -> tag tables (hrx_defs.hpp pair_tags)
-    // scratch, all [chunk][def][..][n_groups * 64]: which survivor each start state became; the survivors' states after the chunk and
-    // before its last byte; 1 = more than kSpecSlots survivors
-    uint8_t *cls;
-    uint16_t *ends;
-    uint8_t *fail;
+    // scratch: one row per (chunk, def, string), [chunk][def][n_groups * 64][row_bytes]: smax bytes "the state start state s reached after
+    // the scout's stage A" + a 32-byte record (8 keys | where each key ends | where it is before the chunk's last byte | fail flag)
+    uint8_t *rows;
+    uint32_t row_bytes;                      // smax + 32, a multiple of 16
+    uint32_t dbg;                            // profiling only (ablation build, HRX_SPEC_DBG): 1 no tag load, 2 no init store in compose
     uint32_t *init;                          // [chunk][B][D] -> WitnessArgs::vs_init
     const uint2 *vinfo;                      // [chunk][B] <- WitnessArgs::vs_info
     const uint64_t *vstatus;                 // [chunk][B] <- WitnessArgs::vs_status

@@ -40,7 +40,7 @@ constexpr uint32_t kSpecSlots = 4;     // survivors walked to the chunk's end; m
 // ---------------------------------------------------------------------------------------------
 // scout: lane = (chunk, string); the narrow fused table in LDS
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
+__global__ __launch_bounds__(512) void spec_scout_kernel(const SpecArgs a) {
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -70,10 +70,12 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
             uint32_t key[kSpecKeys], NK = 0, fail = 0;
 #pragma unroll
             for (uint32_t j = 0; j < kSpecKeys; ++j) key[j] = 0xffffffffu;
-            uint8_t *cls = a.cls + ((size_t)(k * a.D + d) * a.smax) * Bpad + b;
+            // this (chunk, def, string)'s row of the scratch: smax bytes "which key did start state s become" + the 32-byte record below
+            uint8_t *rowp = a.rows + ((size_t)(k * a.D + d) * Bpad + b) * a.row_bytes;
             // ---- stage A: every real state over the chunk's first kSpecStageA bytes, four independent chains at a time; cls[s] = the
             // state reached (chunk 0 starts in first_state: one candidate)
-            const uint32_t s_begin = k == 0u ? a.dc[d].first_state : 0u, s_end = k == 0u ? s_begin + 1u : S;
+            const uint32_t only = k == 0u ? a.dc[d].first_state : 0xffffffffu;          // chunk 0: the one candidate
+            const uint32_t s_begin = k == 0u ? (only & ~3u) : 0u, s_end = k == 0u ? only + 1u : S;
             for (uint32_t s0 = s_begin; s0 < s_end; s0 += 4u) {
                 uint32_t e[4];
 #pragma unroll
@@ -84,9 +86,10 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j) e[j] = lds_u32((e[j] & ~kTagMask) | c4);
                 }
+                uint32_t clsw = 0;        // the four candidates' states after stage A, one byte each
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; ++j) {
-                    if (s0 + j < s_end) {
+                    if (s0 + j < s_end && (only == 0xffffffffu || s0 + j == only)) {
                         const uint32_t v = e[j] & ~kTagMask;
                         bool have = false;
 #pragma unroll
@@ -100,9 +103,10 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
                                 fail = 1;
                             }
                         }
-                        if (b < a.B) cls[(size_t)(s0 + j) * Bpad] = (uint8_t)((v >> kNextShift) - base);
+                        clsw |= (((v >> kNextShift) - base) & 0xffu) << (8u * j);
                     }
                 }
+                if (b < a.B) *reinterpret_cast<uint32_t *>(rowp + s0) = clsw;
             }
             // ---- stage B: the keys over the rest of the prefix (as many groups of four chains as the wave's busiest lane has keys), then
             // their distinct survivors: slot[] and, per key, which slot it became
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
             }
             if (b < a.B) {
                 // per KEY (a state reached after stage A): the key itself, where it is at the chunk's end and before the chunk's last byte
-                uint16_t *ends = a.ends + ((size_t)(k * a.D + d) * 3u * kSpecKeys) * Bpad + b;
+                // one 32-byte record per (chunk, def, string): keys[8] | where each key ends [8] | where it is before the last byte [8] | fail | pad
+                uint32_t rw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 const uint32_t dead_row = S + 1u;
                 // did a walked survivor die, and had it died before the chunk's last byte already?
                 bool died = false, died_m1 = false;
@@ -225,64 +230,84 @@ __global__ __launch_bounds__(256) void spec_scout_kernel(const SpecArgs a) {
                     uint32_t end = 0, endm1 = 0;
 #pragma unroll
                     for (uint32_t t = 0; t < kSpecSlots; ++t) if (kslot[j] == t) { end = s_end_v[t]; endm1 = s_endm1_v[t]; }
-                    ends[(size_t)j * Bpad] = j < NK ? (uint16_t)((key[j] >> kNextShift) - base) : (uint16_t)0xffffu;
-                    ends[(size_t)(kSpecKeys + j) * Bpad] = (uint16_t)end;
-                    ends[(size_t)(2u * kSpecKeys + j) * Bpad] = (uint16_t)endm1;
+                    const uint32_t kv = j < NK ? ((key[j] >> kNextShift) - base) & 0xffu : 0xffu;     // (0xff: no such key; states are <= 254 here)
+                    rw[j >> 2] |= kv << (8u * (j & 3u));
+                    rw[2u + (j >> 2)] |= (end & 0xffu) << (8u * (j & 3u));
+                    rw[4u + (j >> 2)] |= (endm1 & 0xffu) << (8u * (j & 3u));
                 }
-                a.fail[(size_t)(k * a.D + d) * Bpad + b] = (uint8_t)fail;
+                rw[6] = fail;
+                uint4 *rp = reinterpret_cast<uint4 *>(rowp + a.smax);
+                rp[0] = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+                rp[1] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// compose: thread = (string, def)
+// compose: one WAVE per (string, def), lanes = chunks
 // ---------------------------------------------------------------------------------------------
+// Lane l loads chunk l's row of the scout's scratch — all chunks at once: one memory round trip (a thread that walked the chunks one
+// after the other waited ~6 us per chunk for its row: 220 us for 32 chunks at D = 3).  Then the chain: the wave steps through the
+// chunks with the running state in a scalar; at step k every lane evaluates "where does this state end in MY chunk" on its own
+// row and lane k's answer is taken (v_readlane); lane k also remembers the state it was entered with.  No memory access on the
+// chain.  Finally every lane looks up the tag of the transition into its chunk and writes its init word.
 __global__ __launch_bounds__(256) void spec_compose_kernel(const SpecArgs a) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = idx % (a.n_groups * 64u), d = idx / (a.n_groups * 64u);
-    if (idx == 0u) a.work_count[0] = 0u;     // the repair list of this launch (stitch appends, repair reads): zeroed here, two launches ahead
-    if (b >= a.B || d >= a.D) return;
-    const uint32_t Bpad = a.n_groups * 64u, rows = a.tiles_per_chunk * 64u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) a.work_count[0] = 0u;     // the repair list of this launch (stitch appends, repair reads): zeroed here, two launches ahead
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pidx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pidx >= a.B * a.D) return;
+    const uint32_t b = pidx % a.B, d = pidx / a.B;
+    const uint32_t Bpad = a.n_groups * 64u, rows = a.tiles_per_chunk * 64u, C = a.C;
     const uint32_t S = a.n_states[d], base = a.dc[d].row_base;
     const uint32_t n = min(a.lens[b], a.M);
     const uint32_t dead = S + 1u;             // table rows: real states 0 .. S - 1, the dummy row S, the dead row S + 1
-    const uint32_t *T = a.table_image + (size_t)base * 256u;
-    const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
-    const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(b - blk0) * 16u;
-    uint32_t s = a.dc[d].first_state, prev = 0xffffffffu;
-    // what chunk k's step needs besides the start state — its fail flag and the survivors' 2 x kSpecSlots states — is loaded a chunk
-    // ahead, so that one dependent load per chunk (which survivor the start state became) is the thread's whole chain
-    auto load_chunk = [&](const uint32_t k, uint32_t &fl, uint32_t (&en)[3u * kSpecKeys]) {
-        const size_t at = (size_t)(k * a.D + d);
-        fl = a.fail[at * Bpad + b];
-        const uint16_t *ends = a.ends + (at * 3u * kSpecKeys) * Bpad + b;
-#pragma unroll
-        for (uint32_t j = 0; j < 3u * kSpecKeys; ++j) en[j] = ends[(size_t)j * Bpad];
-    };
-    uint32_t fl_n = 0, en_n[3u * kSpecKeys];
-    load_chunk(0, fl_n, en_n);
-    for (uint32_t k = 0; k < a.C; ++k) {
+    const bool small = a.smax <= 32u;
+    // ---- my chunk's row
+    const uint32_t kc = min(lane, C - 1u);
+    const uint8_t *rowp = a.rows + ((size_t)(kc * a.D + d) * Bpad + b) * a.row_bytes;
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+    if (small) {
+        c0 = *reinterpret_cast<const uint4 *>(rowp);
+        if (a.smax > 16u) c1 = *reinterpret_cast<const uint4 *>(rowp + 16);
+    }
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(rowp + a.smax), q1 = *reinterpret_cast<const uint4 *>(rowp + a.smax + 16);
+    const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const uint32_t w[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+    const uint32_t my_fail = q1.z;
+    // ---- the chain
+    uint32_t s = a.dc[d].first_state, prev = 0xffffffffu;     // wave-uniform
+    uint32_t my_s = 0, my_prev = 0xffffffffu;
+    for (uint32_t k = 0; k < C; ++k) {
+        if (lane == k) { my_s = s; my_prev = prev; }
         const uint32_t r0 = k * rows;
-        uint32_t tag = 0;
-        if (prev < S && s < S && r0 <= n) tag = a.pair_tags[d][(size_t)prev * S + s];     // (prev, s): the transition into the chunk's first row
-        // rows beyond n hold the dummy state (table row S: lib.rs:413); row n itself holds s[n]
-        a.init[((size_t)k * a.B + b) * a.D + d] = (r0 > n ? S : s) | (tag & 0xffu) << 16 | ((tag >> 9) & 1u) << 24;
-        const uint32_t fl = fl_n;
-        uint32_t en[3u * kSpecKeys];
-#pragma unroll
-        for (uint32_t j = 0; j < 3u * kSpecKeys; ++j) en[j] = en_n[j];
-        if (k + 1u < a.C) load_chunk(k + 1u, fl_n, en_n);
         if (r0 + rows > n) { prev = 0xffffffffu; continue; }   // the string ends in this chunk: every later chunk is padding (its start state is never looked at)
         if (s >= S) { prev = s; continue; }                    // dead (an undefined transition further up, lib.rs:817): absorbing
+        const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)my_fail, (int)k);
         if (!fl) {
-            const uint32_t v = a.cls[(((size_t)(k * a.D + d)) * a.smax + s) * Bpad + b];   // the state after stage A: one of the chunk's keys
+            uint32_t v;                                        // the state after stage A in MY chunk: one of its keys
+            if (small) {
+                uint32_t word = cw[0];
+#pragma unroll
+                for (uint32_t j = 1; j < 8u; ++j) if ((s >> 2) == j) word = cw[j];
+                v = (word >> (8u * (s & 3u))) & 0xffu;
+            } else {
+                v = rowp[s];
+            }
             uint32_t ns = dead, np = dead;
 #pragma unroll
-            for (uint32_t j = 0; j < kSpecKeys; ++j) if (en[j] == v) { ns = en[kSpecKeys + j]; np = en[2u * kSpecKeys + j]; }
-            s = ns; prev = np;
+            for (uint32_t j = 0; j < kSpecKeys; ++j) {
+                const uint32_t kj = (w[j >> 2] >> (8u * (j & 3u))) & 0xffu;
+                if (kj == v) { ns = (w[2u + (j >> 2)] >> (8u * (j & 3u))) & 0xffu; np = (w[4u + (j >> 2)] >> (8u * (j & 3u))) & 0xffu; }
+            }
+            s = (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)k);
+            prev = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)k);
         } else {
-            // the chunk's start states did not merge into kSpecSlots survivors: walk it here (any DFA stays correct)
+            // the chunk's start states did not merge into the scout's bounds: walk it here, one lane's worth of work for the whole wave
+            // (any DFA stays correct; forgetful ones never get here)
+            const uint32_t *T = a.table_image + (size_t)base * 256u;
+            const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
+            const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(b - blk0) * 16u;
             for (uint32_t r = r0; r < r0 + rows; ++r) {
                 const uint32_t c = cptr[(size_t)(r >> 4) * nb * 16u + (r & 15u)];
                 prev = s;
@@ -292,6 +317,14 @@ __global__ __launch_bounds__(256) void spec_compose_kernel(const SpecArgs a) {
             }
         }
         if (s >= S) s = dead;
+    }
+    // ---- my chunk's init word: the state at its first row, and the substr id / end flag of the transition into that row
+    if (lane < C) {
+        const uint32_t r0 = lane * rows;
+        uint32_t tag = 0;
+        if (my_prev < S && my_s < S && r0 <= n && !(a.dbg & 1u)) tag = a.pair_tags[d][(size_t)my_prev * S + my_s];
+        // rows beyond n hold the dummy state (table row S: lib.rs:413); row n itself holds s[n]
+        if (!(a.dbg & 2u)) a.init[((size_t)lane * a.B + b) * a.D + d] = (r0 > n ? S : my_s) | (tag & 0xffu) << 16 | ((tag >> 9) & 1u) << 24;
     }
 }
 
@@ -450,16 +483,18 @@ hipError_t launch_spec_scout(const SpecArgs &a, int num_cus, hipStream_t stream)
     (void)hipGetDevice(&dev);
     hipError_t e = ensure_lds(spec_scout_kernel, granted[dev & 63], a.table_bytes);
     if (e != hipSuccess) return e;
+    // 16 waves per CU (the lookups saturate the LDS pipe from there): workgroups of 4 waves while four copies of the table fit LDS, of 8 above
     const size_t waves = (size_t)a.n_groups * a.C;
-    const size_t per_cu = std::max<size_t>(1, std::min<size_t>(kLdsLimit / std::max<uint32_t>(a.table_bytes, 1u), 4));   // workgroups of 4 waves per CU
-    const size_t grid = std::min<size_t>((waves + 3) / 4, (size_t)num_cus * per_cu);
-    hipLaunchKernelGGL(spec_scout_kernel, dim3((unsigned)std::max<size_t>(grid, 1)), dim3(256), a.table_bytes, stream, a);
+    const size_t copies = std::max<size_t>(1, kLdsLimit / std::max<uint32_t>(a.table_bytes, 1u));
+    const size_t wpw = copies >= 4 ? 4 : 8, per_cu = std::min<size_t>(copies, 16 / wpw);
+    const size_t grid = std::min<size_t>((waves + wpw - 1) / wpw, (size_t)num_cus * per_cu);
+    hipLaunchKernelGGL(spec_scout_kernel, dim3((unsigned)std::max<size_t>(grid, 1)), dim3((unsigned)(64 * wpw)), a.table_bytes, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_spec_compose(const SpecArgs &a, hipStream_t stream) {
-    const size_t threads = (size_t)a.n_groups * 64u * a.D;
-    hipLaunchKernelGGL(spec_compose_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a);
+    const size_t waves = (size_t)a.B * a.D;       // one wave per (string, def), four per workgroup
+    hipLaunchKernelGGL(spec_compose_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
