@@ -11,9 +11,10 @@
 //            kSpecSlots) distinct survivors and which survivor each start state became, then walk only the survivors to the
 //            chunk's end; no rows are written — a chunk costs ~S x 32 + 2 x (chunk - 32) table lookups, several independent
 //            chains per lane.
-//   compose  one thread per (string, def): from first_state, chunk by chunk, the state at every chunk's first row (a table
-//            lookup per chunk) and the substr id / end flag of the transition into it.  A chunk whose start states did not
-//            merge into kSpecSlots survivors is simply walked here, sequentially — correct for any DFA, fast for forgetful ones.
+//   compose  one wave per (string, def), a chunk per lane: from first_state, chunk by chunk, the state at every chunk's first row
+//            (an evaluation of the chunk's scout row per chunk, all in registers) and the substr id / end flag of the transition
+//            into it.  A chunk whose start states did not merge into kSpecSlots survivors is walked here by the whole wave, a 64th
+//            of it per lane from every state — correct for any DFA, fast for forgetful ones.
 //   walk     the ordinary loader / walker / finisher kernel (hrx_kernel_pm.hip) over chunks as virtual groups: B x C "strings"
 //            fill the chip, the launch is bound by the memory system again.  Rows are final except for what crosses a
 //            chunk's borders in the reveal-mask scans (lib.rs:598-714): a chunk assumes no open span at its first row
@@ -303,18 +304,41 @@ __global__ __launch_bounds__(256) void spec_compose_kernel(const SpecArgs a) {
             s = (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)k);
             prev = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)k);
         } else {
-            // the chunk's start states did not merge into the scout's bounds: walk it here, one lane's worth of work for the whole wave
-            // (any DFA stays correct; forgetful ones never get here)
+            // the chunk's start states did not merge into the scout's bounds: the wave walks it here.  Lane l takes the chunk's l-th
+            // 64th and walks it from EVERY real state (four independent chains at a time, table and bytes from L2): its map "entered
+            // in s -> left in" goes to LDS; then the true state runs through the 64 maps.  ~S x rows / 64 lookups per lane instead of
+            // a chain of `rows` dependent ones (200 us for 1024 rows).  Any DFA stays correct; forgetful ones rarely get here.
             const uint32_t *T = a.table_image + (size_t)base * 256u;
             const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
             const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(b - blk0) * 16u;
-            for (uint32_t r = r0; r < r0 + rows; ++r) {
-                const uint32_t c = cptr[(size_t)(r >> 4) * nb * 16u + (r & 15u)];
-                prev = s;
-                const uint32_t e = T[s * 256u + c];
-                s = (e >> kNextShift) - base;
-                if (s >= S) { s = dead; break; }
+            const uint32_t per = rows >> 6;
+            uint8_t *maps = smem + (threadIdx.x >> 6) * (65u * a.smax);          // [64 lanes][smax] + lane 63's "before the last byte"
+            for (uint32_t s0 = 0; s0 < S; s0 += 4u) {
+                uint32_t e[4], em1[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) { e[j] = min(s0 + j, S - 1u); em1[j] = e[j]; }
+                for (uint32_t i = 0; i < per; ++i) {
+                    const uint32_t r = r0 + lane * per + i;
+                    const uint32_t c = cptr[(size_t)(r >> 4) * nb * 16u + (r & 15u)];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) { em1[j] = e[j]; e[j] = (T[e[j] * 256u + c] >> kNextShift) - base; }    // (the dead row S + 1 leads to itself)
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    if (s0 + j < S) {
+                        maps[lane * a.smax + s0 + j] = (uint8_t)e[j];
+                        if (lane == 63u) maps[64u * a.smax + s0 + j] = (uint8_t)em1[j];
+                    }
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t l = 0; l < 64u && s < S; ++l) {
+                if (l == 63u) prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)maps[64u * a.smax + s]);
+                s = (uint32_t)__builtin_amdgcn_readfirstlane((int)maps[l * a.smax + s]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if (s >= S) s = dead;
     }
@@ -494,7 +518,13 @@ hipError_t launch_spec_scout(const SpecArgs &a, int num_cus, hipStream_t stream)
 
 hipError_t launch_spec_compose(const SpecArgs &a, hipStream_t stream) {
     const size_t waves = (size_t)a.B * a.D;       // one wave per (string, def), four per workgroup
-    hipLaunchKernelGGL(spec_compose_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, a);
+    const size_t lds = 4u * 65u * (size_t)a.smax;   // per wave: the maps of a chunk the scout gave up on
+    static std::atomic<size_t> granted[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t e = ensure_lds(spec_compose_kernel, granted[dev & 63], lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spec_compose_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -657,6 +657,35 @@ def test_fuzz_chunked_launch_on_random_definitions(hra, oracle, seed, monkeypatc
     assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
 
 
+@pytest.mark.parametrize("S", [7, 40])
+def test_chunked_launch_of_a_dfa_that_never_forgets(hra, oracle, S):
+    """A counter modulo S: every byte permutes the states, so no two start states ever merge and the scout gives up on EVERY
+    chunk past the first (S > its survivor bound) — the compose launch's own walk (a 64th of the chunk per lane, from every
+    state) carries the whole string.  The planner's natural chunk size (16 tiles), ragged lengths, one substring definition
+    whose span crosses chunk borders; against the oracle, bit for bit."""
+    import torch
+    alpha = np.array([97, 98, 99], dtype=np.uint8)
+    lines = ["0", str(S - 1), str(S - 1)] + ["%d %d %d" % (st, (st + 1 + i) % S, int(ch)) for st in range(S) for i, ch in enumerate(alpha)]
+    pairs = sorted({(st, (st + 1 + i) % S) for st in range(S) for i in range(3)})
+    sub = "\n".join(["8", "0", "99", "0 ", "%d " % (S - 1)] + ["%d %d" % p for p in pairs[: len(pairs) // 2]]) + "\n"
+    text = "\n".join(lines) + "\n"
+    B, M = 96, 8192
+    rng = np.random.default_rng(S)
+    chars = alpha[rng.integers(0, 3, size=(B, M))]
+    lens = rng.integers(M // 2, M + 1, size=B).astype(np.uint32)
+    lens[:8] = [M, M - 1, 1024, 1025, 1023, 0, 4096, 7 * 1024]
+    cfg = hra.RegexVerifyConfig.configure(M, [hra.RegexDefs(hra.AllstrRegexDef(text), [hra.SubstrRegexDef(sub)])], device=0)
+    assert "chunked=8x16 tiles" in cfg.describe_launch(B, layout=3)
+    orec, omsk, ost = OracleDefs(oracle, [(text, [sub])]).witness_batch(chars, lens, M)
+    dev = torch.device("cuda", 0)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    rec, msk, st = cfg.witness_batch_position_major(hra.chars_to_position_major(d_chars), d_lens, chars_pm_stride=M)
+    torch.cuda.synchronize()
+    r1, m1 = hra.position_major_to_string_major(rec, msk, B, M, 1)
+    assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+    assert np.array_equal(r1.cpu().numpy().view(np.uint32), orec) and np.array_equal(m1.cpu().numpy().view(np.uint16), omsk)
+
+
 def test_three_defs_every_kernel_agrees_at_a_chip_filling_size(hra, oracle, monkeypatch):
     """D = 3, 16384 x 1024-byte strings (one group per CU): the def-parallel kernel (the planner's choice), the regular
     position-major kernel, its narrow-table build and the string-major path must produce the same bytes, and every string
