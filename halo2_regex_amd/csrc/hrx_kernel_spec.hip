@@ -41,7 +41,7 @@ constexpr uint32_t kSpecSlots = 4;     // survivors walked to the chunk's end; m
 // ---------------------------------------------------------------------------------------------
 // scout: lane = (chunk, string); the narrow fused table in LDS
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void spec_scout_kernel(const SpecArgs a) {
+__global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(512) void spec_scout_kernel(const SpecArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t rows = a.tiles_per_chunk * 64u;
     const uint32_t row_cap = (uint32_t)a.stride - 16u;
-    for (uint32_t vw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); vw < a.n_groups * a.C; vw += gridDim.x * (blockDim.x >> 6)) {
+    for (uint32_t vw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); vw_ < a.n_groups * a.C; vw_ += gridDim.x * (blockDim.x >> 6)) {
+        const uint32_t vw = (uint32_t)__builtin_amdgcn_readfirstlane((int)vw_);
         const uint32_t k = vw / a.n_groups, g = vw % a.n_groups;
         const uint32_t b = g * 64u + lane, bc = min(b, a.B - 1u);
         const uint32_t r0 = k * rows;
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(512) void spec_scout_kernel(const SpecArgs a) {
             uint32_t NKw = NK;
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) NKw = max(NKw, (uint32_t)__shfl_xor((int)NKw, sft, 64));
+            NKw = (uint32_t)__builtin_amdgcn_readfirstlane((int)NKw);
             uint32_t kb[kSpecKeys];
 #pragma unroll
             for (uint32_t j = 0; j < kSpecKeys; ++j) kb[j] = key[j] == 0xffffffffu ? (base << kNextShift) : key[j];
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(512) void spec_scout_kernel(const SpecArgs a) {
             uint32_t Kw = nw;
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) Kw = max(Kw, (uint32_t)__shfl_xor((int)Kw, sft, 64));
+            Kw = (uint32_t)__builtin_amdgcn_readfirstlane((int)Kw);
             uint32_t e[kSpecSlots], em1[kSpecSlots];
 #pragma unroll
             for (uint32_t j = 0; j < kSpecSlots; ++j) {
@@ -184,22 +187,31 @@ __global__ __launch_bounds__(512) void spec_scout_kernel(const SpecArgs a) {
                 e[j] = v; em1[j] = v;
             }
             const uint32_t npieces = rows / 16u;
-            uint4 cur = piece(kSpecPrefix / 16u), nxt = piece(min(kSpecPrefix / 16u + 1u, npieces - 1u));
-            for (uint32_t i = kSpecPrefix / 16u; i < npieces; ++i) {
-                const uint4 nn = piece(min(i + 2u, npieces - 1u));      // two pieces ahead of the chains
-                const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+            // (one copy of the loop per chain count: a count in a register costs a branch per lookup)
+            auto to_end = [&](auto kc) {
+                constexpr uint32_t KC = decltype(kc)::value;
+                uint4 cur = piece(kSpecPrefix / 16u), nxt = piece(min(kSpecPrefix / 16u + 1u, npieces - 1u));
+                for (uint32_t i = kSpecPrefix / 16u; i < npieces; ++i) {
+                    const uint4 nn = piece(min(i + 2u, npieces - 1u));      // two pieces ahead of the chains
+                    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-                for (uint32_t q = 0; q < 16u; ++q) {
-                    const uint32_t c4 = ((w[q >> 2] >> (8u * (q & 3u))) & 0xffu) << 2;
-                    if (q == 15u) {
+                    for (uint32_t q = 0; q < 16u; ++q) {
+                        const uint32_t c4 = ((w[q >> 2] >> (8u * (q & 3u))) & 0xffu) << 2;
+                        if (q == 15u) {
 #pragma unroll
-                        for (uint32_t j = 0; j < kSpecSlots; ++j) em1[j] = e[j];    // the state BEFORE the piece's last byte (kept for the chunk's last piece)
+                            for (uint32_t j = 0; j < KC; ++j) em1[j] = e[j];    // the state BEFORE the piece's last byte (kept for the chunk's last piece)
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < KC; ++j) e[j] = lds_u32((e[j] & ~kTagMask) | c4);
                     }
-#pragma unroll
-                    for (uint32_t j = 0; j < kSpecSlots; ++j)
-                        if (j < Kw) e[j] = lds_u32((e[j] & ~kTagMask) | c4);
+                    cur = nxt; nxt = nn;
                 }
-                cur = nxt; nxt = nn;
+            };
+            switch (Kw) {
+                case 0: case 1: to_end(std::integral_constant<uint32_t, 1>{}); break;
+                case 2: to_end(std::integral_constant<uint32_t, 2>{}); break;
+                case 3: to_end(std::integral_constant<uint32_t, 3>{}); break;
+                default: to_end(std::integral_constant<uint32_t, 4>{}); break;
             }
             if (b < a.B) {
                 // per KEY (a state reached after stage A): the key itself, where it is at the chunk's end and before the chunk's last byte
@@ -507,10 +519,10 @@ hipError_t launch_spec_scout(const SpecArgs &a, int num_cus, hipStream_t stream)
     (void)hipGetDevice(&dev);
     hipError_t e = ensure_lds(spec_scout_kernel, granted[dev & 63], a.table_bytes);
     if (e != hipSuccess) return e;
-    // 16 waves per CU (the lookups saturate the LDS pipe from there): workgroups of 4 waves while four copies of the table fit LDS, of 8 above
+    // 16 waves per CU (the lookups saturate the LDS pipe from there): workgroups of 4 waves while four copies of the table fit LDS, of 8 while two do, of 16 above
     const size_t waves = (size_t)a.n_groups * a.C;
     const size_t copies = std::max<size_t>(1, kLdsLimit / std::max<uint32_t>(a.table_bytes, 1u));
-    const size_t wpw = copies >= 4 ? 4 : 8, per_cu = std::min<size_t>(copies, 16 / wpw);
+    const size_t wpw = copies >= 4 ? 4 : copies >= 2 ? 8 : 16, per_cu = std::min<size_t>(copies, 16 / wpw);
     const size_t grid = std::min<size_t>((waves + wpw - 1) / wpw, (size_t)num_cus * per_cu);
     hipLaunchKernelGGL(spec_scout_kernel, dim3((unsigned)std::max<size_t>(grid, 1)), dim3((unsigned)(64 * wpw)), a.table_bytes, stream, a);
     return hipGetLastError();
