@@ -416,7 +416,7 @@ def run_rank(args, rank, world, device_index, barrier):
         if g is not None:
             # untimed replays of the same graph, ~100 launches: graph upload, and the memory system's own warm-up — a kernel trace of this
             # script shows the launches of a replay that follows a pause or other kernels taking 92 -> 84 us over its first twenty
-            # (profiles/r03_probes/trace_replays.txt); W = 5 eager steps do not cover that
+            # (profiles/r03_pm_trace_replays.txt); W = 5 eager steps do not cover that
             untimed = max(2, -(-100 // args.steps))
             for _ in range(untimed):
                 g.replay()
