@@ -156,10 +156,10 @@ static void build_pair_table(DefsSet &s) {
 }
 
 // BYTE image (hrx_lane.h) of def 0 from its dense 4-byte table and its (state, next) -> tag matrix.
-// The tags go into a 4096-slot table addressed by an ARITHMETIC perfect hash of the pair: slot = (state * A + next * B) & 4095
+// The tags go into a table of 256 .. 4096 two-byte slots addressed by an ARITHMETIC perfect hash of the pair: slot = (state * A + next * B) & (slots - 1)
 // with (A, B) searched so that no two tagged pairs share a slot; a lookup reads the slot of ANY pair and takes the tag only if
-// the slot's key is the pair.  No (A, B) within the search budget (hundreds of tagged pairs): no BYTE image — the HALF table
-// serves the def.
+// the slot's key is the pair's next state (A is odd and slots >= 256: slot and next determine the state).  Substr ids of 64 and more (a slot has 6 bits for the id), or no (A, B) within the search budget (hundreds of
+// tagged pairs): no BYTE image — the HALF table or the global table serves the def.
 static void build_byte_table(DefsSet &s) {
     s.byte = ByteTable();
     if (s.defs.size() != 1) return;
@@ -176,30 +176,36 @@ static void build_byte_table(DefsSet &s) {
     b.dead = total ? kByteNoDead : S;
     const std::vector<uint16_t> &pt = s.pair_tags[0];   // [(L+1)^2]
     std::vector<uint32_t> keys;                          // state << 8 | next of every tagged pair
+    bool narrow_ids = true;                              // a slot has 6 bits for the substr id (like the HALF entry)
     for (uint32_t cur = 0; cur < S; ++cur)
         for (uint32_t nx = 0; nx < S; ++nx)
-            if (pt[(size_t)cur * S + nx]) keys.push_back(cur << 8 | nx);
+            if (pt[(size_t)cur * S + nx]) { keys.push_back(cur << 8 | nx); narrow_ids = narrow_ids && (pt[(size_t)cur * S + nx] & 0xffu) < 64u; }
+    if (!narrow_ids) return;
+    // the smallest table (256 .. kByteSlots slots) that is at most a quarter full and has a collision-free (A, B) within the budget
     std::vector<uint32_t> seen(kByteSlots, 0xffffffffu);
-    uint32_t A = 0, B = 0, stamp = 0;
-    bool found = keys.empty();
-    if (found) { A = 1; B = 1; }
-    // deterministic search: odd B, any A, in a fixed pseudo-random order
-    uint64_t x = 0x9e3779b97f4a7c15ull;
-    for (uint32_t tries = 0; !found && tries < 200000; ++tries, ++stamp) {
-        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-        const uint32_t a = (uint32_t)(x >> 20) & 0xfffu, bb = ((uint32_t)(x >> 40) & 0xfffu) | 1u;
-        bool ok = true;
-        for (uint32_t k : keys) {
-            const uint32_t slot = ((k >> 8) * a + (k & 0xffu) * bb) & (kByteSlots - 1);
-            if (seen[slot] == stamp) { ok = false; break; }
-            seen[slot] = stamp;
+    uint32_t A = 0, B = 0, stamp = 0, slots = 0;
+    bool found = false;
+    for (uint32_t ns = kByteMinSlots; ns <= kByteSlots && !found; ns <<= 1) {
+        if (ns < kByteSlots && keys.size() * 4 > ns) continue;
+        if (keys.empty()) { A = 1; B = 1; slots = ns; found = true; break; }
+        // deterministic search: odd A (so that slot and next determine the state: a slot's key is the next state alone), odd B, in a fixed pseudo-random order
+        uint64_t x = 0x9e3779b97f4a7c15ull;
+        for (uint32_t tries = 0; !found && tries < (ns < kByteSlots ? 20000u : 200000u); ++tries, ++stamp) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            const uint32_t a = ((uint32_t)(x >> 20) & 0xfffu) | 1u, bb = ((uint32_t)(x >> 40) & 0xfffu) | 1u;
+            bool ok = true;
+            for (uint32_t k : keys) {
+                const uint32_t slot = ((k >> 8) * a + (k & 0xffu) * bb) & (ns - 1);
+                if (seen[slot] == stamp) { ok = false; break; }
+                seen[slot] = stamp;
+            }
+            if (ok) { A = a; B = bb; slots = ns; found = true; }
         }
-        if (ok) { A = a; B = bb; found = true; }
     }
     if (!found) return;
-    b.mul_a = A; b.mul_b = B;
-    b.ptab_off = (rows * 256 + kByteSlots * 4 - 1) & ~(kByteSlots * 4 - 1);   // 16-KiB aligned: slot address = (hash & 0x3ffc) | ptab_off, one v_and_or_b32
-    b.bytes = b.ptab_off + kByteSlots * 4;
+    b.mul_a = A; b.mul_b = B; b.slots = slots;
+    b.ptab_off = (rows * 256 + slots * 2 - 1) & ~(slots * 2 - 1);   // aligned to its size: slot address = (hash & (slots - 1) * 2) | ptab_off, one v_and_or_b32
+    b.bytes = b.ptab_off + slots * 2;
     b.image.assign(b.bytes, 0);
     for (uint32_t st = 0; st < rows; ++st)
         for (int ch = 0; ch < 256; ++ch) {
@@ -210,10 +216,13 @@ static void build_byte_table(DefsSet &s) {
             }
             b.image[(size_t)st * 256 + ch] = (uint8_t)nx;   // (total: every entry is a real state; partial: dead = S <= 255)
         }
-    std::vector<uint32_t> slot(kByteSlots, 0xffffu);      // key 0xffff: empty (no pair has state 0xff AND next 0xff tagged... see below)
-    for (uint32_t k : keys) slot[((k >> 8) * A + (k & 0xffu) * B) & (kByteSlots - 1)] = k | (uint32_t)pt[(size_t)(k >> 8) * S + (k & 0xffu)] << 16;
-    // an empty slot must not look like the pair (0xff, 0xff): give empty slots the tag 0 (already) — a key match then yields tag 0, which is what an untagged pair has
-    std::memcpy(&b.image[b.ptab_off], slot.data(), (size_t)kByteSlots * 4);
+    // slot: next | substr id << 8 | is_start << 14 | is_end << 15.  An empty slot is 0: whatever pair reads it gets tag 0 — what an untagged pair has.
+    std::vector<uint16_t> slot(slots, 0);
+    for (uint32_t k : keys) {
+        const uint32_t t = pt[(size_t)(k >> 8) * S + (k & 0xffu)];     // 10-bit tag: id | is_start << 8 | is_end << 9
+        slot[((k >> 8) * A + (k & 0xffu) * B) & (slots - 1)] = (uint16_t)((k & 0xffu) | (t & 0x3fu) << 8 | (t >> 8) << 14);
+    }
+    std::memcpy(&b.image[b.ptab_off], slot.data(), (size_t)slots * 2);
     s.byte = std::move(b);
 }
 

@@ -73,8 +73,9 @@ struct PairTable {
 struct ByteTable {
     uint32_t n_rows = 0;      // real states (+ one absorbing dead row if the DFA is partial)
     uint32_t dead = 0x100;    // row number of the dead row; 0x100: the DFA is total, there is none
-    uint32_t ptab_off = 0;    // LDS byte offset of u32 ptab[kByteSlots]: low 16 bits the pair state << 8 | next (0xffff: empty), high 16 bits its 10-bit tag
-    uint32_t mul_a = 0, mul_b = 0;   // slot of pair (state, next) = (state * mul_a + next * mul_b) & (kByteSlots - 1): collision-free over the tagged pairs
+    uint32_t slots = 0;       // pair-tag slots: a power of two, kByteMinSlots .. kByteSlots
+    uint32_t ptab_off = 0;    // LDS byte offset of u16 ptab[slots] (aligned to its size): next | substr id << 8 | is_start << 14 | is_end << 15 (0: empty)
+    uint32_t mul_a = 0, mul_b = 0;   // slot of pair (state, next) = (state * mul_a + next * mul_b) & (slots - 1), mul_a odd: collision-free over the tagged pairs
     uint32_t bytes = 0;       // size of the LDS image, a multiple of 16
     std::vector<uint8_t> image;
 };

@@ -234,6 +234,26 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         }
         return false;
     }
+    // ---- walker/storer kernel on the BYTE table: string-major outputs of one def of up to 256 states whose 4-byte table does not fit
+    // LDS (cfg 5; it used to take the position-major kernel + a transpose launch: 0.23 of peak)
+    if (!(a.layout & 1u) && a.D == 1 && a.M % 8u == 0 && a.byte_image && out.gtab && !(a.debug & (kDbgNoByte | kDbgForceHalf | kDbgForceGlobalTable | kDbgForceOneWave))) {
+        const size_t slot = 64 * 128 + 64 * 8 + 64 * 32, fixed = 16 + 256;
+        int pairs = 4;
+        while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        for (; pairs >= 1; --pairs) {
+            if (a.byte_bytes + pairs * (2 * slot + fixed) > kLdsLimit) continue;
+            size_t ns = (kLdsLimit - a.byte_bytes - pairs * fixed) / (pairs * slot);
+            if (ns > 4) ns = 4;
+            out.split = 1; out.gtab = 0; out.byte = 1;
+            out.waves_per_wg = 2 * pairs;
+            out.nslots = (int)ns;
+            out.lds_bytes = a.byte_bytes + pairs * (ns * slot + fixed);
+            const size_t need = ((size_t)a.n_groups + pairs - 1) / pairs;
+            out.grid = (int)(need < (size_t)num_cus ? need : (size_t)num_cus);
+            if (out.grid < 1) out.grid = 1;
+            return true;
+        }
+    }
     // ---- walker/storer kernel: D in {1,2}, rows in multiples of 8, ring of >= 2 slots per pair
     if ((a.D == 1 || a.D == 2) && a.M % 8u == 0 && !(a.debug & kDbgForceOneWave) && !out.gtab) {
         const size_t slot = 64 * 128 + 64 * 8 + 64 * (a.D == 1 ? 32 : 16), fixed = 16 + 256;  // + the storer's LDS-DMA sink

@@ -117,6 +117,73 @@ __device__ __forceinline__ TileBits walk_tile(LaneRegs<D> &L, const uint4 (&cq)[
     return tb;
 }
 
+// BYTE table walk (hrx_lane.h, hrx_walk_pm.h walk_tile_pm_byte): a DFA of up to 256 states whose 4-byte table does not fit LDS (cfg 5)
+// under the walker/storer kernel.  Chain: ds_read_u8 next[state << 8 | byte]; off the chain, one row later, the pair's slot of the
+// perfect-hash tag table; the record and the three bitvector bits of row p - 2 are built in the shadow of both.  L.e[0] is the STATE
+// here (not a table entry), L.mx[0] the largest state reached by a real transition (the dead row is the highest).
+typedef __attribute__((address_space(3))) const uint8_t lds_cbyte;
+__device__ __forceinline__ uint32_t lds_byte(uint32_t off) { return *(lds_cbyte *)(uintptr_t)off; }
+typedef __attribute__((address_space(3))) const uint16_t lds_chalf;
+__device__ __forceinline__ uint32_t lds_half(uint32_t off) { return *(lds_chalf *)(uintptr_t)off; }
+
+template <bool FULL, int T, class Chunks>
+__device__ __forceinline__ TileBits walk_tile_byte(LaneRegs<1> &L, const uint4 (&cq)[T / 16], const WitnessArgs &a, const Chunks &chunk, int rem, int mrem) {
+    uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
+    uint32_t rbuf[4];
+    uint32_t cw[T / 4];
+#pragma unroll
+    for (int i = 0; i < T / 16; ++i) { cw[4 * i] = cq[i].x; cw[4 * i + 1] = cq[i].y; cw[4 * i + 2] = cq[i].z; cw[4 * i + 3] = cq[i].w; }
+    const uint32_t A2 = a.byte_mul_a2, B2 = a.byte_mul_b2, ptab = a.byte_ptab_off, smask = a.byte_slot_mask2;
+    uint32_t cur = L.e[0];                  // state at the row whose chain lookup is issued next
+    uint32_t s1 = 0, n1 = 0;                // row p - 1: its state and its next state
+    uint32_t k2 = 0, pe2 = 0;               // row p - 2: its pair (state << 8 | next) and its pair slot
+
+    auto post = [&](const int p, const uint32_t key, const uint32_t pe) {
+        uint32_t state = key >> 8;
+        uint32_t tag = ((pe ^ key) & 0xffu) == 0u ? ((pe >> 8) & 0x3fu) | (pe >> 14) << 8 : 0u;   // the slot's key is this pair's next state: (state, next) is tagged
+        if (!FULL) {
+            if (p >= rem) tag = 0;                                   // padding rows: their lookups ran on stand-in states (lib.rs:404-418)
+            if (p > rem) state = a.dc[0].dummy_state;                // lib.rs:413
+            if (p >= mrem) tag &= ~kTagEnd;
+        }
+        rbuf[p & 3] = state | (tag << 16);
+        if ((p & 3) == 3) *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)chunk(p >> 2) = v4u32{rbuf[0], rbuf[1], rbuf[2], rbuf[3]};
+        const uint32_t sid = tag & 0xffu;
+        st[p >> 5] |= ((tag >> 8) & 1u) << (p & 31);
+        en1[p >> 5] |= ((tag >> 9) & 1u) << (p & 31);
+        ch[p >> 5] |= (sid != L.sid_prev ? 1u : 0u) << (p & 31);
+        L.sid_prev = sid;
+    };
+#pragma unroll
+    for (int p = 0; p < T + 2; ++p) {
+        uint32_t raw_n = 0, raw_pe = 0;
+        if (p < T) {
+            const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
+            raw_n = lds_byte((cur << 8) | c);                        // delta(state, byte): lib.rs:810
+        }
+        if (p >= 1 && p < T + 1) raw_pe = lds_half(((__umul24(s1, A2) + __umul24(n1, B2)) & smask) | ptab);
+        if (p >= 2) {
+            post(p - 2, k2, pe2);
+            asm volatile("" : "+v"(st[(p - 2) >> 5]), "+v"(en1[(p - 2) >> 5]), "+v"(ch[(p - 2) >> 5]), "+v"(L.sid_prev));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        k2 = (s1 << 8) | n1; pe2 = raw_pe;
+        if (p < T) {
+            const uint32_t nxt = (FULL || p < rem) ? raw_n : 0u;    // rows >= n: any valid row; post() writes the dummy state and no tag
+            L.mx[0] = max(L.mx[0], nxt);                              // reaching the dead row = an undefined transition (lib.rs:817)
+            asm volatile("" : "+v"(L.mx[0]));
+            s1 = cur; n1 = nxt;
+            cur = nxt;
+        }
+    }
+    L.e[0] = cur;
+    TileBits tb;
+    tb.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
+    tb.en1 = (uint64_t)en1[0] | ((uint64_t)en1[1] << 32);
+    tb.ch = (uint64_t)ch[0] | ((uint64_t)ch[1] << 32);
+    return tb;
+}
+
 // 64 bytes of this lane's string, 16 B per load.  The loads are unconditional (no exec-masked merge that would
 // force an early s_waitcnt): chunks that start at or beyond byte n are redirected to the string's last valid
 // chunk (`last`), so nothing outside [0, stride) of the lane's own string is ever read; bytes >= n are never
@@ -462,9 +529,13 @@ struct SplitGeom {
     static constexpr uint32_t kSlotBytes = kSlotChr + 64u * T;
     static constexpr uint32_t kPairFixed = 16u;                  // prod / cons
 };
-template <int D, int T>
+// BYTE: the 1-byte next-state table + perfect-hash pair tags (hrx_lane.h) instead of the 4-byte fused table: one def of up to 256 states
+// whose 4-byte table does not fit LDS (cfg 5) — its string-major outputs used to take the position-major kernel + a transpose launch.
+template <int D, int T, bool BYTE = false>
 __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a, const uint32_t nslots) {
+    static_assert(!BYTE || D == 1, "the BYTE table serves one def");
     using G = SplitGeom<D, T>;
+    const uint32_t tab_bytes = BYTE ? a.byte_bytes : a.table_bytes;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t pairs = blockDim.x >> 7;  // walker waves 0..pairs-1, storer waves pairs..2*pairs-1
@@ -473,13 +544,13 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
     const uint32_t pair_bytes = nslots * G::kSlotBytes + G::kPairFixed;
-    const uint32_t ring_base = a.table_bytes + pair * pair_bytes;
+    const uint32_t ring_base = tab_bytes + pair * pair_bytes;
     const uint32_t prod_off = ring_base + nslots * G::kSlotBytes, cons_off = prod_off + 4u;
-    const uint32_t scratch_off = a.table_bytes + pairs * pair_bytes + pair * 256u;  // 256 B per storer: LDS-DMA sink
+    const uint32_t scratch_off = tab_bytes + pairs * pair_bytes + pair * 256u;  // 256 B per storer: LDS-DMA sink
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
+        const uint4 *src = BYTE ? reinterpret_cast<const uint4 *>(a.byte_image) : reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) dst[i] = src[i];
         if (is_walker && lane == 0) { lds_store_u32(prod_off, 0); lds_store_u32(cons_off, 0); }
     }
     __syncthreads();
@@ -505,7 +576,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
             LaneRegs<D> L;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                L.e[d] = a.dc[d].first_entry;  // states[d][0] = first_state_val: lib.rs:807
+                L.e[d] = BYTE ? a.dc[d].first_state : a.dc[d].first_entry;  // states[d][0] = first_state_val: lib.rs:807
                 L.mx[d] = 0;
             }
             L.sid_prev = 0;
@@ -548,6 +619,10 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 const bool full = (t0 + T < min_n);
                 if (a.debug & kDbgSplitNoWalk) {
                     // profiling only: no walk, the storer moves whatever the slot holds
+                } else if constexpr (BYTE) {
+                    const uint4 (&cqt)[CPT] = reinterpret_cast<const uint4 (&)[CPT]>(act);
+                    if (full) tb = walk_tile_byte<true, T>(L, cqt, a, chunks, 0, 0);
+                    else tb = walk_tile_byte<false, T>(L, cqt, a, chunks, (int)n - (int)t0, (int)M - 1 - (int)t0);
                 } else if (full)
                     tb = walk_tile<D, true, T>(L, act, a, chunks, 0, 0, t0);
                 else
@@ -558,16 +633,16 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 uint32_t newly = 0;
 #pragma unroll
                 for (int d = 0; d < D; ++d)
-                    if (!((dead >> d) & 1u) && L.mx[d] >= a.dc[d].dead_entry) newly |= 1u << d;
+                    if (!((dead >> d) & 1u) && (BYTE ? L.mx[d] >= a.byte_dead : L.mx[d] >= a.dc[d].dead_entry)) newly |= 1u << d;
                 if (__any(newly != 0)) {
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
                         if ((newly >> d) & 1u) {
-                            const uint32_t dead_state = a.dc[d].n_rows - 1u;
+                            const uint32_t dead_state = BYTE ? a.byte_dead : a.dc[d].n_rows - 1u;
                             for (uint32_t p = 0; p < (uint32_t)T; ++p) {
                                 const uint32_t s_p = lds_u32(rec_addr(p * D + d)) & 0xffffu;
                                 const uint32_t s_n = (p + 1u < (uint32_t)T) ? (lds_u32(rec_addr((p + 1u) * D + d)) & 0xffffu)
-                                                                            : ((L.e[d] >> kNextShift) - a.dc[d].row_base);
+                                                                            : BYTE ? L.e[d] : ((L.e[d] >> kNextShift) - a.dc[d].row_base);
                                 if (s_n == dead_state && s_p != dead_state) {
                                     err_pos[d] = t0 + p;
                                     err_state[d] = s_p;
@@ -590,7 +665,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                         accept = 0;
 #pragma unroll
                         for (int d = 0; d < D; ++d)
-                            accept |= (((L.e[d] >> kNextShift) - a.dc[d].row_base) == a.dc[d].accepted_state ? 1u : 0u) << d;
+                            accept |= ((BYTE ? L.e[d] : (L.e[d] >> kNextShift) - a.dc[d].row_base) == a.dc[d].accepted_state ? 1u : 0u) << d;
                     }
                 }
                 // ---------------- reveal masks: lib.rs:598-764 ----------------
@@ -777,9 +852,9 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
     }
 }
 
-template <int D, int T>
+template <int D, int T, bool BYTE = false>
 static hipError_t launch_split(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto k = witness_split_kernel<D, T>;
+    auto k = witness_split_kernel<D, T, BYTE>;
     static std::atomic<size_t> granted[64];  // per device: the attribute is set on the current device's function
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -802,7 +877,7 @@ static hipError_t launch_t(const WitnessArgs &a, const LaunchInfo &li, hipStream
 }
 
 hipError_t launch_witness_sm(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    if (li.split) return a.D == 1 ? launch_split<1, 32>(a, li, stream) : launch_split<2, 16>(a, li, stream);
+    if (li.split) return li.byte ? launch_split<1, 32, true>(a, li, stream) : a.D == 1 ? launch_split<1, 32>(a, li, stream) : launch_split<2, 16>(a, li, stream);
     const bool al = (a.M % 8u) == 0;
     if (li.gtab) {
         switch (a.D) {

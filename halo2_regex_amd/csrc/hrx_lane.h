@@ -63,13 +63,13 @@ HRX_HD uint32_t half_image_bytes(uint32_t rows) { return kHalfUpperBase + rows *
 // walker spending 46 % of its cycles in the tile-end work (reveal masks, held rows, repairs, masked-row stores).  Here the
 // dependent chain reads a 1-byte next-state table — entry (row, c) at LDS byte address row << 8 | c, 64 KiB for 256 rows, one
 // v_lshl_or_b32 + one ds_read_u8 per row — and the substring tag of a row, which is a function of the PAIR (state, next)
-// (lib.rs:831-840, 861-866, 874-879), comes off the chain from a perfect-hash table: 4096 u32 slots {state << 8 | next (0xffff:
-// empty), tag << 16} at slot (state * A + next * B) & 4095, with (A, B) searched at finalize time so that the tagged pairs do
-// not collide; the tag counts only if the slot's key is the row's pair.  One more LDS read per row (a row-displacement table
+// (lib.rs:831-840, 861-866, 874-879), comes off the chain from a perfect-hash table: 256 .. 4096 u16 slots {next, substr id << 8,
+// is_start << 14, is_end << 15} at slot (state * A + next * B) & (slots - 1), with (A, B) searched at finalize time so that the tagged
+// pairs do not collide; the tag counts only if the slot's key is the row's next state (A odd: slot and next determine the state).  One more LDS read per row (a row-displacement table
 // with its u16 disp[state] took two: 162 cycles per row against the HALF walk's 113), software-pipelined two rows deep, not on
 // the chain.  Rows: the real states, then one absorbing dead row if the DFA is partial (lib.rs:817).
 constexpr uint32_t kByteNoDead = 0x100u;
-constexpr uint32_t kByteSlots = 4096u;
+constexpr uint32_t kByteSlots = 4096u, kByteMinSlots = 256u;   // most / fewest pair-tag slots
 
 // PAIR table (position-major kernel hrx_kernel_pp.hip; one def, at most kPairMaxClasses byte-equivalence classes): one
 // dependent lookup per TWO input bytes.  Bytes are mapped to classes first (class LUT, value = class * 8); block s holds

@@ -186,7 +186,7 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
 // ---------------------------------------------------------------------------------------------
 // BYTE-table walk (hrx_lane.h; one def).  Per row two LDS reads, neither of which waits for the other:
 //   iteration p:  next-state byte of row p  (the dependent chain: address = state << 8 | byte),
-//                 pair slot of row p - 1    (address ((state * A4 + next * B4) & 0x3ffc) | ptab_off, both known since the previous iteration),
+//                 pair slot of row p - 1    (address ((state * A2 + next * B2) & (slots - 1) * 2) | ptab_off, both known since the previous iteration),
 //   and in their shadow the record / flag / id work of row p - 2, whose slot arrived an iteration ago.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
@@ -199,14 +199,14 @@ __device__ __forceinline__ TileBits walk_tile_pm_byte(LaneRegs<1> &L, const uint
     uint32_t rbuf[4];
     const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                              cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
-    const uint32_t A4 = a.byte_mul_a4, B4 = a.byte_mul_b4, ptab = a.byte_ptab_off;
+    const uint32_t A2 = a.byte_mul_a2, B2 = a.byte_mul_b2, ptab = a.byte_ptab_off, smask = a.byte_slot_mask2;
     uint32_t cur = L.e[0];                  // state at the row whose chain lookup is issued next
     uint32_t s1 = 0, n1 = 0;                // row p - 1: its state and its next state
-    uint32_t k2 = 0, pe2 = 0xffffu;         // row p - 2: its pair key (state << 8 | next) and its pair slot
+    uint32_t k2 = 0, pe2 = 0;               // row p - 2: its pair (state << 8 | next) and its pair slot
 
     auto post = [&](const int p, const uint32_t key, const uint32_t pe) {
         uint32_t state = key >> 8;
-        uint32_t tag = ((pe & 0xffffu) == key) ? (pe >> 16) : 0u;   // the slot holds this pair: (state, next) is tagged
+        uint32_t tag = ((pe ^ key) & 0xffu) == 0u ? ((pe >> 8) & 0x3fu) | (pe >> 14) << 8 : 0u;   // the slot's key is this pair's next state: (state, next) is tagged
         if (!FULL) {
             if (p >= rem) tag = 0;                                   // padding rows: their lookups ran on stand-in states (lib.rs:404-418)
             if (p > rem) state = a.dc[0].dummy_state;                // lib.rs:413
@@ -227,12 +227,12 @@ __device__ __forceinline__ TileBits walk_tile_pm_byte(LaneRegs<1> &L, const uint
     for (int i = 0; i < 16; ++i) sidq[i] = 0;
 #pragma unroll
     for (int p = 0; p < 66; ++p) {
-        uint32_t raw_n = 0, raw_pe = 0xffffu;
+        uint32_t raw_n = 0, raw_pe = 0;
         if (p < 64) {
             const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
             raw_n = lds_u8((cur << 8) | c);                          // delta(state, byte): lib.rs:810
         }
-        if (p >= 1 && p < 65) raw_pe = lds_u32(((__umul24(s1, A4) + __umul24(n1, B4)) & ((kByteSlots - 1u) << 2)) | ptab);
+        if (p >= 1 && p < 65) raw_pe = lds_u16(((__umul24(s1, A2) + __umul24(n1, B2)) & smask) | ptab);
         if (p >= 2) {
             post(p - 2, k2, pe2);
             asm volatile("" : "+v"(st[(p - 2) >> 5]), "+v"(en1[(p - 2) >> 5]), "+v"(ch[(p - 2) >> 5]), "+v"(L.sid_prev));

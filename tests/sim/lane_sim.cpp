@@ -168,21 +168,21 @@ long sim_check_half_image(void *p) {
 }
 
 // BYTE image (1-byte next states + the pair tags in a perfect-hash table, hrx_lane.h) against the 4-byte fused table: every
-// (state, byte) — the kernel's lookups restated: next = image[state << 8 | byte], slot = ptab[(state * A + next * B) & 4095],
-// tag = slot.key == (state << 8 | next) ? slot.tag : 0.  Returns the number of entries compared, -1 without a BYTE image, -2 - index on a mismatch.
+// (state, byte) — the kernel's lookups restated: next = image[state << 8 | byte], slot = ptab[(state * A + next * B) & (slots - 1)],
+// tag = slot.next == next ? slot.tag : 0.  Returns the number of entries compared, -1 without a BYTE image, -2 - index on a mismatch.
 long sim_check_byte_image(void *p) {
     const DefsSet &s = *(DefsSet *)p;
     if (s.byte.image.empty()) return -1;
     const DefConsts &c = s.consts[0];
     const ByteTable &b = s.byte;
-    if (b.ptab_off % (kByteSlots * 4) || b.ptab_off + kByteSlots * 4 != b.bytes) return -2;
+    if (b.slots < kByteMinSlots || b.slots > kByteSlots || (b.slots & (b.slots - 1)) || b.ptab_off % (b.slots * 2) || b.ptab_off + b.slots * 2 != b.bytes || !(b.mul_a & 1u)) return -2;
     long n = 0;
     for (uint32_t st = 0; st < b.n_rows; ++st)
         for (uint32_t ch = 0; ch < 256; ++ch, ++n) {
             const uint32_t nx = b.image[(size_t)st << 8 | ch];
-            uint32_t slot;
-            std::memcpy(&slot, &b.image[b.ptab_off + (((st * b.mul_a + nx * b.mul_b) & (kByteSlots - 1)) << 2)], 4);
-            const uint32_t tag = (slot & 0xffffu) == (st << 8 | nx) ? slot >> 16 : 0u;
+            uint16_t slot;
+            std::memcpy(&slot, &b.image[b.ptab_off + (((st * b.mul_a + nx * b.mul_b) & (b.slots - 1)) << 1)], 2);
+            const uint32_t tag = (slot & 0xffu) == nx ? ((slot >> 8) & 0x3fu) | (uint32_t)(slot >> 14) << 8 : 0u;
             if (st == b.dead) {                                   // the absorbing dead row (partial DFAs only)
                 if (nx != b.dead || tag) return -2 - n;
                 continue;

@@ -155,9 +155,14 @@ def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     d = cfg.describe_launch(65536, layout=3)
     assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8 ") and "lds=%d" % (128 * 1024 + 4 * (4096 + 128)) in d
     monkeypatch.delenv("HRX_DEBUG_FLAGS")
-    # string-major outputs: the same position-major kernel into context scratch + the transpose kernel (rows in multiples of 8; else the one-wave global-table walk)
+    # string-major outputs: the walker/storer kernel on the BYTE table (rows in multiples of 8; else the one-wave global-table walk) ...
     d = cfg.describe_launch(65536, layout=0)
-    assert d.startswith("hrx::witness_pm_kernel<1, false, false, false, false, true> ") and d.endswith("+ hrx::transpose_pm_to_sm_kernel")
+    assert d.startswith("hrx::witness_split_kernel<1, 32, true> grid=256 waves=8 ring=2 ")
+    # ... without a BYTE image: the HALF-table position-major kernel into context scratch + the transpose kernel
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", str(0x8000))
+    d = cfg.describe_launch(65536, layout=0)
+    assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> ") and d.endswith("+ hrx::transpose_pm_to_sm_kernel")
+    monkeypatch.delenv("HRX_DEBUG_FLAGS")
     assert RegexVerifyConfig.configure(4097, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None).describe_launch(65536, layout=0).startswith("hrx::witness_kernel<1, false, true> ")
     # beyond 256 states there is no HALF image: global-table walk
     a_txt, sub_txt = synth.random_dfa(300, seed=2)
