@@ -671,6 +671,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 // ---------------- reveal masks: lib.rs:598-764 ----------------
                 TileMasks tm = tile_masks<T>(tb, mc, t0, tile_is_exact(t0, n, M, T), rows_below(t0, n));
                 if (!active) { tm.mask = 0; tm.fix = 0; }
+                if (a.debug & kDbgSkipFixups) tm.fix = 0;  // profiling only
                 *(__attribute__((address_space(3))) v2u32 *)(uintptr_t)(slot + G::kSlotHdr + lane * 8u) =
                     v2u32{(uint32_t)tm.mask, tm.fix ? tm.fix_start : kNoFix};
                 if (__any(tm.mask != 0)) {
