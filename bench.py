@@ -45,7 +45,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=["regex1", "regex23", "regex123", "headers3", "headers5", "dfa256"], default="regex1",
                     help="regex1: BASELINE configs[1] (the metric's workload); regex23: configs[2] shape (D=2); regex123: D=3 with the "
                     "reference's three DFAs; headers3: configs[3] shape (D=3 from/to/subject header definitions, 5 substrs); dfa256: configs[4] shape (synthetic total 256-state DFA over all 256 byte values)")
-    ap.add_argument("--untimed-replays", type=int, default=0, help="untimed replays of the K-step graph before the timed one (default: ~1000 launches)")
+    ap.add_argument("--untimed-replays", type=int, default=0, help="untimed replays of the K-step graph before the timed one (default: ~100 ms of them)")
     ap.add_argument("--substr-pairs", type=int, default=200, help="dfa256: transitions in the random substring definition")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed buffers with the oracle")
@@ -415,12 +415,14 @@ def run_rank(args, rank, world, device_index, barrier):
     if not args.eager:
         g = graph_of(launch, args.steps)
         if g is not None:
-            # untimed replays of the same graph, ~1000 launches (80 ms): graph upload, and the device's own ramp — with 100 launches (8 ms)
+            # untimed replays of the same graph, ~100 ms of them (1300 launches of the bench line): graph upload, and the device's own ramp — with 100 launches (8 ms)
             # behind it a 20-step replay averaged 80.0 us per launch, with 1000 launches 77.9, and from K = 100 on the count no longer matters
             # (profiles/r03_probes/warmup_ramp.txt; a kernel trace shows the launches of a replay that follows a pause taking 92 -> 84 us over
             # its first twenty, profiles/r03_pm_trace_replays.txt); W = 5 eager steps do not cover that
-            untimed = args.untimed_replays if args.untimed_replays > 0 else max(2, -(-1000 // args.steps))
-            for _ in range(untimed):
+            g.replay(); torch.cuda.synchronize()            # (upload)
+            tr = time.perf_counter(); g.replay(); torch.cuda.synchronize(); tr = max(time.perf_counter() - tr, 1e-5)
+            untimed = args.untimed_replays if args.untimed_replays > 0 else max(2, min(1000, int(0.1 / tr) + 1))    # ~100 ms of load
+            for _ in range(untimed - 2):
                 g.replay()
             torch.cuda.synchronize()
             run_steps, launch_mode = g.replay, "hipGraph of %d kernel nodes (after %d untimed replays of it)" % (args.steps, untimed)
