@@ -894,7 +894,7 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     std::vector<void *> spacers;       // rejected candidates: they are what pushes the next candidate further down
     void *best = nullptr;
     size_t spent = 0;
-    double best_us = -1.0, best_rate = 0.0;
+    double best_us = -1.0, best_rate = 0.0, worst_rate = 0.0;
     for (int i = 0; i < ctx->place_max_steps && spent + cand_bytes <= budget; ++i) {
         void *cand = nullptr;
         if (hipMalloc(&cand, cand_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
@@ -909,11 +909,19 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
         void *loser = better ? best : cand;
         if (better) { best = cand; best_us = us; best_rate = rate; rep.chosen_step = i; }
         if (loser) spacers.push_back(loser);
-        // accepted: clearly above the same-block reference AND close to the best pairing this context has ever measured (a later
-        // buffer set whose own reference is slow — 4.3-5.1 TB/s seen — would otherwise stop at a first candidate 15 % below the pairing
-        // the first set found: cfg 5, 0.365 -> 0.417 ms per step on such a box)
+        if (rate > 0 && (worst_rate == 0.0 || rate < worst_rate)) worst_rate = rate;
         ctx->place_seen_rate = std::max(ctx->place_seen_rate, rate);
-        if (rate > 0 && ref_rate > 0 && rate >= kPlaceMargin * ref_rate && rate >= kPlaceNearBest * ctx->place_seen_rate) { rep.accepted = 1; break; }
+        // Candidates come in two kinds — pairings that collide (5.7-6.1 TB/s on the probe) and clear ones (7.0-7.2), about one in eight.
+        // The walk ends when the fastest candidate so far is clearly (>= 10 %) above BOTH the same-block reference and the slowest
+        // candidate seen — at least two candidates, so that a reference that happens to be slow (4.3-5.1 TB/s seen) cannot wave a
+        // colliding first candidate through — and within 7 % of the best pairing any walk of this context has measured (a later
+        // buffer set must not settle for less than the first one found: cfg 5, 0.365 -> 0.417 ms per step on such a box).
+        if (i >= 1 && best_rate > 0 && ref_rate > 0 && best_rate >= kPlaceMargin * std::max(ref_rate, worst_rate) && best_rate >= kPlaceNearBest * ctx->place_seen_rate) {
+            rep.accepted = 1;
+            break;
+        }
+        // no two kinds on this box / for this pair of sizes: ten candidates within 5 % of each other — the fastest will do
+        if (i >= 9 && worst_rate > 0 && best_rate < 1.05 * worst_rate) { rep.accepted = best_rate >= kPlaceMargin * ref_rate ? 1 : 0; break; }
     }
     for (void *p : spacers) (void)hipFree(p);
     rep.best_us = best_us;
