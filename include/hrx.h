@@ -208,12 +208,13 @@ typedef struct hrx_place_report {
     int searched;                /* 0: two plain allocations (small buffers, HRX_PLACE=0, or no memory to walk with); 1: this call walked;
                                     2: served from the arena pair an earlier call measured (the numbers below are that walk's) */
     int steps;                   /* candidates measured */
-    int accepted;                /* 1: the kept candidate beat the same-neighbourhood reference by the margin; 0: the fastest measured */
+    int accepted;                /* 1: the kept candidate is >= 10 % above both the same-neighbourhood reference and the slowest candidate of the
+                                    walk (and within 7 % of the best pairing the context has measured); 0: simply the fastest measured */
     int chosen_step;
     double ref_us;               /* the reference: both probe streams inside one neighbourhood (device clock) */
     double first_us, best_us;    /* the first candidate (what two plain allocations would have been) and the kept one */
     double ref_gbs, first_gbs, best_gbs;   /* the same three as bytes written per time (GB/s): what acceptance compares — the reference pass
-                                    writes fewer bytes than a candidate pass; accepted = best_gbs >= 1.10 ref_gbs */
+                                    writes fewer bytes than a candidate pass */
     size_t probe_bytes;          /* bytes one probe pass writes */
     size_t peak_candidate_bytes; /* most memory the walk held at once: rejected candidates stay allocated, as the spacers that push the
                                     next candidate further, until the walk ends */
