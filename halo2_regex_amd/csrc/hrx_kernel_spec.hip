@@ -11,10 +11,10 @@
 //            kSpecSlots) distinct survivors and which survivor each start state became, then walk only the survivors to the
 //            chunk's end; no rows are written — a chunk costs ~S x 32 + 2 x (chunk - 32) table lookups, several independent
 //            chains per lane.
-//   compose  one wave per (string, def), a chunk per lane: from first_state, chunk by chunk, the state at every chunk's first row
-//            (an evaluation of the chunk's scout row per chunk, all in registers) and the substr id / end flag of the transition
-//            into it.  A chunk whose start states did not merge into kSpecSlots survivors is walked here by the whole wave, a 64th
-//            of it per lane from every state — correct for any DFA, fast for forgetful ones.
+//   compose  a lane per string, one wave per (64 strings, def): from first_state, chunk by chunk, the state at every chunk's first row
+//            (an evaluation of the chunk's scout row, loaded four chunks ahead of the chain) and the substr id / end flag of the
+//            transition into it.  A chunk whose start states did not merge into kSpecSlots survivors is walked here by the whole
+//            wave, a 64th of it per lane from every state — correct for any DFA, fast for forgetful ones.
 //   walk     the ordinary loader / walker / finisher kernel (hrx_kernel_pm.hip) over chunks as virtual groups: B x C "strings"
 //            fill the chip, the launch is bound by the memory system again.  Rows are final except for what crosses a
 //            chunk's borders in the reveal-mask scans (lib.rs:598-714): a chunk assumes no open span at its first row
@@ -268,109 +268,149 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// compose: one WAVE per (string, def), lanes = chunks
+// compose: lane = string, one wave per (64 strings, def)
 // ---------------------------------------------------------------------------------------------
-// Lane l loads chunk l's row of the scout's scratch — all chunks at once: one memory round trip (a thread that walked the chunks one
-// after the other waited ~6 us per chunk for its row: 220 us for 32 chunks at D = 3).  Then the chain: the wave steps through the
-// chunks with the running state in a scalar; at step k every lane evaluates "where does this state end in MY chunk" on its own
-// row and lane k's answer is taken (v_readlane); lane k also remembers the state it was entered with.  No memory access on the
-// chain.  Finally every lane looks up the tag of the transition into its chunk and writes its init word.
-__global__ __launch_bounds__(256) void spec_compose_kernel(const SpecArgs a) {
-    if (blockIdx.x == 0u && threadIdx.x == 0u) a.work_count[0] = 0u;     // the repair list of this launch (stitch appends, repair reads): zeroed here, two launches ahead
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t pidx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (pidx >= a.B * a.D) return;
-    const uint32_t b = pidx % a.B, d = pidx / a.B;
-    const uint32_t Bpad = a.n_groups * 64u, rows = a.tiles_per_chunk * 64u, C = a.C;
-    const uint32_t S = a.n_states[d], base = a.dc[d].row_base;
-    const uint32_t n = min(a.lens[b], a.M);
-    const uint32_t dead = S + 1u;             // table rows: real states 0 .. S - 1, the dummy row S, the dead row S + 1
-    const bool small = a.smax <= 32u;
-    // ---- my chunk's row
-    const uint32_t kc = min(lane, C - 1u);
-    const uint8_t *rowp = a.rows + ((size_t)(kc * a.D + d) * Bpad + b) * a.row_bytes;
-    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-    if (small) {
-        c0 = *reinterpret_cast<const uint4 *>(rowp);
-        if (a.smax > 16u) c1 = *reinterpret_cast<const uint4 *>(rowp + 16);
+// The chain over a string's chunks: s[k + 1] = "where does s[k] end in chunk k", read off chunk k's scout row (64 bytes for DFAs of up
+// to 32 states: which key each start state became | keys | where each key ends).  A lane walks its own string; the rows do not depend
+// on the state, so they are loaded kAheadRows chunks ahead of the chain, and the (state, next) -> tag lookups of the init words trail
+// kAheadRows chunks behind it: no memory access waits on the chain.  (One wave per (string, def) with the chunks in its lanes paid
+// 64 lanes of VALU work for one useful answer per step: 31 us at D = 1, 81 us at D = 3 for 8192 strings.)
+// A chunk the scout gave up on is walked by the whole wave for the one lane that needs it (spec_walk_flagged below).
+constexpr uint32_t kAheadRows = 4;
+
+// chunk k of string b (def d): the wave walks it — lane l takes the chunk's l-th 64th from EVERY real state (four independent chains at
+// a time, table and bytes from L2), its map "entered in s -> left in" goes to LDS; then the true state runs through the 64 maps.
+// ~S x rows / 64 lookups per lane instead of a chain of `rows` dependent ones (200 us for 1024 rows).  All arguments wave-uniform.
+__device__ __forceinline__ void spec_walk_flagged(const SpecArgs &a, const uint32_t b, const uint32_t d, const uint32_t k, uint32_t &s, uint32_t &prev, const uint32_t lane, uint8_t *maps) {
+    const uint32_t S = a.n_states[d], base = a.dc[d].row_base, rows = a.tiles_per_chunk * 64u, r0 = k * rows;
+    const uint32_t *T = a.table_image + (size_t)base * 256u;
+    const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
+    const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(b - blk0) * 16u;
+    const uint32_t per = rows >> 6;
+    for (uint32_t s0 = 0; s0 < S; s0 += 4u) {
+        uint32_t e[4], em1[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) { e[j] = min(s0 + j, S - 1u); em1[j] = e[j]; }
+        for (uint32_t i = 0; i < per; ++i) {
+            const uint32_t r = r0 + lane * per + i;
+            const uint32_t c = cptr[(size_t)(r >> 4) * nb * 16u + (r & 15u)];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) { em1[j] = e[j]; e[j] = (T[e[j] * 256u + c] >> kNextShift) - base; }    // (the dead row S + 1 leads to itself)
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (s0 + j < S) {
+                maps[lane * a.smax + s0 + j] = (uint8_t)e[j];
+                if (lane == 63u) maps[64u * a.smax + s0 + j] = (uint8_t)em1[j];
+            }
+        }
     }
-    const uint4 q0 = *reinterpret_cast<const uint4 *>(rowp + a.smax), q1 = *reinterpret_cast<const uint4 *>(rowp + a.smax + 16);
-    const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    const uint32_t w[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
-    const uint32_t my_fail = q1.z;
-    // ---- the chain
-    uint32_t s = a.dc[d].first_state, prev = 0xffffffffu;     // wave-uniform
-    uint32_t my_s = 0, my_prev = 0xffffffffu;
-    for (uint32_t k = 0; k < C; ++k) {
-        if (lane == k) { my_s = s; my_prev = prev; }
-        const uint32_t r0 = k * rows;
-        if (r0 + rows > n) { prev = 0xffffffffu; continue; }   // the string ends in this chunk: every later chunk is padding (its start state is never looked at)
-        if (s >= S) { prev = s; continue; }                    // dead (an undefined transition further up, lib.rs:817): absorbing
-        const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)my_fail, (int)k);
-        if (!fl) {
-            uint32_t v;                                        // the state after stage A in MY chunk: one of its keys
-            if (small) {
-                uint32_t word = cw[0];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t l = 0; l < 64u && s < S; ++l) {
+        if (l == 63u) prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)maps[64u * a.smax + s]);
+        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)maps[l * a.smax + s]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// SMALL: at most 32 table rows per def — a chunk's "which key did start state s become" bytes ride in two registers (a run-time test here
+// put a wait for every outstanding load into each step)
+template <bool SMALL>
+__global__ __launch_bounds__(64) void spec_compose_kernel(const SpecArgs a) {
+    if (blockIdx.x == 0u && threadIdx.x == 0u) a.work_count[0] = 0u;     // the repair list of this launch (stitch appends, repair reads): zeroed here, two launches ahead
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g = blockIdx.x % a.n_groups, d = blockIdx.x / a.n_groups;
+    const uint32_t b = g * 64u + lane, bc = min(b, a.B - 1u);
+    const bool active = b < a.B;
+    const uint32_t Bpad = a.n_groups * 64u, rows = a.tiles_per_chunk * 64u, C = a.C;
+    const uint32_t S = a.n_states[d];
+    const uint32_t n = min(a.lens[bc], a.M);
+    const uint32_t dead = S + 1u;             // table rows: real states 0 .. S - 1, the dummy row S, the dead row S + 1
+    constexpr bool small = SMALL;
+    const size_t row_step = (size_t)a.D * Bpad * a.row_bytes;                      // chunk k + 1's row of the same (def, string)
+    const uint8_t *row0 = a.rows + ((size_t)d * Bpad + bc) * a.row_bytes;          // chunk 0's
+    struct Row { uint4 c0, c1, q0, q1; };
+    auto load_row = [&](const uint32_t k) -> Row {
+        const uint8_t *rp = row0 + (size_t)min(k, C - 1u) * row_step;
+        Row r;
+        r.c0 = make_uint4(0, 0, 0, 0); r.c1 = r.c0;
+        if (small) {
+            r.c0 = *reinterpret_cast<const uint4 *>(rp);
+            r.c1 = *reinterpret_cast<const uint4 *>(rp + (a.smax > 16u ? 16 : 0));      // (unconditional: a load, not a branch)
+        }
+        r.q0 = *reinterpret_cast<const uint4 *>(rp + a.smax);
+        r.q1 = *reinterpret_cast<const uint4 *>(rp + a.smax + 16);
+        return r;
+    };
+    Row ring[kAheadRows];
 #pragma unroll
-                for (uint32_t j = 1; j < 8u; ++j) if ((s >> 2) == j) word = cw[j];
-                v = (word >> (8u * (s & 3u))) & 0xffu;
-            } else {
-                v = rowp[s];
-            }
-            uint32_t ns = dead, np = dead;
+    for (uint32_t u = 0; u < kAheadRows; ++u) ring[u] = load_row(u);
+    // the init words trail the chain: chunk k's word is written when its slot comes round again (its tag load was issued kAheadRows steps ago)
+    uint32_t pend_state[kAheadRows], pend_tag[kAheadRows];
+    auto write_init = [&](const uint32_t k, const uint32_t st, const uint32_t tag) {
+        if (active && !(a.dbg & 2u)) a.init[((size_t)k * a.B + b) * a.D + d] = st | (tag & 0xffu) << 16 | ((tag >> 9) & 1u) << 24;
+    };
+    uint32_t s = a.dc[d].first_state, prev = 0xffffffffu;
+    for (uint32_t k0 = 0; k0 < C; k0 += kAheadRows) {
 #pragma unroll
-            for (uint32_t j = 0; j < kSpecKeys; ++j) {
-                const uint32_t kj = (w[j >> 2] >> (8u * (j & 3u))) & 0xffu;
-                if (kj == v) { ns = (w[2u + (j >> 2)] >> (8u * (j & 3u))) & 0xffu; np = (w[4u + (j >> 2)] >> (8u * (j & 3u))) & 0xffu; }
-            }
-            s = (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)k);
-            prev = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)k);
-        } else {
-            // the chunk's start states did not merge into the scout's bounds: the wave walks it here.  Lane l takes the chunk's l-th
-            // 64th and walks it from EVERY real state (four independent chains at a time, table and bytes from L2): its map "entered
-            // in s -> left in" goes to LDS; then the true state runs through the 64 maps.  ~S x rows / 64 lookups per lane instead of
-            // a chain of `rows` dependent ones (200 us for 1024 rows).  Any DFA stays correct; forgetful ones rarely get here.
-            const uint32_t *T = a.table_image + (size_t)base * 256u;
-            const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
-            const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(b - blk0) * 16u;
-            const uint32_t per = rows >> 6;
-            uint8_t *maps = smem + (threadIdx.x >> 6) * (65u * a.smax);          // [64 lanes][smax] + lane 63's "before the last byte"
-            for (uint32_t s0 = 0; s0 < S; s0 += 4u) {
-                uint32_t e[4], em1[4];
+        for (uint32_t u = 0; u < kAheadRows; ++u) {
+            const uint32_t k = k0 + u;
+            if (k < C) {
+                if (k >= kAheadRows) write_init(k - kAheadRows, pend_state[u], pend_tag[u]);
+                const uint32_t r0 = k * rows;
+                // ---- chunk k's init word: the state at its first row (rows beyond n hold the dummy state, table row S: lib.rs:413; row n itself
+                // holds s[n]) and the substr id / end flag of the transition into that row
+                const bool tagged = prev < S && s < S && r0 <= n && !(a.dbg & 1u);
+                const uint32_t tag = a.pair_tags[d][tagged ? (size_t)prev * S + s : (size_t)0];     // (unconditional: a load, not a branch)
+                pend_state[u] = r0 > n ? S : s; pend_tag[u] = tagged ? tag : 0u;
+                // ---- through chunk k
+                const Row rw = ring[u];
+                ring[u] = load_row(k + kAheadRows);
+                const bool ends_here = r0 + rows > n;          // the string ends in this chunk: every later chunk is padding (its start state is never looked at)
+                const bool is_dead = s >= S;                   // an undefined transition further up (lib.rs:817): absorbing
+                uint32_t ns = dead, np = dead;
+                {
+                    const uint32_t cw[8] = {rw.c0.x, rw.c0.y, rw.c0.z, rw.c0.w, rw.c1.x, rw.c1.y, rw.c1.z, rw.c1.w};
+                    const uint32_t w[6] = {rw.q0.x, rw.q0.y, rw.q0.z, rw.q0.w, rw.q1.x, rw.q1.y};
+                    uint32_t v;                                // the state after stage A in this chunk: one of its keys
+                    if (small) {
+                        uint32_t word = cw[0];
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) { e[j] = min(s0 + j, S - 1u); em1[j] = e[j]; }
-                for (uint32_t i = 0; i < per; ++i) {
-                    const uint32_t r = r0 + lane * per + i;
-                    const uint32_t c = cptr[(size_t)(r >> 4) * nb * 16u + (r & 15u)];
+                        for (uint32_t j = 1; j < 8u; ++j) if ((s >> 2) == j) word = cw[j];
+                        v = (word >> (8u * (s & 3u))) & 0xffu;
+                    } else {
+                        v = (row0 + (size_t)k * row_step)[min(s, S - 1u)];
+                    }
 #pragma unroll
-                    for (uint32_t j = 0; j < 4u; ++j) { em1[j] = e[j]; e[j] = (T[e[j] * 256u + c] >> kNextShift) - base; }    // (the dead row S + 1 leads to itself)
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) {
-                    if (s0 + j < S) {
-                        maps[lane * a.smax + s0 + j] = (uint8_t)e[j];
-                        if (lane == 63u) maps[64u * a.smax + s0 + j] = (uint8_t)em1[j];
+                    for (uint32_t j = 0; j < kSpecKeys; ++j) {
+                        const uint32_t kj = (w[j >> 2] >> (8u * (j & 3u))) & 0xffu;
+                        if (kj == v) { ns = (w[2u + (j >> 2)] >> (8u * (j & 3u))) & 0xffu; np = (w[4u + (j >> 2)] >> (8u * (j & 3u))) & 0xffu; }
                     }
                 }
+                // the chunk's start states did not merge into the scout's bounds: the wave walks it for this lane
+                uint64_t flagged = __ballot(active && !ends_here && !is_dead && rw.q1.z != 0u);
+                while (flagged) {
+                    const int j = __ffsll((unsigned long long)flagged) - 1;
+                    flagged &= flagged - 1;
+                    uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)s, j), pj = 0;
+                    spec_walk_flagged(a, g * 64u + (uint32_t)j, d, k, sj, pj, lane, smem);
+                    if (lane == (uint32_t)j) { ns = sj; np = pj; }
+                }
+                if (ends_here) prev = 0xffffffffu;
+                else if (is_dead) prev = s;
+                else { s = ns >= S ? dead : ns; prev = np; }
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t l = 0; l < 64u && s < S; ++l) {
-                if (l == 63u) prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)maps[64u * a.smax + s]);
-                s = (uint32_t)__builtin_amdgcn_readfirstlane((int)maps[l * a.smax + s]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-        if (s >= S) s = dead;
     }
-    // ---- my chunk's init word: the state at its first row, and the substr id / end flag of the transition into that row
-    if (lane < C) {
-        const uint32_t r0 = lane * rows;
-        uint32_t tag = 0;
-        if (my_prev < S && my_s < S && r0 <= n && !(a.dbg & 1u)) tag = a.pair_tags[d][(size_t)my_prev * S + my_s];
-        // rows beyond n hold the dummy state (table row S: lib.rs:413); row n itself holds s[n]
-        if (!(a.dbg & 2u)) a.init[((size_t)lane * a.B + b) * a.D + d] = (r0 > n ? S : my_s) | (tag & 0xffu) << 16 | ((tag >> 9) & 1u) << 24;
+    // (slot u holds chunk k with k % kAheadRows == u: the last one of each slot)
+#pragma unroll
+    for (uint32_t u = 0; u < kAheadRows; ++u) {
+        if (u < C) {
+            const uint32_t last = ((C - 1u - u) / kAheadRows) * kAheadRows + u;
+            write_init(last, pend_state[u], pend_tag[u]);
+        }
     }
 }
 
@@ -539,14 +579,16 @@ hipError_t launch_spec_scout(const SpecArgs &a, int num_cus, hipStream_t stream)
 }
 
 hipError_t launch_spec_compose(const SpecArgs &a, hipStream_t stream) {
-    const size_t waves = (size_t)a.B * a.D;       // one wave per (string, def), four per workgroup
-    const size_t lds = 4u * 65u * (size_t)a.smax;   // per wave: the maps of a chunk the scout gave up on
+    const size_t lds = 65u * (size_t)a.smax;        // the maps of a chunk the scout gave up on (spec_walk_flagged)
     static std::atomic<size_t> granted[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    hipError_t e = ensure_lds(spec_compose_kernel, granted[dev & 63], lds);
+    const bool small = a.smax <= 32u;
+    hipError_t e = small ? ensure_lds(spec_compose_kernel<true>, granted[dev & 63], lds) : ensure_lds(spec_compose_kernel<false>, granted[(dev & 31) + 32], lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(spec_compose_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, stream, a);
+    // one wave per (64 strings, def)
+    if (small) hipLaunchKernelGGL(spec_compose_kernel<true>, dim3(a.n_groups * a.D), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL(spec_compose_kernel<false>, dim3(a.n_groups * a.D), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
