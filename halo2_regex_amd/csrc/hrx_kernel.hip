@@ -2,6 +2,7 @@
 // small auxiliary kernels: the states-in entry points of lib.rs:825-888 and the field-cell expansion.
 #include <hip/hip_runtime.h>
 
+#include "hrx_device.h"
 #include "hrx_fr.h"
 #include "hrx_kernel.hpp"
 #include "hrx_lane.h"
@@ -385,7 +386,8 @@ hipError_t launch_endpoint_flags(const EndpointArgs &a, const uint8_t *const *me
 // result columns (lib.rs:752-771), F = bn256::Fr in Montgomery form (hrx_fr.h), column-major [col][string][row][4 limbs].
 // Write-bound: 32 B per cell x (4 + 4 D) cells per row.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kFrRowsPerBlock = 512u;
+constexpr uint32_t kFrJ = 4u;                                  // store instructions (32 rows each) per wave and column
+constexpr uint32_t kFrRowsPerBlock = 4u * 32u * kFrJ;
 __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
     // thread = (row, half of the 32-byte cell): both lanes of a pair compute the cell, each stores its 16 bytes, so that a
     // store instruction writes 1 KiB of full lines (one lane per row stored half of every 32 bytes per instruction)
@@ -394,36 +396,68 @@ __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
     const uint32_t b = a.b_begin + bi;
     const uint32_t n = min(a.lens[b], a.M);
     const bool pm = (a.layout & 1u) != 0, in_pm = (a.layout & 2u) != 0;
-#pragma unroll 2
-    for (uint32_t it = 0; it < kFrRowsPerBlock / 128u; ++it) {
-    const uint32_t r = blockIdx.x * kFrRowsPerBlock + it * 128u + (threadIdx.x >> 1);
-    if (r >= a.M) return;
-    const uint32_t live = r < n ? 1u : 0u;
-    uint32_t c = 0;
+    // a wave owns 32 kFrJ consecutive rows and writes them column by column: kFrJ store instructions in a row put 4 KiB
+    // of ONE column down before the next column's turn (interleaving the columns instruction by instruction left every stream in
+    // 1-KiB pieces)
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t rbase = blockIdx.x * kFrRowsPerBlock + wave * (32u * kFrJ) + (lane >> 1);
     const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0), bl = b - blk0;   // the string's block of the position-major buffers
-    if (live) c = in_pm ? a.chars[(size_t)blk0 * a.stride + ((size_t)(r >> 4) * nb + bl) * 16u + (r & 15u)] : a.chars[(size_t)b * a.stride + r];
     const size_t col_cells = (size_t)a.col_cells;   // cells per column
-    uint64_t *out = a.cells + ((size_t)bi * a.M + r) * 4u + half * 2u;
-    auto put = [&](const uint32_t col, const uint32_t v) {
-        uint32_t w[8];
-        fr_from_u32(v, w, a.canonical != 0);
-        uint4 *p = reinterpret_cast<uint4 *>(out + (size_t)col * col_cells * 4u);
-        *p = half ? make_uint4(w[4], w[5], w[6], w[7]) : make_uint4(w[0], w[1], w[2], w[3]);
+    uint64_t *out0 = a.cells + ((size_t)bi * a.M + rbase) * 4u + half * 2u;
+    auto put_rows = [&](const uint32_t col, const uint32_t (&v)[kFrJ]) {
+#pragma unroll
+        for (uint32_t j = 0; j < kFrJ; ++j) {
+            if (rbase + j * 32u < a.M) {
+                uint32_t w[8];
+                fr_from_u32(v[j], w, a.canonical != 0);
+                unsigned char *p = reinterpret_cast<unsigned char *>(out0 + (size_t)col * col_cells * 4u + (size_t)j * 32u * 4u);
+                store16_nt(p, half ? make_uint4(w[4], w[5], w[6], w[7]) : make_uint4(w[0], w[1], w[2], w[3]));    // streaming: nothing reads the cells back here
+            }
+        }
     };
-    put(0, live);   // char_enable                        lib.rs:342,346
-    put(1, c);      // characters                         lib.rs:343,347
+    uint32_t live[kFrJ], c[kFrJ];
+#pragma unroll
+    for (uint32_t j = 0; j < kFrJ; ++j) {
+        const uint32_t r = min(rbase + j * 32u, a.M - 1u);
+        live[j] = (rbase + j * 32u) < n ? 1u : 0u;
+        c[j] = 0;
+        if (live[j]) c[j] = in_pm ? a.chars[(size_t)blk0 * a.stride + ((size_t)(r >> 4) * nb + bl) * 16u + (r & 15u)] : a.chars[(size_t)b * a.stride + r];
+    }
+    put_rows(0, live);   // char_enable                        lib.rs:342,346
+    put_rows(1, c);      // characters                         lib.rs:343,347
     for (uint32_t d = 0; d < a.D; ++d) {
-        const uint32_t rec = pm ? a.records[((size_t)blk0 * ((a.M + 3u) / 4u) * a.D + ((size_t)(r >> 2) * a.D + d) * nb + bl) * 4u + (r & 3u)]
-                                : a.records[((size_t)b * a.rec_pitch + r) * a.D + d];
-        put(2 + 4 * d, rec & 0xffffu);            // states[d]         lib.rs:390,415
-        put(3 + 4 * d, (rec >> 16) & 0xffu);      // substr_ids[d]     lib.rs:394,405
-        put(4 + 4 * d, (rec >> 24) & 1u);         // start_enable[d]   lib.rs:483-491
-        put(5 + 4 * d, (rec >> 25) & 1u);         // end_enable[d]     lib.rs:502-511
+        uint32_t rec[kFrJ], f[kFrJ];
+#pragma unroll
+        for (uint32_t j = 0; j < kFrJ; ++j) {
+            const uint32_t r = min(rbase + j * 32u, a.M - 1u);
+            rec[j] = pm ? a.records[((size_t)blk0 * ((a.M + 3u) / 4u) * a.D + ((size_t)(r >> 2) * a.D + d) * nb + bl) * 4u + (r & 3u)]
+                        : a.records[((size_t)b * a.rec_pitch + r) * a.D + d];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kFrJ; ++j) f[j] = rec[j] & 0xffffu;
+        put_rows(2 + 4 * d, f);            // states[d]         lib.rs:390,415
+#pragma unroll
+        for (uint32_t j = 0; j < kFrJ; ++j) f[j] = (rec[j] >> 16) & 0xffu;
+        put_rows(3 + 4 * d, f);            // substr_ids[d]     lib.rs:394,405
+#pragma unroll
+        for (uint32_t j = 0; j < kFrJ; ++j) f[j] = (rec[j] >> 24) & 1u;
+        put_rows(4 + 4 * d, f);            // start_enable[d]   lib.rs:483-491
+#pragma unroll
+        for (uint32_t j = 0; j < kFrJ; ++j) f[j] = (rec[j] >> 25) & 1u;
+        put_rows(5 + 4 * d, f);            // end_enable[d]     lib.rs:502-511
     }
-    const uint32_t mk = pm ? a.masked[((size_t)blk0 * ((a.M + 7u) / 8u) + (size_t)(r >> 3) * nb + bl) * 8u + (r & 7u)] : a.masked[(size_t)b * a.msk_pitch + r];
-    put(2 + 4 * a.D, mk & 0xffu);                 // masked_characters  lib.rs:752-757
-    put(3 + 4 * a.D, mk >> 8);                    // all_substr_ids     lib.rs:758-761
+    uint32_t mk[kFrJ], f[kFrJ];
+#pragma unroll
+    for (uint32_t j = 0; j < kFrJ; ++j) {
+        const uint32_t r = min(rbase + j * 32u, a.M - 1u);
+        mk[j] = pm ? a.masked[((size_t)blk0 * ((a.M + 7u) / 8u) + (size_t)(r >> 3) * nb + bl) * 8u + (r & 7u)] : a.masked[(size_t)b * a.msk_pitch + r];
     }
+#pragma unroll
+    for (uint32_t j = 0; j < kFrJ; ++j) f[j] = mk[j] & 0xffu;
+    put_rows(2 + 4 * a.D, f);              // masked_characters  lib.rs:752-757
+#pragma unroll
+    for (uint32_t j = 0; j < kFrJ; ++j) f[j] = mk[j] >> 8;
+    put_rows(3 + 4 * a.D, f);              // all_substr_ids     lib.rs:758-761
 }
 
 hipError_t launch_fr_columns(const FrArgs &a, hipStream_t stream) {
