@@ -426,6 +426,7 @@ struct SpecWork { uint32_t b, k_sm_em; };
 // (hrx_lane.h fill_up / fill_down), 64 rows per step.
 __global__ __launch_bounds__(64) void spec_repair_kernel(const SpecArgs a) {
     __shared__ uint64_t smbits[kSpecMaxChunkTiles];
+    __shared__ uint32_t packed[kSpecMaxChunkTiles * 64u];      // per row of the chunk: sid | st << 10 | en1 << 11 | byte << 16
     const uint32_t lane = threadIdx.x;
     const uint32_t count = min(a.work_count[0], a.work_cap);
     const SpecWork *work = reinterpret_cast<const SpecWork *>(a.work);
@@ -450,12 +451,30 @@ __global__ __launch_bounds__(64) void spec_repair_kernel(const SpecArgs a) {
                 sid += (w >> 16) & 0xffu; st |= (w >> 24) & 1u; en1 |= (w >> 25) & 1u;
             }
         };
+        // ---- the chunk's rows into LDS, eight steps' loads in flight at once (a pass that waited for every step's loads took 16 x 2
+        // round trips per item: 41 us at D = 3)
+        for (uint32_t s0 = 0; s0 < steps; s0 += 8u) {
+            uint32_t pk[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t p = r0 + min(s0 + u, steps - 1u) * 64u + lane;
+                uint32_t sid, st, en1;
+                row(p, sid, st, en1);
+                const uint32_t c = cptr[(size_t)(p >> 4) * nb * 16u + (p & 15u)];
+                pk[u] = sid | st << 10 | en1 << 11 | c << 16;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) if (s0 + u < steps) packed[(s0 + u) * 64u + lane] = pk[u];
+        }
         // ---- forward: start_mask (lib.rs:598-645)
         uint32_t c_sid = 0, c_en = 0, t_st;
         if (r0 > 0u) row(r0 - 1u, c_sid, t_st, c_en);       // the row before the chunk (every lane loads the same word)
+        uint32_t n_sid = 0, n_st = 0, t_en;
+        row(r1, n_sid, n_st, t_en);                          // row r1 (zeros if r1 == M: SID[M] = 0, ST[M] = 0)
+        __syncthreads();
         for (uint32_t s = 0; s < steps; ++s) {
-            uint32_t sid, st, en1;
-            row(r0 + s * 64u + lane, sid, st, en1);
+            const uint32_t w = packed[s * 64u + lane];
+            const uint32_t sid = w & 0x3ffu, st = (w >> 10) & 1u, en1 = (w >> 11) & 1u;
             uint32_t sidp = (uint32_t)__shfl_up((int)sid, 1, 64), en = (uint32_t)__shfl_up((int)en1, 1, 64);
             if (lane == 0u) { sidp = c_sid; en = c_en; }
             const bool chg = sid != sidp;
@@ -468,13 +487,11 @@ __global__ __launch_bounds__(64) void spec_repair_kernel(const SpecArgs a) {
         }
         __syncthreads();
         // ---- backward: end_mask (lib.rs:663-714); the event of position p is made of row p + 1's quantities
-        uint32_t n_sid = 0, n_st = 0, t_en;
-        row(r1, n_sid, n_st, t_en);                          // row r1 (zeros if r1 == M: SID[M] = 0, ST[M] = 0)
         uint32_t em = 0;                                     // e_M = 0; for r1 < M the chunk's last row is forced to em_last below
         for (uint32_t s = steps; s-- > 0u;) {
             const uint32_t p = r0 + s * 64u + lane;
-            uint32_t sid, st, enp1;
-            row(p, sid, st, enp1);
+            const uint32_t w = packed[s * 64u + lane];
+            const uint32_t sid = w & 0x3ffu, st = (w >> 10) & 1u, enp1 = (w >> 11) & 1u, c = w >> 16;
             uint32_t sid1 = (uint32_t)__shfl_down((int)sid, 1, 64), st1 = (uint32_t)__shfl_down((int)st, 1, 64);
             if (lane == 63u) { sid1 = n_sid; st1 = n_st; }
             const bool chg = sid1 != sid;
@@ -483,7 +500,6 @@ __global__ __launch_bounds__(64) void spec_repair_kernel(const SpecArgs a) {
             const uint64_t bits = fill_down(__ballot(set), __ballot(rst), em);
             em = (uint32_t)bits & 1u;
             const uint32_t mask = (uint32_t)((smbits[s] >> lane) & (bits >> lane) & 1ull) && p < n ? 1u : 0u;
-            const uint32_t c = cptr[(size_t)(p >> 4) * nb * 16u + (p & 15u)];
             msk[((size_t)(p >> 3) * nb + bl) * 8u + (p & 7u)] = mask ? (uint16_t)(c | sid << 8) : (uint16_t)0;
             n_sid = (uint32_t)__shfl((int)sid, 0, 64);
             n_st = (uint32_t)__shfl((int)st, 0, 64);
