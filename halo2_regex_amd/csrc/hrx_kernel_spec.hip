@@ -155,7 +155,8 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
             }
             // ---- the survivors to the chunk's end.  A QUASI-ABSORBING survivor (hrx_kernel.hpp SpecArgs::qabs: every byte keeps it where it is
             // or — only bytes NO state has a transition for — kills it: the accept state behind a finished match) is not walked: it ends
-            // where it started unless a walked survivor died, and then it died at the same byte.  The walked ones go first; as many
+            // where it started as long as no walked survivor died (a byte without any column kills every walked one; if one did die the
+            // chunk is flagged below, the byte may have been undefined for that state only).  The walked ones go first; as many
             // chains as the wave's busiest lane has of them (at least one: somebody has to see such a byte).
             uint32_t walk[kSpecSlots], idle[kSpecSlots], nw = 0, ni = 0;      // slot numbers in walking order
 #pragma unroll
@@ -237,6 +238,11 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
                         died_m1 = died_m1 || (em1[j] >> kNextShift) - base == dead_row;
                     }
                 }
+                // A walked survivor that died says nothing about the derived ones unless the byte that killed it has no column at all: in a
+                // PARTIAL DFA a byte may be undefined for the walked state only, and the quasi-absorbing one lives on (fuzz seed 2499: two-byte
+                // alphabet, 36 states, 60 of 200 strings reported dead at the next chunk's first row).  Such a chunk goes to the compose
+                // wave's exact walk; strings of the reference's total DFAs get here only with a byte outside the alphabet, i.e. as errors.
+                if (died && ni != 0u) fail = 1;
                 uint32_t s_end_v[kSpecSlots], s_endm1_v[kSpecSlots];
 #pragma unroll
                 for (uint32_t t = 0; t < kSpecSlots; ++t) {          // slot t: walked as chain j, or derived

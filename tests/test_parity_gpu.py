@@ -609,11 +609,11 @@ def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
 
 def _spec_fuzz_seeds():
     """the suite's seeds, plus a range named in HRX_FUZZ_SPEC_EXTRA ("1000:1400") for a soak run (profiles/r03_soak.txt)"""
-    seeds = list(range(300, 316))
+    seeds = list(range(300, 316)) + [2499]     # 2499: a partial DFA whose quasi-absorbing survivor outlives a walked one (the scout once declared both dead)
     part = os.environ.get("HRX_FUZZ_SPEC_EXTRA", "")
     if ":" in part:
         a, b = part.split(":")
-        seeds += list(range(int(a), int(b)))
+        seeds += [x for x in range(int(a), int(b)) if x not in seeds]
     return seeds
 
 
