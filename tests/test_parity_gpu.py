@@ -509,6 +509,20 @@ def test_chunked_launch_is_what_a_batch_of_few_long_strings_gets(hra, oracle):
         assert len(st) == 4096
 
 
+@pytest.mark.parametrize("M,want", [(65536, "chunked=32x32 tiles"), (131072, "chunked=32x64 tiles")])
+def test_chunked_launch_with_longer_chunks(hra, oracle, M, want):
+    """Beyond 32768 rows the chunks grow (32 chunks of 32 / 64 tiles: the stitch launch holds 32 summaries per string, the repair wave a
+    chunk of up to 64 tiles in LDS): 70 strings, ragged, planted matches, every string against the oracle and the MockProver."""
+    from halo2_regex_amd import synth
+    cfg = _cfg(hra, CFG_1, M)
+    assert want in cfg.describe_launch(70, layout=3)
+    chars, lens = synth.regex1_planted(70, M - 1, seed=M, stride=M)
+    lens[::3] = np.random.default_rng(M).integers(0, M, size=len(lens[::3]))
+    lens[1] = M
+    st = _full_check(hra, OracleDefs.from_files(oracle, CFG_1), cfg, [(chars, lens)], M, 1)
+    assert len(st) == 70
+
+
 @pytest.mark.parametrize("flags", ["65536", "196608"], ids=["one-wave-gs64", "one-wave-gs32"])
 def test_one_wave_kernel_variants(hra, oracle, flags, monkeypatch):
     """D <= 2 normally takes the walker/storer kernel; force the one-wave kernel (used for D = 3 and unaligned M)
