@@ -623,7 +623,7 @@ def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
 
 def _spec_fuzz_seeds():
     """the suite's seeds, plus a range named in HRX_FUZZ_SPEC_EXTRA ("1000:1400") for a soak run (profiles/r03_soak.txt)"""
-    seeds = list(range(300, 316)) + [2499]     # 2499: a partial DFA whose quasi-absorbing survivor outlives a walked one (the scout once declared both dead)
+    seeds = list(range(300, 316)) + [100000, 100001, 100002, 100003] + [2499]     # 2499: a partial DFA whose quasi-absorbing survivor outlives a walked one (the scout once declared both dead)
     part = os.environ.get("HRX_FUZZ_SPEC_EXTRA", "")
     if ":" in part:
         a, b = part.split(":")
@@ -633,17 +633,18 @@ def _spec_fuzz_seeds():
 
 @pytest.mark.parametrize("seed", _spec_fuzz_seeds())
 def test_fuzz_chunked_launch_on_random_definitions(hra, oracle, seed, monkeypatch):
-    """Seeded fuzz of the chunked launch (forced, chunks of 4 tiles): random DFAs — partial ones included, and random transition
+    """Seeded fuzz of the chunked launch (forced, chunks of 4 tiles; seeds from 100000 on: the planner's own 16-tile chunks of 4096-8192 rows): random DFAs — partial ones included, and random transition
     functions need not forget their start state: chunks whose start states do not merge into the scout's bounds are walked by the
     compose launch — 1-3 defs, 2-8 chunks per string, ragged lengths incl. 0, M and > M, bytes outside the alphabets, flag overlap;
     against the oracle, bit for bit."""
     import torch
-    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(0x80))
+    natural = seed >= 100000                                  # the planner's own chunking (16 tiles) instead of forced 4-tile chunks
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(0 if natural else 0x80))
     rng = np.random.default_rng(5000 + seed)
     D = int(rng.integers(1, 4))
     defs_t = _random_defs(rng, D, False)
-    M = int(rng.choice([512, 768, 1024, 1280, 2048]))
-    B = int(rng.choice([1, 64, 65, 200, 333]))
+    M = int(rng.choice([4096, 5120, 8192])) if natural else int(rng.choice([512, 768, 1024, 1280, 2048]))
+    B = int(rng.choice([1, 64, 65, 130])) if natural else int(rng.choice([1, 64, 65, 200, 333]))
     stride = M
     common = defs_t[0][2]
     for _, _, a in defs_t[1:]:

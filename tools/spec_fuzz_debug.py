@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """one seed of test_fuzz_chunked_launch_on_random_definitions, with the differences decoded"""
 import os, sys
-os.environ["HRX_DEBUG_FLAGS"] = str(0x80 | 0x20000000)
+os.environ["HRX_DEBUG_FLAGS"] = str((0 if int(sys.argv[1]) >= 100000 else 0x80) | 0x20000000)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
@@ -12,8 +12,9 @@ seed = int(sys.argv[1])
 rng = np.random.default_rng(5000 + seed)
 D = int(rng.integers(1, 4))
 defs_t = T._random_defs(rng, D, False)
-M = int(rng.choice([512, 768, 1024, 1280, 2048]))
-B = int(rng.choice([1, 64, 65, 200, 333]))
+natural = seed >= 100000
+M = int(rng.choice([4096, 5120, 8192])) if natural else int(rng.choice([512, 768, 1024, 1280, 2048]))
+B = int(rng.choice([1, 64, 65, 130])) if natural else int(rng.choice([1, 64, 65, 200, 333]))
 stride = M
 common = defs_t[0][2]
 for _, _, a in defs_t[1:]:
