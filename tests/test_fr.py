@@ -72,16 +72,17 @@ def _expected_cells(o, chars, lens, M, D, lut):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M", [200, 1096])     # 1096 rows: three workgroups per string, the last wave's rows end inside its 128
 @pytest.mark.parametrize("layout", ["string-major", "position-major", "position-major-input"])
-def test_fr_columns_match_f_from_of_every_assigned_cell(oracle, layout):
+def test_fr_columns_match_f_from_of_every_assigned_cell(oracle, layout, M):
     import torch
     from halo2_regex_amd import synth
     dev = torch.device("cuda", 0)
-    M, D = 200, 2
+    D = 2
     defs = [hra.RegexDefs(hra.AllstrRegexDef.read_from_text(DFA_DIR + "/" + a), [hra.SubstrRegexDef.read_from_text(DFA_DIR + "/" + s) for s in subs])
             for a, subs in CFG_A]
     cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
-    chars, lens = synth.reveal_stress(96, 200, seed=5)
+    chars, lens = synth.reveal_stress(96, M, seed=5)
     lens = np.minimum(lens, M).astype(np.uint32)
     lens[0], lens[1] = 0, M
     o = OracleDefs.from_files(oracle, CFG_A)
