@@ -111,6 +111,8 @@ struct hrx_ctx {
     };
     std::vector<GroupDev> groups;
     DevBuf mp_masked;
+    DevBuf mp_ov;          // multi-pass configs whose last pass merges the summaries: its cross-group overlap rows (WitnessArgs::merge_ov)
+    bool mp_combine = false;   // HRX_MP_COMBINE=1: always the separate combine launch
     DevBuf tp_records, tp_masked;   // string-major callers served by the position-major path + transpose_pm_to_sm_kernel (hrx_kernel_tp.hip)
     DevBuf spec_cls, spec_ends, spec_fail, spec_init, spec_vstatus, spec_vinfo, spec_work;
     bool spec_qabs_ready = false;
@@ -327,6 +329,7 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     c->debug = debug_flags_from_env();
     // tuning knobs of the placement search: HRX_PLACE=0 switches it off, HRX_PLACE_MAX_STEPS bounds the walk, HRX_PLACE_TRACE=1 prints every measured step to stderr
     if (const char *v = std::getenv("HRX_PLACE")) c->place_enabled = std::atoi(v) != 0;
+    if (const char *v = std::getenv("HRX_MP_COMBINE")) c->mp_combine = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_PLACE_TRACE")) c->place_trace = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_PLACE_MAX_STEPS")) { const int n = std::atoi(v); if (n >= 1 && n <= 256) c->place_max_steps = n; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -395,7 +398,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
         if (g.d_bytetab) (void)hipFree(g.d_bytetab);
         g.records.release(); g.status.release(); g.summary.release();
     }
-    c->mp_masked.release();
+    c->mp_masked.release(); c->mp_ov.release();
     c->tp_records.release(); c->tp_masked.release();
     c->spec_cls.release(); c->spec_ends.release(); c->spec_fail.release(); c->spec_init.release(); c->spec_vstatus.release(); c->spec_vinfo.release(); c->spec_work.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
@@ -437,9 +440,13 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     const uint16_t *const *d_pair_tags = ctx->s.groups.empty() && !ctx->d_pair.empty() ? ctx->d_pair.data() : nullptr;
     auto launch_set = [&](const DefsSet &set, const uint32_t *d_table, const uint64_t *d_wide, const uint16_t *d_half, const uint8_t *d_pairtab,
                           const uint8_t *d_bytetab, int lay, uint32_t *rec, uint16_t *msk, uint64_t *stat, size_t rp, size_t mp,
-                          uint32_t rec_D = 0, uint32_t rec_d0 = 0, uint32_t *summary = nullptr) -> int {
+                          uint32_t rec_D = 0, uint32_t rec_d0 = 0, uint32_t *summary = nullptr,
+                          uint32_t merge_G = 0, const uint32_t *const *merge_summary = nullptr, uint32_t *merge_ov = nullptr) -> int {
         WitnessArgs a{};
         a.rec_D = rec_D; a.rec_d0 = rec_d0; a.summary = summary;
+        a.merge_G = merge_G; a.merge_ov = merge_ov;
+        for (uint32_t g = 0; g < merge_G && g < kMaxMergeGroups; ++g) a.merge_summary[g] = merge_summary[g];
+        const bool pass = summary != nullptr || merge_G != 0;    // a pass of a multi-pass config
         a.rec_pitch = (uint32_t)rp; a.msk_pitch = (uint32_t)mp;
         a.layout = (uint32_t)lay;
         a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
@@ -457,15 +464,15 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         a.debug = debug_flags_from_env();   // tools/ab_flags.py switches ablations between launches of one process
 #endif
         // a summary-writing pass is the loader / walker / finisher kernel: no pair-step or def-parallel variant, no HALF table
-        if (summary) a.debug |= kDbgNoPair | kDbgNoDefParallel;
+        if (pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;
         for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = set.consts[d];
         LaunchInfo li;
         if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
-        if (summary && li.half) {   // (a group of one big DFA: walk its 4-byte table out of L2 instead)
+        if (pass && li.half) {   // (a group of one big DFA: walk its 4-byte table out of L2 instead)
             a.debug |= kDbgForceGlobalTable;
             if (!plan_witness_launch(a, ctx->num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
         }
-        if (summary && li.split != 2) return fail(HRX_ERR_STATE, "multi-pass: the planner did not pick the position-major loader/walker kernel");
+        if (pass && li.split != 2) return fail(HRX_ERR_STATE, "multi-pass: the planner did not pick the position-major loader/walker kernel");
         SpecArgs sp{};
         if (li.spec_tiles) {
             // ---- chunked launch (hrx_kernel_spec.hip): scout + compose find every chunk's start state, the walk below runs over the
@@ -612,13 +619,22 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     }
     const bool summary_mode = (layout & HRX_LAYOUT_POSITION_MAJOR) != 0;   // position-major outputs: the passes write the caller's record planes themselves
     if (!summary_mode) HIP_TRY(ctx->mp_masked.reserve(q8 * 8 * B * 2));
+    // position-major outputs, up to kMaxMergeGroups + 1 groups: the LAST pass reads the earlier groups' summaries itself and writes the final
+    // masked rows; a one-thread-per-string launch merges the status words.  (HRX_MP_COMBINE=1: the separate combine launch, as with more groups.)
+    const bool merge_last = summary_mode && G - 1 <= kMaxMergeGroups && !ctx->mp_combine;
+    if (merge_last) HIP_TRY(ctx->mp_ov.reserve(B * 4));
     CombineArgs ca{};
     for (size_t g = 0; g < G; ++g) {
         const DefsSet &gs = ctx->s.groups[g];
         hrx_ctx::GroupDev &gd = ctx->groups[g];
         HIP_TRY(gd.status.reserve(B * 8));
         int rc;
-        if (summary_mode) {
+        if (summary_mode && merge_last && g + 1 == G) {
+            const uint32_t *ms[kMaxMergeGroups] = {nullptr, nullptr, nullptr};
+            for (size_t e = 0; e + 1 < G; ++e) ms[e] = ca.gsummary[e];
+            rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, gd.d_bytetab, layout, records, masked, (uint64_t *)gd.status.p, M, M,
+                            (uint32_t)ctx->s.defs.size(), ctx->s.group_first[g], nullptr, (uint32_t)(G - 1), ms, (uint32_t *)ctx->mp_ov.p);
+        } else if (summary_mode) {
             HIP_TRY(gd.summary.reserve(ntiles * 5 * B * 16));
             rc = launch_set(gs, gd.d_table, gd.d_wide, gd.d_half, gd.d_pairtab, gd.d_bytetab, layout, records, masked, (uint64_t *)gd.status.p, M, M,
                             (uint32_t)ctx->s.defs.size(), ctx->s.group_first[g], (uint32_t *)gd.summary.p);
@@ -638,7 +654,12 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     ca.D = (uint32_t)ctx->s.defs.size(); ca.G = (uint32_t)G; ca.layout = (uint32_t)layout;
     ca.rec_pitch = (uint32_t)rec_pitch; ca.msk_pitch = (uint32_t)msk_pitch;
     ca.records = records; ca.masked = masked; ca.status = status;
-    HIP_TRY(launch_combine(ca, st));
+    if (merge_last) {
+        ca.merge_ov = (const uint32_t *)ctx->mp_ov.p;
+        HIP_TRY(launch_merge_status(ca, st));
+    } else {
+        HIP_TRY(launch_combine(ca, st));
+    }
     if (via_tp) {
         TransposeArgs ta{records, masked, (uint32_t)B, (uint32_t)M, (uint32_t)ctx->s.defs.size(), caller_records, caller_masked, (uint32_t)rec_pitch, (uint32_t)msk_pitch};
         HIP_TRY(launch_transpose(ta, st));
@@ -700,7 +721,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     a.byte_image = s.byte.image.empty() ? nullptr : s.byte.image.data(); a.byte_bytes = s.byte.bytes; a.byte_dead = s.byte.dead;
     a.D = (uint32_t)s.defs.size();
     a.debug = debug_flags_from_env();   // what a context created now would run with (kernel-selection bits only in a release build)
-    if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a summary-writing pass is the loader / walker / finisher kernel)
+    if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a pass of a multi-pass config is the loader / walker / finisher kernel)
     LaunchInfo li;
     if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
     if (summary_pass && li.half) {
@@ -748,7 +769,10 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
             text += "[defs " + std::to_string(s.group_first[g]) + ".." + std::to_string(s.group_first[g] + s.groups[g].defs.size() - 1) + ": " + one + "] ";
         }
         const bool via_tp = !(layout & 1) && M % 8 == 0;
-        text += (layout & 1) || via_tp ? "+ hrx::witness_combine_summary_kernel" : "+ hrx::witness_combine_kernel<true>";
+        const char *mpc = std::getenv("HRX_MP_COMBINE");
+        const bool merge_last = ((layout & 1) || via_tp) && s.groups.size() - 1 <= kMaxMergeGroups && !(mpc && std::atoi(mpc) != 0);
+        text += merge_last ? "(the last pass merges the summaries) + hrx::witness_merge_status_kernel"
+                           : (layout & 1) || via_tp ? "+ hrx::witness_combine_summary_kernel" : "+ hrx::witness_combine_kernel<true>";
         if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
     }
     std::snprintf(out, cap, "%s", text.c_str());

@@ -27,6 +27,12 @@ __device__ __forceinline__ uint4 lds_u128(uint32_t off) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// one bit per non-zero byte, byte i -> bit i
+__device__ __forceinline__ uint32_t nonzero_bytes4(uint32_t x) {
+    const uint32_t nz = ((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;
+    return ((nz * 0x01020408u) >> 24) & 0xfu;
+}
+
 // delta lookup.  GTAB: the fused table did not fit the LDS budget and is read from global memory (it stays L2/MALL
 // resident: every wave hammers the same few hundred KiB); same entry format, same byte offsets, ~10x the latency.
 template <bool GTAB>

@@ -47,6 +47,12 @@ struct WitnessArgs {
     // kernel needs — per tile and string 80 bytes: ST / EN bitvectors + one substr-id byte per row, [tile][5][B][16 B]
     uint32_t rec_D, rec_d0;       // 0 / 0: this launch's defs are the whole config
     uint32_t *summary;            // NULL: an ordinary launch
+    // the LAST pass of a multi-pass config reads the earlier groups' tile summaries itself (its finisher has everything else in hand: this
+    // group's bitvectors and id bytes, the input bytes, the reveal-mask carries) and writes the FINAL masked rows: no combine launch,
+    // this group's summary never written, the others' read once.  0: not such a pass.
+    uint32_t merge_G;                              // earlier groups (<= kMaxMergeGroups)
+    const uint32_t *merge_summary[3];              // their WitnessArgs::summary buffers
+    uint32_t *merge_ov;                            // [B]: lowest row that defs of DIFFERENT groups flag together (0xffffffff: none) -> witness_merge_status_kernel
     // chunked launch of the loader / walker / finisher kernel (hrx_kernel_spec.hip): NULL / 0 in an ordinary launch
     const uint32_t *vs_init;      // [chunk][B][D]: state | substr id of the transition into the chunk's first row << 16 | its end flag << 24
     uint32_t vs_chunks, vs_tiles, vs_groups;   // chunks per string, tiles per chunk, REAL groups (n_groups = vs_groups * vs_chunks)
@@ -173,6 +179,7 @@ constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096
 // records buffer in its layout, and computes what needs ALL defs of a row: Sum(substr_id), Sum(is_start), Sum(is_end) ->
 // reveal masks and masked rows (lib.rs:467-519, 593-764), the flag-overlap row, the merged status word.
 constexpr uint32_t kMaxGroups = 32;
+constexpr uint32_t kMaxMergeGroups = 3;   // earlier groups the last pass of a multi-pass config can merge itself (WitnessArgs::merge_summary); more: the combine launch
 struct CombineArgs {
     const uint8_t *chars;
     uint64_t stride;
@@ -185,10 +192,14 @@ struct CombineArgs {
     uint64_t *status;
     const uint32_t *grec[kMaxGroups];      // copy mode: the groups' private records buffers; summary mode: NULL
     const uint32_t *gsummary[kMaxGroups];  // summary mode (position-major outputs): the groups' tile summaries (WitnessArgs::summary)
+    const uint32_t *merge_ov;              // launch_merge_status: WitnessArgs::merge_ov of the last pass
     const uint64_t *gstatus[kMaxGroups];
     uint8_t gD[kMaxGroups], gfirst[kMaxGroups];
 };
 hipError_t launch_combine(const CombineArgs &a, hipStream_t stream);
+// the status words of a multi-pass config whose last pass merged the summaries itself: one thread per string (bad length, the lowest def's
+// undefined transition, the lowest overlap row, the accept bits of all groups)
+hipError_t launch_merge_status(const CombineArgs &a, hipStream_t stream);
 
 // CHUNKED walk (hrx_kernel_spec.hip): scout -> compose -> the loader / walker / finisher kernel over chunks (WitnessArgs::vs_*) -> stitch
 constexpr uint32_t kSpecMaxChunks = 32, kSpecMaxChunkTiles = 64;

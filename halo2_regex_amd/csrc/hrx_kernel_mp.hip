@@ -18,12 +18,6 @@
 
 namespace hrx {
 
-// one bit per non-zero byte, byte i -> bit i
-__device__ __forceinline__ uint32_t nonzero_bytes4(uint32_t x) {
-    const uint32_t nz = ((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;
-    return ((nz * 0x01020408u) >> 24) & 0xfu;
-}
-
 template <bool SM>
 __global__ __launch_bounds__(256) void witness_combine_kernel(const CombineArgs a) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -309,6 +303,37 @@ __global__ __launch_bounds__(256) void witness_combine_summary_kernel(const Comb
     }
     if (!done) sw = ov_row != 0xffffffffu ? status_overlap(ov_row) : status_ok(accept);
     a.status[b] = sw;
+}
+
+// The status words of a multi-pass config whose LAST pass merged the groups' summaries itself (WitnessArgs::merge_G): what the tail of the
+// combine kernel does, one thread per string.
+__global__ __launch_bounds__(256) void witness_merge_status_kernel(const CombineArgs a) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    uint64_t sw = 0;
+    bool done = false;
+    if (a.lens[b] > a.M) { sw = kStatusBadLength; done = true; }
+    uint32_t accept = 0, ov_row = a.merge_ov[b];
+    for (uint32_t g = 0; g < a.G && !done; ++g) {
+        const uint64_t s = a.gstatus[g][b];
+        const uint32_t code = (uint32_t)(s & 0xffu);
+        if (code == kStatusInvalidTransition) {          // the lowest def's: the reference walks def by def (lib.rs:806)
+            sw = (s & ~0xff00ull) | ((((s >> 8) & 0xffu) + a.gfirst[g]) << 8);
+            done = true;
+        } else if (code == kStatusFlagOverlap) {
+            ov_row = min(ov_row, (uint32_t)(s >> 40));   // two defs of this group flag the same row
+        } else if (code == kStatusOk) {
+            accept |= (uint32_t)((s >> 8) & 0xffu) << a.gfirst[g];
+        }
+    }
+    if (!done) sw = ov_row != 0xffffffffu ? status_overlap(ov_row) : status_ok(accept);
+    a.status[b] = sw;
+}
+
+hipError_t launch_merge_status(const CombineArgs &a, hipStream_t stream) {
+    if (a.B == 0) return hipSuccess;
+    hipLaunchKernelGGL(witness_merge_status_kernel, dim3((a.B + 255u) / 256u), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_combine(const CombineArgs &a, hipStream_t stream) {

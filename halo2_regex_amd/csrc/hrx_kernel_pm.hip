@@ -129,6 +129,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
         unsigned char *mp_f = nullptr;
         size_t mstep_f = 0;
         uint32_t f = 0;
+        uint32_t mg_sum_prev = 0, mg_ov_row = 0xffffffffu;   // merge pass (WitnessArgs::merge_G): the summed substr id of the row before the tile; lowest cross-group overlap row
         // HOLD (BYTE table — the random-DFA shape of cfg 5, where the optimistic end mask of hrx_lane.h is wrong for ~10 % of all masked
         // rows): the masked rows of the last kHoldF tiles stay in the finisher's registers, so that a fix-up that arrives within
         // kHoldF tiles zeroes them THERE; only what is older was stored already and is repaired at the memory (2-byte scattered stores).
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 mstep_f = (a.debug & kDbgFixedLines) ? (size_t)0 : (size_t)nb_f * 16u;
                 mc = MaskCarry{0, 0, 0, 0};
                 n_held = 0;
+                mg_sum_prev = 0; mg_ov_row = 0xffffffffu;
             }
 #ifdef HRX_STAMPS
             const unsigned long long fk_a = clock64();
@@ -193,6 +195,37 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             tb.en1 = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
             tb.ch = (uint64_t)s1.x | ((uint64_t)s1.y << 32);
             const uint32_t n_f = s1.z;          // the string's length (<= M; the walker clamps bad lengths)
+            if (a.merge_G) {
+                // the LAST pass of a multi-pass config: the earlier groups' tile summaries join this group's — what needs ALL defs of a row
+                // (lib.rs:467-519, 593-764): any is_start / is_end, Sum(substr_id) and where it changes, two defs flagging one row
+                const uint32_t bcl = min(b0_f + lane, B - 1u);
+                uint64_t ov_st = 0, ov_en = 0;
+                for (uint32_t g = 0; g < a.merge_G; ++g) {
+                    const uint4 *sp = reinterpret_cast<const uint4 *>(a.merge_summary[g]) + ((size_t)tf * 5u * B + bcl);
+                    const uint4 h = sp[0];
+                    const uint64_t gst = (uint64_t)h.x | ((uint64_t)h.y << 32), gen = (uint64_t)h.z | ((uint64_t)h.w << 32);
+                    ov_st |= tb.st & gst; ov_en |= tb.en1 & gen;
+                    tb.st |= gst; tb.en1 |= gen;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        const uint4 v = sp[(size_t)(i + 1u) * B];
+                        sidq[4 * i] += v.x; sidq[4 * i + 1] += v.y; sidq[4 * i + 2] += v.z; sidq[4 * i + 3] += v.w;   // byte sums <= 255 (finalize_defs)
+                    }
+                }
+                if (mg_ov_row == 0xffffffffu) {
+                    if (ov_st) mg_ov_row = t0 + (uint32_t)ctz64(ov_st);
+                    if (ov_en) mg_ov_row = min(mg_ov_row, t0 + (uint32_t)ctz64(ov_en) + 1u);
+                }
+                uint64_t ch = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t x = sidq[q], y = (x << 8) | (q ? (sidq[q - 1] >> 24) : mg_sum_prev);
+                    ch |= (uint64_t)nonzero_bytes4(x ^ y) << (4 * q);
+                }
+                mg_sum_prev = sidq[15] >> 24;
+                tb.ch = ch;
+                if (tf + 1u == tf0 + gt && active_f) a.merge_ov[b0_f + lane] = mg_ov_row;
+            }
             if (vs && tf == tf0) mc.en = s1.w;  // a chunk: the is_end flag that lands on its first row (from the row before it)
             // ---------------- reveal masks: lib.rs:598-764 ----------------
             TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n_f, M), rows_below(t0, n_f));

@@ -794,19 +794,23 @@ CFG_D7 = CFG_123 + [CFG_EX[0]] + HDR                    # def 3 = the partial ex
 CFG_D8 = CFG_123 + HDR + [CFG_1[0], CFG_A[1]]           # regex1 and regex2 a second time: both copies flag the same rows
 
 
+@pytest.mark.parametrize("combine", [False, True], ids=["merged-by-the-last-pass", "combine-launch"])
 @pytest.mark.parametrize("names", [CFG_D4, CFG_D5, CFG_D7, CFG_D8], ids=["D4", "D5", "D7", "D8"])
-def test_more_than_three_regex_defs_multi_pass(hra, oracle, names):
-    """regex_defs is a Vec of any length (src/lib.rs:112): more than three defs are walked in passes (groups of defs) and combined
-    per row by hrx::witness_combine_kernel — every layout (string-major, position-major, position-major input), substr ids counting
-    on across the groups (lib.rs:827,842), merged status words: the lowest def's undefined transition, the flag-overlap row, the
-    accept mask with a bit per def; then every ok string through the integer MockProver."""
+def test_more_than_three_regex_defs_multi_pass(hra, oracle, names, combine, monkeypatch):
+    """regex_defs is a Vec of any length (src/lib.rs:112): more than three defs are walked in passes (groups of defs); what needs all
+    defs of a row is formed by the LAST pass from the earlier groups' tile summaries (position-major outputs, up to four groups) or by
+    hrx::witness_combine_kernel / _summary_kernel (HRX_MP_COMBINE=1 forces it) — every layout (string-major, position-major,
+    position-major input), substr ids counting on across the groups (lib.rs:827,842), merged status words: the lowest def's undefined
+    transition, the flag-overlap row, the accept mask with a bit per def; then every ok string through the integer MockProver."""
     import torch
     from halo2_regex_amd import synth
     from mock_prover import IntegerMockProver, FAIL_ACCEPT
     D = len(names)
+    monkeypatch.setenv("HRX_MP_COMBINE", "1" if combine else "0")
     for M in (328, 203):                                       # aligned and unaligned row counts
         cfg = _cfg(hra, names, M)
-        assert cfg.describe_launch(700, layout=3).startswith("multi-pass, ") and "witness_combine_summary_kernel" in cfg.describe_launch(700, layout=3)
+        d = cfg.describe_launch(700, layout=3)
+        assert d.startswith("multi-pass, ") and ("witness_combine_summary_kernel" if combine else "witness_merge_status_kernel") in d
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=31)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=3, stride=chars.shape[1])
         chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
