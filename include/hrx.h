@@ -71,10 +71,13 @@ int hrx_defs_push_substr(hrx_defs *defs, size_t n_pairs, const uint64_t *pair_cu
 /* Validate and build the dense fused (state,char) tables.  Required before any call below.
  * regex_defs is a Vec of any length in the reference (src/lib.rs:112; loops at :387, :806, :828, :855): up to HRX_MAX_DEFS
  * RegexDefs per config.  Up to three defs are walked side by side by one kernel launch; a larger config is walked in passes
- * over consecutive groups of defs (each group's tables LDS-resident) and a combine launch forms the per-row sums over all
- * defs (reveal masks, flag overlap) and the merged status — same buffers, same results; with position-major outputs the passes
- * write the caller's record planes directly and the extra cost is ~2.25 bytes per row and group (string-major outputs are
- * copied into place by the combine launch and are several times slower: ask for position-major buffers). */
+ * over consecutive groups of defs (each group's tables LDS-resident); the per-row sums over all defs (reveal masks, flag
+ * overlap) and the merged status are formed by the last pass itself from 80-byte tile summaries the earlier passes leave
+ * (position-major outputs, up to four groups) or by a combine launch — same buffers, same results; with position-major outputs
+ * the passes write the caller's record planes directly and the extra cost is ~2.5 bytes per row and earlier group (string-major
+ * outputs with row counts in multiples of 8 are produced position-major in context scratch and transposed; other row counts are
+ * copied into place by the combine launch and are several times slower: ask for position-major buffers).
+ * HRX_MP_COMBINE=1 in the environment of hrx_ctx_create keeps the separate combine launch. */
 #define HRX_MAX_DEFS 32
 int hrx_defs_finalize(hrx_defs *defs);
 
