@@ -447,6 +447,8 @@ def run_rank(args, rank, world, device_index, barrier):
     ev0.record()
     run_steps()                                            # EXACTLY K steps
     ev1.record()
+    while not ev1.query():                                 # (spin: a blocking wait's wake-up occasionally costs 100+ us — 10 % of a 20-step region)
+        pass
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
