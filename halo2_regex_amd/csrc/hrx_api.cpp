@@ -493,7 +493,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
             HIP_TRY(ctx->spec_vstatus.reserve((size_t)C * B * 8));
             HIP_TRY(ctx->spec_vinfo.reserve((size_t)C * B * 8));
             HIP_TRY(ctx->spec_work.reserve(16 + (size_t)C * B * 8));
-            sp.chars = chars; sp.stride = stride; sp.lens = lens; sp.B = (uint32_t)B; sp.M = (uint32_t)M; sp.D = Dn;
+            sp.chars = chars; sp.stride = stride; sp.lens = lens; sp.B = (uint32_t)B; sp.M = (uint32_t)M; sp.D = Dn; sp.in_pm = (lay & HRX_LAYOUT_INPUT_POSITION_MAJOR) ? 1u : 0u;
             sp.C = C; sp.tiles_per_chunk = (uint32_t)li.spec_tiles; sp.n_groups = G;
             sp.table_image = d_table; sp.table_bytes = a.table_bytes;
             sp.smax = smax;

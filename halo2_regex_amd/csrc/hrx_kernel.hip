@@ -64,7 +64,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
     // (n x 29-50 ns) with three quarters of the walker slots empty.  Cut every string into chunks of 16 tiles, find the chunks' start
     // states (scout + compose) and walk the chunks as groups of their own: the chip is full again.  From two groups per CU on the
     // sequential kernels are bound by the memory system anyway (32768 x 32768 B: 1.3 ms of traffic against 0.95 ms of chain).
-    if ((a.layout & 3u) == 3u && !out.gtab && !a.summary && !a.merge_G && !a.vs_init && !(a.debug & (kDbgNoSpec | kDbgForceHalf | kDbgForceByte | kDbgForceGlobalTable | kDbgForcePair | kDbgForceDefParallel))) {
+    if ((a.layout & 1u) && !out.gtab && !a.summary && !a.merge_G && !a.vs_init && !(a.debug & (kDbgNoSpec | kDbgForceHalf | kDbgForceByte | kDbgForceGlobalTable | kDbgForcePair | kDbgForceDefParallel))) {
         const uint32_t ntiles = (a.M + 63u) / 64u;
         uint32_t tpc = 0;
         if (a.debug & kDbgForceSpec) {

@@ -208,6 +208,7 @@ struct SpecArgs {
     uint64_t stride;
     const uint32_t *lens;
     uint32_t B, M, D;
+    uint32_t in_pm;                          // 1: position-major input ([stride/16][B][16]), 0: string-major ([B][stride])
     uint32_t C, tiles_per_chunk, n_groups;   // chunks per string, 64-row tiles per chunk, REAL groups of 64 strings
     const uint32_t *table_image;             // the narrow fused table (global copy; the scout stages it into LDS)
     uint32_t table_bytes;

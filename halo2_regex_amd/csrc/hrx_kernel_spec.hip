@@ -61,9 +61,11 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
         // nothing of this chunk matters if no string of the wave reaches it (rows >= n are padding: lib.rs:404-418)
         if (__ballot(n > r0) == 0ull) continue;
         const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
-        const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(bc - blk0) * 16u;   // position-major input: 16-byte piece i at + i * nb * 16
+        // position-major input: 16-byte piece i of the string at + i * nb * 16; string-major: at + 16 i
+        const uint8_t *cptr = a.in_pm ? a.chars + (size_t)blk0 * a.stride + (size_t)(bc - blk0) * 16u : a.chars + (size_t)bc * a.stride;
+        const size_t cmul = a.in_pm ? (size_t)nb : (size_t)1;
         auto piece = [&](const uint32_t i) -> uint4 {   // bytes [r0 + 16 i, r0 + 16 i + 16) of the string (clamped inside its stride)
-            return *reinterpret_cast<const uint4 *>(cptr + (size_t)min(r0 + 16u * i, row_cap) * nb);
+            return *reinterpret_cast<const uint4 *>(cptr + (size_t)min(r0 + 16u * i, row_cap) * cmul);
         };
         const uint4 p0 = piece(0), p1 = piece(1);
         const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
@@ -291,7 +293,8 @@ __device__ __forceinline__ void spec_walk_flagged(const SpecArgs &a, const uint3
     const uint32_t S = a.n_states[d], base = a.dc[d].row_base, rows = a.tiles_per_chunk * 64u, r0 = k * rows;
     const uint32_t *T = a.table_image + (size_t)base * 256u;
     const uint32_t blk0 = (b / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0);
-    const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)(b - blk0) * 16u;
+    const uint8_t *cptr = a.in_pm ? a.chars + (size_t)blk0 * a.stride + (size_t)(b - blk0) * 16u : a.chars + (size_t)b * a.stride;
+    const size_t cmul = a.in_pm ? (size_t)nb * 16u : (size_t)16u;     // byte r of the string at + (r >> 4) * cmul + (r & 15)
     const uint32_t per = rows >> 6;
     for (uint32_t s0 = 0; s0 < S; s0 += 4u) {
         uint32_t e[4], em1[4];
@@ -299,7 +302,7 @@ __device__ __forceinline__ void spec_walk_flagged(const SpecArgs &a, const uint3
         for (uint32_t j = 0; j < 4u; ++j) { e[j] = min(s0 + j, S - 1u); em1[j] = e[j]; }
         for (uint32_t i = 0; i < per; ++i) {
             const uint32_t r = r0 + lane * per + i;
-            const uint32_t c = cptr[(size_t)(r >> 4) * nb * 16u + (r & 15u)];
+            const uint32_t c = cptr[(size_t)(r >> 4) * cmul + (r & 15u)];
 #pragma unroll
             for (uint32_t j = 0; j < 4u; ++j) { em1[j] = e[j]; e[j] = (T[e[j] * 256u + c] >> kNextShift) - base; }    // (the dead row S + 1 leads to itself)
         }
@@ -447,7 +450,8 @@ __global__ __launch_bounds__(64) void spec_repair_kernel(const SpecArgs a) {
         const size_t q4 = (a.M + 3u) / 4u, q8 = (a.M + 7u) / 8u;
         const uint32_t *rec = a.records + (size_t)blk0 * q4 * D * 4u;
         uint16_t *msk = a.masked + (size_t)blk0 * q8 * 8u;
-        const uint8_t *cptr = a.chars + (size_t)blk0 * a.stride + (size_t)bl * 16u;
+        const uint8_t *cptr = a.in_pm ? a.chars + (size_t)blk0 * a.stride + (size_t)bl * 16u : a.chars + (size_t)b * a.stride;
+        const size_t cmul = a.in_pm ? (size_t)nb * 16u : (size_t)16u;
         // row r: sid = sum of the defs' substr ids, st = any start_enable, en1 = any end_enable (= EN[r + 1], lib.rs:501-519); zeros beyond M
         auto row = [&](const uint32_t r, uint32_t &sid, uint32_t &st, uint32_t &en1) {
             sid = 0; st = 0; en1 = 0;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(64) void spec_repair_kernel(const SpecArgs a) {
                 const uint32_t p = r0 + min(s0 + u, steps - 1u) * 64u + lane;
                 uint32_t sid, st, en1;
                 row(p, sid, st, en1);
-                const uint32_t c = cptr[(size_t)(p >> 4) * nb * 16u + (p & 15u)];
+                const uint32_t c = cptr[(size_t)(p >> 4) * cmul + (p & 15u)];
                 pk[u] = sid | st << 10 | en1 << 11 | c << 16;
             }
 #pragma unroll
