@@ -20,6 +20,7 @@ $B --config dfa256 --len 4095 --rows 4096 --steps 20 --warmup 3 --layout string-
 $B --batch 8192 --len 32767 --rows 32768 --steps 10 --warmup 2                       > $O/regex1_8192x32768_long.json
 $B --batch 16384 --len 32767 --rows 32768 --steps 10 --warmup 2                      > $O/regex1_16384x32768_long.json
 $B --config headers3 --batch 8192 --len 32767 --rows 32768 --steps 5 --warmup 2      > $O/headers3_8192x32768_long.json
+$B --config regex23 --batch 8192 --len 32767 --rows 32768 --steps 5 --warmup 2       > $O/regex23_8192x32768_long.json
 HRX_DEBUG_FLAGS=0x80000000 $B --allow-debug-flags --batch 8192 --len 32767 --rows 32768 --steps 10 --warmup 2 > $O/regex1_8192x32768_long_sequential.json
 HRX_DEBUG_FLAGS=0x80000000 $B --allow-debug-flags --config headers3 --batch 8192 --len 32767 --rows 32768 --steps 5 --warmup 2 > $O/headers3_8192x32768_long_sequential.json
 for f in $O/*.json; do python3 -c "
