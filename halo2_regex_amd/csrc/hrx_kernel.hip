@@ -71,7 +71,11 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
             tpc = 4;
             while (tpc <= kSpecMaxChunkTiles && (ntiles % tpc != 0u || ntiles / tpc > kSpecMaxChunks)) tpc *= 2;
             if (tpc > kSpecMaxChunkTiles || ntiles / tpc < 2u) tpc = 0;
-        } else if ((size_t)a.n_groups <= (size_t)num_cus && ntiles >= 64u) {
+        } else if (ntiles >= 64u && (a.D == 1u ? (size_t)a.n_groups < 2u * (size_t)num_cus
+                                               : (size_t)a.n_groups * 4u <= (size_t)num_cus * (a.D == 2u ? 7u : 6u))) {
+            // below two groups per CU the sequential kernels run for one or two chains with most walker slots empty (32768-byte strings,
+            // 20480 / 28672 strings: D = 1 2.07 / 2.20 ms against 1.05 / 1.41 chunked; D = 2 2.10 / 2.34 against 1.67 / 2.28; D = 3 2.77 / 2.79
+            // against 2.37 / 3.23: tools/spec_threshold.sh); from two groups per CU on they are memory-bound and win   // (D = 2: the def-parallel kernel's chain is 1.8 ms per 32768 rows; chunked wins up to 1.25 groups per CU)
             tpc = 16;
             while (tpc <= kSpecMaxChunkTiles && (ntiles % tpc != 0u || ntiles / tpc > kSpecMaxChunks)) tpc *= 2;
             if (tpc > kSpecMaxChunkTiles) tpc = 0;
@@ -160,8 +164,10 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
     if ((a.layout & 1u) && a.D == 1 && a.pair_image &&
         ((size_t)a.n_groups < (size_t)num_cus * 4 || (a.debug & kDbgForcePair)) &&
         !(a.debug & (kDbgNoPair | kDbgForceNarrow | kDbgForceWide | kDbgForceHalf | kDbgForceGlobalTable))) {
+        // as few pairs per workgroup as cover the batch in ONE round (small batches spread over the CUs); the 76-KiB table leaves room
+        // for one workgroup per CU, so "fewer pairs" must not mean "a second round" (24576 x 32768 B ran 2.1 ms with one pair per CU)
         int pairs = 4;
-        while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        while (pairs > 1 && (size_t)a.n_groups <= (size_t)num_cus * (pairs - 1)) --pairs;
         for (; pairs >= 1; --pairs) {
             for (int ns = 4; ns >= 2; --ns) {
                 const size_t lds = a.pair_bytes + (size_t)pairs * pp_pair_bytes((size_t)ns);
