@@ -60,6 +60,27 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         if (a.debug & kDbgForceDynamicGroups) return (size_t)a.n_groups > slots ? 1 : 0;
         return ((size_t)a.n_groups >= 8 * slots && (a.M + 63u) / 64u >= 32u) ? 1 : 0;
     };
+    // "As few walker pairs per workgroup as the batch needs" spreads a small batch over the CUs — but never at the price of a second
+    // round: where the table leaves LDS for ONE workgroup per CU, 257-511 groups with one pair per workgroup ran twice as long as with
+    // two (pair-step kernel, 24576 x 32768 B: 2.1 vs 1.4 ms).  fixed: table bytes; ring_min(p): the p pairs' smallest rings; wpp: waves per
+    // pair; max_waves: per CU.
+    auto one_round_pairs = [&](int pairs, const size_t fixed, auto pair_bytes /* (ns) -> one pair's bytes */, const int ns_max, const int ns_min, const int wpp,
+                               const int max_waves) {
+        auto lds_of = [&](const int p) -> size_t {      // what the loops below pick for p pairs: the deepest ring that fits
+            for (int ns = ns_max; ns >= ns_min; --ns)
+                if (fixed + (size_t)p * pair_bytes(ns) <= kLdsLimit) return fixed + (size_t)p * pair_bytes(ns);
+            return 0;
+        };
+        for (; pairs < 4; ++pairs) {
+            const size_t lds = lds_of(pairs);
+            size_t per_cu = lds ? kLdsLimit / lds : 0;
+            if (per_cu * (size_t)(wpp * pairs) > (size_t)max_waves) per_cu = (size_t)max_waves / (size_t)(wpp * pairs);
+            if (per_cu < 1) per_cu = 1;
+            if ((size_t)a.n_groups <= (size_t)num_cus * pairs * per_cu) break;           // one round
+            if (!lds_of(pairs + 1)) break;                                                // no room for another pair
+        }
+        return pairs;
+    };
     // ---- CHUNKED launch (hrx_kernel_spec.hip): a batch of at most one group per CU runs for as long as one string's dependent chain
     // (n x 29-50 ns) with three quarters of the walker slots empty.  Cut every string into chunks of 16 tiles, find the chunks' start
     // states (scout + compose) and walk the chunks as groups of their own: the chip is full again.  From two groups per CU on the
@@ -109,6 +130,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         // lacks: a finisher wave and a ring of more than one slot (its walker spent 46 % of its cycles in the tile-end work).
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        pairs = one_round_pairs(pairs, a.byte_bytes, [](int ns) { return pm_pair_bytes((size_t)ns, false, true); }, 4, 2, 3, 12);
         for (; pairs >= 1; --pairs) {
             for (int ns = 4; ns >= 2; --ns) {
                 const size_t lds = a.byte_bytes + (size_t)pairs * pm_pair_bytes((size_t)ns, false, true);
@@ -134,6 +156,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         // fit LDS (cfg 5: 256 x 256 -> 128 KiB) stay LDS-resident instead of being walked out of L2 (kDbgForceHalf forces it)
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        pairs = one_round_pairs(pairs, a.half_bytes, [](int ns) { return pm_pair_bytes((size_t)ns, true, false); }, 4, 1, 2, 8);
         for (; pairs >= 1; --pairs) {
             for (int ns = 4; ns >= 1; --ns) {
                 const size_t lds = a.half_bytes + (size_t)pairs * pm_pair_bytes((size_t)ns, true, false);
@@ -215,6 +238,11 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         // ---- loader/walker kernel: table + per pair a ring of up to 4 input tiles (4 KiB each)
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        {
+            const bool fin = (a.layout & 1u) != 0;
+            const int wpp0 = fin ? 3 : 2;
+            pairs = one_round_pairs(pairs, a.table_bytes, [fin](int ns) { return pm_pair_bytes((size_t)ns, false, fin); }, 4, 2, wpp0, 4 * wpp0);
+        }
         for (; pairs >= 1; --pairs) {
             for (int ns = 4; ns >= 2; --ns) {
                 const size_t lds = a.table_bytes + (size_t)pairs * pm_pair_bytes((size_t)ns, false, (a.layout & 1u) != 0);   // position-major outputs: the loader finishes the tiles
@@ -247,6 +275,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         const size_t slot = 64 * 128 + 64 * 8 + 64 * 32, fixed = 16 + 256;
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
+        pairs = one_round_pairs(pairs, a.byte_bytes, [=](int ns) { return (size_t)ns * slot + fixed; }, 4, 2, 2, 8);
         for (; pairs >= 1; --pairs) {
             if (a.byte_bytes + pairs * (2 * slot + fixed) > kLdsLimit) continue;
             size_t ns = (kLdsLimit - a.byte_bytes - pairs * fixed) / (pairs * slot);
@@ -266,6 +295,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         const size_t slot = 64 * 128 + 64 * 8 + 64 * (a.D == 1 ? 32 : 16), fixed = 16 + 256;  // + the storer's LDS-DMA sink
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;  // small batches: spread over the CUs
+        pairs = one_round_pairs(pairs, a.table_bytes, [=](int ns) { return (size_t)ns * slot + fixed; }, 4, 2, 2, 8);
         for (; pairs >= 1; --pairs) {
             if (a.table_bytes + pairs * (2 * slot + fixed) > kLdsLimit) continue;
             size_t ns = (kLdsLimit - a.table_bytes - pairs * fixed) / (pairs * slot);
