@@ -129,6 +129,26 @@ def test_compute_fails_loudly_without_a_device():
         cfg.witness_batch_host(np.zeros((1, 16), np.uint8), np.zeros(1, np.uint32))
 
 
+def test_planner_thresholds_of_round_3():
+    """Where the chunked launch stops (below 2 / up to 1.75 / up to 1.5 groups of 64 strings per CU at D = 1 / 2 / 3, either input layout,
+    position-major outputs, 4096 rows or more) and the one-round rule for small batches (profiles/r03_probes/spec_threshold.txt)."""
+    M = 32768
+    one = RegexVerifyConfig.configure(M, _defs(CFG_A[:1]), device=None)
+    two = RegexVerifyConfig.configure(M, _defs(CFG_A), device=None)
+    for lay in (3, 1):
+        assert "chunked=32x16 tiles" in one.describe_launch(8192, layout=lay)
+        assert "chunked=" in one.describe_launch(32704, layout=lay) and "chunked=" not in one.describe_launch(32768, layout=lay)     # 511 / 512 groups
+        assert "chunked=" in two.describe_launch(28672, layout=lay) and "chunked=" not in two.describe_launch(28736, layout=lay)     # 448 / 449 groups
+    assert "chunked=" not in one.describe_launch(8192, layout=0) and "chunked=" not in one.describe_launch(8192, layout=2)           # string-major outputs: never
+    short = RegexVerifyConfig.configure(2048, _defs(CFG_A[:1]), device=None)
+    assert "chunked=" not in short.describe_launch(8192, layout=3)                                                                 # fewer than 4096 rows: never
+    # 257-511 groups on the pair-step kernel (76-KiB table: one workgroup per CU): two pairs per workgroup, one round — not one pair and two rounds
+    assert short.describe_launch(20480, layout=3).startswith("hrx::witness_pp_kernel grid=160 waves=6 ")
+    # 513-768 groups, D = 2 on the WIDE table: three pairs per workgroup cover them in one round
+    short2 = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
+    assert short2.describe_launch(40000, layout=3).startswith("hrx::witness_pm_kernel<2, false, true, false> grid=209 waves=9 ")
+
+
 def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     """hrx_describe_launch (host-only): which kernel and table format serve which shape on a 256-CU MI355X."""
     from halo2_regex_amd import synth
