@@ -86,6 +86,50 @@ def oracle_handle(names, allow_build=True):
     return oracle_lib.OracleDefs(oracle_lib.load_oracle(), names)
 
 
+def single_string(cfg, hra, o, chars, lens, M, calls=2000):
+    """BASELINE configs[0]: the reference's own CPU-runnable case — ONE string per call, what `cargo test --release` exercises through
+    RegexVerifyConfig::match_substrs (lib.rs:311-773, the test at lib.rs:1068).  The product serves it with the native host walk behind
+    hrx_match_substrs (csrc/hrx_host_walk.cpp; no device work, no PCIe); the oracle's orc_match_substrs is timed beside it on the same
+    string, both through ctypes with preallocated output columns (the foreign-call overhead, ~1-2 us, is in both figures)."""
+    import ctypes as C
+    import numpy as np
+    b = int(np.argmax(lens))
+    n = int(lens[b])
+    ch = np.ascontiguousarray(chars[b, :n])
+    D = cfg.num_defs
+    u8p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
+    cols = [np.zeros(M, np.uint64), np.zeros(M, np.uint64)] + [np.zeros((D, M), np.uint64) for _ in range(4)] + [np.zeros(M, np.uint64), np.zeros(M, np.uint64)]
+    ptrs = [c.ctypes.data_as(u64p) for c in cols]
+    status = np.zeros(1, np.uint64)
+    ctx, cp = cfg._need_ctx(), ch.ctypes.data_as(u8p)
+    fn = hra.lib.hrx_match_substrs
+    st = status.ctypes.data_as(u64p)
+    for _ in range(20):
+        rc = fn(ctx, cp, n, M, *ptrs, st)
+    if rc != 0:
+        return None
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        fn(ctx, cp, n, M, *ptrs, st)
+    us = (time.perf_counter() - t0) / calls * 1e6
+    out = {"us_per_call": us, "rows_per_s": n / (us * 1e-6), "n": n, "max_chars_size": M, "calls": calls, "cores": 1,
+           "what": "hrx_match_substrs (the C-ABI stand-in for RegexVerifyConfig::match_substrs, lib.rs:311-773) on one %d-byte string of the batch, integer columns of "
+                   "all %d witness rows out; the native host walk, one thread, timed through ctypes" % (n, M)}
+    if o is not None:
+        info = np.zeros(5, np.uint64)
+        ofn, oh, ip = o.lib.orc_match_substrs, o.h, info.ctypes.data_as(u64p)
+        for _ in range(5):
+            ofn(oh, cp, n, M, *ptrs, ip)
+        oc = max(50, calls // 10)
+        t0 = time.perf_counter()
+        for _ in range(oc):
+            ofn(oh, cp, n, M, *ptrs, ip)
+        ous = (time.perf_counter() - t0) / oc * 1e6
+        out["oracle_us_per_call"] = ous
+        out["oracle_what"] = "orc_match_substrs (oracle/hrx_oracle.c: the reference's hash-map / hash-set walk and the gate-by-gate mask recurrences on integers), same string, %d calls" % oc
+    return out
+
+
 def cpu_baseline(o, names, chars, lens, M, budget_s=8.0):
     """The oracle (oracle/hrx_oracle.c, the reference-faithful C port) timed single-threaded on a bounded sample of
     the same workload — the reference itself is single-threaded — plus, as extra context, the same port
@@ -405,9 +449,11 @@ def run_rank(args, rank, world, device_index, barrier):
             per.append(e0.elapsed_time(e1) / count)
         return per
 
+    t_warm = time.perf_counter()
     for i in range(args.warmup):
         launch(i)
     sync_barrier()
+    warm_launches = args.warmup
     # The K timed steps are K kernel launches, step i over buffer set i % nsets.  They are recorded once into a HIP graph and the
     # graph is replayed inside the timed region, so that a slow host thread cannot turn the measurement into a launch-rate test
     # (one launch is ~80 us of device time); --eager launches them one by one.
@@ -418,30 +464,24 @@ def run_rank(args, rank, world, device_index, barrier):
             # untimed replays of the same graph, ~100 ms of them (1300 launches of the bench line): graph upload, and the device's own ramp — with 100 launches (8 ms)
             # behind it a 20-step replay averaged 80.0 us per launch, with 1000 launches 77.9, and from K = 100 on the count no longer matters
             # (profiles/r03_probes/warmup_ramp.txt; a kernel trace shows the launches of a replay that follows a pause taking 92 -> 84 us over
-            # its first twenty, profiles/r03_pm_trace_replays.txt); W = 5 eager steps do not cover that
+            # its first twenty, profiles/r03_pm_trace_replays.txt); W = 5 eager steps do not cover that.  The line says so: `warmup_effective`.
             g.replay(); torch.cuda.synchronize()            # (upload)
             tr = time.perf_counter(); g.replay(); torch.cuda.synchronize(); tr = max(time.perf_counter() - tr, 1e-5)
             untimed = args.untimed_replays if args.untimed_replays > 0 else max(2, min(1000, int(0.1 / tr) + 1))    # ~100 ms of load
             for _ in range(untimed - 2):
                 g.replay()
             torch.cuda.synchronize()
+            warm_launches += untimed * args.steps
             run_steps, launch_mode = g.replay, "hipGraph of %d kernel nodes (after %d untimed replays of it = ~100 ms; the end of the timed replay is awaited by spinning on its end event)" % (args.steps, untimed)
     if run_steps is None:
         def run_steps():
             for i in range(args.steps):
                 launch(i)   # launched on torch's current stream, where the events sit
-    # poison the outputs: what the verification reads afterwards was written by the timed launches.  Status words entirely; records and
-    # masked rows at one element per ~64 KiB — filling the 3 GB of buffers outright would leave the memory system (256 MB of dirty lines in
-    # the Infinity Cache, everything written once more) in a state no steady series of launches ever sees, right before the timed region.
-    for _, _, out in sets:
-        if pm:                                 # (prime strides: every string and every row position gets its share of the spots)
-            out[0].view(-1)[::16411].fill_(-1)
-            out[1].view(-1)[::32771].fill_(-1)
-        else:                                  # (string-major outputs are pitched views: every 64th row of every string)
-            out[0][:, ::64].fill_(-1)
-            out[1][:, ::64].fill_(-1)
-        out[2].fill_(-1)
+    # (Round 3 poisoned the outputs HERE, between the untimed replays and the timed one: the timed replay then was the first thing after
+    # a burst of strided fills and read 5 % slower than the replays that follow it.  The poison now comes AFTER the timed region, in front
+    # of one more replay of the very same graph, and that replay's outputs are what the verification reads — see below.)
     sync_barrier()
+    warm_ms = (time.perf_counter() - t_warm) * 1e3
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -454,6 +494,21 @@ def run_rank(args, rank, world, device_index, barrier):
     barrier()
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch duration, HIP events on the launch stream
 
+    # What the verification reads must have been written by the timed work: poison the outputs — status words entirely; records and
+    # masked rows at one element per ~64 KiB (filling the 3 GB of buffers outright would take seconds of host-visible time for nothing:
+    # a launch that skipped a string, a tile or a plane shows at these spots as surely) — and replay the SAME executable graph (or the same
+    # eager sequence) once more.  Every launch of the timed region is one of this replay's launches, with the same arguments.
+    for _, _, out in sets:
+        if pm:                                 # (prime strides: every string and every row position gets its share of the spots)
+            out[0].view(-1)[::16411].fill_(-1)
+            out[1].view(-1)[::32771].fill_(-1)
+        else:                                  # (string-major outputs are pitched views: every 64th row of every string)
+            out[0][:, ::64].fill_(-1)
+            out[1][:, ::64].fill_(-1)
+        out[2].fill_(-1)
+    torch.cuda.synchronize()
+    run_steps()
+    torch.cuda.synchronize()
     # sanity: every string of every buffer set the timed steps wrote finished with status 0
     written = min(nsets, args.steps)
     for k in range(written):
@@ -461,7 +516,10 @@ def run_rank(args, rank, world, device_index, barrier):
         assert ((st & np.uint64(0xff)) == 0).all(), "status != ok in the bench workload (buffer set %d)" % k
 
     res = {"rank": rank, "device": device_index, "rows": rows_per_step * args.steps, "elapsed_s": elapsed, "avg_launch_ms": kern_ms,
-           "debug_flags": dbg or None, "numa_node": numa, "strings": B, "shard_begin": b_begin}
+           "debug_flags": dbg or None, "numa_node": numa, "strings": B, "shard_begin": b_begin,
+           "warmup_effective": {"launches": warm_launches, "eager_steps": args.warmup, "graph_replays": (warm_launches - args.warmup) // max(args.steps, 1),
+                                "ms": warm_ms, "note": "every launch of this workload that ran before the timed region (the --warmup eager steps + the untimed replays of the K-step graph), "
+                                                       "and the wall time from the first of them to the barrier in front of the timed region (includes graph capture)"}}
     profiled = under_profiler()
     o = None
     if (not args.no_verify and (rank == 0 or args.verify_all_ranks)) or (rank == 0 and not args.no_cpu_baseline):
@@ -541,26 +599,17 @@ def run_rank(args, rank, world, device_index, barrier):
             res["traffic"] = measured_traffic(args.argv, device_index)
     if not args.no_cpu_baseline and o is not None:
         res["cpu_baseline"] = cpu_baseline(o, names, chars, lens, M)
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            res["single_string"] = single_string(cfg, hra, o, chars, lens, M)
+        except Exception as e:                                   # a side figure must never break the bench line
+            sys.stderr.write("single-string timing failed: %s\n" % e)
     return res
 
 
 # ----------------------------------------------------------------------------------------------------------------
 # aggregation (imported by tests/test_dist_cpu.py)
 # ----------------------------------------------------------------------------------------------------------------
-def pmc_traffic(args):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json:
-    WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect counters
-    itself; None unless the committed passes were taken on the workload and kernel being run."""
-    try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r02_pm_pmc.json" if args.layout == "position-major" else "r01_split_pmc.json")))
-        if (args.config == "regex1" and args.batch == 65536 and args.n == 1023 and args.rows == 1024 and args.dist == "planted"
-                and not args.dense):
-            return p["hbm_bytes_per_launch"]["total"]
-    except Exception:
-        pass
-    return None
-
-
 def aggregate(per_rank, args):
     """The JSON line from the per-rank results: value = rows of ALL ranks / MAX over ranks of the elapsed time."""
     per_rank = sorted(per_rank, key=lambda r: r["rank"])
@@ -580,7 +629,7 @@ def aggregate(per_rank, args):
         "scaling": getattr(args, "scaling", "weak"), "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": r0["config"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": (r0.get("traffic") or {}).get("total") or pmc_traffic(args),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": (r0.get("traffic") or {}).get("total"),   # null when the two rocprofv3 --pmc child passes did not run (--no-pmc, N > 1) or failed: never a number from another run
                      "kernel": r0["desc"].split(" grid=")[0], "launch": "grid=" + r0["desc"].split(" grid=")[1],
                      "avg_launch_ms": kern_ms,
                      "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_row": BYTES_PER_ROW(D),
@@ -595,7 +644,7 @@ def aggregate(per_rank, args):
     }
     if r0.get("library"):
         line["library"] = r0["library"]
-    line["roofline"]["traffic_source"] = r0["traffic"] if r0.get("traffic") else ("profiles/r02_pm_pmc.json (committed rocprofv3 PMC passes of this command)" if line["roofline"]["traffic"] else None)
+    line["roofline"]["traffic_source"] = r0["traffic"] if r0.get("traffic") else None
     if r0.get("verified"):
         line["verified"] = r0["verified"]
     if r0.get("spread"):
@@ -636,6 +685,10 @@ def aggregate(per_rank, args):
         line["roofline"]["mix_ceiling"] = ceil
     if r0.get("cpu_baseline"):
         line["cpu_baseline"] = r0["cpu_baseline"]
+    if r0.get("single_string"):
+        line["single_string"] = r0["single_string"]
+    if r0.get("warmup_effective"):
+        line["warmup_effective"] = r0["warmup_effective"]
     return line
 
 
@@ -754,6 +807,9 @@ def main(argv=None):
         dist.destroy_process_group()
         return
     if args.gpus > 1:
+        if under_profiler():   # the profiler's preloaded library has initialised the GPU in THIS process: it must not fork + exec children
+            raise SystemExit("bench.py --gpus %d under rocprofv3: profile one rank (--gpus 1), or wrap each rank of a torch.distributed.run launch; "
+                             "a bare multi-GPU run spawns children and must not start under a profiler" % args.gpus)
         print(json.dumps(spawn_children(args, argv)), flush=True)
         return
     res = run_rank(args, 0, 1, 0, lambda: None)

@@ -456,8 +456,9 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         a.half_image = d_half; a.half_bytes = (uint32_t)(set.half_image.size() * 2);
         a.pair_image = d_pairtab; a.pair_bytes = set.pair.bytes; a.pair_classes = set.pair.n_classes;
         a.pair_blk_bytes = set.pair.blk_bytes; a.pair_lut_off = set.pair.lut_off;
-        a.byte_image = d_bytetab; a.byte_bytes = set.byte.bytes; a.byte_ptab_off = set.byte.ptab_off; a.byte_mul_a2 = set.byte.mul_a * 2; a.byte_mul_b2 = set.byte.mul_b * 2; a.byte_slot_mask2 = (set.byte.slots - 1u) * 2u;
+        a.byte_image = d_bytetab; a.byte_bytes = set.byte.bytes; a.byte_ptab_off = set.byte.ptab_off; a.byte_mul_a4 = set.byte.mul_a * 4; a.byte_mul_b4 = set.byte.mul_b * 4; a.byte_slot_mask4 = (set.byte.slots - 1u) * 4u;
         a.byte_dead = set.byte.dead;
+        a.byte_rows_bytes = set.byte.n_rows * 256u; a.byte16_bytes = set.byte.bytes16; a.byte16_ptab_off = set.byte.ptab16_off;
         a.D = (uint32_t)set.defs.size();
         a.debug = ctx->debug;
 #ifdef HRX_ABLATION
@@ -718,7 +719,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     a.half_bytes = (uint32_t)(s.half_image.size() * 2);
     a.pair_image = s.pair.image.empty() ? nullptr : s.pair.image.data(); a.pair_bytes = s.pair.bytes; a.pair_classes = s.pair.n_classes;
     a.pair_blk_bytes = s.pair.blk_bytes; a.pair_lut_off = s.pair.lut_off;
-    a.byte_image = s.byte.image.empty() ? nullptr : s.byte.image.data(); a.byte_bytes = s.byte.bytes; a.byte_dead = s.byte.dead;
+    a.byte_image = s.byte.image.empty() ? nullptr : s.byte.image.data(); a.byte_bytes = s.byte.bytes; a.byte_dead = s.byte.dead; a.byte16_bytes = s.byte.bytes16;
     a.D = (uint32_t)s.defs.size();
     a.debug = debug_flags_from_env();   // what a context created now would run with (kernel-selection bits only in a release build)
     if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a pass of a multi-pass config is the loader / walker / finisher kernel)
@@ -730,12 +731,11 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     }
     char name[128], line[256];
     const char *tf[2] = {"false", "true"};
+    // the names rocprofv3 lists: every template argument spelled out, defaulted ones too (an exact-match join with a kernel_stats.csv works)
     if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
     else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u>", a.D);
-    else if (li.split == 2 && li.byte) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, false, false, false, false, true>", a.D);
-    else if (li.split == 2) std::snprintf(name, sizeof name, (layout & 1) ? "hrx::witness_pm_kernel<%u, %s, %s, %s>" : "hrx::witness_pm_kernel<%u, %s, %s, %s, true>", a.D, tf[li.gtab], tf[li.wide], tf[li.half]);
-    else if (li.split == 1 && li.byte) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<1, 32, true>");
-    else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u>", a.D, 32u / a.D);
+    else if (li.split == 2) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, %s, %s, %s, %s, %s>", a.D, tf[li.gtab], tf[li.wide], tf[li.half], tf[!(layout & 1)], tf[li.byte]);
+    else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u, %s>", a.D, li.byte ? 32u : 32u / a.D, tf[li.byte]);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
     std::snprintf(line, sizeof line, "%s grid=%d waves=%d ring=%d lds=%zu%s", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes, li.dyn ? " groups=dynamic" : "");
     out = line;

@@ -2,6 +2,7 @@
 #include "hrx_defs.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "../../include/hrx.h"
@@ -156,7 +157,7 @@ static void build_pair_table(DefsSet &s) {
 }
 
 // BYTE image (hrx_lane.h) of def 0 from its dense 4-byte table and its (state, next) -> tag matrix.
-// The tags go into a table of 256 .. 4096 two-byte slots addressed by an ARITHMETIC perfect hash of the pair: slot = (state * A + next * B) & (slots - 1)
+// The tags go into a table of 256 .. 4096 four-byte slots addressed by an ARITHMETIC perfect hash of the pair: slot = (state * A + next * B) & (slots - 1)
 // with (A, B) searched so that no two tagged pairs share a slot; a lookup reads the slot of ANY pair and takes the tag only if
 // the slot's key is the pair's next state (A is odd and slots >= 256: slot and next determine the state).  Substr ids of 64 and more (a slot has 6 bits for the id), or no (A, B) within the search budget (hundreds of
 // tagged pairs): no BYTE image — the HALF table or the global table serves the def.
@@ -188,9 +189,12 @@ static void build_byte_table(DefsSet &s) {
     for (uint32_t ns = kByteMinSlots; ns <= kByteSlots && !found; ns <<= 1) {
         if (ns < kByteSlots && keys.size() * 4 > ns) continue;
         if (keys.empty()) { A = 1; B = 1; slots = ns; found = true; break; }
+        // a random (A, B) is collision-free with probability ~exp(-k (k - 1) / (2 ns)): sizes that leave the budget less than a few expected hits are skipped
+        const uint32_t budget = 200000u;
+        if (ns < kByteSlots && std::exp(-(double)keys.size() * (double)(keys.size() - 1) / (2.0 * ns)) * budget < 4.0) continue;
         // deterministic search: odd A (so that slot and next determine the state: a slot's key is the next state alone), odd B, in a fixed pseudo-random order
         uint64_t x = 0x9e3779b97f4a7c15ull;
-        for (uint32_t tries = 0; !found && tries < (ns < kByteSlots ? 20000u : 200000u); ++tries, ++stamp) {
+        for (uint32_t tries = 0; !found && tries < budget; ++tries, ++stamp) {
             x ^= x << 13; x ^= x >> 7; x ^= x << 17;
             const uint32_t a = ((uint32_t)(x >> 20) & 0xfffu) | 1u, bb = ((uint32_t)(x >> 40) & 0xfffu) | 1u;
             bool ok = true;
@@ -204,9 +208,11 @@ static void build_byte_table(DefsSet &s) {
     }
     if (!found) return;
     b.mul_a = A; b.mul_b = B; b.slots = slots;
-    b.ptab_off = (rows * 256 + slots * 2 - 1) & ~(slots * 2 - 1);   // aligned to its size: slot address = (hash & (slots - 1) * 2) | ptab_off, one v_and_or_b32
-    b.bytes = b.ptab_off + slots * 2;
-    b.image.assign(b.bytes, 0);
+    b.ptab_off = (rows * 256 + slots * 4 - 1) & ~(slots * 4 - 1);   // aligned to its size: slot address = (hash & (slots - 1) * 4) | ptab_off, one v_and_or_b32
+    b.bytes = b.ptab_off + slots * 4;
+    b.ptab16_off = (rows * 256 + slots * 2 - 1) & ~(slots * 2 - 1);
+    b.bytes16 = b.ptab16_off + slots * 2;
+    b.image.assign((size_t)b.bytes + slots * 2, 0);
     for (uint32_t st = 0; st < rows; ++st)
         for (int ch = 0; ch < 256; ++ch) {
             uint32_t nx = b.dead;
@@ -216,13 +222,14 @@ static void build_byte_table(DefsSet &s) {
             }
             b.image[(size_t)st * 256 + ch] = (uint8_t)nx;   // (total: every entry is a real state; partial: dead = S <= 255)
         }
-    // slot: next | substr id << 8 | is_start << 14 | is_end << 15.  An empty slot is 0: whatever pair reads it gets tag 0 — what an untagged pair has.
-    std::vector<uint16_t> slot(slots, 0);
+    // slot (hrx_lane.h): next | tag byte << 8 | record half << 16.  An empty slot is 0: whatever pair reads it gets tag 0 — what an untagged pair has.
+    std::vector<uint32_t> slot(slots, 0);
     for (uint32_t k : keys) {
         const uint32_t t = pt[(size_t)(k >> 8) * S + (k & 0xffu)];     // 10-bit tag: id | is_start << 8 | is_end << 9
-        slot[((k >> 8) * A + (k & 0xffu) * B) & (slots - 1)] = (uint16_t)((k & 0xffu) | (t & 0x3fu) << 8 | (t >> 8) << 14);
+        slot[((k >> 8) * A + (k & 0xffu) * B) & (slots - 1)] = (k & 0xffu) | (t & 0x3fu) << 8 | (t >> 8) << 14 | t << 16;
     }
-    std::memcpy(&b.image[b.ptab_off], slot.data(), (size_t)slots * 2);
+    std::memcpy(&b.image[b.ptab_off], slot.data(), (size_t)slots * 4);
+    for (uint32_t i = 0; i < slots; ++i) { const uint16_t lo = (uint16_t)slot[i]; std::memcpy(&b.image[(size_t)b.bytes + 2 * i], &lo, 2); }
     s.byte = std::move(b);
 }
 

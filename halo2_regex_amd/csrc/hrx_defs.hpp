@@ -74,10 +74,15 @@ struct ByteTable {
     uint32_t n_rows = 0;      // real states (+ one absorbing dead row if the DFA is partial)
     uint32_t dead = 0x100;    // row number of the dead row; 0x100: the DFA is total, there is none
     uint32_t slots = 0;       // pair-tag slots: a power of two, kByteMinSlots .. kByteSlots
-    uint32_t ptab_off = 0;    // LDS byte offset of u16 ptab[slots] (aligned to its size): next | substr id << 8 | is_start << 14 | is_end << 15 (0: empty)
+    uint32_t ptab_off = 0;    // LDS byte offset of u32 ptab[slots] (aligned to its size): next | substr id << 8 | is_start << 14 | is_end << 15 | (substr id | is_start << 8 | is_end << 9) << 16 (0: empty)
     uint32_t mul_a = 0, mul_b = 0;   // slot of pair (state, next) = (state * mul_a + next * mul_b) & (slots - 1), mul_a odd: collision-free over the tagged pairs
     uint32_t bytes = 0;       // size of the LDS image, a multiple of 16
-    std::vector<uint8_t> image;
+    // the walker/storer kernel (string-major outputs, hrx_kernel_sm.hip) stages the same next-state bytes and, instead of the 4-byte
+    // slots, their low halves only (next | substr id << 8 | is_start << 14 | is_end << 15): the table is 8 KiB smaller at 4096 slots,
+    // which is a fourth walker/storer pair.  The 2-byte slots follow the LDS image in `image` (at image[bytes ..]).
+    uint32_t ptab16_off = 0;  // LDS byte offset of u16 ptab16[slots] in THAT kernel's image (aligned to its size)
+    uint32_t bytes16 = 0;     // size of that LDS image
+    std::vector<uint8_t> image;   // [0, bytes): the position-major kernel's LDS image; [bytes, bytes + slots * 2): ptab16
 };
 
 constexpr size_t kMaxDefs = 32;          // RegexDefs per config: the status word's accept mask (bits 8..39, include/hrx.h)

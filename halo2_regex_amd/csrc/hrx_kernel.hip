@@ -275,15 +275,15 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         const size_t slot = 64 * 128 + 64 * 8 + 64 * 32, fixed = 16 + 256;
         int pairs = 4;
         while (pairs > 1 && (size_t)a.n_groups < (size_t)num_cus * pairs) --pairs;
-        pairs = one_round_pairs(pairs, a.byte_bytes, [=](int ns) { return (size_t)ns * slot + fixed; }, 4, 2, 2, 8);
+        pairs = one_round_pairs(pairs, a.byte16_bytes, [=](int ns) { return (size_t)ns * slot + fixed; }, 4, 2, 2, 8);
         for (; pairs >= 1; --pairs) {
-            if (a.byte_bytes + pairs * (2 * slot + fixed) > kLdsLimit) continue;
-            size_t ns = (kLdsLimit - a.byte_bytes - pairs * fixed) / (pairs * slot);
+            if (a.byte16_bytes + pairs * (2 * slot + fixed) > kLdsLimit) continue;
+            size_t ns = (kLdsLimit - a.byte16_bytes - pairs * fixed) / (pairs * slot);
             if (ns > 4) ns = 4;
             out.split = 1; out.gtab = 0; out.byte = 1;
             out.waves_per_wg = 2 * pairs;
             out.nslots = (int)ns;
-            out.lds_bytes = a.byte_bytes + pairs * (ns * slot + fixed);
+            out.lds_bytes = a.byte16_bytes + pairs * (ns * slot + fixed);
             const size_t need = ((size_t)a.n_groups + pairs - 1) / pairs;
             out.grid = (int)(need < (size_t)num_cus ? need : (size_t)num_cus);
             if (out.grid < 1) out.grid = 1;

@@ -6,6 +6,39 @@
 
 namespace hrx {
 
+// BYTE table (hrx_walk_pm.h walk_tile_pm_byte): the walker hands ONE TAG BYTE per row over — substr id | is_start << 6 | is_end << 7,
+// four rows to a dword — and the finisher derives what the reveal-mask scans need from the tile's 16 dwords, eight rows at a time:
+// bit 6 / bit 7 of eight tag bytes -> one byte of ST / EN with two v_dot4_u32_u8 (weights 1, 2, 4, 8 and 16, 32, 64, 128; the byte
+// arrives shifted by the bit's position), "id differs from the id of the row before" the same way from (ids ^ ids shifted by one row)
+// + 0x3f per byte (bit 6 = the byte is not zero; ids are < 64), and the substr-id bytes themselves are the tag bytes & 0x3f.
+// ~23 vector instructions per eight rows; one row at a time this cost the walker ~12 per row (lib.rs:831-888 per row).
+__device__ __forceinline__ TileBits byte_tile_bits(uint32_t (&sidq)[16], uint32_t &sid_prev) {
+    uint32_t st[2] = {0, 0}, en[2] = {0, 0}, ch[2] = {0, 0};
+    uint32_t prevw = sid_prev << 24;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const uint32_t ta = sidq[2 * o], tb = sidq[2 * o + 1];
+        const uint32_t sa = ta & 0x3f3f3f3fu, sb = tb & 0x3f3f3f3fu;
+        const uint32_t s8 = __builtin_amdgcn_udot4(tb & 0x40404040u, 0x80402010u, __builtin_amdgcn_udot4(ta & 0x40404040u, 0x08040201u, 0u, false), false);   // ST byte << 6
+        const uint32_t e8 = __builtin_amdgcn_udot4(tb & 0x80808080u, 0x80402010u, __builtin_amdgcn_udot4(ta & 0x80808080u, 0x08040201u, 0u, false), false);   // EN byte << 7
+        const uint32_t ya = __builtin_amdgcn_alignbit(sa, prevw, 24), yb = __builtin_amdgcn_alignbit(sb, sa, 24);                                             // the ids of rows p - 1
+        const uint32_t za = ((sa ^ ya) + 0x3f3f3f3fu) & 0x40404040u, zb = ((sb ^ yb) + 0x3f3f3f3fu) & 0x40404040u;
+        const uint32_t c8 = __builtin_amdgcn_udot4(zb, 0x80402010u, __builtin_amdgcn_udot4(za, 0x08040201u, 0u, false), false);                               // CH byte << 6
+        prevw = sb;
+        const int sh = 8 * (o & 3);
+        st[o >> 2] |= (s8 >> 6) << sh;
+        en[o >> 2] |= (e8 >> 7) << sh;
+        ch[o >> 2] |= (c8 >> 6) << sh;
+        sidq[2 * o] = sa; sidq[2 * o + 1] = sb;
+    }
+    sid_prev = prevw >> 24;
+    TileBits out;
+    out.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
+    out.en1 = (uint64_t)en[0] | ((uint64_t)en[1] << 32);
+    out.ch = (uint64_t)ch[0] | ((uint64_t)ch[1] << 32);
+    return out;
+}
+
 // =============================================================================================
 // Position-major kernel (layout 1): records [ceil(M/4)][D][B][4] u32, masked [ceil(M/8)][B][8] u16.
 //
@@ -129,6 +162,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
         unsigned char *mp_f = nullptr;
         size_t mstep_f = 0;
         uint32_t f = 0;
+        uint32_t byte_sid_prev = 0;   // BYTE: the substr id of the row before the tile (hrx_walk_pm.h: the walker hands tag bytes over, not bitvectors)
         uint32_t mg_sum_prev = 0, mg_ov_row = 0xffffffffu;   // merge pass (WitnessArgs::merge_G): the summed substr id of the row before the tile; lowest cross-group overlap row
         // HOLD (BYTE table — the random-DFA shape of cfg 5, where the optimistic end mask of hrx_lane.h is wrong for ~10 % of all masked
         // rows): the masked rows of the last kHoldF tiles stay in the finisher's registers, so that a fix-up that arrives within
@@ -170,7 +204,9 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             const unsigned long long fk_b = clock64();
             fk_wait += fk_b - fk_a;
 #endif
-            const uint4 s0 = lds_u128(sum_off + lane * 16u), s1 = lds_u128(sum_off + 1024u + lane * 16u);
+            uint4 s0 = make_uint4(0, 0, 0, 0);
+            if constexpr (!BYTE) s0 = lds_u128(sum_off + lane * 16u);
+            const uint4 s1 = lds_u128(sum_off + 1024u + lane * 16u);
             uint32_t sidq[16], cw[16];
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
@@ -181,6 +217,16 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             }
             ring_post(sum_freed_off, f + 1u);   // (its release fence waits for the reads above)
             lds_store_u32(freed2_off, f + 1u);
+            TileBits tb;
+            if constexpr (BYTE) {
+                if (tf == tf0) byte_sid_prev = s1.x;   // (a chunk: the id of the transition into its first row; else 0)
+                tb = byte_tile_bits(sidq, byte_sid_prev);
+                s0 = make_uint4((uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32));
+            } else {
+                tb.st = (uint64_t)s0.x | ((uint64_t)s0.y << 32);
+                tb.en1 = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
+                tb.ch = (uint64_t)s1.x | ((uint64_t)s1.y << 32);
+            }
             if (a.summary) {   // a pass of a multi-pass config: the combine kernel forms the sums over all defs (hrx_kernel_mp.hip)
                 if (active_f) {
                     uint4 *sp = reinterpret_cast<uint4 *>(a.summary) + ((size_t)tf * 5u * B + (b0_f + lane));
@@ -190,10 +236,6 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 }
                 continue;
             }
-            TileBits tb;
-            tb.st = (uint64_t)s0.x | ((uint64_t)s0.y << 32);
-            tb.en1 = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
-            tb.ch = (uint64_t)s1.x | ((uint64_t)s1.y << 32);
             const uint32_t n_f = s1.z;          // the string's length (<= M; the walker clamps bad lengths)
             if (a.merge_G) {
                 // the LAST pass of a multi-pass config: the earlier groups' tile summaries join this group's — what needs ALL defs of a row
@@ -458,11 +500,12 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 for (int d = 0; d < D; ++d) {
                     const uint32_t w = ip[d];
                     const uint32_t row = a.dc[d].row_base + (w & 0xffffu);
-                    L.e[d] = WIDE ? row << kWideRowShift : row << kNextShift;
+                    L.e[d] = BYTE ? (w & 0xffffu) : WIDE ? row << kWideRowShift : row << kNextShift;
                     L.sid_prev += (w >> 16) & 0xffu;
                     vs_en |= (w >> 24) & 1u;
                 }
             }
+            const uint32_t byte_sid0 = L.sid_prev;   // BYTE: handed to the finisher, which tracks the ids itself
             MaskCarry mc = {0, 0, 0, 0};
             uint32_t dead = 0, accept = 0;
             uint32_t err_pos[D], err_state[D], err_char[D], acc_state[D];
@@ -568,8 +611,10 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                         hb &= 0x80808080u;
                     }
                 } else if constexpr (BYTE) {
-                    if (full) tb = walk_tile_pm_byte<true>(L, cq, a, sink, 0, 0, t0, sidq, acc_state);
-                    else tb = walk_tile_pm_byte<false>(L, cq, a, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, t0, sidq, acc_state);
+                    // (sidq: the tile's TAG bytes here, and no bitvectors — the finisher derives them, byte_tile_bits)
+                    tb = TileBits{0, 0, 0};
+                    if (full) walk_tile_pm_byte<true>(L, cq, a, sink, 0, 0, sidq, acc_state);
+                    else walk_tile_pm_byte<false>(L, cq, a, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, sidq, acc_state);
                 } else if (full)
                     tb = walk_tile_pm<D, true, GTAB, HALF>(L, cq, a, sink, 0, 0, t0, sidq, acc_state);
                 else
@@ -692,8 +737,12 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                     // ---------------- hand the tile over to the finisher wave: bitvectors, substr-id bytes, the string's length ----------------
                     ring_wait(sum_freed_off, seq);   // it has consumed the previous tile's summary (one summary area per pair)
                     typedef __attribute__((address_space(3))) v4u32 lds_v4u32;
-                    *(lds_v4u32 *)(uintptr_t)(sum_off + lane * 16u) = v4u32{(uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32)};
-                    *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{(uint32_t)tb.ch, (uint32_t)(tb.ch >> 32), n, vs_en};
+                    if constexpr (BYTE) {   // tag bytes instead of bitvectors; word 0: the substr id of the row before the group's first tile
+                        *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{byte_sid0, 0u, n, vs_en};
+                    } else {
+                        *(lds_v4u32 *)(uintptr_t)(sum_off + lane * 16u) = v4u32{(uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32)};
+                        *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{(uint32_t)tb.ch, (uint32_t)(tb.ch >> 32), n, vs_en};
+                    }
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i)
                         *(lds_v4u32 *)(uintptr_t)(sum_off + 2048u + i * 1024u + lane * 16u) = v4u32{sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]};

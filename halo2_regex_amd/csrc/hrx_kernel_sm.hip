@@ -133,7 +133,7 @@ __device__ __forceinline__ TileBits walk_tile_byte(LaneRegs<1> &L, const uint4 (
     uint32_t cw[T / 4];
 #pragma unroll
     for (int i = 0; i < T / 16; ++i) { cw[4 * i] = cq[i].x; cw[4 * i + 1] = cq[i].y; cw[4 * i + 2] = cq[i].z; cw[4 * i + 3] = cq[i].w; }
-    const uint32_t A2 = a.byte_mul_a2, B2 = a.byte_mul_b2, ptab = a.byte_ptab_off, smask = a.byte_slot_mask2;
+    const uint32_t A2 = a.byte_mul_a4 >> 1, B2 = a.byte_mul_b4 >> 1, ptab = a.byte16_ptab_off, smask = a.byte_slot_mask4 >> 1;   // this kernel stages the 2-byte slots (hrx_defs.hpp ByteTable::ptab16_off)
     uint32_t cur = L.e[0];                  // state at the row whose chain lookup is issued next
     uint32_t s1 = 0, n1 = 0;                // row p - 1: its state and its next state
     uint32_t k2 = 0, pe2 = 0;               // row p - 2: its pair (state << 8 | next) and its pair slot
@@ -535,7 +535,7 @@ template <int D, int T, bool BYTE = false>
 __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a, const uint32_t nslots) {
     static_assert(!BYTE || D == 1, "the BYTE table serves one def");
     using G = SplitGeom<D, T>;
-    const uint32_t tab_bytes = BYTE ? a.byte_bytes : a.table_bytes;
+    const uint32_t tab_bytes = BYTE ? a.byte16_bytes : a.table_bytes;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t pairs = blockDim.x >> 7;  // walker waves 0..pairs-1, storer waves pairs..2*pairs-1
@@ -550,7 +550,14 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
     {
         const uint4 *src = BYTE ? reinterpret_cast<const uint4 *>(a.byte_image) : reinterpret_cast<const uint4 *>(a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        if (BYTE) {   // next-state bytes, then the 2-byte pair slots that follow the position-major kernel's image in the device blob
+            for (uint32_t i = threadIdx.x; i < a.byte_rows_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+            const uint4 *src16 = reinterpret_cast<const uint4 *>(a.byte_image + a.byte_bytes);
+            uint4 *dst16 = reinterpret_cast<uint4 *>(smem + a.byte16_ptab_off);
+            for (uint32_t i = threadIdx.x; i < (tab_bytes - a.byte16_ptab_off) / 16u; i += blockDim.x) dst16[i] = src16[i];
+        } else {
+            for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        }
         if (is_walker && lane == 0) { lds_store_u32(prod_off, 0); lds_store_u32(cons_off, 0); }
     }
     __syncthreads();

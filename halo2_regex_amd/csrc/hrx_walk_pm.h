@@ -185,62 +185,64 @@ __device__ __forceinline__ TileBits walk_tile_pm(LaneRegs<D> &L, const uint4 (&c
 
 // ---------------------------------------------------------------------------------------------
 // BYTE-table walk (hrx_lane.h; one def).  Per row two LDS reads, neither of which waits for the other:
-//   iteration p:  next-state byte of row p  (the dependent chain: address = state << 8 | byte),
-//                 pair slot of row p - 1    (address ((state * A2 + next * B2) & (slots - 1) * 2) | ptab_off, both known since the previous iteration),
-//   and in their shadow the record / flag / id work of row p - 2, whose slot arrived an iteration ago.
+//   iteration p:  next-state byte of row p  (the dependent chain: address = state << 8 | byte, ONE v_perm_b32),
+//                 pair slot of row p - 1    (address ((state * A4 + next * B4) & (slots - 1) * 4) | ptab_off, both known since the previous iteration),
+//   and in their shadow the record of row p - 2, whose slot arrived an iteration ago.
+// A wave alone issues one vector instruction per 4 cycles (MI355X_MICROARCH.md: 'vector-instruction ISSUE cost'), and round 3's walker
+// spent 27 of them per row (disassembly: 108 issue cycles against the ~55 of the chain itself; in-kernel stamps: 164 cycles per row,
+// the launch's whole duration) on work that does not need the chain: the three tile bitvectors and the substr-id bytes, one row at a
+// time.  Now the 4-byte pair slot carries the record's high half ready-made (record = slot & 0xffff0000 | state: one v_and_or_b32) and a
+// TAG BYTE (substr id | is_start << 6 | is_end << 7) that the walker only packs four to a dword (one v_perm_b32 per row): the finisher
+// wave derives bitvectors and id bytes from the 16 dwords of a tile with byte-parallel arithmetic (hrx_kernel_pm.hip byte_tile_bits:
+// ~3 instructions per row instead of ~12).  10 vector instructions per row are left here.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
 __device__ __forceinline__ uint32_t lds_u8(uint32_t off) { return *(lds_cu8 *)(uintptr_t)off; }
 
 template <bool FULL, class Sink>
-__device__ __forceinline__ TileBits walk_tile_pm_byte(LaneRegs<1> &L, const uint4 (&cq)[4], const WitnessArgs &a, Sink &sink, int rem, int mrem,
-                                                      uint32_t t0, uint32_t (&sidq)[16], uint32_t (&acc_state)[1]) {
-    uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
+__device__ __forceinline__ void walk_tile_pm_byte(LaneRegs<1> &L, const uint4 (&cq)[4], const WitnessArgs &a, Sink &sink, int rem, int mrem,
+                                                  uint32_t (&tagq)[16], uint32_t (&acc_state)[1]) {
     uint32_t rbuf[4];
     const uint32_t cw[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                              cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
-    const uint32_t A2 = a.byte_mul_a2, B2 = a.byte_mul_b2, ptab = a.byte_ptab_off, smask = a.byte_slot_mask2;
+    const uint32_t A4 = a.byte_mul_a4, B4 = a.byte_mul_b4, smask = a.byte_slot_mask4;
+    uint32_t ptab = a.byte_ptab_off;
+    asm volatile("" : "+v"(ptab));          // in a vector register: (hash & smask) | ptab is ONE v_and_or_b32 then (an instruction reads at most one scalar register)
     uint32_t cur = L.e[0];                  // state at the row whose chain lookup is issued next
     uint32_t s1 = 0, n1 = 0;                // row p - 1: its state and its next state
-    uint32_t k2 = 0, pe2 = 0;               // row p - 2: its pair (state << 8 | next) and its pair slot
+    uint32_t s2 = 0, n2 = 0, pe2 = 0;       // row p - 2: its state, its next state and its pair slot
 
-    auto post = [&](const int p, const uint32_t key, const uint32_t pe) {
-        uint32_t state = key >> 8;
-        uint32_t tag = ((pe ^ key) & 0xffu) == 0u ? ((pe >> 8) & 0x3fu) | (pe >> 14) << 8 : 0u;   // the slot's key is this pair's next state: (state, next) is tagged
+    auto post = [&](const int p, uint32_t state, const uint32_t next, const uint32_t pe) {
+        uint32_t x = (pe & 0xffu) == next ? pe : 0u;                 // the slot's key is this pair's next state: (state, next) is tagged
         if (!FULL) {
-            if (p >= rem) tag = 0;                                   // padding rows: their lookups ran on stand-in states (lib.rs:404-418)
+            if (p >= rem) x = 0;                                     // padding rows: their lookups ran on stand-in states (lib.rs:404-418)
             if (p > rem) state = a.dc[0].dummy_state;                // lib.rs:413
-            if (p >= mrem) tag &= ~kTagEnd;
+            if (p >= mrem) x &= ~(kRecEndBit | 0x8000u);             // end_enable of row M - 1 is never assigned (lib.rs:501): record half and tag byte
             if (p == rem) acc_state[0] = state;                      // the state at row n (lib.rs:437-457)
         }
-        rbuf[p & 3] = state | (tag << 16);
+        rbuf[p & 3] = (x & 0xffff0000u) | state;
         if ((p & 3) == 3) sink.quad(0, p, FULL, mrem, make_uint4(rbuf[0], rbuf[1], rbuf[2], rbuf[3]));
-        const uint32_t sid = tag & 0xffu;
-        st[p >> 5] |= ((tag >> 8) & 1u) << (p & 31);
-        en1[p >> 5] |= ((tag >> 9) & 1u) << (p & 31);
-        ch[p >> 5] |= (sid != L.sid_prev ? 1u : 0u) << (p & 31);
-        L.sid_prev = sid;
-        if (Sink::kSidq) sidq[p >> 2] |= sid << (8 * (p & 3));
+        // the row's tag byte (byte 1 of the slot) -> byte p & 3 of the quad's dword
+        uint32_t &t = tagq[p >> 2];
+        if ((p & 3) == 0) t = (x >> 8) & 0xffu;
+        else if ((p & 3) == 1) t = __builtin_amdgcn_perm(x, t, 0x0c0c0500u);
+        else if ((p & 3) == 2) t = __builtin_amdgcn_perm(x, t, 0x0c050100u);
+        else t = __builtin_amdgcn_perm(x, t, 0x05020100u);
         sink.row(p);
     };
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sidq[i] = 0;
-#pragma unroll
     for (int p = 0; p < 66; ++p) {
         uint32_t raw_n = 0, raw_pe = 0;
-        if (p < 64) {
-            const uint32_t c = (cw[p >> 2] >> (8 * (p & 3))) & 0xffu;
-            raw_n = lds_u8((cur << 8) | c);                          // delta(state, byte): lib.rs:810
-        }
-        if (p >= 1 && p < 65) raw_pe = lds_u16(((__umul24(s1, A2) + __umul24(n1, B2)) & smask) | ptab);
+        if (p < 64)   // delta(state, byte): lib.rs:810.  address = state << 8 | byte (p & 3) of the quad's dword
+            raw_n = lds_u8(__builtin_amdgcn_perm(cur, cw[p >> 2], 0x0c0c0400u | (uint32_t)(p & 3)));
+        if (p >= 1 && p < 65) raw_pe = lds_u32(((__umul24(s1, A4) + __umul24(n1, B4)) & smask) | ptab);
         if (p >= 2) {
-            post(p - 2, k2, pe2);
-            asm volatile("" : "+v"(st[(p - 2) >> 5]), "+v"(en1[(p - 2) >> 5]), "+v"(ch[(p - 2) >> 5]), "+v"(L.sid_prev));
-            if (Sink::kSidq) asm volatile("" : "+v"(sidq[(p - 2) >> 2]));
+            post(p - 2, s2, n2, pe2);
+            asm volatile("" : "+v"(tagq[(p - 2) >> 2]));
             if (!FULL) asm volatile("" : "+v"(acc_state[0]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        k2 = (s1 << 8) | n1; pe2 = raw_pe;
+        s2 = s1; n2 = n1; pe2 = raw_pe;
         if (p < 64) {
             const uint32_t nxt = (FULL || p < rem) ? raw_n : 0u;    // rows >= n: any valid row; post() writes the dummy state and no tag
             L.mx[0] = max(L.mx[0], nxt);                              // reaching the dead row = an undefined transition (lib.rs:817)
@@ -250,11 +252,6 @@ __device__ __forceinline__ TileBits walk_tile_pm_byte(LaneRegs<1> &L, const uint
         }
     }
     L.e[0] = cur;
-    TileBits tb;
-    tb.st = (uint64_t)st[0] | ((uint64_t)st[1] << 32);
-    tb.en1 = (uint64_t)en1[0] | ((uint64_t)en1[1] << 32);
-    tb.ch = (uint64_t)ch[0] | ((uint64_t)ch[1] << 32);
-    return tb;
 }
 
 // ---------------------------------------------------------------------------------------------

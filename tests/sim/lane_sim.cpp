@@ -175,14 +175,16 @@ long sim_check_byte_image(void *p) {
     if (s.byte.image.empty()) return -1;
     const DefConsts &c = s.consts[0];
     const ByteTable &b = s.byte;
-    if (b.slots < kByteMinSlots || b.slots > kByteSlots || (b.slots & (b.slots - 1)) || b.ptab_off % (b.slots * 2) || b.ptab_off + b.slots * 2 != b.bytes || !(b.mul_a & 1u)) return -2;
+    if (b.slots < kByteMinSlots || b.slots > kByteSlots || (b.slots & (b.slots - 1)) || b.ptab_off % (b.slots * 4) || b.ptab_off + b.slots * 4 != b.bytes || !(b.mul_a & 1u)) return -2;
     long n = 0;
     for (uint32_t st = 0; st < b.n_rows; ++st)
         for (uint32_t ch = 0; ch < 256; ++ch, ++n) {
             const uint32_t nx = b.image[(size_t)st << 8 | ch];
-            uint16_t slot;
-            std::memcpy(&slot, &b.image[b.ptab_off + (((st * b.mul_a + nx * b.mul_b) & (b.slots - 1)) << 1)], 2);
-            const uint32_t tag = (slot & 0xffu) == nx ? ((slot >> 8) & 0x3fu) | (uint32_t)(slot >> 14) << 8 : 0u;
+            uint32_t slot;
+            std::memcpy(&slot, &b.image[b.ptab_off + (((st * b.mul_a + nx * b.mul_b) & (b.slots - 1)) << 2)], 4);
+            const uint32_t tag = (slot & 0xffu) == nx ? ((slot >> 8) & 0x3fu) | ((slot >> 14) & 3u) << 8 : 0u;   // the tag byte: what the finisher gets
+            if ((slot & 0xffu) == nx && (slot >> 16) != tag) return -2 - n;                                       // the record half: what the walker stores
+            if ((slot & 0xffu) != nx && slot != 0 && ((slot & 0xffu) >= b.n_rows)) return -2 - n;
             if (st == b.dead) {                                   // the absorbing dead row (partial DFAs only)
                 if (nx != b.dead || tag) return -2 - n;
                 continue;

@@ -146,24 +146,24 @@ def test_planner_thresholds_of_round_3():
     assert short.describe_launch(20480, layout=3).startswith("hrx::witness_pp_kernel grid=160 waves=6 ")
     # 513-768 groups, D = 2 on the WIDE table: three pairs per workgroup cover them in one round
     short2 = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
-    assert short2.describe_launch(40000, layout=3).startswith("hrx::witness_pm_kernel<2, false, true, false> grid=209 waves=9 ")
+    assert short2.describe_launch(40000, layout=3).startswith("hrx::witness_pm_kernel<2, false, true, false, false, false> grid=209 waves=9 ")
 
 
 def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     """hrx_describe_launch (host-only): which kernel and table format serve which shape on a 256-CU MI355X."""
     from halo2_regex_amd import synth
     cfg = RegexVerifyConfig.configure(1024, _defs(CFG_A[:1]), device=None)
-    assert cfg.describe_launch(65536, layout=3).startswith("hrx::witness_pm_kernel<1, false, false, false> grid=256 waves=12 ring=4 ")   # a full chip: one byte per lookup; walker + loader + finisher wave per pair
+    assert cfg.describe_launch(65536, layout=3).startswith("hrx::witness_pm_kernel<1, false, false, false, false, false> grid=256 waves=12 ring=4 ")   # a full chip: one byte per lookup; walker + loader + finisher wave per pair
     assert cfg.describe_launch(32768, layout=3).startswith("hrx::witness_pp_kernel grid=256 waves=6 ")     # walker slots left empty: one def, 18 byte classes -> the pair-step table (76 KiB), two bytes per lookup
-    assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_split_kernel<1, 32> ")
+    assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_split_kernel<1, 32, false> ")
     cfg = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
     assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pmd_kernel<2> grid=256 waves=6 ")       # <= 2 groups per CU: one walker per def
-    assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false> ")     # D >= 2: the WIDE table
+    assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false, false, false> ")     # D >= 2: the WIDE table
     d = cfg.describe_launch(1 << 20, layout=1)
-    assert d.startswith("hrx::witness_pm_kernel<2, false, true, false> grid=256 waves=12 ") and d.endswith(" groups=dynamic")   # >= 3 groups per walker pair: drawn from a counter
+    assert d.startswith("hrx::witness_pm_kernel<2, false, true, false, false, false> grid=256 waves=12 ") and d.endswith(" groups=dynamic")   # >= 3 groups per walker pair: drawn from a counter
     assert "groups=dynamic" not in cfg.describe_launch(65536, layout=1)
     cfg3 = RegexVerifyConfig.configure(1024, _defs(CFG_A + CFG_3), device=None)
-    assert cfg3.describe_launch(65536, layout=0).startswith("hrx::witness_pm_kernel<3, false, true, false, true> ")   # string-major D = 3: lane-direct stores
+    assert cfg3.describe_launch(65536, layout=0).startswith("hrx::witness_pm_kernel<3, false, true, false, true, false> ")   # string-major D = 3: lane-direct stores
     assert RegexVerifyConfig.configure(1001, _defs(CFG_A + CFG_3), device=None).describe_launch(65536, layout=0).startswith("hrx::witness_kernel<3, false, false> ")
     # cfg 5: 256 states x 256 symbols = 258 KiB of 4-byte entries -> the 128-KiB HALF table, LDS-resident
     a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=np.arange(256, dtype=np.uint8), n_substr_pairs=200)
@@ -173,7 +173,7 @@ def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     assert d.startswith("hrx::witness_pm_kernel<1, false, false, false, false, true> grid=256 waves=12 ring=2 ")
     monkeypatch.setenv("HRX_DEBUG_FLAGS", str(0x8000))          # kDbgNoByte: the 128-KiB HALF table, walker + loader only
     d = cfg.describe_launch(65536, layout=3)
-    assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8 ") and "lds=%d" % (128 * 1024 + 4 * (4096 + 128)) in d
+    assert d.startswith("hrx::witness_pm_kernel<1, false, false, true, false, false> grid=256 waves=8 ") and "lds=%d" % (128 * 1024 + 4 * (4096 + 128)) in d
     monkeypatch.delenv("HRX_DEBUG_FLAGS")
     # string-major outputs: the walker/storer kernel on the BYTE table (rows in multiples of 8; else the one-wave global-table walk) ...
     d = cfg.describe_launch(65536, layout=0)
@@ -181,10 +181,10 @@ def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     # ... without a BYTE image: the HALF-table position-major kernel into context scratch + the transpose kernel
     monkeypatch.setenv("HRX_DEBUG_FLAGS", str(0x8000))
     d = cfg.describe_launch(65536, layout=0)
-    assert d.startswith("hrx::witness_pm_kernel<1, false, false, true> ") and d.endswith("+ hrx::transpose_pm_to_sm_kernel")
+    assert d.startswith("hrx::witness_pm_kernel<1, false, false, true, false, false> ") and d.endswith("+ hrx::transpose_pm_to_sm_kernel")
     monkeypatch.delenv("HRX_DEBUG_FLAGS")
     assert RegexVerifyConfig.configure(4097, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None).describe_launch(65536, layout=0).startswith("hrx::witness_kernel<1, false, true> ")
     # beyond 256 states there is no HALF image: global-table walk
     a_txt, sub_txt = synth.random_dfa(300, seed=2)
     cfg = RegexVerifyConfig.configure(1024, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)
-    assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<1, true, false, false> ")
+    assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<1, true, false, false, false, false> ")

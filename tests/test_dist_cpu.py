@@ -40,7 +40,7 @@ b, c = hra.shard_range(1000, world, rank)
 res = {"rank": rank, "device": rank, "rows": c * 1023 * args.steps, "elapsed_s": 0.5 + 0.25 * rank, "avg_launch_ms": 0.08 + 0.01 * rank,
        "debug_flags": None}
 if rank == 0:
-    res.update(desc="hrx::witness_pm_kernel<1, false, false, false> grid=256 waves=8 ring=4 lds=113728", D=1, rows_per_step=c * 1023,
+    res.update(desc="hrx::witness_pm_kernel<1, false, false, false, false, false> grid=256 waves=8 ring=4 lds=113728", D=1, rows_per_step=c * 1023,
                config={"workload": "test"}, verified={"strings": 4, "rows": 4092, "bit_exact": True, "against": "test"})
 dist.barrier()
 line = bench.gather_and_aggregate(res, args)

@@ -403,7 +403,7 @@ def test_half_table_kernel_on_dfas_of_up_to_256_states(hra, oracle, flags, monke
         M = 328
         cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
         assert cfg.table_bytes() == (nstates + 2) * 1024
-        assert ("witness_pm_kernel<1, false, false, true>" if flags else "witness_pm_kernel<1, false, false, false, false, true>") in cfg.describe_launch(700, layout=1)
+        assert ("witness_pm_kernel<1, false, false, true, false, false>" if flags else "witness_pm_kernel<1, false, false, false, false, true>") in cfg.describe_launch(700, layout=1)
         o = OracleDefs(oracle, [(allstr, [sub])])
         chars, lens = synth.ragged(700, M, seed=nstates, planted=False, alphabet=alpha)
         if len(alpha) < 256:
@@ -1177,7 +1177,7 @@ def test_full_size_cfg3_two_defs_2pow20_strings_16_blocks(hra, oracle):
     base_c, base_l = synth.regex23_planted(hra.PM_BLOCK, n, seed=1, stride=2048)
     blocks = _rolled_blocks(base_c, base_l, 16, seed=3)
     cfg = _cfg(hra, CFG_23, M)
-    assert "witness_pm_kernel<2, false, true, false>" in cfg.describe_launch(1 << 20, layout=3)
+    assert "witness_pm_kernel<2, false, true, false, false, false>" in cfg.describe_launch(1 << 20, layout=3)
     st = _full_check(hra, OracleDefs.from_files(oracle, CFG_23), cfg, blocks, M, 2, need_accept=0.0)
     assert len(st) == 1 << 20 and (st & np.uint64(0xff) == 0).all()
 
