@@ -172,10 +172,11 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
 #define HRX_HOLDF 2
 #endif
         constexpr int kHoldF = BYTE ? HRX_HOLDF : 0;
-        uint4 held[kHoldF ? kHoldF : 1][8];
+        uint32_t hcw[kHoldF ? kHoldF : 1][16], hsid[kHoldF ? kHoldF : 1][16];
+        uint64_t hmask[kHoldF ? kHoldF : 1];
         uint32_t n_held = 0;
 #ifdef HRX_STAMPS
-        unsigned long long fk_wait = 0, fk_work = 0;
+        unsigned long long fk_wait = 0, fk_work = 0, fk_bits = 0, fk_masks = 0, fk_fix = 0, fk_rows = 0;
 #endif
         for (uint32_t j = 0;; ++j) {
           const uint32_t vgf = group_at(j);
@@ -227,6 +228,10 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 tb.en1 = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
                 tb.ch = (uint64_t)s1.x | ((uint64_t)s1.y << 32);
             }
+#ifdef HRX_STAMPS
+            const unsigned long long fk_c = clock64();
+            fk_bits += fk_c - fk_b;
+#endif
             if (a.summary) {   // a pass of a multi-pass config: the combine kernel forms the sums over all defs (hrx_kernel_mp.hip)
                 if (active_f) {
                     uint4 *sp = reinterpret_cast<uint4 *>(a.summary) + ((size_t)tf * 5u * B + (b0_f + lane));
@@ -280,26 +285,22 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             if (a.debug & kDbgSkipFixups) tm.fix = 0;
             const uint32_t fix_regs = tm.fix;   // held rows: shadow lanes too (they store the same rows to the same addresses as string B - 1)
             if (!active_f) tm.fix = 0;
+#ifdef HRX_STAMPS
+            const unsigned long long fk_d = clock64();
+            fk_masks += fk_d - fk_c;
+#endif
             uint32_t fix_end = t0;     // rows [fix_start, fix_end) were stored already and are fixed at the memory
             if constexpr (kHoldF > 0) {
-                // held[i] = the masked rows of tile tf - 1 - i, rows [t0 - 64 (i + 1), t0 - 64 i): zero what lies at or after fix_start
+                // held tile i = tile tf - 1 - i, rows [t0 - 64 (i + 1), t0 - 64 i), kept as what its masked rows are MADE of — raw bytes, id bytes and the
+                // 64 mask bits: a fix-up clears mask bits (a handful of instructions per held tile; re-masking finished rows took ~900 cycles of nearly
+                // every tile, because some lane of the wave almost always has one), and the rows are assembled when the tile leaves
                 fix_end = t0 - n_held * 64u;
                 if (fix_regs) {
 #pragma unroll
                     for (int i = 0; i < kHoldF; ++i) {
-                        if ((uint32_t)i < n_held) {
-                            const uint32_t base = t0 - 64u * (uint32_t)(i + 1);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const uint32_t row0 = base + 8u * (uint32_t)k;
-                                // u16 index of the first row to zero inside this octet: 0 = all of it, >= 8 = none
-                                const uint32_t keep = tm.fix_start <= row0 ? 0u : min(tm.fix_start - row0, 8u);
-                                uint32_t w[4] = {held[i][k].x, held[i][k].y, held[i][k].z, held[i][k].w};
-#pragma unroll
-                                for (uint32_t q = 0; q < 4u; ++q) w[q] = keep > 2u * q + 1u ? w[q] : (keep > 2u * q ? (w[q] & 0xffffu) : 0u);
-                                held[i][k] = make_uint4(w[0], w[1], w[2], w[3]);
-                            }
-                        }
+                        const uint32_t base = t0 - 64u * (uint32_t)(i + 1);
+                        const uint32_t keep = tm.fix_start <= base ? 0u : min(tm.fix_start - base, 64u);     // rows of the tile in front of fix_start
+                        if ((uint32_t)i < n_held) hmask[i] &= keep >= 64u ? ~0ull : ((1ull << keep) - 1ull);
                     }
                 }
             }
@@ -309,57 +310,73 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 fixm &= fixm - 1;
                 const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
                 const uint32_t bj = b0_f + (uint32_t)j;
-                for (uint32_t r = fs + lane; r < fix_end; r += 64u) {
-                    const uint32_t rr = (a.debug & kDbgFixToDummy) ? (r & 63u) : r;
-                    a.masked[((size_t)blk0_f * q8 + (size_t)(rr >> 3) * nb_f + (bj - blk0_f)) * 8u + (rr & 7u)] = 0;
-                }
-            }
-            // ---------------- masked rows of this tile: 8 x 16 B per string, [M/8][B][8] (lib.rs:752-761) ----------------
-            const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
-            unsigned char *mp = mp_f + (size_t)tf * 8u * mstep_f;
-            if constexpr (kHoldF > 0) {
-                // the oldest held tile (tf - kHoldF) leaves now; the others move up
-                if (n_held == (uint32_t)kHoldF && !(a.debug & kDbgSkipMasked)) {
-                    unsigned char *op = mp_f + (size_t)(tf - (uint32_t)kHoldF) * 8u * mstep_f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) store16(op + (size_t)k * mstep_f, held[kHoldF - 1][k], nt_msk);   // (a held tile is never the last one: all 8 octets exist)
-                }
-#pragma unroll
-                for (int i = kHoldF - 1; i > 0; --i)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) held[i][k] = held[i - 1][k];
-                if (n_held < (uint32_t)kHoldF) ++n_held;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (mbyte) v = masked_octet(cw[2 * k], cw[2 * k + 1], sidq[2 * k], sidq[2 * k + 1], mbyte);
-                if (kHoldF > 0) held[0][k] = v;
-                else if (t0 + (uint32_t)k * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_msk);
-            }
-            if constexpr (kHoldF > 0) {
-                if (tf + 1u == tf0 + gt && !(a.debug & kDbgSkipMasked)) {   // the group's last tile: the held tiles leave, oldest first; only the octets that exist
-#pragma unroll
-                    for (int i = kHoldF - 1; i >= 0; --i) {
-                        if ((uint32_t)i < n_held) {
-                            const uint32_t tt = tf0 + gt - 1u - (uint32_t)i;
-#pragma unroll
-                            for (int k = 0; k < 8; ++k)
-                                if ((tt << 6) + (uint32_t)k * 8u < M) store16(mp_f + ((size_t)tt * 8u + (size_t)k) * mstep_f, held[i][k], nt_msk);
-                        }
+                if constexpr (kHoldF > 0) {
+                    // the whole wave zeroes ONE string's rows [fs, fix_end): the rows up to the next octet border two bytes at a time (lanes 0 .. 6), then a
+                    // whole octet — 16 bytes — per lane: 512 rows per store instruction (fix_end is a multiple of 64; one row per lane took a store
+                    // instruction, each touching eight lines, per 64 rows — and a random DFA's repairs reach back hundreds of rows)
+                    const uint32_t o0 = (fs + 7u) >> 3, o1 = fix_end >> 3;
+                    const uint32_t rh = fs + lane;
+                    if (rh < (o0 << 3)) {
+                        const uint32_t rr = (a.debug & kDbgFixToDummy) ? (rh & 63u) : rh;
+                        a.masked[((size_t)blk0_f * q8 + (size_t)(rr >> 3) * nb_f + (bj - blk0_f)) * 8u + (rr & 7u)] = 0;
+                    }
+                    for (uint32_t o = o0 + lane; o < o1; o += 64u) {
+                        const uint32_t oo = (a.debug & kDbgFixToDummy) ? (o & 7u) : o;
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0_f * q8 + (size_t)oo * nb_f + (bj - blk0_f)) * 16u) = make_uint4(0, 0, 0, 0);
+                    }
+                } else {
+                    for (uint32_t r = fs + lane; r < fix_end; r += 64u) {
+                        const uint32_t rr = (a.debug & kDbgFixToDummy) ? (r & 63u) : r;
+                        a.masked[((size_t)blk0_f * q8 + (size_t)(rr >> 3) * nb_f + (bj - blk0_f)) * 8u + (rr & 7u)] = 0;
                     }
                 }
             }
 #ifdef HRX_STAMPS
-            fk_work += clock64() - fk_b;
+            const unsigned long long fk_e = clock64();
+            fk_fix += fk_e - fk_d;
+#endif
+            // ---------------- masked rows: 8 x 16 B per tile and string, [M/8][B][8] (lib.rs:752-761) ----------------
+            auto octets_out = [&](const uint32_t tt, const uint32_t (&c)[16], const uint32_t (&sd)[16], const uint64_t mask, const bool all) {
+                const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+                unsigned char *mp = mp_f + (size_t)tt * 8u * mstep_f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (mbyte) v = masked_octet(c[2 * k], c[2 * k + 1], sd[2 * k], sd[2 * k + 1], mbyte);
+                    if ((all || (tt << 6) + (uint32_t)k * 8u < M) && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_msk);   // only the octets that exist
+                }
+            };
+            if constexpr (kHoldF > 0) {
+                // the oldest held tile (tf - kHoldF) leaves now (a held tile that leaves here is never the group's last one: all 8 octets exist); the others move up
+                if (n_held == (uint32_t)kHoldF) octets_out(tf - (uint32_t)kHoldF, hcw[kHoldF - 1], hsid[kHoldF - 1], hmask[kHoldF - 1], true);
+#pragma unroll
+                for (int i = kHoldF - 1; i > 0; --i) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { hcw[i][q] = hcw[i - 1][q]; hsid[i][q] = hsid[i - 1][q]; }
+                    hmask[i] = hmask[i - 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { hcw[0][q] = cw[q]; hsid[0][q] = sidq[q]; }
+                hmask[0] = tm.mask;
+                if (n_held < (uint32_t)kHoldF) ++n_held;
+                if (tf + 1u == tf0 + gt) {   // the group's last tile: the held tiles leave, oldest first
+#pragma unroll
+                    for (int i = kHoldF - 1; i >= 0; --i)
+                        if ((uint32_t)i < n_held) octets_out(tf0 + gt - 1u - (uint32_t)i, hcw[i], hsid[i], hmask[i], false);
+                }
+            } else {
+                octets_out(tf, cw, sidq, tm.mask, false);
+            }
+#ifdef HRX_STAMPS
+            { const unsigned long long fk_z = clock64(); fk_work += fk_z - fk_b; fk_rows += fk_z - fk_e; }
 #endif
           }
         }
 #ifdef HRX_STAMPS
         if (a.stamps && lane == 0) {
             unsigned long long *o = a.stamps + (size_t)(blockIdx.x * pairs + pair) * 16u + 8u;
-            o[0] += fk_wait; o[1] += fk_work;
+            o[0] += fk_wait; o[1] += fk_work; o[2] += fk_bits; o[3] += fk_masks; o[4] += fk_fix; o[5] += fk_rows;
         }
 #endif
         return;

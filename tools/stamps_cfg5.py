@@ -44,3 +44,5 @@ nt = (n + 63) // 64
 print("walker cycles per TILE: input wait %.0f  walk (incl. record stores) %.0f  tile end (masks, repairs, masked rows) %.0f  total %.0f" %
       (wait.mean() / nt, walk.mean() / nt, end.mean() / nt, grp.mean() / nt))
 print("finisher cycles per TILE: waiting for the walker's summary %.0f  work (masks, repairs, masked rows) %.0f" % (s[:, 8].mean() / nt, s[:, 9].mean() / nt))
+print("  of the work: summary reads + bitvectors %.0f  mask scans %.0f  held-row edits + repairs at the memory %.0f  masked rows (assembly, hold, stores) %.0f" %
+      tuple(s[:, 10 + i].mean() / nt for i in range(4)))
