@@ -8,7 +8,7 @@
 // now run the position-major path into context scratch and this kernel turns the rows around: pure streaming, 4 D + 2 bytes read
 // and written per row, every global access a run of full lines.
 //
-// A workgroup takes a tile of 64 strings x R rows, R = 32 / 64 / 128 for D >= 3 / 2 / 1 (a string's R x D records are the run a store
+// A workgroup takes a tile of 64 strings x R rows, R = 16 / 32 / 64 / 128 for D >= 10 / >= 3 / 2 / 1 (a string's R x D records are the run a store
 // instruction's lanes write: at least 512 bytes; with 32 rows at D = 1 the 128-byte runs ran at 3.5 TB/s).  In: per (def, row quad) the 64 strings' 16-byte pieces are 1 KiB contiguous
 // (lane = string), written to LDS as they come.  Out: a string's 32 rows x D records are 128 D contiguous bytes = D lines; a
 // wave store writes one line of each of 8 strings (8 lanes x 16 B per string), and every lane gathers its four dwords — four
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void transpose_pm_to_sm_kernel(const Transpose
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t rows_here = min(kTpRows, M - row0);
     const uint32_t inv = (65536u + D - 1u) / D;                 // i / D = (i * inv) >> 16 for i < 1024 (D <= 32)
-    const uint32_t lines = kTpRows * D / 32u;                   // 128-byte lines of a string's [R][D] tile
+    const uint32_t lines = (kTpRows * D + 31u) / 32u;           // 128-byte lines of a string's [R][D] tile (the last one half a line at R = 16 and odd D)
     for (uint32_t item = wave; item < 8u * lines; item += 4u) {
         const uint32_t sg = item / lines, line = item % lines;
         const uint32_t sl = sg * 8u + (lane & 7u), w = lane >> 3;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void transpose_pm_to_sm_kernel(const Transpose
         uint32_t v[4];
 #pragma unroll
         for (uint32_t t = 0; t < 4u; ++t) {
-            const uint32_t i = i0 + t, r = (i * inv) >> 16, d = i - r * D;
+            const uint32_t i = min(i0 + t, kTpRows * D - 1u), r = (i * inv) >> 16, d = i - r * D;
             v[t] = *reinterpret_cast<const uint32_t *>(smem + ((d * (kTpRows / 4u) + (r >> 2)) * 64u + sl) * 16u + (r & 3u) * 4u);
         }
         if (b < B && i0 < rows_here * D) {
@@ -101,7 +101,8 @@ static hipError_t launch_tp(const TransposeArgs &a, hipStream_t stream) {
 
 hipError_t launch_transpose(const TransposeArgs &a, hipStream_t stream) {
     if (a.B == 0 || a.M == 0) return hipSuccess;
-    return a.D == 1 ? launch_tp<128>(a, stream) : a.D == 2 ? launch_tp<64>(a, stream) : launch_tp<32>(a, stream);
+    // D >= 10: 16-row tiles — the planes of a 32-row tile (8 D + 4 KiB) pass the 160 KiB of LDS at D = 20, and from D = 10 on leave room for one workgroup per CU only
+    return a.D == 1 ? launch_tp<128>(a, stream) : a.D == 2 ? launch_tp<64>(a, stream) : a.D < 10 ? launch_tp<32>(a, stream) : launch_tp<16>(a, stream);
 }
 
 }  // namespace hrx

@@ -464,13 +464,13 @@ int orc_match_substrs(const orc *o, const uint8_t *characters, size_t n, size_t 
 
 /* status word shared with the HIP path (include/hrx.h):
  *   bits 0..7  code
- *   code 0: bits 8..15 accept mask (bit d: state at row n == accepted_state_val of def d)
+ *   code 0: bits 8..39 accept mask (bit d: state at row n == accepted_state_val of def d; up to 32 defs, HRX_MAX_DEFS)
  *   code 1: bits 8..15 def, 16..23 char, 24..39 state, 40..63 position
  *   code 2: bits 40..63 row
  */
 static uint64_t pack_status(int rc, const uint64_t *info) {
     switch (rc) {
-    case ORC_OK: return (info[4] & 0xff) << 8;
+    case ORC_OK: return (info[4] & 0xffffffffull) << 8;
     case ORC_INVALID_TRANSITION:
         return 1ull | (info[0] & 0xff) << 8 | (info[3] & 0xff) << 16 | (info[2] & 0xffff) << 24 | (info[1] & 0xffffff) << 40;
     case ORC_FLAG_OVERLAP: return 2ull | (info[1] & 0xffffff) << 40;
@@ -540,12 +540,12 @@ void orc_witness_batch_mt(const orc *o, const uint8_t *chars, size_t stride, con
  * derives from that pair — next | substr_id<<16 | is_start<<24 | is_end<<25 | valid<<31 — filled by asking the
  * reference-shaped containers above, then one table read per (row, def).  tests/test_oracle_golden.py checks it
  * equal to orc_witness_batch; bench.py times it as the strongest CPU line next to the port. */
-typedef struct { uint32_t *tab[8]; uint64_t first[8], accepted[8], dummy[8]; size_t n_defs; } orc_dense;
+typedef struct { uint32_t *tab[32]; uint64_t first[32], accepted[32], dummy[32]; size_t n_defs; } orc_dense;
 
 void orc_dense_free(orc_dense *t) { if (!t) return; for (size_t d = 0; d < t->n_defs; d++) free(t->tab[d]); free(t); }
 
 orc_dense *orc_dense_new(const orc *o) {
-    if (o->n_defs > 8) return NULL;
+    if (o->n_defs > 32) return NULL;
     orc_dense *t = calloc(1, sizeof(orc_dense));
     t->n_defs = o->n_defs;
     uint64_t off = 1;

@@ -90,3 +90,16 @@ def test_cpp_host_mirror_builds_and_runs():
                            "-L" + csrc, "-lhrx", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "dfa")], capture_output=True, text=True)
     assert out.returncode == 0 and "host ok" in out.stdout
+
+
+def test_c_struct_entry_points_equal_the_text_parsers():
+    """tests/host_c/test_push_structs.c replays bindings/rust/hrx.rs HrxHandle::new in C: hrx_defs_push_allstr with the map's entries SHUFFLED and their explicit
+    line indices (table.rs:103-108), a duplicate key (defs.rs:100: the last insert wins), hrx_defs_push_substr with shuffled pairs — same fixed-table rows and the
+    same witness rows (host walk here) as the text parsers."""
+    exe = "/tmp/hrx_test_push_structs"
+    csrc = os.path.join(ROOT, "halo2_regex_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "host_c", "test_push_structs.c"), "-o", exe,
+                           "-L" + csrc, "-lhrx", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "dfa")], capture_output=True, text=True)
+    assert out.returncode == 0 and "host ok" in out.stdout, out.stdout + out.stderr
+

@@ -125,6 +125,19 @@ def test_cpp_host_mirror_runs_the_reference_test(hra):
     assert out.returncode == 0 and "gpu ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_c_struct_entry_points_on_the_device(hra):
+    """tests/host_c/test_push_structs.c (the Rust binding's call sequence: shuffled hrx_defs_push_allstr entries with explicit line indices, a duplicate key,
+    hrx_defs_push_substr) with the witness rows of both configs computed on the device"""
+    import subprocess
+    from oracle_lib import ROOT
+    exe = "/tmp/hrx_test_push_structs_gpu"
+    csrc = os.path.join(ROOT, "halo2_regex_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "host_c", "test_push_structs.c"), "-o", exe,
+                           "-L" + csrc, "-lhrx", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.run([exe, DFA_DIR, "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and "gpu ok" in out.stdout, out.stdout + out.stderr
+
+
 # ---------------------------------------------------------------------------------------------
 # batches against the oracle
 # ---------------------------------------------------------------------------------------------
@@ -568,7 +581,7 @@ def _random_defs(rng, D, big=False):
 
 def _fuzz_seeds():
     """the suite's seeds, plus ranges named in HRX_FUZZ_EXTRA ("16:400,106:200") for a soak run (profiles/r02_soak.txt)"""
-    seeds = list(range(16)) + [100, 101, 102, 103, 104, 105] + [20000, 20001, 20002, 20003, 20004, 20005]
+    seeds = list(range(16)) + [100, 101, 102, 103, 104, 105] + [20000, 20001, 20002, 20003, 20004, 20005] + [30000, 30001, 30002, 30003, 30004, 30005]
     for part in os.environ.get("HRX_FUZZ_EXTRA", "").split(","):
         if ":" in part:
             a, b = part.split(":")
@@ -585,7 +598,17 @@ def test_fuzz_random_definitions_shapes_and_layouts(hra, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     big = 100 <= seed < 10000                                                # one big DFA: the HALF-table / global-table kernels (soak seeds >= 10000: small again)
     D = 1 if big else (int(rng.integers(4, 8)) if seed >= 20000 else int(rng.integers(1, 4)))     # seeds >= 20000: more defs than one launch walks (passes + combine)
+    if seed >= 30000:                                                        # ... up to HRX_MAX_DEFS = 32: more than four groups (always the combine launch), accept bits 8..39
+        D = int(rng.choice([9, 13, 16, 21, 32]))
     defs_t = _random_defs(rng, D, big)
+    if seed >= 30000:       # masked_substr_id is a u8: the ids of all defs' LAST substrings must sum to <= 255 (hrx_defs_finalize) — defs beyond that keep their DFA only
+        off, total = 1, 0
+        for k, (a_t, subs, al) in enumerate(defs_t):
+            if total + off + len(subs) - 1 > 255 or rng.random() < 0.4:
+                defs_t[k] = (a_t, [], al)
+            else:
+                total += off + len(subs) - 1
+                off += len(subs)
     M = int(rng.choice([5, 31, 64, 100, 129, 256, 321, 520, 777]))
     B = int(rng.choice([1, 63, 64, 65, 200, 333, 500]))
     stride = (M + 40 + 15) // 16 * 16
@@ -840,6 +863,48 @@ def test_more_than_three_regex_defs_multi_pass(hra, oracle, names, combine, monk
         ok = codes == 0
         accepted = ((st >> np.uint64(8)) == np.uint64((1 << D) - 1)) | (lens >= M)
         assert (code[ok & accepted] == 0).all() and (code[ok & ~accepted] == FAIL_ACCEPT).all()
+
+
+NOSUB = lambda cfg: [[a, []] for a, _ in cfg]                # the same DFAs without substring definitions: walked for acceptance only (no flags, no ids)
+CFG_D13 = CFG_123 + HDR + NOSUB(CFG_123 + HDR) + [CFG_EX[0]]                          # five groups: past what the last pass merges itself
+CFG_D16 = HDR + NOSUB(CFG_123) + CFG_123 + NOSUB(HDR + CFG_123) + [CFG_1[0]]          # def 15 = regex1 + substr1 again (also def 6): flags of groups 2 and 5 overlap
+CFG_D32 = CFG_123 + NOSUB(HDR + CFG_123) * 4 + HDR + NOSUB(CFG_A)                     # HRX_MAX_DEFS: accept bits 8 .. 39
+
+
+@pytest.mark.parametrize("combine", [False, True], ids=["default", "combine-launch"])
+@pytest.mark.parametrize("names", [CFG_D13, CFG_D16, CFG_D32], ids=["D13", "D16", "D32"])
+def test_up_to_32_regex_defs(hra, oracle, names, combine, monkeypatch):
+    """HRX_MAX_DEFS = 32 RegexDefs per config (the status word's accept mask, bits 8..39; include/hrx.h): 13, 16 and 32 defs = 5 .. 11 groups — more than the last
+    pass merges itself, so the combine launch forms what needs all defs of a row whatever HRX_MP_COMBINE says — string-major outputs (through the position-major path
+    and the transpose kernel for row counts in multiples of 8: 16-row tiles from 10 defs on, hrx_kernel_tp.hip; the copy-mode combine otherwise), position-major outputs
+    with both input layouts; accept masks with a bit per def, the lowest def's undefined transition, flags of defs in different groups on one row."""
+    from halo2_regex_amd import synth
+    D = len(names)
+    assert D == {id(CFG_D13): 13, id(CFG_D16): 16, id(CFG_D32): 32}[id(names)]
+    monkeypatch.setenv("HRX_MP_COMBINE", "1" if combine else "0")
+    for M in (328, 203):                                       # aligned (transpose kernel) and unaligned (copy-mode combine) row counts
+        cfg = _cfg(hra, names, M)
+        d = cfg.describe_launch(700, layout=3)
+        assert d.startswith("multi-pass, ") and "witness_combine_summary_kernel" in d and d.count("[defs ") >= 5
+        assert ("transpose_pm_to_sm_kernel" in cfg.describe_launch(700, layout=0)) == (M % 8 == 0)
+        chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=41)
+        h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=5, stride=chars.shape[1])
+        chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
+        if names is not CFG_D13:
+            chars[7, 50] = 250                                   # a byte no DFA has a transition for
+        lens[11] = M + 72                                        # n > M
+        lens[12], lens[13] = 0, min(M, chars.shape[1])
+        st, _ = _check_batch(hra, oracle, names, chars, lens, M)              # string-major (host buffers -> device batch kernels)
+        _check_batch_pm(hra, oracle, names, chars, lens, M)                   # position-major outputs, both input layouts
+        codes = st & np.uint64(0xff)
+        assert (codes == 3).any()
+        if names is CFG_D13:
+            assert ((st[codes == 1] >> np.uint64(8)) & np.uint64(0xff) == 12).sum() > 300     # def 12 = the partial example DFA
+        elif names is CFG_D16:
+            assert (codes == 2).sum() > 100                      # regex1 + substr1 as def 6 and def 15
+        else:
+            masks = set(int(x) for x in st[codes == 0] >> np.uint64(8))
+            assert (codes == 0).sum() > 100 and len(masks) > 2 and max(masks) >= 1 << 24      # accept bits of defs beyond 24
 
 
 def test_multi_pass_at_a_chip_filling_size_two_blocks(hra, oracle):
