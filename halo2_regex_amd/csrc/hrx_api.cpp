@@ -476,6 +476,9 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         if (pass && li.split != 2) return fail(HRX_ERR_STATE, "multi-pass: the planner did not pick the position-major loader/walker kernel");
         SpecArgs sp{};
         if (li.spec_tiles) {
+            // the chunked launch's state (quasi-absorbing states, pair-tag tables) belongs to the WHOLE config: a group of a multi-pass config is never chunked
+            // (today because a summary / merge pass is excluded by the planner; made explicit so that a planner change cannot walk into a NULL table)
+            if (&set != &ctx->s || !d_pair_tags) return fail(HRX_ERR_STATE, "chunked launch planned for a group of a multi-pass config");
             // ---- chunked launch (hrx_kernel_spec.hip): scout + compose find every chunk's start state, the walk below runs over the
             // chunks, the stitch launch behind it settles what crosses the chunk borders.  Context scratch, like the group buffers.
             if (ctx->scratch_used && ctx->scratch_stream != st && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) {
@@ -860,15 +863,25 @@ struct hrx_place_arena {
 static std::mutex g_arena_mu;
 static std::map<uintptr_t, hrx_place_arena *> g_arena_of;   // sub-buffer -> arena (hrx_device_free has no context argument)
 
-static void *arena_take(hrx_place_arena *a, size_t bytes) {
+// used / live / retired of an arena are only ever touched under g_arena_mu: hrx_device_free (any thread, no context argument — e.g. a finalizer
+// while another thread allocates) releases sub-buffers concurrently with the owning context's takes.
+static void *arena_take_locked(hrx_place_arena *a, size_t bytes) {
     const size_t need = (bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
-    if (!a || a->used + need > a->bytes) return nullptr;
     void *p = (unsigned char *)a->base + a->used;
     a->used += need;
     ++a->live;
-    std::lock_guard<std::mutex> lk(g_arena_mu);
     g_arena_of[(uintptr_t)p] = a;
     return p;
+}
+// a records and a masked-row sub-buffer out of the pair, or neither: the capacity check and both takes are ONE critical section
+static bool arena_take_pair(hrx_place_arena *ra, size_t r_bytes, hrx_place_arena *ma, size_t m_bytes, void **r, void **m) {
+    const size_t r_need = (r_bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
+    const size_t m_need = (m_bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    if (ra->used + r_need > ra->bytes || ma->used + m_need > ma->bytes) return false;
+    *r = arena_take_locked(ra, r_bytes);
+    *m = arena_take_locked(ma, m_bytes);
+    return true;
 }
 static void arena_retire(hrx_place_arena *a) {
     if (!a) return;
@@ -905,7 +918,10 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);   // 16 bytes of the context's 64-byte scratch word area
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    const size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
+    // never more than kPlaceBudgetFrac of what is free NOW — and, for the 2-GiB arena candidates of bench-sized outputs, never more than 24 of them (48 GiB):
+    // several contexts or ranks on one device walk at the same time without pushing each other out of memory
+    size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
+    if (cand_bytes == kPlaceArenaBytes && budget > 24 * kPlaceArenaBytes) budget = 24 * kPlaceArenaBytes;
     rep.searched = 1;
     double ref_rate = 0.0;   // bytes per microsecond
     {   // the reference: both streams inside ONE block, in the launch's byte ratio (4 D : 2)
@@ -989,10 +1005,8 @@ int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_byte
     if (records_bytes > kPlaceArenaBytes || masked_bytes > kPlaceArenaBytes) return plain();
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (ctx->arena_rec && ctx->arena_msk) {
-            const size_t r_need = (records_bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
-            const size_t m_need = (masked_bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
-            if (ctx->arena_rec->used + r_need <= ctx->arena_rec->bytes && ctx->arena_msk->used + m_need <= ctx->arena_msk->bytes) {
-                void *r = arena_take(ctx->arena_rec, records_bytes), *m = arena_take(ctx->arena_msk, masked_bytes);
+            void *r = nullptr, *m = nullptr;
+            if (arena_take_pair(ctx->arena_rec, records_bytes, ctx->arena_msk, masked_bytes, &r, &m)) {
                 if (attempt == 0) { rep = ctx->arena_report; rep.searched = 2; }   // served from the pair an earlier call measured
                 return done(r, m);
             }
