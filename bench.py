@@ -390,13 +390,16 @@ def run_rank(args, rank, world, device_index, barrier):
     # generating 8 x 64 MiB of planted text on the host would take longer than everything else in this script); its oracle rows
     # are the rotated oracle rows of set 0.
     shift = (B // nsets + 37) % B if nsets > 1 else 0
-    sets, placement = [], []
+    sets, placement, sm_sets = [], [], []
+    keep_sm = pm and world == 1 and not args.no_spread and nsets * B * stride <= (4 << 30)
     for r in range(world):        # one rank at a time: the placement search times memory traffic
         if r == rank:
             for k in range(nsets):
                 c_k = d_chars0 if k == 0 else torch.roll(d_chars0, shifts=k * shift, dims=0)
                 l_k = d_lens0 if k == 0 else torch.roll(d_lens0, shifts=k * shift, dims=0)
                 if pm:
+                    if keep_sm:
+                        sm_sets.append(c_k.contiguous())          # the reference's input shape (one contiguous string per row): for roofline.from_string_major_input
                     c_k = hra.chars_to_position_major(c_k)       # [stride/16][B][16]: done once, outside the timed region
                     out = cfg.alloc_outputs_position_major(B, dev)
                 else:
@@ -574,6 +577,29 @@ def run_rank(args, rank, world, device_index, barrier):
             del gt
         except Exception as e:
             sys.stderr.write("traffic-pass probe failed: %s\n" % e)
+    # Starting from the reference's input shape — B contiguous strings (lib.rs:311-315) instead of the position-major chunks the headline reads:
+    # (a) hrx_chars_to_position_major_device alone, (b) that + the same launch (what a caller holding &[u8] strings pays for the fast path),
+    # (c) the position-major kernel reading the strings directly (HRX_LAYOUT_POSITION_MAJOR without HRX_LAYOUT_INPUT_POSITION_MAJOR: 16 bytes per lane, a stride apart).
+    if sm_sets and world == 1:
+        try:
+            fsm = {}
+            tr = lambda i: cfg.chars_to_position_major_device(sm_sets[i % nsets], out=sets[i % nsets][0])
+            both = lambda i: (tr(i), launch(i))
+            direct = lambda i: cfg.witness_batch_position_major(sm_sets[i % nsets], sets[i % nsets][1], out=sets[i % nsets][2])
+            for key, fn in (("transpose", tr), ("transpose_plus_launch", both), ("string_major_input_launch", direct)):
+                gg = graph_of(fn, args.steps) if not args.eager else None
+                rr = gg.replay if gg is not None else (lambda fn=fn: [fn(i) for i in range(args.steps)])
+                rr(); torch.cuda.synchronize()
+                fsm[key + "_ms"] = statistics.median(timed_replays(rr, 5, args.steps))
+                del gg
+            # the transposer leaves the very bytes the headline launch read: the outputs after (b) are the verified ones
+            st_ok = all(((sets[k][2][2].cpu().numpy().view(np.uint64) & np.uint64(0xff)) == 0).all() for k in range(min(nsets, args.steps)))
+            fsm["status_ok_after"] = bool(st_ok)
+            fsm["kernel_of_string_major_input_launch"] = cfg.describe_launch(B, layout=1, num_cus=torch.cuda.get_device_properties(dev).multi_processor_count).split(" grid=")[0]
+            res["from_string_major_input"] = fsm
+        except Exception as e:
+            sys.stderr.write("string-major-input probe failed: %s\n" % e)
+    del sm_sets
     res["desc"] = desc
     res["placement"] = placement
     res["library"] = os.path.realpath(hra.LIB_PATH)
@@ -683,6 +709,15 @@ def aggregate(per_rank, args):
             ceil["mixceil"] = {"us_per_launch": mc, "what": "tools/mixceil --brief, a separate process with its own plain allocations: copy = plain dwordx4 copy of the "
                                "byte count; pair* = the bench line's slabs with write-back / streaming / mixed stores, one buffer set; *_fresh = over 8 buffer sets in turn"}
         line["roofline"]["mix_ceiling"] = ceil
+    if r0.get("from_string_major_input"):
+        f = dict(r0["from_string_major_input"])
+        f["frac_transpose_plus_launch"] = algo_bytes / (f["transpose_plus_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        f["frac_string_major_input_launch"] = algo_bytes / (f["string_major_input_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        f["what"] = ("the same K steps over the same buffer sets starting from the reference's input shape, B contiguous strings (lib.rs:311-315): transpose = "
+                     "hrx_chars_to_position_major_device alone; transpose_plus_launch = that followed by the headline's launch (the cost of the fast path for a caller "
+                     "holding &[u8] strings); string_major_input_launch = the position-major kernel reading the strings directly (each lane's 16-byte pieces a stride apart). "
+                     "frac_* = the headline's algorithmic bytes over that time, of 8 TB/s")
+        line["roofline"]["from_string_major_input"] = f
     if r0.get("cpu_baseline"):
         line["cpu_baseline"] = r0["cpu_baseline"]
     if r0.get("single_string"):

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hrx_defs_push_substr_text", "hrx_defs_push_substr_file", "hrx_defs_push_allstr", "hrx_defs_push_substr",
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
-    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_device_free",
+    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_chars_to_position_major_device", "hrx_device_free",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
@@ -110,6 +110,7 @@ def _load():
         "hrx_device_free": (i, [vp]),
         "hrx_alloc_last_report": (i, [vp, C.POINTER(_PlaceReportC)]),
         "hrx_traffic_pass_device": (i, [vp, vp, sz, sz, sz, vp, vp, vp]),
+        "hrx_chars_to_position_major_device": (i, [vp, vp, sz, sz, vp, vp]),
         "hrx_multi_create": (i, [vp, C.POINTER(i), i, C.POINTER(vp)]),
         "hrx_multi_destroy": (None, [vp]),
         "hrx_multi_num_shards": (i, [vp]),
@@ -656,6 +657,19 @@ class RegexVerifyConfig:
         s = torch.cuda.current_stream(chars_pm.device) if stream is None else stream
         _check(lib.hrx_traffic_pass_device(self._need_device(chars_pm, rec, msk), chars_pm.data_ptr(), int(chars_pm_stride), int(B), self.max_chars_size,
                                            rec.data_ptr(), msk.data_ptr(), s.cuda_stream))
+
+    def chars_to_position_major_device(self, chars, out=None, stream=None):
+        """hrx_chars_to_position_major_device: (B, stride) string-major bytes on the device (stride % 16 == 0, one contiguous string per row: the reference's
+        input shape, lib.rs:311-315) -> the flat HRX_LAYOUT_INPUT_POSITION_MAJOR buffer (the library's own kernel; chars_to_position_major above does
+        the same with torch ops).  Asynchronous on `stream` (default: torch's current stream)."""
+        B, stride = chars.shape
+        if not chars.is_contiguous():
+            chars = chars.contiguous()
+        if out is None:
+            out = torch.empty((B * stride,), dtype=torch.uint8, device=chars.device)
+        s = torch.cuda.current_stream(chars.device) if stream is None else stream
+        _check(lib.hrx_chars_to_position_major_device(self._need_device(chars, out), chars.data_ptr(), int(stride), int(B), out.data_ptr(), s.cuda_stream))
+        return out
 
     def witness_batch_position_major(self, chars, lens, out=None, stream=None, chars_pm_stride=None):
         """Like witness_batch, outputs in HRX_LAYOUT_POSITION_MAJOR (use position_major_to_string_major to view them per

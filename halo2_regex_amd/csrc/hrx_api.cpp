@@ -1051,6 +1051,21 @@ int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, s
     return HRX_OK;
 }
 
+int hrx_chars_to_position_major_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, uint8_t *chars_pm, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
+    if (B == 0) return HRX_OK;
+    if (!chars || !chars_pm) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (B > 0xffffffffull - 64 || stride / 16 > 0xffffffffull) return fail(HRX_ERR_ARG, "shape out of range");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)chars_pm & 15))
+        return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
+    if (chars == chars_pm) return fail(HRX_ERR_ARG, "in-place conversion is not supported");
+    DeviceGuard guard;      // (stateless: no context scratch, no lock)
+    HIP_TRY(guard.set(ctx->device));
+    HIP_TRY(launch_chars_to_position_major(chars, stride, B, chars_pm, (hipStream_t)stream));
+    return HRX_OK;
+}
+
 int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked) {
     if (!ctx || !records || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_outputs_position_major: bad argument");
     size_t nr = 0, nm = 0;

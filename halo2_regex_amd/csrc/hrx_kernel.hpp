@@ -249,6 +249,8 @@ struct TransposeArgs {
     uint32_t rec_pitch, msk_pitch;  // rows, multiples of 8
 };
 hipError_t launch_transpose(const TransposeArgs &a, hipStream_t stream);
+// string-major input bytes [B][stride] -> HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of kPmBlock strings, [stride/16][nb][16]); hrx_kernel_tp.hip
+hipError_t launch_chars_to_position_major(const uint8_t *chars_sm, size_t stride, size_t B, uint8_t *chars_pm, hipStream_t stream);
 
 // states-in entry points (lib.rs:825-888): tags[d*n+i] = pair_tag(states[d][i], states[d][i+1])
 hipError_t launch_pair_tags(const uint64_t *states, size_t n, uint32_t D, const uint16_t *const *pair_tags,

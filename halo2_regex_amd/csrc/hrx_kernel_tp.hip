@@ -99,6 +99,45 @@ static hipError_t launch_tp(const TransposeArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The INPUT the other way round: string-major bytes (one contiguous &[u8] per string: what the reference's caller holds, src/lib.rs:311-315) ->
+// HRX_LAYOUT_INPUT_POSITION_MAJOR ([stride/16][nb][16] per block of kPmBlock strings).  A workgroup turns a tile of 64 strings x 16 units of 16 bytes
+// around through 16 KiB of LDS: in, a wave load reads 256-byte runs of four strings (lane = string * 16 + unit); out, a wave store writes one unit of all
+// 64 strings, 1 KiB contiguous (lane = string).  The LDS rows are 17 units long: the column reads of the way out fall into different banks.
+// Pure streaming: stride bytes read and written per string.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chars_sm_to_pm_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const uint32_t B, const uint32_t units /* stride / 16 */) {
+    const uint32_t tiles_u = (units + 15u) / 16u;
+    const uint32_t g = blockIdx.x / tiles_u, tu = blockIdx.x % tiles_u;
+    const uint32_t b0 = g * 64u, u0 = tu * 16u;
+    const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);
+    const uint32_t tid = threadIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(in);
+    uint4 *dst = reinterpret_cast<uint4 *>(out);
+    uint4 *tile = reinterpret_cast<uint4 *>(smem);                 // [64 strings][17 units]
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {                             // 1024 units of the tile, 256 threads
+        const uint32_t i = k * 256u + tid, sl = i >> 4, u = i & 15u;
+        const uint32_t b = min(b0 + sl, B - 1u), uu = min(u0 + u, units - 1u);
+        tile[sl * 17u + u] = src[(size_t)b * units + uu];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t i = k * 256u + tid, u = i >> 6, sl = i & 63u;
+        const uint32_t b = b0 + sl;
+        if (b < B && u0 + u < units) dst[(size_t)blk0 * units + (size_t)(u0 + u) * nb + (b - blk0)] = tile[sl * 17u + u];
+    }
+}
+
+hipError_t launch_chars_to_position_major(const uint8_t *chars_sm, size_t stride, size_t B, uint8_t *chars_pm, hipStream_t stream) {
+    if (B == 0) return hipSuccess;
+    const uint32_t units = (uint32_t)(stride / 16);
+    const size_t tiles = ((B + 63) / 64) * ((units + 15u) / 16u);
+    hipLaunchKernelGGL(chars_sm_to_pm_kernel, dim3((unsigned)tiles), dim3(256), 64 * 17 * 16, stream, chars_sm, chars_pm, (uint32_t)B, units);
+    return hipGetLastError();
+}
+
 hipError_t launch_transpose(const TransposeArgs &a, hipStream_t stream) {
     if (a.B == 0 || a.M == 0) return hipSuccess;
     // D >= 10: 16-row tiles — the planes of a 32-row tile (8 D + 4 KiB) pass the 160 KiB of LDS at D = 20, and from D = 10 on leave room for one workgroup per CU only

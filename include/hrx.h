@@ -231,6 +231,11 @@ int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out);
  * box's ceiling for the launch's byte mix on these very buffers (bench.py: roofline.mix_ceiling).  Asynchronous on `stream`. */
 int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records,
                             uint16_t *masked, void *stream);
+/* From the reference's input shape to the coalesced one, on the device: `chars` = B strings of `stride` bytes each, back to back — one contiguous
+ * &[u8] per string is what RegexVerifyConfig::match_substrs is handed (src/lib.rs:311-315) — -> `chars_pm` (B * stride bytes, another buffer) in
+ * HRX_LAYOUT_INPUT_POSITION_MAJOR.  Pure streaming (2 * stride bytes of traffic per string; measured beside the bench line: bench.py
+ * roofline.from_string_major_input).  Asynchronous on `stream`; no context state is touched. */
+int hrx_chars_to_position_major_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, uint8_t *chars_pm, void *stream);
 int hrx_device_free(void *ptr);
 /* Which kernel and launch geometry the planner picks for a batch of B strings x M rows in `layout` on a gfx950 device
  * with `num_cus` compute units (MI355X: 256), as text: "hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8

@@ -125,6 +125,28 @@ def test_cpp_host_mirror_runs_the_reference_test(hra):
     assert out.returncode == 0 and "gpu ok" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("B,stride", [(1, 16), (63, 48), (64, 1024), (65, 272), (200, 4096), (70000, 64)])
+def test_chars_to_position_major_device_equals_the_layout_definition(hra, B, stride):
+    """hrx_chars_to_position_major_device (the library's route from the reference's input shape, one contiguous string per row, lib.rs:311-315, to
+    HRX_LAYOUT_INPUT_POSITION_MAJOR) against the layout's definition (blocks of 65536 strings, [stride/16][nb][16]) — and a witness launch on its output
+    against the launch on the string-major bytes."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(B * 131 + stride)
+    chars = torch.from_numpy(rng.integers(0, 256, size=(B, stride), dtype=np.uint8)).to(dev)
+    cfg = _cfg(hra, CFG_1, max(16, min(stride, 64)))
+    got = cfg.chars_to_position_major_device(chars)
+    torch.cuda.synchronize()
+    want = hra.chars_to_position_major(chars)
+    assert got.shape == want.shape and torch.equal(got, want)
+    lens = torch.from_numpy(rng.integers(0, cfg.max_chars_size + 1, size=B).astype(np.int32)).to(dev)
+    a = cfg.witness_batch_position_major(chars, lens)
+    b = cfg.witness_batch_position_major(got, lens, chars_pm_stride=stride)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_c_struct_entry_points_on_the_device(hra):
     """tests/host_c/test_push_structs.c (the Rust binding's call sequence: shuffled hrx_defs_push_allstr entries with explicit line indices, a duplicate key,
     hrx_defs_push_substr) with the witness rows of both configs computed on the device"""
