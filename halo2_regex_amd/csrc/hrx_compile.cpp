@@ -65,79 +65,89 @@ static bool utf8_to_units(const char *s, size_t n, std::vector<uint16_t> &out, s
 enum NodeType { N_EMPTY, N_TEXT, N_CAT, N_OR, N_STAR };
 struct Ast { NodeType type; uint16_t ch = 0; std::vector<int> parts; int sub = -1; };
 
+// Recursive descent over the token string: alternation -> concatenation -> postfix -> atom.  What the reference's compiler defines (regex.js:236-352) and the
+// golden vectors pin (tests/golden/compiler/cases.json, produced by the reference's own script under node) is the TREE — the DFA's state numbers follow its shape:
+//   * an alternation of one alternative is that alternative, a concatenation of one factor is that factor;
+//   * x+ is cat(x, star(x)) with x's subtree shared (the NFA builder visits it twice), x? is or(x, empty);
+//   * a bar splits the scope it is in only while the brackets seen since the scope's start balance: a ')' without a '(' is an ordinary character, and so
+//     is every bar behind it in that scope ("a)|b" is the four-character string);
+//   * an empty scope — "", "a|", "()" — and a postfix operator without an operand are errors; so is a '(' whose ')' is missing.
+// depth[i] = brackets open in front of token i (negative behind a stray ')'): one pass up front, then every scope is a token range.
 struct Parser {
     std::vector<Ast> nodes;
     std::string err;
-    // parse_sub recurses twice per bracket level.  The reference's JS throws a catchable RangeError when its own stack runs out
-    // (V8: around 10^4 levels); this library promises integer status returns and nothing unwinding (include/hrx.h), so nesting
-    // beyond kMaxNesting levels is refused as a parse error instead of overflowing the native stack.
+    // Two levels of recursion per bracket level.  The reference's JS throws a catchable RangeError when its own stack runs out (V8: around 10^4 levels); this
+    // library promises integer status returns and nothing unwinding (include/hrx.h), so nesting beyond kMaxNesting levels is refused as a parse error.
     static constexpr int kMaxNesting = 2000;
-    int depth = 0;
-    struct DepthGuard { int &d; explicit DepthGuard(int &x) : d(x) { ++d; } ~DepthGuard() { --d; } };
+    const std::vector<Tok> *toks = nullptr;
+    std::vector<long> depth;
 
     int add(const Ast &a) { nodes.push_back(a); return (int)nodes.size() - 1; }
-    bool raw(const Tok &t, char c) const { return !t.lit && t.ch == (uint16_t)(uint8_t)c; }
+    bool raw(size_t i, char c) const { const Tok &k = (*toks)[i]; return !k.lit && k.ch == (uint16_t)(uint8_t)c; }
+    int fail(const std::string &what, size_t at) { err = "Error: " + what + " at " + std::to_string(at) + "."; return -1; }
 
-    // parseSub(text.slice(lo,hi), begin, end, first); returns node index or -1 with err set
-    int parse_sub(const std::vector<Tok> &t, size_t lo, size_t hi, size_t begin, bool first) {
-        DepthGuard guard(depth);
-        if (depth > 2 * kMaxNesting + 2) { err = "Error: brackets nested deeper than " + std::to_string(kMaxNesting) + " levels at " + std::to_string(begin) + "."; return -1; }
-        const size_t len = hi - lo;
-        if (len == 0) { err = "Error: empty input at " + std::to_string(begin) + "."; return -1; }
-        std::vector<int> parts;
-        if (first) {
-            size_t last = 0;
-            long stack = 0;
-            for (size_t i = 0; i <= len; i++) {
-                if (i == len || (raw(t[lo + i], '|') && stack == 0)) {
-                    if (last == 0 && i == len) return parse_sub(t, lo, hi, begin, false);
-                    int sub = parse_sub(t, lo + last, lo + i, begin + last, true);
-                    if (sub < 0) return -1;
-                    parts.push_back(sub);
-                    last = i + 1;
-                } else if (raw(t[lo + i], '(')) stack += 1;
-                else if (raw(t[lo + i], ')')) stack -= 1;
-            }
-            if (parts.size() == 1) return parts[0];
-            Ast n; n.type = N_OR; n.parts = parts;
-            return add(n);
+    // the whole expression; returns the root's node index or -1 with err set
+    int parse(const std::vector<Tok> &t) {
+        toks = &t;
+        depth.assign(t.size() + 1, 0);
+        for (size_t i = 0; i < t.size(); ++i) depth[i + 1] = depth[i] + (raw(i, '(') ? 1 : raw(i, ')') ? -1 : 0);
+        return alternation(0, t.size(), 0);
+    }
+
+    // scope [lo, hi): alternatives separated by the bars at the scope's own bracket depth
+    int alternation(const size_t lo, const size_t hi, const int nest) {
+        if (lo == hi) return fail("empty input", lo);
+        if (nest > kMaxNesting) return fail("brackets nested deeper than " + std::to_string(kMaxNesting) + " levels", lo);
+        std::vector<int> alts;
+        size_t from = lo;
+        int result = -2;
+        for (size_t i = lo; i <= hi && result == -2; ++i) {
+            if (i < hi && !(raw(i, '|') && depth[i] == depth[lo])) continue;
+            if (from == lo && i == hi) { result = concatenation(lo, hi, nest); break; }      // no bar: the scope is one concatenation
+            const int a = from == i ? fail("empty input", from) : alternation(from, i, nest);   // (an alternative holds no bar of this depth: it comes back as a concatenation)
+            if (a < 0) { result = -1; break; }
+            alts.push_back(a);
+            from = i + 1;
         }
-        for (size_t i = 0; i < len; i++) {
-            const Tok &k = t[lo + i];
-            if (raw(k, '(')) {
-                size_t last = i + 1;
-                i += 1;
-                long stack = 1;
-                while (i < len && stack != 0) {
-                    if (raw(t[lo + i], '(')) stack += 1;
-                    else if (raw(t[lo + i], ')')) stack -= 1;
-                    i += 1;
-                }
-                if (stack != 0) { err = "Error: missing right bracket for " + std::to_string(begin + last) + "."; return -1; }
-                i -= 1;
-                int sub = parse_sub(t, lo + last, lo + i, begin + last, true);
+        if (result != -2) return result;
+        Ast n; n.type = N_OR; n.parts = alts;
+        return add(n);
+    }
+
+    // factors of [lo, hi), each an atom with its postfix operators applied as they come
+    int concatenation(const size_t lo, const size_t hi, const int nest) {
+        std::vector<int> parts;
+        for (size_t i = lo; i < hi; ++i) {
+            const Tok &k = (*toks)[i];
+            if (raw(i, '(')) {                                   // atom: a bracketed scope, up to where the depth is back at this bracket's
+                size_t j = i + 1;
+                while (j < hi && depth[j + 1] != depth[i]) ++j;
+                if (j >= hi) return fail("missing right bracket for", i + 1);
+                const int sub = alternation(i + 1, j, nest + 1);
                 if (sub < 0) return -1;
                 parts.push_back(sub);
-            } else if (raw(k, '*')) {
-                if (parts.empty()) { err = "Error: unexpected * at " + std::to_string(begin + i) + "."; return -1; }
-                Ast n; n.type = N_STAR; n.sub = parts.back();
-                parts.back() = add(n);
-            } else if (raw(k, '+')) {            // S+ -> S S*   (the same subtree is visited twice by the NFA builder)
-                if (parts.empty()) { err = "Error: unexpected + at " + std::to_string(begin + i) + "."; return -1; }
-                Ast star; star.type = N_STAR; star.sub = parts.back();
-                int s = add(star);
-                Ast cat; cat.type = N_CAT; cat.parts = {parts.back(), s};
-                parts.back() = add(cat);
-            } else if (raw(k, '?')) {            // S? -> (S | empty)
-                if (parts.empty()) { err = "Error: unexpected + at " + std::to_string(begin + i) + "."; return -1; }   // sic
-                Ast e; e.type = N_EMPTY;
-                int en = add(e);
-                Ast o; o.type = N_OR; o.parts = {parts.back(), en};
-                parts.back() = add(o);
+                i = j;
+            } else if (raw(i, '*') || raw(i, '+') || raw(i, '?')) {   // postfix: on the factor in front of it
+                if (parts.empty()) return fail(std::string("unexpected ") + (char)k.ch, i);
+                const int x = parts.back();
+                if (raw(i, '*')) {
+                    Ast n; n.type = N_STAR; n.sub = x;
+                    parts.back() = add(n);
+                } else if (raw(i, '+')) {                        // x+ = x x*, the subtree shared
+                    Ast star; star.type = N_STAR; star.sub = x;
+                    const int s = add(star);
+                    Ast cat; cat.type = N_CAT; cat.parts = {x, s};
+                    parts.back() = add(cat);
+                } else {                                         // x? = (x | empty)
+                    Ast e; e.type = N_EMPTY;
+                    const int en = add(e);
+                    Ast o; o.type = N_OR; o.parts = {x, en};
+                    parts.back() = add(o);
+                }
             } else if (!k.lit && k.ch == kEpsilonChar) {
                 Ast e; e.type = N_EMPTY;
                 parts.push_back(add(e));
-            } else {
+            } else {                                             // a character (a ')' or '|' that closes / splits nothing included)
                 Ast x; x.type = N_TEXT; x.ch = k.ch;
                 parts.push_back(add(x));
             }
@@ -516,7 +526,7 @@ bool compile_regex(const char *regex, size_t len, std::string *json_out, std::st
         } else { toks.push_back({units[i], false}); i += 1; }
     }
     rx::Parser p;
-    int root = p.parse_sub(toks, 0, toks.size(), 0, true);
+    int root = p.parse(toks);
     if (root < 0) { err = p.err; return false; }
     rx::Nfa nfa;
     int start = nfa.fresh(), accept = nfa.fresh();

@@ -24,7 +24,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/hrx.h"
+#include "../include/hrx.h"
 
 extern "C" int hrx_chunked_alloc(int device, size_t bytes, void **out);
 extern "C" int hrx_chunked_free(void *ptr);
