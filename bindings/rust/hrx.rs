@@ -59,6 +59,8 @@ extern "C" {
     pub fn hrx_alloc_outputs_position_major(ctx: *mut hrx_ctx, b: usize, m: usize, records: *mut *mut u32, masked: *mut *mut u16) -> c_int;
     pub fn hrx_alloc_output_pair(ctx: *mut hrx_ctx, records_bytes: usize, masked_bytes: usize, records: *mut *mut c_void, masked: *mut *mut c_void) -> c_int;
     pub fn hrx_device_free(ptr: *mut c_void) -> c_int;
+    /// B contiguous strings on the device (one &[u8] per string: lib.rs:311-315) -> HRX_LAYOUT_INPUT_POSITION_MAJOR, the fast path's input
+    pub fn hrx_chars_to_position_major_device(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, chars_pm: *mut u8, stream: *mut c_void) -> c_int;
     /// what the context's last placement-aware allocation did (steps measured, reference / first / kept probe times, memory held)
     pub fn hrx_alloc_last_report(ctx: *const hrx_ctx, out: *mut hrx_place_report) -> c_int;
     /// roofline diagnostic: the memory traffic of one position-major launch over these buffers, no DFA work (overwrites the outputs)
@@ -159,6 +161,43 @@ impl HrxHandle {
         flat.chunks(n + 1).map(|c| c.to_vec()).collect()
     }
 
+    /// Drop-in for `RegexVerifyConfig::derive_substr_ids` (src/lib.rs:825-845): `states` as derive_states returned them.
+    pub fn derive_substr_ids(&self, states: &[Vec<u64>]) -> Vec<Vec<usize>> {
+        let n = states[0].len() - 1;
+        let flat: Vec<u64> = states.iter().flat_map(|s| s.iter().cloned()).collect();
+        let mut out = vec![0u64; states.len() * n];
+        let rc = unsafe { hrx_derive_substr_ids(self.ctx, flat.as_ptr(), n, out.as_mut_ptr()) };
+        if rc != 0 { panic!("{}", last_error()); }
+        out.chunks(n.max(1)).take(states.len()).map(|c| c.iter().map(|v| *v as usize).collect()).collect()
+    }
+
+    /// Drop-in for `RegexVerifyConfig::derive_is_start_end` (src/lib.rs:847-888): (is_starts, is_ends), n + 1 flags per def each
+    /// (is_starts[d][n] = false, is_ends[d][0] = false, is_ends[d][i + 1] belongs to transition i).
+    pub fn derive_is_start_end(&self, states: &[Vec<u64>], substr_ids: &[Vec<usize>]) -> (Vec<Vec<bool>>, Vec<Vec<bool>>) {
+        let n = states[0].len() - 1;
+        let d = states.len();
+        let fs: Vec<u64> = states.iter().flat_map(|s| s.iter().cloned()).collect();
+        let fi: Vec<u64> = substr_ids.iter().flat_map(|s| s.iter().map(|v| *v as u64)).collect();
+        let (mut st, mut en) = (vec![0u8; d * (n + 1)], vec![0u8; d * (n + 1)]);
+        let rc = unsafe { hrx_derive_is_start_end(self.ctx, fs.as_ptr(), fi.as_ptr(), n, st.as_mut_ptr(), en.as_mut_ptr()) };
+        if rc != 0 { panic!("{}", last_error()); }
+        let split = |v: &Vec<u8>| v.chunks(n + 1).map(|c| c.iter().map(|x| *x != 0).collect()).collect();
+        (split(&st), split(&en))
+    }
+
+    /// `match_substrs`' integer columns for ONE string (src/lib.rs:311-773 on integers): what the cells of a circuit hold, in the order
+    /// enable, character, states[d], substr_ids[d], start_enable[d], end_enable[d], masked_char, masked_substr_id.
+    pub fn match_substrs_columns(&self, num_defs: usize, characters: &[u8], max_chars_size: usize) -> MatchColumns {
+        let (m, d) = (max_chars_size, num_defs);
+        let mut c = MatchColumns { enable: vec![0; m], character: vec![0; m], state: vec![0; d * m], substr_id: vec![0; d * m],
+                                   start_enable: vec![0; d * m], end_enable: vec![0; d * m], masked_char: vec![0; m], masked_substr_id: vec![0; m], status: 0 };
+        let rc = unsafe { hrx_match_substrs(self.ctx, characters.as_ptr(), characters.len(), m, c.enable.as_mut_ptr(), c.character.as_mut_ptr(),
+                                            c.state.as_mut_ptr(), c.substr_id.as_mut_ptr(), c.start_enable.as_mut_ptr(), c.end_enable.as_mut_ptr(),
+                                            c.masked_char.as_mut_ptr(), c.masked_substr_id.as_mut_ptr(), &mut c.status) };
+        if rc != 0 { panic!("{}", last_error()); }
+        c
+    }
+
     /// The batch surface: compact witness rows for many strings (one circuit each) sharing this config.
     /// records[b][r][d] = state | substr_id<<16 | start_enable<<24 | end_enable<<25; masked[b][r] = char | id<<8.
     pub fn witness_batch(&self, num_defs: usize, chars: &[u8], stride: usize, lens: &[u32], max_chars_size: usize)
@@ -178,3 +217,68 @@ impl HrxHandle {
 impl Drop for HrxHandle {
     fn drop(&mut self) { unsafe { hrx_ctx_destroy(self.ctx); hrx_defs_destroy(self.defs); } }
 }
+
+/// The integer columns of one circuit (hrx_match_substrs).  state / substr_id / start_enable / end_enable are [def][row].
+pub struct MatchColumns {
+    pub enable: Vec<u64>, pub character: Vec<u64>, pub state: Vec<u64>, pub substr_id: Vec<u64>, pub start_enable: Vec<u64>, pub end_enable: Vec<u64>,
+    pub masked_char: Vec<u64>, pub masked_substr_id: Vec<u64>, pub status: u64,
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SURVEY §8 f3 — the batch-aware witness fill (src/lib.rs:339-773), as far as it can be written without a Rust toolchain.
+//
+// `match_substrs` starts with three lines (lib.rs:316-318):
+//     let states = self.derive_states(characters);
+//     let substr_ids = self.derive_substr_ids(states.as_slice());
+//     let (is_starts, is_ends) = self.derive_is_start_end(&states, &substr_ids);
+// and everything below them (lib.rs:339-773: the advice assignments, the accept chain, the per-def sums and the reveal-mask gates) reads ONLY those four
+// values, `characters` and `self`.  So the fill of circuit b of a batch is the same body fed from the compact records of string b:
+//     1. move the body below lib.rs:318 into `fn match_substrs_with(&self, ctx, characters, states, substr_ids, is_starts, is_ends)`
+//        (a pure refactor: `match_substrs` = the three lines + that call);
+//     2. per circuit of the batch: `let w = WitnessOf::new(&records[b * m * d ..][.. m * d], d, characters.len(), &config.regex_defs);`
+//        `config.match_substrs_with(ctx, characters, &w.states, &w.substr_ids, &w.is_starts, &w.is_ends)`.
+// The decode below is exact, not approximate: for idx < n the enable cell is 1, so start_enable[idx] = is_start[idx] and end_enable[idx] = is_end[idx + 1]
+// (lib.rs:467-519); is_starts[n] is false by construction (lib.rs:868), is_ends[0] likewise (lib.rs:881), and is_ends[n] is the flag of transition
+// n - 1 = end_enable[n - 1].  The masked columns the kernels also return are NOT needed by the fill (the gates recompute them, lib.rs:593-764); a prover that
+// wants to skip witness generation inside the gates can compare them against `masked`.
+// ---------------------------------------------------------------------------------------------------------------------
+pub struct WitnessOf {
+    pub states: Vec<Vec<u64>>,        // [def][n + 1]   as derive_states returns them
+    pub substr_ids: Vec<Vec<usize>>,  // [def][n]       as derive_substr_ids
+    pub is_starts: Vec<Vec<bool>>,    // [def][n + 1]   as derive_is_start_end
+    pub is_ends: Vec<Vec<bool>>,      // [def][n + 1]
+}
+
+impl WitnessOf {
+    /// `rec`: the m x d compact records of one string, string-major (record = state | substr_id << 16 | start_enable << 24 | end_enable << 25);
+    /// `n` = characters.len() <= m.  Row n of the records holds the state after the last character (lib.rs:404-411); when n == m that row does not
+    /// exist and the state after the last character is not part of any cell either (the reference's states[d][m] is computed and never assigned).
+    pub fn new(rec: &[u32], d: usize, n: usize, m: usize) -> Self {
+        let mut w = WitnessOf { states: vec![vec![0; n + 1]; d], substr_ids: vec![vec![0; n]; d], is_starts: vec![vec![false; n + 1]; d], is_ends: vec![vec![false; n + 1]; d] };
+        for di in 0..d {
+            for idx in 0..n.min(m) {
+                let r = rec[idx * d + di];
+                w.states[di][idx] = (r & 0xffff) as u64;
+                w.substr_ids[di][idx] = ((r >> 16) & 0xff) as usize;
+                w.is_starts[di][idx] = (r >> 24) & 1 != 0;
+                w.is_ends[di][idx + 1] = (r >> 25) & 1 != 0;
+            }
+            if n < m { w.states[di][n] = (rec[n * d + di] & 0xffff) as u64; }
+            // n == m: states[di][m] stays 0 — match_substrs never reads it (lib.rs:388-418 stop at max_chars_size) — and is_ends[di][m], the flag of the last
+            // transition, is dropped by the reference as well (lib.rs:501: the loop ends at max_chars_size - 2)
+        }
+        w
+    }
+
+    /// The same view out of HRX_LAYOUT_POSITION_MAJOR records ([ceil(m/4)][d][nb][4] per block of 65536 strings): string `b` of a batch of `batch` strings.
+    pub fn from_position_major(rec_pm: &[u32], batch: usize, b: usize, d: usize, n: usize, m: usize) -> Self {
+        const BLOCK: usize = 65536;
+        let (blk0, q4) = (b / BLOCK * BLOCK, (m + 3) / 4);
+        let nb = BLOCK.min(batch - blk0);
+        let base = blk0 * q4 * d * 4;
+        let at = |row: usize, di: usize| rec_pm[base + ((row / 4 * d + di) * nb + (b - blk0)) * 4 + row % 4];
+        let flat: Vec<u32> = (0..m).flat_map(|row| (0..d).map(move |di| (row, di))).map(|(row, di)| at(row, di)).collect();
+        Self::new(&flat, d, n, m)
+    }
+}
+

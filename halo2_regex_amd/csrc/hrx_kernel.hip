@@ -32,6 +32,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
 
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.gs = 64;
+    a.sm_no_touch = 0;
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
     return plan_witness_launch_groups(a, num_cus, out);
 }
@@ -281,6 +282,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
             size_t ns = (kLdsLimit - a.byte16_bytes - pairs * fixed) / (pairs * slot);
             if (ns > 4) ns = 4;
             out.split = 1; out.gtab = 0; out.byte = 1;
+            a.sm_no_touch = 1;   // (hrx_kernel_sm.hip: the storer's L2 warm-up costs this shape a second pass over the input)
             out.waves_per_wg = 2 * pairs;
             out.nslots = (int)ns;
             out.lds_bytes = a.byte16_bytes + pairs * (ns * slot + fixed);

@@ -729,13 +729,15 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
             // prefetch distance can cover, and its vmcnt is in-order, so it cannot run far-ahead loads itself.  The storer
             // never waits on vmcnt, so every 128 rows it issues ONE LDS-DMA load (no VGPR destination; 4 bytes per lane into
             // a scratch word nobody reads) that pulls each string's 128-byte line of kTouch batches ahead into L2.
+            // (Not on the BYTE table — cfg 5's 4096-byte strings: there the touched lines are evicted again before the walker reads them, the input crosses
+            // the HBM twice (2179 against 1879 MB per launch, profiles/r03_cfg5_sm_pmc.json) and the launch is 4 % slower with the touches than without.)
             constexpr uint32_t kBlk = 64u;
             constexpr uint32_t kTouchRows = 128u, kTouchAhead = 5u * 128u;
             const uint32_t n_s = active ? min(a.lens[b], M) : M;
             const uint32_t last_line = n_s ? ((n_s - 1u) & ~127u) : 0u;
             const uint8_t *tptr = a.chars + (size_t)(active ? b : a.B - 1u) * a.stride;
             auto touch = [&](uint32_t row) {
-                if (!(a.debug & kDbgNoTouch)) {
+                if (!(a.debug & kDbgNoTouch) && !a.sm_no_touch) {
                     uint32_t saved_m0;  // M0 = LDS base of the DMA; restored, the compiler does not expect it to change
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                                  : "=&s"(saved_m0)

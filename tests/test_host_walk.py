@@ -201,3 +201,61 @@ def test_random_definitions(oracle):
         defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs, _ in defs_t]
         cfg = hra.RegexVerifyConfig.configure(M, defs, device=hra.HRX_DEVICE_NONE)
         _check_batch(oracle, None, chars, lens, M, cfg=cfg, o=OracleDefs(oracle, [(a, subs) for a, subs, _ in defs_t]))
+
+
+def _witness_of(rec, D, n, M):
+    """bindings/rust/hrx.rs WitnessOf::new restated: the four values lib.rs:316-318 derive, out of one string's compact records (M x D)."""
+    states = np.zeros((D, n + 1), np.uint64)
+    sids = np.zeros((D, n), np.uint64)
+    st = np.zeros((D, n + 1), bool)
+    en = np.zeros((D, n + 1), bool)
+    for d in range(D):
+        for idx in range(min(n, M)):
+            r = int(rec[idx, d])
+            states[d, idx] = r & 0xffff
+            sids[d, idx] = (r >> 16) & 0xff
+            st[d, idx] = bool((r >> 24) & 1)
+            en[d, idx + 1] = bool((r >> 25) & 1)
+        if n < M:
+            states[d, n] = int(rec[n, d]) & 0xffff
+    return states, sids, st, en
+
+
+@pytest.mark.parametrize("names", [CFG_1, CFG_A, CFG_123], ids=["D1", "D2", "D3"])
+def test_records_decode_to_what_derive_states_ids_flags_return(oracle, names):
+    """SURVEY §8 f3, the part that can be pinned without a Rust toolchain: the batch fill feeds lib.rs:339-773 from the compact records instead of the three
+    derive_* calls (bindings/rust/hrx.rs WitnessOf).  The decode must give EXACTLY what derive_states / derive_substr_ids / derive_is_start_end return
+    (lib.rs:804-888; the oracle's restatement of them) — every reference test string, planted and stress strings, n = 0 and n = M included; the one value
+    the records cannot hold (states[d][M] and the last transition's end flag when n == M) is one the reference computes and never assigns (lib.rs:388-418, 501)."""
+    M = 160
+    D = len(names)
+    cfg = _cfg(names, M)
+    o = OracleDefs.from_files(oracle, names)
+    texts = [c["input"].encode() if isinstance(c.get("input"), str) else None for c in reference_cases()]
+    texts = [t for t in texts if t is not None and len(t) <= M]
+    c2, l2 = synth.reveal_stress(60, M, seed=77)
+    texts += [bytes(c2[b, :l2[b]]) for b in range(60)] + [b"", bytes(c2[0, :1])]
+    full = bytes(synth.regex1_planted(1, M, seed=5, stride=M)[0][0, :M])
+    texts.append(full)                                       # n == M
+    chars = np.zeros((len(texts), M), np.uint8)
+    lens = np.zeros(len(texts), np.uint32)
+    for b, t in enumerate(texts):
+        chars[b, :len(t)] = np.frombuffer(t, np.uint8)
+        lens[b] = len(t)
+    rec, msk, st = cfg.witness_batch_host(chars, lens)
+    checked = 0
+    for b, t in enumerate(texts):
+        if int(st[b]) & 0xff:
+            continue                                         # an undefined transition: the reference panics in derive_states (lib.rs:817); no records to decode
+        n = len(t)
+        want_states = o.derive_states(t)
+        want_sids = o.derive_substr_ids(want_states)
+        want_st, want_en = o.derive_is_start_end(want_states, want_sids)
+        g_states, g_sids, g_st, g_en = _witness_of(rec[b], D, n, M)
+        if n == M:                                           # what no cell ever holds
+            want_states = want_states.copy(); want_states[:, M] = 0
+            want_en = want_en.copy(); want_en[:, M] = False
+        assert np.array_equal(g_states, want_states) and np.array_equal(g_sids, want_sids), t
+        assert np.array_equal(g_st, want_st) and np.array_equal(g_en, want_en), t
+        checked += 1
+    assert checked >= 40
