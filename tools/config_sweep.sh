@@ -1,7 +1,7 @@
 #!/bin/bash
-# One bench line per BASELINE config shape (per-GPU sizes) -> gpurun_out/r03_config_sweep/*.json; copied to profiles/r03_config_sweep/.
+# One bench line per BASELINE config shape (per-GPU sizes) -> gpurun_out/r04_config_sweep/*.json; copied to profiles/r04_config_sweep/.
 # Every line in the HBM-only regime (the timed steps rotate over as many buffer sets as fit 48 GiB, up to 8) and verified over every string.
-cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r03_config_sweep; rm -rf $O; mkdir -p $O
+cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r04_config_sweep; rm -rf $O; mkdir -p $O
 B="python3 bench.py --no-cpu-baseline --no-pmc"
 $B                                                                                   > $O/cfg2_regex1_65536x1024.json
 $B --layout string-major                                                             > $O/cfg2_regex1_65536x1024_string_major.json
