@@ -929,6 +929,43 @@ def test_up_to_32_regex_defs(hra, oracle, names, combine, monkeypatch):
             assert (codes == 0).sum() > 100 and len(masks) > 2 and max(masks) >= 1 << 24      # accept bits of defs beyond 24
 
 
+@pytest.mark.parametrize("big_first", [True, False], ids=["big-def-first", "big-def-last"])
+@pytest.mark.parametrize("combine", [False, True], ids=["merged-by-the-last-pass", "combine-launch"])
+def test_multi_pass_with_a_group_on_the_byte_table(hra, oracle, big_first, combine, monkeypatch):
+    """A config of four defs one of which is a 200-state DFA: that def is a group of its own whose 4-byte table does not fit LDS — its pass runs on the BYTE table
+    (tag bytes -> bitvectors in the finisher, hrx_kernel_pm.hip byte_tile_bits) and either writes the tile summaries the other passes' merge reads (big def first)
+    or is the LAST pass that merges the earlier groups' summaries itself (big def last); both output layouts, every string against the oracle."""
+    import torch
+    from halo2_regex_amd import synth
+    monkeypatch.setenv("HRX_MP_COMBINE", "1" if combine else "0")
+    read = lambda f: open(os.path.join(DFA_DIR, f)).read()
+    small = [(read(a), [read(x) for x in subs]) for a, subs in CFG_123]
+    big_a, big_s = synth.random_dfa(200, seed=12, n_substr_pairs=60)
+    defs_t = ([(big_a, [big_s])] + small) if big_first else (small + [(big_a, [big_s])])
+    M, B = 328, 700
+    chars, lens = synth.reveal_stress(B - 200, M - 8, seed=51)
+    n_c, n_l = synth.noise(200, M - 8, seed=2, stride=chars.shape[1])
+    chars, lens = np.concatenate([chars, n_c]), np.concatenate([lens, n_l])
+    lens[5], lens[6] = 0, M
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in defs_t]
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    d = cfg.describe_launch(B, layout=3)
+    assert d.startswith("multi-pass, 2 groups") and "witness_pm_kernel<1, false, false, false, false, true>" in d     # the big def's group: the BYTE table
+    o = OracleDefs(oracle, defs_t)
+    orec, omsk, ost = o.witness_batch(chars, lens, M)
+    ok = (ost & np.uint64(0xff)) == 0
+    assert ok.sum() > 100
+    grec, gmsk, gst = cfg.witness_batch_host(chars, lens)                   # string-major outputs (position-major passes + transpose)
+    assert np.array_equal(ost, gst) and np.array_equal(orec[ok], grec[ok]) and np.array_equal(omsk[ok], gmsk[ok])
+    dev = torch.device("cuda", 0)
+    d_chars, d_lens = torch.from_numpy(chars).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    rec, msk, st = cfg.witness_batch_position_major(hra.chars_to_position_major(d_chars), d_lens, chars_pm_stride=chars.shape[1])
+    torch.cuda.synchronize()
+    r1, m1 = hra.position_major_to_string_major(rec, msk, B, M, 4)
+    assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+    assert np.array_equal(r1.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(m1.cpu().numpy().view(np.uint16)[ok], omsk[ok])
+
+
 def test_multi_pass_at_a_chip_filling_size_two_blocks(hra, oracle):
     """D = 5 at 70000 x 1023 bytes (two blocks of the position-major buffers): every string against the oracle and the MockProver."""
     from halo2_regex_amd import synth
