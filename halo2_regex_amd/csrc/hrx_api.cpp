@@ -852,7 +852,8 @@ constexpr size_t kPlaceFromBytes = (size_t)128 << 20;    // below this the whole
 constexpr size_t kPlaceDirectFrom = (size_t)1 << 30;
 constexpr size_t kPlaceArenaBytes = (size_t)2 << 30, kPlaceArenaAlign = (size_t)2 << 20;
 constexpr double kPlaceMargin = 1.10, kPlaceBudgetFrac = 0.70;   // accepted: >= 10 % more bytes per microsecond than two streams inside one block (colliding pairs: +-4 %, clear ones: +20-25 %)
-constexpr double kPlaceNearBest = 0.93;                           // ... and within 7 % of the best pairing any walk of this context has measured
+constexpr double kPlaceAsSeen = 0.97, kPlaceWalkMs = 250.0;       // ... at once if within 3 % of it; a walk past its eighth candidate ends after a quarter of a second
+constexpr double kPlaceNearBest = 0.96;                           // ... and within 4 % of the best pairing any walk of this context has measured
 
 struct hrx_place_arena {
     void *base = nullptr;
@@ -935,6 +936,9 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     void *best = nullptr;
     size_t spent = 0;
     double best_us = -1.0, best_rate = 0.0, worst_rate = 0.0;
+    std::vector<double> rates;         // of every candidate measured so far
+    const double seen_before = ctx->place_seen_rate;   // the fastest pairing earlier walks of this context measured
+    const auto t_walk = std::chrono::steady_clock::now();
     for (int i = 0; i < ctx->place_max_steps && spent + cand_bytes <= budget; ++i) {
         void *cand = nullptr;
         if (hipMalloc(&cand, cand_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
@@ -951,13 +955,30 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
         if (loser) spacers.push_back(loser);
         if (rate > 0 && (worst_rate == 0.0 || rate < worst_rate)) worst_rate = rate;
         ctx->place_seen_rate = std::max(ctx->place_seen_rate, rate);
-        // Candidates come in two kinds — pairings that collide (5.7-6.1 TB/s on the probe) and clear ones (7.0-7.2), about one in eight.
-        // The walk ends when the fastest candidate so far is clearly (>= 10 %) above BOTH the same-block reference and the slowest
-        // candidate seen — at least two candidates, so that a reference that happens to be slow (4.3-5.1 TB/s seen) cannot wave a
-        // colliding first candidate through — and within 7 % of the best pairing any walk of this context has measured (a later
-        // buffer set must not settle for less than the first one found: cfg 5, 0.365 -> 0.417 ms per step on such a box).
-        if (i >= 1 && best_rate > 0 && ref_rate > 0 && best_rate >= kPlaceMargin * std::max(ref_rate, worst_rate) && best_rate >= kPlaceNearBest * ctx->place_seen_rate) {
+        // Candidates come in kinds — pairings that collide (4.7 and 5.7-6.1 TB/s on the probe: two such kinds on some boxes) and clear ones (6.9-7.2), about one
+        // in eight.  The walk ends when the fastest candidate so far is clearly (>= 10 %) above BOTH the same-block reference and the MEDIAN candidate seen —
+        // at least four candidates, so that the median is a colliding one: round 3's rule (10 % above the SLOWEST of at least two) took a 6.1 for clear next to
+        // a 4.7 and cost cfg 5 at 393216 x 4096 a fifth of its rate (profiles/r04_probes/cfg5_batch_sweep.txt) — and within 4 % of the best pairing any walk of
+        // this context has measured (a later buffer set must not settle for less than the first one found: cfg 5, 0.365 -> 0.417 ms per step on such a box).
+        if (rate > 0) rates.push_back(rate);
+        if (i >= 3 && best_rate > 0 && ref_rate > 0 && !rates.empty()) {
+            std::vector<double> sorted(rates);
+            std::sort(sorted.begin(), sorted.end());
+            const double median = sorted[(sorted.size() - 1) / 2];   // (the lower middle: two clear ones among four candidates must not hide each other)
+            if (best_rate >= kPlaceMargin * std::max(ref_rate, median) && best_rate >= kPlaceNearBest * ctx->place_seen_rate) {
+                rep.accepted = 1;
+                break;
+            }
+        }
+        // ... or as soon as it is as good as the pairing an EARLIER walk of this context kept (where most neighbours are clear the median rule never fires:
+        // 48 steps and 1.6 s for one buffer set of cfg 5 seen)
+        if (i >= 1 && seen_before > 0 && ref_rate > 0 && best_rate >= kPlaceAsSeen * seen_before && best_rate >= kPlaceMargin * ref_rate) {
             rep.accepted = 1;
+            break;
+        }
+        // ... or when it has cost too much: allocating and freeing candidates of several GiB takes tens of milliseconds each
+        if (i >= 7 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count() > kPlaceWalkMs) {
+            rep.accepted = best_rate >= kPlaceMargin * ref_rate ? 1 : 0;
             break;
         }
         // no two kinds on this box / for this pair of sizes: ten candidates within 5 % of each other — the fastest will do
