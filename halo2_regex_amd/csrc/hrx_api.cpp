@@ -852,6 +852,7 @@ constexpr size_t kPlaceFromBytes = (size_t)128 << 20;    // below this the whole
 constexpr size_t kPlaceDirectFrom = (size_t)1 << 30;
 constexpr size_t kPlaceArenaBytes = (size_t)2 << 30, kPlaceArenaAlign = (size_t)2 << 20;
 constexpr double kPlaceMargin = 1.10, kPlaceBudgetFrac = 0.70;   // accepted: >= 10 % more bytes per microsecond than two streams inside one block (colliding pairs: +-4 %, clear ones: +20-25 %)
+constexpr int kPlaceArenaSoftSteps = 24, kPlaceArenaHardSteps = 96;
 constexpr double kPlaceAsSeen = 0.97, kPlaceWalkMs = 250.0;       // ... at once if within 3 % of it; a walk past its eighth candidate ends after a quarter of a second
 constexpr double kPlaceNearBest = 0.96;                           // ... and within 4 % of the best pairing any walk of this context has measured
 
@@ -919,10 +920,13 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);   // 16 bytes of the context's 64-byte scratch word area
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    // never more than kPlaceBudgetFrac of what is free NOW — and, for the 2-GiB arena candidates of bench-sized outputs, never more than 24 of them (48 GiB):
-    // several contexts or ranks on one device walk at the same time without pushing each other out of memory
-    size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
-    if (cand_bytes == kPlaceArenaBytes && budget > 24 * kPlaceArenaBytes) budget = 24 * kPlaceArenaBytes;
+    // never more than kPlaceBudgetFrac of what is free NOW.  The 2-GiB arena candidates of bench-sized outputs: 24 of them (48 GiB) as a rule — several contexts
+    // or ranks on one device walk at the same time without pushing each other out of memory — and on only while NOTHING clearly above the same-block reference
+    // has turned up (one lease of round 4: 24 candidates between 5.6 and 6.07 TB/s against a reference of 5.9, the bench line at 0.722 instead of 0.76; round 3's
+    // unbounded walk had found a clear partner on every lease, up to ~100 candidates down), re-reading the free memory at every further step.
+    const bool arena_walk = cand_bytes == kPlaceArenaBytes;
+    const size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
+    const int max_steps = arena_walk ? std::max(ctx->place_max_steps, kPlaceArenaHardSteps) : ctx->place_max_steps;
     rep.searched = 1;
     double ref_rate = 0.0;   // bytes per microsecond
     {   // the reference: both streams inside ONE block, in the launch's byte ratio (4 D : 2)
@@ -939,7 +943,13 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     std::vector<double> rates;         // of every candidate measured so far
     const double seen_before = ctx->place_seen_rate;   // the fastest pairing earlier walks of this context measured
     const auto t_walk = std::chrono::steady_clock::now();
-    for (int i = 0; i < ctx->place_max_steps && spent + cand_bytes <= budget; ++i) {
+    for (int i = 0; i < max_steps && spent + cand_bytes <= budget; ++i) {
+        if (arena_walk && i >= kPlaceArenaSoftSteps) {
+            if (best_rate >= kPlaceMargin * ref_rate) break;    // the soft cap: something clear of the reference is in hand
+            size_t f2 = 0, t2 = 0;                              // beyond it: leave other walkers / contexts of this device their share
+            if (hipMemGetInfo(&f2, &t2) != hipSuccess) { (void)hipGetLastError(); break; }
+            if ((double)f2 < (1.0 - kPlaceBudgetFrac) * (double)t2) break;
+        }
         void *cand = nullptr;
         if (hipMalloc(&cand, cand_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
         spent += cand_bytes;
@@ -977,12 +987,12 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
             break;
         }
         // ... or when it has cost too much: allocating and freeing candidates of several GiB takes tens of milliseconds each
-        if (i >= 7 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count() > kPlaceWalkMs) {
+        if (i >= 7 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count() > (arena_walk ? 4.0 * kPlaceWalkMs : kPlaceWalkMs)) {
             rep.accepted = best_rate >= kPlaceMargin * ref_rate ? 1 : 0;
             break;
         }
         // no two kinds on this box / for this pair of sizes: ten candidates within 5 % of each other — the fastest will do
-        if (i >= 9 && worst_rate > 0 && best_rate < 1.05 * worst_rate) { rep.accepted = best_rate >= kPlaceMargin * ref_rate ? 1 : 0; break; }
+        if (!arena_walk && i >= 9 && worst_rate > 0 && best_rate < 1.05 * worst_rate) { rep.accepted = best_rate >= kPlaceMargin * ref_rate ? 1 : 0; break; }
     }
     for (void *p : spacers) (void)hipFree(p);
     rep.best_us = best_us;
