@@ -23,6 +23,7 @@
 #include "hrx_fr.h"
 #include "hrx_host_walk.hpp"
 #include "hrx_kernel.hpp"
+#include "hrx_place_rule.hpp"
 #include "hrx_lane.h"
 
 using namespace hrx;
@@ -851,10 +852,7 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
 constexpr size_t kPlaceFromBytes = (size_t)128 << 20;    // below this the whole launch lives in the Infinity Cache: plain allocations
 constexpr size_t kPlaceDirectFrom = (size_t)1 << 30;
 constexpr size_t kPlaceArenaBytes = (size_t)2 << 30, kPlaceArenaAlign = (size_t)2 << 20;
-constexpr double kPlaceMargin = 1.10, kPlaceBudgetFrac = 0.70;   // accepted: >= 10 % more bytes per microsecond than two streams inside one block (colliding pairs: +-4 %, clear ones: +20-25 %)
-constexpr int kPlaceArenaSoftSteps = 24, kPlaceArenaHardSteps = 96;
-constexpr double kPlaceAsSeen = 0.97, kPlaceWalkMs = 250.0;       // ... at once if within 3 % of it; a walk past its eighth candidate ends after a quarter of a second
-constexpr double kPlaceNearBest = 0.96;                           // ... and within 4 % of the best pairing any walk of this context has measured
+constexpr double kPlaceBudgetFrac = 0.70;   // (the acceptance rule and its margins: hrx_place_rule.hpp)
 
 struct hrx_place_arena {
     void *base = nullptr;
@@ -926,7 +924,7 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     // unbounded walk had found a clear partner on every lease, up to ~100 candidates down), re-reading the free memory at every further step.
     const bool arena_walk = cand_bytes == kPlaceArenaBytes;
     const size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
-    const int max_steps = arena_walk ? std::max(ctx->place_max_steps, kPlaceArenaHardSteps) : ctx->place_max_steps;
+    const int max_steps = arena_walk ? std::max(ctx->place_max_steps, hrx::kPlaceArenaHardSteps) : ctx->place_max_steps;
     rep.searched = 1;
     double ref_rate = 0.0;   // bytes per microsecond
     {   // the reference: both streams inside ONE block, in the launch's byte ratio (4 D : 2)
@@ -939,14 +937,16 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     std::vector<void *> spacers;       // rejected candidates: they are what pushes the next candidate further down
     void *best = nullptr;
     size_t spent = 0;
-    double best_us = -1.0, best_rate = 0.0, worst_rate = 0.0;
-    std::vector<double> rates;         // of every candidate measured so far
-    const double seen_before = ctx->place_seen_rate;   // the fastest pairing earlier walks of this context measured
+    double best_us = -1.0;
+    hrx::PlaceWalk walk;               // the rates measured and when to stop: hrx_place_rule.hpp
+    walk.ref_rate = ref_rate;
+    walk.seen_before = ctx->place_seen_rate;   // the fastest pairing earlier walks of this context measured
+    walk.arena = arena_walk;
     const auto t_walk = std::chrono::steady_clock::now();
     for (int i = 0; i < max_steps && spent + cand_bytes <= budget; ++i) {
-        if (arena_walk && i >= kPlaceArenaSoftSteps) {
-            if (best_rate >= kPlaceMargin * ref_rate) break;    // the soft cap: something clear of the reference is in hand
-            size_t f2 = 0, t2 = 0;                              // beyond it: leave other walkers / contexts of this device their share
+        if (!walk.may_take_another()) break;                    // the arena soft cap: something clear of the reference is in hand
+        if (arena_walk && i >= hrx::kPlaceArenaSoftSteps) {     // beyond it: leave other walkers / contexts of this device their share
+            size_t f2 = 0, t2 = 0;
             if (hipMemGetInfo(&f2, &t2) != hipSuccess) { (void)hipGetLastError(); break; }
             if ((double)f2 < (1.0 - kPlaceBudgetFrac) * (double)t2) break;
         }
@@ -961,39 +961,15 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
         if (i == 0) { rep.first_us = us; rep.first_gbs = rate * 1e-3; }
         const bool better = us >= 0 && (best_us < 0 || us < best_us);
         void *loser = better ? best : cand;
-        if (better) { best = cand; best_us = us; best_rate = rate; rep.chosen_step = i; }
+        if (better) { best = cand; best_us = us; rep.chosen_step = i; }
         if (loser) spacers.push_back(loser);
-        if (rate > 0 && (worst_rate == 0.0 || rate < worst_rate)) worst_rate = rate;
+        walk.rates.push_back(rate);
         ctx->place_seen_rate = std::max(ctx->place_seen_rate, rate);
-        // Candidates come in kinds — pairings that collide (4.7 and 5.7-6.1 TB/s on the probe: two such kinds on some boxes) and clear ones (6.9-7.2), about one
-        // in eight.  The walk ends when the fastest candidate so far is clearly (>= 10 %) above BOTH the same-block reference and the MEDIAN candidate seen —
-        // at least four candidates, so that the median is a colliding one: round 3's rule (10 % above the SLOWEST of at least two) took a 6.1 for clear next to
-        // a 4.7 and cost cfg 5 at 393216 x 4096 a fifth of its rate (profiles/r04_probes/cfg5_batch_sweep.txt) — and within 4 % of the best pairing any walk of
-        // this context has measured (a later buffer set must not settle for less than the first one found: cfg 5, 0.365 -> 0.417 ms per step on such a box).
-        if (rate > 0) rates.push_back(rate);
-        if (i >= 3 && best_rate > 0 && ref_rate > 0 && !rates.empty()) {
-            std::vector<double> sorted(rates);
-            std::sort(sorted.begin(), sorted.end());
-            const double median = sorted[(sorted.size() - 1) / 2];   // (the lower middle: two clear ones among four candidates must not hide each other)
-            if (best_rate >= kPlaceMargin * std::max(ref_rate, median) && best_rate >= kPlaceNearBest * ctx->place_seen_rate) {
-                rep.accepted = 1;
-                break;
-            }
-        }
-        // ... or as soon as it is as good as the pairing an EARLIER walk of this context kept (where most neighbours are clear the median rule never fires:
-        // 48 steps and 1.6 s for one buffer set of cfg 5 seen)
-        if (i >= 1 && seen_before > 0 && ref_rate > 0 && best_rate >= kPlaceAsSeen * seen_before && best_rate >= kPlaceMargin * ref_rate) {
-            rep.accepted = 1;
-            break;
-        }
-        // ... or when it has cost too much: allocating and freeing candidates of several GiB takes tens of milliseconds each
-        if (i >= 7 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count() > (arena_walk ? 4.0 * kPlaceWalkMs : kPlaceWalkMs)) {
-            rep.accepted = best_rate >= kPlaceMargin * ref_rate ? 1 : 0;
-            break;
-        }
-        // no two kinds on this box / for this pair of sizes: ten candidates within 5 % of each other — the fastest will do
-        if (!arena_walk && i >= 9 && worst_rate > 0 && best_rate < 1.05 * worst_rate) { rep.accepted = best_rate >= kPlaceMargin * ref_rate ? 1 : 0; break; }
+        const hrx::PlaceVerdict v = walk.decide(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count());
+        if (v == hrx::PlaceVerdict::accept) { rep.accepted = 1; break; }
+        if (v == hrx::PlaceVerdict::settle) { rep.accepted = walk.clear_of_reference() ? 1 : 0; break; }
     }
+    const double best_rate = walk.best();
     for (void *p : spacers) (void)hipFree(p);
     rep.best_us = best_us;
     rep.best_gbs = best_rate * 1e-3;

@@ -92,6 +92,16 @@ def test_cpp_host_mirror_builds_and_runs():
     assert out.returncode == 0 and "host ok" in out.stdout
 
 
+def test_placement_walk_rule_on_recorded_candidate_sequences():
+    """csrc/hrx_place_rule.hpp (when hrx_alloc_output_pair's walk over placement candidates stops) replayed on the probe rates round 4's leases recorded: a middle-kind
+    candidate next to a slow one is not taken for a clear one, a later buffer set does not settle for less than an earlier one found, an arena walk passes its
+    soft cap only while nothing is clear of the reference, every walk is bounded in time."""
+    exe = "/tmp/hrx_test_place_rule"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "host_cpp", "test_place_rule.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "place rule: ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_c_struct_entry_points_equal_the_text_parsers():
     """tests/host_c/test_push_structs.c replays bindings/rust/hrx.rs HrxHandle::new in C: hrx_defs_push_allstr with the map's entries SHUFFLED and their explicit
     line indices (table.rs:103-108), a duplicate key (defs.rs:100: the last insert wins), hrx_defs_push_substr with shuffled pairs — same fixed-table rows and the
