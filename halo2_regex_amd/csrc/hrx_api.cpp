@@ -557,8 +557,11 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
             a.group_first_dyn = slots;
         }
         a.nt_mix = plan_nt_mix(a, li);
-#if defined(HRX_STAMPS) || defined(HRX_ABLATION)
+#if defined(HRX_STAMPS) || defined(HRX_ABLATION) || defined(HRX_NT_ENV)
         if (const char *nm = std::getenv("HRX_NT_MIX")) a.nt_mix = (uint32_t)std::strtoul(nm, nullptr, 0);
+        if (const char *nf = std::getenv("HRX_NT_FLAGS")) a.nt_mix |= (uint32_t)std::strtoul(nf, nullptr, 0);   // (kNtMix* bits, hrx_kernel.hpp)
+#endif
+#if defined(HRX_STAMPS) || defined(HRX_ABLATION)
         if (const char *pe = std::getenv("HRX_PACE")) a.pace_even = (uint32_t)std::strtoul(pe, nullptr, 0);
 #endif
 #ifdef HRX_STAMPS

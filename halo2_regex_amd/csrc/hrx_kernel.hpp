@@ -158,7 +158,11 @@ hipError_t launch_witness_pp(const WitnessArgs &a, const LaunchInfo &li, hipStre
 // the tiles (reveal masks + masked rows) from a 6-KiB summary the walker hands over; not for the HALF table (a 256-state table
 // leaves no LDS for it) nor for string-major outputs.
 // nt_mix: low byte k: the records of every k-th tile (t % k == k - 1) are stored write-back, 0 = all streaming; bit 8: the masked
-// rows write-back.  plan_nt_mix (hrx_kernel.hip) picks k so that ~128 MiB of a launch's records stay write-back.
+// rows write-back.  plan_nt_mix (hrx_kernel.hip) picks k so that ~128 MiB of a launch's records stay write-back.  Whatever it says, the
+// masked rows of a tile into which an OPEN optimistic span reaches are written back: they may be zeroed later, and a repair that finds
+// its line in L2 costs the memory nothing (hrx_kernel_pm.hip octets_out).  Tools only (the libhrx_ntenv.so build reads HRX_NT_MIX /
+// HRX_NT_FLAGS at every launch, tools/ab_policy.py): bit 9 = not even those, bits 12-15 km = the masked rows of every km-th tile as well.
+constexpr uint32_t kNtMixMaskedWb = 0x100u, kNtMixNoOpenSpan = 0x200u;
 // hrx_place.hip: microseconds (device clock) of a time-aligned two-stream write over two regions (both are overwritten); clk: 16 bytes of device scratch
 double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, unsigned long long *clk, size_t *bytes_written);
 // hrx_place.hip: the memory traffic of one position-major witness launch of this shape and nothing else (roofline diagnostics)

@@ -336,7 +336,14 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             fk_fix += fk_e - fk_d;
 #endif
             // ---------------- masked rows: 8 x 16 B per tile and string, [M/8][B][8] (lib.rs:752-761) ----------------
+            // Streamed (non-temporal) unless some string of the wave still has an OPEN optimistic span that reaches into the tile: those rows may have to be zeroed
+            // once the span is decided, 16 bytes of a 128-byte line at a time — a repair that finds the line in L2 merges there, one that finds it in memory costs the
+            // memory a read-modify-write.  cfg 5 (a random DFA's tags: an event per ~330 rows, half of them a repair reaching back ~5 tiles): 0.716 -> 0.668 ms, and
+            // nothing lost without any tagged pair (0.629 both ways); the bench line gains 1.5 % (its planted matches keep spans open for a tile or two), headers3 loses
+            // 0.9 % (long spans that DO end): same buffers, policies alternating in one process, profiles/r04_probes/ab_policy.txt.
             auto octets_out = [&](const uint32_t tt, const uint32_t (&c)[16], const uint32_t (&sd)[16], const uint64_t mask, const bool all) {
+                const uint32_t km = (a.nt_mix >> 12) & 0xfu;    // (tools only, like bit 0x200 = "never per tile": tools/ab_policy.py)
+                const bool nt_tile = nt_msk && !(!(a.nt_mix & kNtMixNoOpenSpan) && __any(mc.pend != 0u && mc.pend_start < ((tt + 1u) << 6))) && !(km != 0u && tt % km == km - 1u);
                 const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
                 unsigned char *mp = mp_f + (size_t)tt * 8u * mstep_f;
 #pragma unroll
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                     const uint32_t mbyte = ((k < 4 ? mlo : mhi) >> (8 * (k & 3))) & 0xffu;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (mbyte) v = masked_octet(c[2 * k], c[2 * k + 1], sd[2 * k], sd[2 * k + 1], mbyte);
-                    if ((all || (tt << 6) + (uint32_t)k * 8u < M) && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_msk);   // only the octets that exist
+                    if ((all || (tt << 6) + (uint32_t)k * 8u < M) && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)k * mstep_f, v, nt_tile);   // only the octets that exist
                 }
             };
             if constexpr (kHoldF > 0) {

@@ -242,13 +242,15 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
                     a.masked[((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
             }
             {
+                // (streamed unless a string of the wave has an open optimistic span: rows that may be zeroed later stay in L2 for the repair — hrx_kernel_pm.hip octets_out)
+                const bool nt_tile = nt_msk && !(!(a.nt_mix & kNtMixNoOpenSpan) && __any(mc.pend != 0u));
                 const uint32_t mlo = (uint32_t)tm.mask, mhi = (uint32_t)(tm.mask >> 32);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const uint32_t mbyte = ((q < 4 ? mlo : mhi) >> (8 * (q & 3))) & 0xffu;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (mbyte) v = masked_octet(cwl[2 * q], cwl[2 * q + 1], sidq[2 * q], sidq[2 * q + 1], mbyte);  // lib.rs:752-761
-                    if (t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, nt_msk);
+                    if (t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, nt_tile);
                 }
                 mp += 8u * mstep;
             }
