@@ -303,7 +303,7 @@ def workload(args):
     else:
         allb = np.arange(256, dtype=np.uint8)
         a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=args.substr_pairs)
-        names, label, alphabet = [(a_txt.encode(), [sub_txt.encode()])], "synthetic total DFA 256 states x 256 symbols (seed 2)", "all 256 byte values"
+        names, label, alphabet = [(a_txt.encode(), [sub_txt.encode()])], "synthetic total DFA 256 states x 256 symbols (seed 2), one substring definition of %d random tagged (state, next) pairs" % args.substr_pairs, "all 256 byte values"
         gen = lambda B, n, seed=0, stride=None: synth.noise(B, n, seed=seed, alphabet=allb, stride=stride)
     planted = gen in (synth.regex1_planted, synth.regex23_planted, synth.headers_planted)
     return names, label, alphabet, gen, planted
