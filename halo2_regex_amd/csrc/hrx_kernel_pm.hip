@@ -155,7 +155,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     if (is_finisher) {
         // ================================ finisher (FIN) ================================
         const size_t q8 = (M + 7u) / 8u;
-        const bool nt_msk = !(a.nt_mix & 0x100u) && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
+        const bool nt_msk = !(a.nt_mix & kNtMixMaskedWb) && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
         MaskCarry mc = {0, 0, 0, 0};
         uint32_t b0_f = 0, blk0_f = 0, nb_f = 0;
         bool active_f = false;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
 #endif
                 const uint32_t wb_k = a.nt_mix & 0xffu;
                 const bool wb_tile = wb_k != 0u && (t % wb_k) == wb_k - 1u;   // the streaming / write-back mix of the records (kNtMixDefault)
-                const bool nt_rec = !SM && !wb_probe && !wb_tile && !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), nt_msk = !SM && !(a.nt_mix & 0x100u) && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
+                const bool nt_rec = !SM && !wb_probe && !wb_tile && !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), nt_msk = !SM && !(a.nt_mix & kNtMixMaskedWb) && !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked));
                 const bool pend_store = have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
                 // [ceil(M/4)][D][nb][4]: one def's quads of all strings of the block
