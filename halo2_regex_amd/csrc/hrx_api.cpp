@@ -83,6 +83,9 @@ struct DevBuf {
 
 struct hrx_place_arena;
 static void arena_retire(hrx_place_arena *a);
+struct hrx_place_pool;
+static hrx_place_pool *pool_acquire(int device);
+static void pool_release(hrx_place_pool *p);
 
 struct hrx_ctx {
     DefsSet s;  // private copy: the ctx outlives / is independent of the hrx_defs it was made from
@@ -131,8 +134,7 @@ struct hrx_ctx {
     int place_max_steps = 48;
     double place_seen_rate = 0.0;     // bytes per microsecond of the best candidate any placement walk of this context has probed
     hrx_place_report last_place{};
-    struct hrx_place_arena *arena_rec = nullptr, *arena_msk = nullptr;   // bench-sized outputs: the measured arena pair requests are carved from
-    hrx_place_report arena_report{};
+    struct hrx_place_pool *pool = nullptr;   // bench-sized outputs: the device's measured arena pair, shared by every context of that device in this process
 #ifdef HRX_STAMPS
     DevBuf stamps;                  // tools-only build: 8 u64 per walker pair of the position-major kernel (hrx_kernel_pm.hip)
 #endif
@@ -333,6 +335,7 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     if (const char *v = std::getenv("HRX_MP_COMBINE")) c->mp_combine = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_PLACE_TRACE")) c->place_trace = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_PLACE_MAX_STEPS")) { const int n = std::atoi(v); if (n >= 1 && n <= 256) c->place_max_steps = n; }
+    c->pool = pool_acquire(device);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_group_counter, 64);
     if (e == hipSuccess) e = hipMemset(c->d_group_counter, 0, 64);
@@ -403,7 +406,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     c->tp_records.release(); c->tp_masked.release();
     c->spec_cls.release(); c->spec_ends.release(); c->spec_fail.release(); c->spec_init.release(); c->spec_vstatus.release(); c->spec_vinfo.release(); c->spec_work.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
-    arena_retire(c->arena_rec); arena_retire(c->arena_msk);   // released now, or with their last sub-buffer
+    pool_release(c->pool);   // the device's arena pair goes with its last context (now, or with its last sub-buffer)
 #ifdef HRX_STAMPS
     c->stamps.release();
 #endif
@@ -906,6 +909,35 @@ static bool arena_release(void *ptr) {
     return true;
 }
 
+// One measured arena pair per DEVICE and process, not per context: a prover that keeps one context per worker thread (a context serves one stream at a time)
+// would otherwise walk once per context and hold 4 GiB of arenas in each.  mu serialises the walks and the replacement of a full pair; it is taken after the
+// context's own mutex and before g_arena_mu (hrx_device_free takes only the latter).
+struct hrx_place_pool {
+    std::mutex mu;
+    hrx_place_arena *rec = nullptr, *msk = nullptr;
+    hrx_place_report report{};     // of the walk that found the pair
+    double seen_rate = 0.0;        // the fastest pairing any arena walk on this device has probed (bytes per microsecond)
+    int users = 0;                 // live contexts of the device (under g_arena_mu)
+};
+static std::map<int, hrx_place_pool *> g_pools;   // under g_arena_mu; entries are never removed (a few dozen bytes per device)
+static hrx_place_pool *pool_acquire(int device) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    hrx_place_pool *&p = g_pools[device];
+    if (!p) p = new hrx_place_pool();
+    ++p->users;
+    return p;
+}
+static void pool_release(hrx_place_pool *p) {
+    if (!p) return;
+    hrx_place_arena *r = nullptr, *m = nullptr;
+    {
+        std::lock_guard<std::mutex> pl(p->mu);
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        if (--p->users == 0) { r = p->rec; m = p->msk; p->rec = p->msk = nullptr; p->seen_rate = 0.0; p->report = hrx_place_report{}; }
+    }
+    arena_retire(r); arena_retire(m);
+}
+
 static void place_trace(const hrx_ctx *ctx, const char *fmt, ...) {
     if (!ctx->place_trace) return;
     va_list ap;
@@ -1011,25 +1043,29 @@ int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_byte
         if (!best && hipMalloc(&best, masked_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
         return done(rec, best);
     }
-    // ---- bench-sized outputs: sub-buffers of the context's measured arena pair
+    // ---- bench-sized outputs: sub-buffers of the device's measured arena pair
     if (records_bytes > kPlaceArenaBytes || masked_bytes > kPlaceArenaBytes) return plain();
+    hrx_place_pool *pool = ctx->pool;
+    std::lock_guard<std::mutex> pl(pool->mu);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (ctx->arena_rec && ctx->arena_msk) {
+        if (pool->rec && pool->msk) {
             void *r = nullptr, *m = nullptr;
-            if (arena_take_pair(ctx->arena_rec, records_bytes, ctx->arena_msk, masked_bytes, &r, &m)) {
-                if (attempt == 0) { rep = ctx->arena_report; rep.searched = 2; }   // served from the pair an earlier call measured
+            if (arena_take_pair(pool->rec, records_bytes, pool->msk, masked_bytes, &r, &m)) {
+                if (attempt == 0) { rep = pool->report; rep.searched = 2; }   // served from the pair an earlier call (of any context of the device) measured
                 return done(r, m);
             }
-            arena_retire(ctx->arena_rec); arena_retire(ctx->arena_msk);     // full: a new pair
-            ctx->arena_rec = ctx->arena_msk = nullptr;
+            arena_retire(pool->rec); arena_retire(pool->msk);     // full: a new pair
+            pool->rec = pool->msk = nullptr;
         }
         void *A = nullptr;
         if (hipMalloc(&A, kPlaceArenaBytes) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+        ctx->place_seen_rate = std::max(ctx->place_seen_rate, pool->seen_rate);
         void *X = place_walk(ctx, A, kPlaceArenaBytes, kPlaceArenaBytes, rep);
+        pool->seen_rate = std::max(pool->seen_rate, ctx->place_seen_rate);
         if (!X) { (void)hipFree(A); rep = hrx_place_report{}; return plain(); }
-        ctx->arena_rec = new hrx_place_arena(); ctx->arena_rec->base = A; ctx->arena_rec->bytes = kPlaceArenaBytes;
-        ctx->arena_msk = new hrx_place_arena(); ctx->arena_msk->base = X; ctx->arena_msk->bytes = kPlaceArenaBytes;
-        ctx->arena_report = rep;
+        pool->rec = new hrx_place_arena(); pool->rec->base = A; pool->rec->bytes = kPlaceArenaBytes;
+        pool->msk = new hrx_place_arena(); pool->msk->base = X; pool->msk->bytes = kPlaceArenaBytes;
+        pool->report = rep;
     }
     return plain();
 }

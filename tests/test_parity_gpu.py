@@ -1067,7 +1067,7 @@ def test_placement_search_for_bench_sized_buffers_uses_measured_arenas(hra, orac
     """Records below 1 GiB (the bench line: 256 MiB of records, 128 MiB of masked rows) are carved out of a measured pair of 2-GiB
     arenas — a probe over buffers that fit the Infinity Cache would measure the cache: the first call walks (never more than 70 %
     of the free memory), later calls are served from the same pair, a full pair is replaced, hrx_device_free returns sub-buffers
-    and the arenas go with the context, and the buffers are ordinary memory (one launch against the oracle, every string).
+    and the arenas go with the device's last context, and the buffers are ordinary memory (one launch against the oracle, every string).
     HRX_PLACE=0 (read at context creation) turns the search off."""
     import torch
     from halo2_regex_amd import synth
@@ -1107,7 +1107,7 @@ def test_placement_search_for_bench_sized_buffers_uses_measured_arenas(hra, orac
     assert not torch.equal(r3[ok], torch.from_numpy(orec.view(np.int32)).to(dev)[ok])
     assert all(torch.equal(o[0][:4096], b) for k, (o, b) in enumerate(zip(outs, before)) if k != 3)
     del outs, rec, msk, st, r2, m2, r3, d_c, d_l, ok, before
-    del cfg                                                                           # the context goes: its arenas are released
+    del cfg                                                                           # the device's last context goes: the arenas are released
     import gc
     gc.collect()
     torch.cuda.synchronize()
@@ -1117,6 +1117,44 @@ def test_placement_search_for_bench_sized_buffers_uses_measured_arenas(hra, orac
     cfg0 = _cfg(hra, CFG_1, M + 8)
     out = cfg0.alloc_outputs_position_major(B, dev)
     assert cfg0.last_placement_report()["searched"] == 0 and out[0].numel() * 4 == (M + 8) * B * 4
+
+
+def test_placement_arenas_are_shared_by_the_contexts_of_a_device(hra, oracle):
+    """One measured arena pair per device and process: a second context (another config: one context per worker thread is how a prover gets overlap) is served from
+    the pair the first one walked for — no second walk, no second 4 GiB — the pair outlives the context that measured it while another context of the device lives,
+    and goes with the last one."""
+    import gc
+    import torch
+    dev = torch.device("cuda", 0)
+    M, B = 1024, 65536
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    a = _cfg(hra, CFG_1, M)
+    out_a = a.alloc_outputs_position_major(B, dev)
+    assert a.last_placement_report()["searched"] == 1
+    b = _cfg(hra, CFG_23, M)
+    out_b = b.alloc_outputs_position_major(B, dev)
+    rep_b = b.last_placement_report()
+    assert rep_b["searched"] == 2 and rep_b["steps"] == a.last_placement_report()["steps"]           # the first context's walk, reported again
+    assert 0 < out_b[0].data_ptr() - out_a[0].data_ptr() <= (2 << 30) - (512 << 20)                   # inside the same 2-GiB records arena
+    assert free0 - torch.cuda.mem_get_info()[0] < (4 << 30) + (256 << 20)                             # ONE pair of arenas for both contexts
+    del a, out_a
+    gc.collect()
+    out_b2 = b.alloc_outputs_position_major(B, dev)                                                   # the pair outlives the context that measured it
+    assert b.last_placement_report()["searched"] == 2
+    from halo2_regex_amd import synth
+    chars, lens = synth.reveal_stress(B, M - 1, seed=11)
+    d_c, d_l = hra.chars_to_position_major(torch.from_numpy(chars).to(dev)), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    rec, msk, st = b.witness_batch_position_major(d_c, d_l, out=out_b2, chars_pm_stride=chars.shape[1])
+    torch.cuda.synchronize()
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_23).witness_batch(chars, lens, M, threads=os.cpu_count() or 8)
+    r2, m2 = hra.position_major_to_string_major(rec, msk, B, M, 2)
+    ok = torch.from_numpy((ost & np.uint64(0xff)) == 0).to(dev)
+    assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+    assert torch.equal(r2[ok], torch.from_numpy(orec.view(np.int32)).to(dev)[ok]) and torch.equal(m2[ok], torch.from_numpy(omsk.view(np.int16)).to(dev)[ok])
+    del b, out_b, out_b2, rec, msk, st, r2, m2, d_c, d_l, ok
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    assert free0 - torch.cuda.mem_get_info()[0] < (256 << 20)                                          # the last context of the device is gone: so is the pair
 
 
 def test_multi_device_driver_device_resident_shards(hra, oracle):
