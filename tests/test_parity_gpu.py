@@ -1157,6 +1157,60 @@ def test_placement_arenas_are_shared_by_the_contexts_of_a_device(hra, oracle):
     assert free0 - torch.cuda.mem_get_info()[0] < (256 << 20)                                          # the last context of the device is gone: so is the pair
 
 
+def test_one_context_per_thread_on_one_device(hra, oracle):
+    """How a multi-threaded prover uses the library (a context serves one stream at a time; halo2 synthesizes from several threads): four threads, each with a context
+    and a stream of its own, allocate bench-sized outputs (the device's shared arena pair: pool mutex, arena mutex), launch, free and allocate again, concurrently —
+    ctypes drops the GIL inside every call.  Every thread's rows against the oracle."""
+    import gc
+    import threading
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    M, B, T = 1024, 65536, 4
+    chars, lens = synth.reveal_stress(B, M - 1, seed=21)
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_1).witness_batch(chars, lens, M, threads=os.cpu_count() or 8)
+    d_c = hra.chars_to_position_major(torch.from_numpy(chars).to(dev))
+    d_l = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    d_orec, d_omsk = torch.from_numpy(orec.view(np.int32)).to(dev), torch.from_numpy(omsk.view(np.int16)).to(dev)
+    ok = torch.from_numpy((ost & np.uint64(0xff)) == 0).to(dev)
+    torch.cuda.synchronize()
+    errors, reports = [], []
+    start = threading.Barrier(T)
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            cfg = _cfg(hra, CFG_1, M)
+            stream = torch.cuda.Stream(device=dev)
+            start.wait()
+            for it in range(3):
+                out = cfg.alloc_outputs_position_major(B, dev)
+                reports.append(cfg.last_placement_report()["searched"])
+                with torch.cuda.stream(stream):
+                    rec, msk, st = cfg.witness_batch_position_major(d_c, d_l, out=out, chars_pm_stride=chars.shape[1], stream=stream)
+                stream.synchronize()
+                r2, m2 = hra.position_major_to_string_major(rec, msk, B, M, 1)
+                torch.cuda.synchronize()
+                if not np.array_equal(st.cpu().numpy().view(np.uint64), ost):
+                    errors.append("thread %d iteration %d: status words differ" % (k, it))
+                if not (torch.equal(r2[ok], d_orec[ok]) and torch.equal(m2[ok], d_omsk[ok])):
+                    errors.append("thread %d iteration %d: rows differ" % (k, it))
+                del out, rec, msk, st, r2, m2      # hrx_device_free from this thread while the others allocate
+            del cfg
+        except Exception as e:   # noqa: BLE001 — reported by the main thread
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(T)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not any(t.is_alive() for t in threads), "a worker hangs"
+    assert not errors, errors
+    assert sorted(set(reports)) in ([1, 2], [2]) and reports.count(1) <= 2      # one walk for the device (a second only if the first pair filled up), everything else served from the pair
+    gc.collect()
+
+
 def test_multi_device_driver_device_resident_shards(hra, oracle):
     """hrx_multi_witness_batch_device: device pointers per shard, one stream per shard, no PCIe copy, no collective — three shards
     on the one device (two position-major blocks' worth of strings in the middle shard), every string against the oracle."""
