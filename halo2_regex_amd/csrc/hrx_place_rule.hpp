@@ -10,7 +10,9 @@ namespace hrx {
 constexpr double kPlaceMargin = 1.10;      // accepted: >= 10 % more bytes per microsecond than two streams inside one block (colliding pairs: +-4 %, clear ones: +20-25 %)
 constexpr double kPlaceNearBest = 0.96;    // ... and within 4 % of the best pairing any walk of this context has measured
 constexpr double kPlaceAsSeen = 0.97;      // ... at once if within 3 % of what an EARLIER walk of this context kept
-constexpr double kPlaceWalkMs = 250.0;     // a walk past its eighth candidate ends after a quarter of a second (arena candidates: a second)
+constexpr double kPlaceWalkMs = 250.0;     // a walk past its eighth candidate that HAS something clear of the reference ends after a quarter of a second (arena candidates: a second)
+constexpr double kPlaceHardMs = 2000.0, kPlaceArenaHardMs = 8000.0;   // ... and any walk after this, whatever it holds (one lease of round 4 took 66 ms per 2-GiB hipMalloc where the others take 2:
+                                                                      // the one-second bound ended its arena walk at 17 colliding candidates and the bench line ran at 0.70 instead of 0.76)
 constexpr int kPlaceMinCandidates = 4;     // the median of fewer says nothing: clear pairings are about one in eight
 constexpr int kPlaceArenaSoftSteps = 24, kPlaceArenaHardSteps = 96;   // 2-GiB arena candidates: 24 as a rule, on only while nothing clear of the reference is in hand
 
@@ -52,8 +54,10 @@ struct PlaceWalk {
         // ... or as soon as it is as good as the pairing an EARLIER walk of this context kept (where most neighbours are clear the median rule never fires: 48 steps
         // and 1.6 s for one buffer set of cfg 5 seen)
         if (i >= 1 && seen_before > 0 && b >= kPlaceAsSeen * seen_before && clear_of_reference()) return PlaceVerdict::accept;
-        // ... or when it has cost too much: allocating and freeing candidates of several GiB takes tens of milliseconds each
-        if (i >= 7 && elapsed_ms > (arena ? 4.0 * kPlaceWalkMs : kPlaceWalkMs)) return PlaceVerdict::settle;
+        // ... or when it has cost too much: allocating and freeing candidates of several GiB takes tens of milliseconds each — soon if something clear of the
+        // reference is in hand, late if not (a one-time cost of seconds against ~8 % of every launch on those buffers)
+        if (i >= 7 && elapsed_ms > (arena ? 4.0 * kPlaceWalkMs : kPlaceWalkMs) && clear_of_reference()) return PlaceVerdict::settle;
+        if (elapsed_ms > (arena ? kPlaceArenaHardMs : kPlaceHardMs)) return PlaceVerdict::settle;
         // no kinds on this box / for this pair of sizes: ten candidates within 5 % of each other — the fastest will do (not for arenas: their walk is cheap and
         // every lease seen so far had a clear arena pairing somewhere)
         if (!arena && i >= 9 && b < 1.05 * worst()) return PlaceVerdict::settle;

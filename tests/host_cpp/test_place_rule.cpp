@@ -81,6 +81,17 @@ int main() {
         CHECK(!w.may_take_another());
         CHECK(w.clear_of_reference());
     }
+    {   // a box whose 2-GiB allocations take 66 ms each (seen): the soft time bound must not end an arena walk that holds nothing clear of the reference ...
+        PlaceWalk w; w.ref_rate = 5797; w.arena = true;
+        Outcome o = run(w, {6032, 6178, 5900, 5950, 6000, 6100, 5990, 6050, 6010, 6120, 5980, 6040, 6060, 6020, 6090, 6030, 6070, 7150}, 66.0);
+        CHECK(o.verdict == PlaceVerdict::accept && o.steps == 18 && o.kept == 7150);
+        // ... only the hard bound does (8 s), and a direct walk's after 2 s
+        o = run(w, {6032, 6178, 5900, 5950, 6000, 6100, 5990, 6050, 6010, 6120}, 1000.0);
+        CHECK(o.verdict == PlaceVerdict::settle && o.steps == 9);
+        PlaceWalk d; d.ref_rate = 5797;
+        o = run(d, {6032, 6178, 5900, 5950, 6000, 6100, 5990, 6050, 6010, 6120}, 300.0);
+        CHECK(o.verdict == PlaceVerdict::settle && o.steps == 7);
+    }
     {   // failed probes (rate 0) neither count as candidates of a kind nor crash the median
         PlaceWalk w; w.ref_rate = 5000;
         Outcome o = run(w, {0, 0, 0, 0});
