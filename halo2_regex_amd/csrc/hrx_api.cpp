@@ -916,7 +916,8 @@ struct hrx_place_pool {
     std::mutex mu;
     hrx_place_arena *rec = nullptr, *msk = nullptr;
     hrx_place_report report{};     // of the walk that found the pair
-    double seen_rate = 0.0;        // the fastest pairing any arena walk on this device has probed (bytes per microsecond)
+    double seen_rate[HRX_MAX_DEFS + 1] = {};   // per number of defs D (the probe writes its two streams in the launch's ratio 4 D : 2, so rates of different D do not compare):
+                                               // the fastest pairing any arena walk on this device has probed (bytes per microsecond)
     int users = 0;                 // live contexts of the device (under g_arena_mu)
 };
 static std::map<int, hrx_place_pool *> g_pools;   // under g_arena_mu; entries are never removed (a few dozen bytes per device)
@@ -933,7 +934,7 @@ static void pool_release(hrx_place_pool *p) {
     {
         std::lock_guard<std::mutex> pl(p->mu);
         std::lock_guard<std::mutex> lk(g_arena_mu);
-        if (--p->users == 0) { r = p->rec; m = p->msk; p->rec = p->msk = nullptr; p->seen_rate = 0.0; p->report = hrx_place_report{}; }
+        if (--p->users == 0) { r = p->rec; m = p->msk; p->rec = p->msk = nullptr; for (double &v : p->seen_rate) v = 0.0; p->report = hrx_place_report{}; }
     }
     arena_retire(r); arena_retire(m);
 }
@@ -1059,9 +1060,10 @@ int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_byte
         }
         void *A = nullptr;
         if (hipMalloc(&A, kPlaceArenaBytes) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-        ctx->place_seen_rate = std::max(ctx->place_seen_rate, pool->seen_rate);
+        double &pool_seen = pool->seen_rate[std::min<size_t>(ctx->s.defs.size(), HRX_MAX_DEFS)];
+        ctx->place_seen_rate = std::max(ctx->place_seen_rate, pool_seen);
         void *X = place_walk(ctx, A, kPlaceArenaBytes, kPlaceArenaBytes, rep);
-        pool->seen_rate = std::max(pool->seen_rate, ctx->place_seen_rate);
+        pool_seen = std::max(pool_seen, ctx->place_seen_rate);
         if (!X) { (void)hipFree(A); rep = hrx_place_report{}; return plain(); }
         pool->rec = new hrx_place_arena(); pool->rec->base = A; pool->rec->bytes = kPlaceArenaBytes;
         pool->msk = new hrx_place_arena(); pool->msk->base = X; pool->msk->bytes = kPlaceArenaBytes;
