@@ -1006,6 +1006,7 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
         if (v == hrx::PlaceVerdict::settle) { rep.accepted = walk.clear_of_reference() ? 1 : 0; break; }
     }
     const double best_rate = walk.best();
+    if (!rep.accepted && walk.clear_of_reference()) rep.accepted = 1;   // (a walk that ran into a cap with a pairing >= 10 % above the reference in hand)
     for (void *p : spacers) (void)hipFree(p);
     rep.best_us = best_us;
     rep.best_gbs = best_rate * 1e-3;
