@@ -132,6 +132,7 @@ struct hrx_ctx {
     // placement-aware output allocation (hrx_alloc_output_pair): tunables read once at creation, the last call's report
     bool place_enabled = true, place_trace = false;
     int place_max_steps = 48;
+    bool place_max_steps_set = false;   // HRX_PLACE_MAX_STEPS given: it bounds arena walks too (their own cap is kPlaceArenaHardSteps)
     double place_seen_rate = 0.0;     // bytes per microsecond of the best candidate any placement walk of this context has probed
     hrx_place_report last_place{};
     struct hrx_place_pool *pool = nullptr;   // bench-sized outputs: the device's measured arena pair, shared by every context of that device in this process
@@ -334,7 +335,7 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     if (const char *v = std::getenv("HRX_PLACE")) c->place_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_MP_COMBINE")) c->mp_combine = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_PLACE_TRACE")) c->place_trace = std::atoi(v) != 0;
-    if (const char *v = std::getenv("HRX_PLACE_MAX_STEPS")) { const int n = std::atoi(v); if (n >= 1 && n <= 256) c->place_max_steps = n; }
+    if (const char *v = std::getenv("HRX_PLACE_MAX_STEPS")) { const int n = std::atoi(v); if (n >= 1 && n <= 256) { c->place_max_steps = n; c->place_max_steps_set = true; } }
     c->pool = pool_acquire(device);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_group_counter, 64);
@@ -960,7 +961,7 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     // unbounded walk had found a clear partner on every lease, up to ~100 candidates down), re-reading the free memory at every further step.
     const bool arena_walk = cand_bytes == kPlaceArenaBytes;
     const size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
-    const int max_steps = arena_walk ? std::max(ctx->place_max_steps, hrx::kPlaceArenaHardSteps) : ctx->place_max_steps;
+    const int max_steps = arena_walk && !ctx->place_max_steps_set ? std::max(ctx->place_max_steps, hrx::kPlaceArenaHardSteps) : ctx->place_max_steps;
     rep.searched = 1;
     double ref_rate = 0.0;   // bytes per microsecond
     {   // the reference: both streams inside ONE block, in the launch's byte ratio (4 D : 2)
