@@ -464,6 +464,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         a.byte_image = d_bytetab; a.byte_bytes = set.byte.bytes; a.byte_ptab_off = set.byte.ptab_off; a.byte_mul_a4 = set.byte.mul_a * 4; a.byte_mul_b4 = set.byte.mul_b * 4; a.byte_slot_mask4 = (set.byte.slots - 1u) * 4u;
         a.byte_dead = set.byte.dead;
         a.byte_rows_bytes = set.byte.n_rows * 256u; a.byte16_bytes = set.byte.bytes16; a.byte16_ptab_off = set.byte.ptab16_off;
+        a.byte_one_id = (set.defs.size() == 1 && set.defs[0].substrs.size() == 1 && set.consts[0].substr_id_offset >= 1 && set.consts[0].substr_id_offset <= 63) ? set.consts[0].substr_id_offset : 0u;
         a.D = (uint32_t)set.defs.size();
         a.debug = ctx->debug;
 #ifdef HRX_ABLATION

@@ -30,6 +30,7 @@ struct WitnessArgs {
     uint32_t half_bytes;
     const uint8_t *byte_image;    // device copy of DefsSet::byte.image (the exact LDS image: next-state bytes, disp, pair slots), or NULL
     uint32_t byte_bytes, byte_ptab_off, byte_mul_a4, byte_mul_b4, byte_slot_mask4, byte_dead;   // (mul_a * 4, mul_b * 4, (slots - 1) * 4: byte offsets of the 4-byte pair slots)
+    uint32_t byte_one_id;         // BYTE table, position-major: the def's ONE substring id (0: it has several, or none): the finisher then holds three tiles instead of two (hrx_kernel_pm.hip)
     uint32_t byte_rows_bytes, byte16_bytes, byte16_ptab_off;   // the walker/storer kernel's image: next-state bytes [0, byte_rows_bytes) + the 2-byte slots (byte_image + byte_bytes) at byte16_ptab_off
     const uint8_t *pair_image;    // device copy of DefsSet::pair.image (the exact LDS image: blocks + class LUT), or NULL
     uint32_t pair_bytes, pair_classes, pair_blk_bytes, pair_lut_off;

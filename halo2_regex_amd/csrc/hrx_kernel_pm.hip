@@ -173,7 +173,12 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
 #endif
         constexpr int kHoldF = BYTE ? HRX_HOLDF : 0;
         uint32_t hcw[kHoldF ? kHoldF : 1][16], hsid[kHoldF ? kHoldF : 1][16];
-        uint64_t hmask[kHoldF ? kHoldF : 1];
+        uint64_t hmask[kHoldF ? kHoldF + 1 : 1];
+        // A def with ONE substring (WitnessArgs::byte_one_id): a row's id byte is that id or 0 — 64 bits per tile instead of 16 registers — and the registers of the second
+        // tile's id bytes hold a THIRD tile's raw bytes: held tile i = raw bytes hcw[0], hcw[1], hsid[0] for i = 0, 1, 2, id bits hidm[i].  (A random DFA's repairs reach back
+        // ~330 rows on average: a third of the rows they zero in memory with two held tiles are still in registers with three.)
+        uint64_t hidm[kHoldF ? kHoldF + 1 : 1];
+        const uint32_t one_id = (BYTE && kHoldF == 2 && !a.summary && a.merge_G == 0u) ? a.byte_one_id : 0u;   // (a merging last pass sums the other groups' ids in: not one id any more)
         uint32_t n_held = 0;
 #ifdef HRX_STAMPS
         unsigned long long fk_wait = 0, fk_work = 0, fk_bits = 0, fk_masks = 0, fk_fix = 0, fk_rows = 0;
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 fix_end = t0 - n_held * 64u;
                 if (fix_regs) {
 #pragma unroll
-                    for (int i = 0; i < kHoldF; ++i) {
+                    for (int i = 0; i < kHoldF + 1; ++i) {
                         const uint32_t base = t0 - 64u * (uint32_t)(i + 1);
                         const uint32_t keep = tm.fix_start <= base ? 0u : min(tm.fix_start - base, 64u);     // rows of the tile in front of fix_start
                         if ((uint32_t)i < n_held) hmask[i] &= keep >= 64u ? ~0ull : ((1ull << keep) - 1ull);
@@ -355,6 +360,29 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 }
             };
             if constexpr (kHoldF > 0) {
+              if (one_id) {
+                // ---- three held tiles (one substring id): id bytes are rebuilt from the tile's 64 id bits when it leaves
+                auto ids_of = [&](const uint64_t idm, uint32_t (&sd)[16]) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) sd[q] = (__umul24((uint32_t)(idm >> (4 * q)) & 0xfu, 0x204081u) & 0x01010101u) * one_id;   // bit i of the nibble -> byte i
+                };
+                uint32_t sd[16];
+                if (n_held == 3u) { ids_of(hidm[2], sd); octets_out(tf - 3u, hsid[0], sd, hmask[2], true); }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { hsid[0][q] = hcw[1][q]; hcw[1][q] = hcw[0][q]; hcw[0][q] = cw[q]; }
+                hmask[2] = hmask[1]; hmask[1] = hmask[0]; hmask[0] = tm.mask;
+                hidm[2] = hidm[1]; hidm[1] = hidm[0];
+                uint64_t idm = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) idm |= (uint64_t)nonzero_bytes4(sidq[q]) << (4 * q);
+                hidm[0] = idm;
+                if (n_held < 3u) ++n_held;
+                if (tf + 1u == tf0 + gt) {   // the group's last tile: the held tiles leave, oldest first
+                    if (n_held > 2u) { ids_of(hidm[2], sd); octets_out(tf0 + gt - 3u, hsid[0], sd, hmask[2], false); }
+                    if (n_held > 1u) { ids_of(hidm[1], sd); octets_out(tf0 + gt - 2u, hcw[1], sd, hmask[1], false); }
+                    ids_of(hidm[0], sd); octets_out(tf0 + gt - 1u, hcw[0], sd, hmask[0], false);
+                }
+              } else {
                 // the oldest held tile (tf - kHoldF) leaves now (a held tile that leaves here is never the group's last one: all 8 octets exist); the others move up
                 if (n_held == (uint32_t)kHoldF) octets_out(tf - (uint32_t)kHoldF, hcw[kHoldF - 1], hsid[kHoldF - 1], hmask[kHoldF - 1], true);
 #pragma unroll
@@ -372,6 +400,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                     for (int i = kHoldF - 1; i >= 0; --i)
                         if ((uint32_t)i < n_held) octets_out(tf0 + gt - 1u - (uint32_t)i, hcw[i], hsid[i], hmask[i], false);
                 }
+              }
             } else {
                 octets_out(tf, cw, sidq, tm.mask, false);
             }
