@@ -58,9 +58,10 @@ struct PlaceWalk {
         // reference is in hand, late if not (a one-time cost of seconds against ~8 % of every launch on those buffers)
         if (i >= 7 && elapsed_ms > (arena ? 4.0 * kPlaceWalkMs : kPlaceWalkMs) && clear_of_reference()) return PlaceVerdict::settle;
         if (elapsed_ms > (arena ? kPlaceArenaHardMs : kPlaceHardMs)) return PlaceVerdict::settle;
-        // no kinds on this box / for this pair of sizes: ten candidates within 5 % of each other — the fastest will do (not for arenas: their walk is cheap and
-        // every lease seen so far had a clear arena pairing somewhere)
-        if (!arena && i >= 9 && b < 1.05 * worst()) return PlaceVerdict::settle;
+        // no kinds on this box / for this pair of sizes: ten candidates within 5 % of each other — the fastest will do, unless an earlier walk of the context has
+        // measured something clearly better (then this is a neighbourhood of one kind, not a box without kinds: one buffer set of cfg 5 settled for a 6.0 ten
+        // candidates into such a stretch while its context had kept a 6.8; not for arenas either: their walk is cheap and every lease seen had a clear pairing somewhere)
+        if (!arena && i >= 9 && b < 1.05 * worst() && b >= kPlaceNearBest * seen()) return PlaceVerdict::settle;
         return PlaceVerdict::go_on;
     }
 };

@@ -66,6 +66,11 @@ int main() {
         Outcome o = run(w, {6100, 6150, 6120, 6200, 6180, 6110, 6130, 6160, 6190, 6170, 6100});
         CHECK(o.verdict == PlaceVerdict::settle && o.steps == 10);
     }
+    {   // ... but not while the context knows of a better kind: a stretch of ten middle-kind candidates is a neighbourhood, not a box without kinds (cfg 5, 65536 x 4096, set 1 of 8)
+        PlaceWalk w; w.ref_rate = 5398; w.seen_before = 6840;
+        Outcome o = run(w, {5900, 5950, 5920, 5995, 5890, 5910, 5940, 5960, 5930, 5905, 5915, 7010});
+        CHECK(o.verdict == PlaceVerdict::accept && o.steps == 12 && o.kept == 7010);
+    }
     {   // the arena walk of the lease behind profiles/r04_config_sweep_new_rule/: 24 candidates between 5.6 and 6.07 against a reference of 5.9 — nothing clear of the
         // reference, so the walk may pass the soft cap ...
         PlaceWalk w; w.ref_rate = 5896; w.arena = true;
