@@ -10,7 +10,7 @@ namespace hrx {
 constexpr double kPlaceMargin = 1.10;      // accepted: >= 10 % more bytes per microsecond than two streams inside one block (colliding pairs: +-4 %, clear ones: +20-25 %)
 constexpr double kPlaceNearBest = 0.96;    // ... and within 4 % of the best pairing any walk of this context has measured
 constexpr double kPlaceAsSeen = 0.97;      // ... at once if within 3 % of what an EARLIER walk of this context kept
-constexpr double kPlaceWalkMs = 250.0;     // a walk past its eighth candidate that HAS something clear of the reference ends after a quarter of a second (arena candidates: a second)
+constexpr double kPlaceWalkMs = 250.0;     // a walk past its eighth candidate that HAS something clear of the reference — and as good as what the context has seen — ends after a quarter of a second (arena candidates: a second)
 constexpr double kPlaceHardMs = 2000.0, kPlaceArenaHardMs = 8000.0;   // ... and any walk after this, whatever it holds (one lease of round 4 took 66 ms per 2-GiB hipMalloc where the others take 2:
                                                                       // the one-second bound ended its arena walk at 17 colliding candidates and the bench line ran at 0.70 instead of 0.76)
 constexpr int kPlaceMinCandidates = 4;     // the median of fewer says nothing: clear pairings are about one in eight
@@ -56,7 +56,7 @@ struct PlaceWalk {
         if (i >= 1 && seen_before > 0 && b >= kPlaceAsSeen * seen_before && clear_of_reference()) return PlaceVerdict::accept;
         // ... or when it has cost too much: allocating and freeing candidates of several GiB takes tens of milliseconds each — soon if something clear of the
         // reference is in hand, late if not (a one-time cost of seconds against ~8 % of every launch on those buffers)
-        if (i >= 7 && elapsed_ms > (arena ? 4.0 * kPlaceWalkMs : kPlaceWalkMs) && clear_of_reference()) return PlaceVerdict::settle;
+        if (i >= 7 && elapsed_ms > (arena ? 4.0 * kPlaceWalkMs : kPlaceWalkMs) && clear_of_reference() && b >= kPlaceNearBest * seen()) return PlaceVerdict::settle;
         if (elapsed_ms > (arena ? kPlaceArenaHardMs : kPlaceHardMs)) return PlaceVerdict::settle;
         // no kinds on this box / for this pair of sizes: ten candidates within 5 % of each other — the fastest will do, unless an earlier walk of the context has
         // measured something clearly better (then this is a neighbourhood of one kind, not a box without kinds: one buffer set of cfg 5 settled for a 6.0 ten
