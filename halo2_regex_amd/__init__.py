@@ -630,7 +630,9 @@ class RegexVerifyConfig:
         return rec, msk, st
 
     def alloc_outputs_position_major(self, B, device=None):
-        """Flat device buffers for HRX_LAYOUT_POSITION_MAJOR: records int32 [ceil(M/4)*B*4*D], masked int16 [ceil(M/8)*B*8]."""
+        """Flat device buffers for HRX_LAYOUT_POSITION_MAJOR: records int32 [ceil(M/4)*B*4*D], masked int16 [ceil(M/8)*B*8].
+        (The status tensor — and, below the placement threshold, all three — comes from torch's caching allocator on the CURRENT stream: launch on that stream, or order
+        the launch stream behind it, as with any torch tensor used on a side stream.)"""
         dev = torch.device("cuda", self.device) if device is None else device
         nr, nm = C.c_size_t(0), C.c_size_t(0)
         lib.hrx_position_major_sizes(B, self.max_chars_size, self.num_defs, C.byref(nr), C.byref(nm))

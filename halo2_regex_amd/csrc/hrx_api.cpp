@@ -23,6 +23,7 @@
 #include "hrx_fr.h"
 #include "hrx_host_walk.hpp"
 #include "hrx_kernel.hpp"
+#include "hrx_arena_alloc.hpp"
 #include "hrx_place_rule.hpp"
 #include "hrx_lane.h"
 
@@ -864,38 +865,31 @@ constexpr double kPlaceBudgetFrac = 0.70;   // (the acceptance rule and its marg
 
 struct hrx_place_arena {
     void *base = nullptr;
-    size_t bytes = 0, used = 0;
-    int live = 0;            // sub-buffers handed out and not yet freed
-    bool retired = false;    // no context serves requests from it any more: released with its last sub-buffer
+    hrx::ArenaRanges ranges;   // which offsets are handed out (first fit, freed ranges merge: hrx_arena_alloc.hpp) — an alloc / free churn is served from one pair for ever
+    bool retired = false;      // no context serves requests from it any more: released with its last sub-buffer
 };
 static std::mutex g_arena_mu;
 static std::map<uintptr_t, hrx_place_arena *> g_arena_of;   // sub-buffer -> arena (hrx_device_free has no context argument)
 
-// used / live / retired of an arena are only ever touched under g_arena_mu: hrx_device_free (any thread, no context argument — e.g. a finalizer
+// ranges / retired of an arena are only ever touched under g_arena_mu: hrx_device_free (any thread, no context argument — e.g. a finalizer
 // while another thread allocates) releases sub-buffers concurrently with the owning context's takes.
-static void *arena_take_locked(hrx_place_arena *a, size_t bytes) {
-    const size_t need = (bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
-    void *p = (unsigned char *)a->base + a->used;
-    a->used += need;
-    ++a->live;
-    g_arena_of[(uintptr_t)p] = a;
-    return p;
-}
+static inline size_t arena_need(size_t bytes) { return (bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign; }
 // a records and a masked-row sub-buffer out of the pair, or neither: the capacity check and both takes are ONE critical section
 static bool arena_take_pair(hrx_place_arena *ra, size_t r_bytes, hrx_place_arena *ma, size_t m_bytes, void **r, void **m) {
-    const size_t r_need = (r_bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
-    const size_t m_need = (m_bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign;
     std::lock_guard<std::mutex> lk(g_arena_mu);
-    if (ra->used + r_need > ra->bytes || ma->used + m_need > ma->bytes) return false;
-    *r = arena_take_locked(ra, r_bytes);
-    *m = arena_take_locked(ma, m_bytes);
+    if (!ra->ranges.fits(arena_need(r_bytes)) || !ma->ranges.fits(arena_need(m_bytes))) return false;
+    const size_t ro = ra->ranges.take(arena_need(r_bytes)), mo = ma->ranges.take(arena_need(m_bytes));
+    *r = (unsigned char *)ra->base + ro;
+    *m = (unsigned char *)ma->base + mo;
+    g_arena_of[(uintptr_t)*r] = ra;
+    g_arena_of[(uintptr_t)*m] = ma;
     return true;
 }
 static void arena_retire(hrx_place_arena *a) {
     if (!a) return;
     std::lock_guard<std::mutex> lk(g_arena_mu);
     a->retired = true;
-    if (a->live == 0) { (void)hipFree(a->base); delete a; }
+    if (a->ranges.live() == 0) { (void)hipFree(a->base); delete a; }
 }
 // true if ptr was a sub-buffer of an arena (and has been returned to it)
 static bool arena_release(void *ptr) {
@@ -904,10 +898,8 @@ static bool arena_release(void *ptr) {
     if (it == g_arena_of.end()) return false;
     hrx_place_arena *a = it->second;
     g_arena_of.erase(it);
-    if (--a->live == 0) {
-        if (a->retired) { (void)hipFree(a->base); delete a; }
-        else a->used = 0;      // empty again: the measured pair is reused from the start
-    }
+    a->ranges.give((size_t)((unsigned char *)ptr - (unsigned char *)a->base));
+    if (a->ranges.live() == 0 && a->retired) { (void)hipFree(a->base); delete a; }
     return true;
 }
 
@@ -1068,8 +1060,8 @@ int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_byte
         void *X = place_walk(ctx, A, kPlaceArenaBytes, kPlaceArenaBytes, rep);
         pool_seen = std::max(pool_seen, ctx->place_seen_rate);
         if (!X) { (void)hipFree(A); rep = hrx_place_report{}; return plain(); }
-        pool->rec = new hrx_place_arena(); pool->rec->base = A; pool->rec->bytes = kPlaceArenaBytes;
-        pool->msk = new hrx_place_arena(); pool->msk->base = X; pool->msk->bytes = kPlaceArenaBytes;
+        pool->rec = new hrx_place_arena(); pool->rec->base = A; pool->rec->ranges.reset(kPlaceArenaBytes);
+        pool->msk = new hrx_place_arena(); pool->msk->base = X; pool->msk->ranges.reset(kPlaceArenaBytes);
         pool->report = rep;
     }
     return plain();

@@ -102,6 +102,15 @@ def test_placement_walk_rule_on_recorded_candidate_sequences():
     assert out.returncode == 0 and "place rule: ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_arena_offset_allocator_on_a_host():
+    """csrc/hrx_arena_alloc.hpp (the offsets inside a placement arena: first fit, freed ranges merge): eight bench-sized buffers back to back, a million-step alloc / free
+    churn that never exhausts the arena, a seeded random trace against a byte map."""
+    exe = "/tmp/hrx_test_arena_alloc"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "host_cpp", "test_arena_alloc.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "arena ranges: ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_c_struct_entry_points_equal_the_text_parsers():
     """tests/host_c/test_push_structs.c replays bindings/rust/hrx.rs HrxHandle::new in C: hrx_defs_push_allstr with the map's entries SHUFFLED and their explicit
     line indices (table.rs:103-108), a duplicate key (defs.rs:100: the last insert wins), hrx_defs_push_substr with shuffled pairs — same fixed-table rows and the

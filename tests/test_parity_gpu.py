@@ -1184,16 +1184,22 @@ def test_one_context_per_thread_on_one_device(hra, oracle):
             stream = torch.cuda.Stream(device=dev)
             start.wait()
             for it in range(3):
-                out = cfg.alloc_outputs_position_major(B, dev)
-                reports.append(cfg.last_placement_report()["searched"])
+                # everything of this thread on ITS stream — torch tensors included: the status tensor comes from torch's caching allocator, which hands a block freed on
+                # one stream to the next request on the same stream without waiting; allocated on the shared default stream and written on a side stream it was clobbered,
+                # now and then, by another thread's still-pending temporaries (seen: 65535 status words zero, one run in eight)
                 with torch.cuda.stream(stream):
+                    out = cfg.alloc_outputs_position_major(B, dev)
+                    reports.append(cfg.last_placement_report()["searched"])
+                    out[0].fill_(-1); out[1].fill_(-1); out[2].fill_(-1)     # (a reused range still holds an earlier iteration's — correct — rows: the launch must write them again)
                     rec, msk, st = cfg.witness_batch_position_major(d_c, d_l, out=out, chars_pm_stride=chars.shape[1], stream=stream)
+                    r2, m2 = hra.position_major_to_string_major(rec, msk, B, M, 1)
+                    got = st.cpu().numpy().view(np.uint64)
+                    rows_ok = bool(torch.equal(r2[ok], d_orec[ok]) and torch.equal(m2[ok], d_omsk[ok]))
                 stream.synchronize()
-                r2, m2 = hra.position_major_to_string_major(rec, msk, B, M, 1)
-                torch.cuda.synchronize()
-                if not np.array_equal(st.cpu().numpy().view(np.uint64), ost):
-                    errors.append("thread %d iteration %d: status words differ" % (k, it))
-                if not (torch.equal(r2[ok], d_orec[ok]) and torch.equal(m2[ok], d_omsk[ok])):
+                if not np.array_equal(got, ost):
+                    bad = np.nonzero(got != ost)[0]
+                    errors.append("thread %d iteration %d: %d status words differ, first at string %d: 0x%x for 0x%x" % (k, it, bad.size, bad[0], int(got[bad[0]]), int(ost[bad[0]])))
+                if not rows_ok:
                     errors.append("thread %d iteration %d: rows differ" % (k, it))
                 del out, rec, msk, st, r2, m2      # hrx_device_free from this thread while the others allocate
             del cfg
@@ -1207,7 +1213,7 @@ def test_one_context_per_thread_on_one_device(hra, oracle):
         t.join(300)
     assert not any(t.is_alive() for t in threads), "a worker hangs"
     assert not errors, errors
-    assert sorted(set(reports)) in ([1, 2], [2]) and reports.count(1) <= 2      # one walk for the device (a second only if the first pair filled up), everything else served from the pair
+    assert sorted(set(reports)) == [1, 2] and reports.count(1) == 1             # ONE walk for the device: freed sub-buffers go back into the pair (hrx_arena_alloc.hpp), twelve allocations never fill it
     gc.collect()
 
 
