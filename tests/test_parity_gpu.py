@@ -1213,7 +1213,7 @@ def test_one_context_per_thread_on_one_device(hra, oracle):
         t.join(300)
     assert not any(t.is_alive() for t in threads), "a worker hangs"
     assert not errors, errors
-    assert sorted(set(reports)) == [1, 2] and reports.count(1) == 1             # ONE walk for the device: freed sub-buffers go back into the pair (hrx_arena_alloc.hpp), twelve allocations never fill it
+    assert sorted(set(reports)) in ([1, 2], [2]) and reports.count(1) <= 1      # at most ONE walk for the device (none if an earlier context's pair is still there): freed sub-buffers go back into the pair (hrx_arena_alloc.hpp), twelve allocations never fill it
     gc.collect()
 
 
