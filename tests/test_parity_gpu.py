@@ -1073,6 +1073,8 @@ def test_placement_search_for_bench_sized_buffers_uses_measured_arenas(hra, orac
     from halo2_regex_amd import synth
     dev = torch.device("cuda", 0)
     M, B = 1024, 65536
+    import gc
+    gc.collect()                        # (the arena pair belongs to the device: no context of an earlier test may still hold it)
     cfg = _cfg(hra, CFG_1, M)
     torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
