@@ -64,6 +64,11 @@ def parse_args(argv=None):
                     "--config dfa256 --batch 1048576 --len 4096 --rows 4096")
     ap.add_argument("--verify-all-ranks", action="store_true", help="every rank compares its own timed buffers with the oracle (default: rank 0)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure the launch's HBM traffic (roofline.traffic)")
+    ap.add_argument("--distinct", type=int, default=0, help="generate this many DISTINCT strings and build the batch from rotated copies of them, block after block "
+                    "(0 = every string of the batch distinct).  Planting text into 2^20 strings on the host takes minutes; the oracle then walks the distinct "
+                    "strings once and EVERY string of every buffer set is compared with the rows of the string it is a copy of")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the legs over BASELINE configs[2..4] (other_configs in the line)")
+    ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)     # one of the other_configs legs: a child of the default run
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # spawned by a bare --gpus N run
     args = ap.parse_args(argv)
     args.argv = [a for a in argv if a != "--child"]
@@ -169,37 +174,52 @@ def cpu_baseline(o, names, chars, lens, M, budget_s=8.0):
     return res
 
 
-def verify_timed_buffers(o, hra, sets, shift, chars, lens, M, D, pm, dev):
-    """Bit-exact comparison of EVERY buffer set the timed launches wrote with the oracle's rows for every string (position-major:
-    every string of the first block of 65536): the oracle walks the batch once on all host cores, its rows are uploaded, and set k
-    — the batch rotated by k * shift strings — is compared on the device with the rows rotated the same way."""
+def batch_source_index(pos, k, shift, B, nd, sb):
+    """Which of the nd distinct strings sits at position `pos` (a tensor of string positions) of buffer set k: set k is the batch rotated by
+    k * shift strings (torch.roll: out[p] = in[(p - s) % B]) and the batch is ceil(B / nd) blocks of nd strings, block j = the distinct strings
+    rotated by j * sb."""
+    i = (pos - k * shift) % B
+    return (i % nd - (i // nd) * sb) % nd
+
+
+def verify_timed_buffers(o, hra, sets, shift, chars, lens, M, D, pm, dev, B, sb):
+    """Bit-exact comparison of EVERY string of EVERY buffer set with the oracle's rows: the oracle walks the distinct strings of the batch once on
+    all host cores (the whole batch unless --distinct), its rows are uploaded, and every string of set k — the batch rotated by k * shift strings — is
+    compared on the device, where it lies, with the rows of the string it is a copy of (chunks of at most 2^28 record words at a time)."""
     import numpy as np
     import torch
     cores = os.cpu_count() or 1
-    B = len(lens)
-    nstr = min(B, hra.PM_BLOCK) if pm else B
+    nd = len(lens)
     orec, omsk, ost = o.witness_batch(chars, lens, M, threads=cores)
     ok = torch.from_numpy(((ost & np.uint64(0xff)) == 0)).to(dev)
     d_orec = torch.from_numpy(orec.view(np.int32)).to(dev)
     d_omsk = torch.from_numpy(omsk.view(np.int16)).to(dev)
     d_ost = torch.from_numpy(ost.view(np.int64)).to(dev)
-    exact, rows = True, 0
+    d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+    del orec, omsk
+    q4, q8 = (M + 3) // 4, (M + 7) // 8
+    step = max(1, min(hra.PM_BLOCK, (1 << 28) // max(1, M * D)))
+    exact, rows, strings = True, 0, 0
     for k, (_, _, (rec, msk, st)) in enumerate(sets):
-        if pm:
-            # the first block of the position-major buffers holds strings 0 .. nstr - 1
-            q4, q8 = (M + 3) // 4, (M + 7) // 8
-            r = rec[:q4 * D * nstr * 4].reshape(q4, D, nstr, 4).permute(2, 0, 3, 1).reshape(nstr, -1, D)[:, :M]
-            m = msk[:q8 * nstr * 8].reshape(q8, nstr, 8).permute(1, 0, 2).reshape(nstr, -1)[:, :M]
-        else:
-            r, m = rec, msk
-        idx = (torch.arange(nstr, device=dev) - k * shift) % B      # string j of set k is string (j - k shift) mod B of the batch
-        okk = ok[idx]
-        exact = exact and bool(torch.equal(st[:nstr], d_ost[idx])) and bool(torch.equal(r[okk], d_orec[idx][okk])) and bool(torch.equal(m[okk], d_omsk[idx][okk]))
-        rows += int(lens[idx.cpu().numpy()].sum())
-        del idx, okk
-    return {"strings": int(nstr) * len(sets), "strings_per_set": int(nstr), "buffer_sets": len(sets), "rows": rows, "bit_exact": exact,
-            "against": "oracle/hrx_oracle.c (%d threads): status words, records and masked rows of every string%s of every buffer set the timed steps wrote"
-                       % (cores, "" if nstr == B else " of the first position-major block")}
+        for blk in range(0, B, hra.PM_BLOCK):                       # (position-major buffers are blocked by PM_BLOCK strings; string-major ones: just chunks)
+            nb = min(hra.PM_BLOCK, B - blk)
+            for a in range(0, nb, step):
+                e = min(nb, a + step)
+                if pm:
+                    r = rec.view(-1)[blk * q4 * D * 4:][:q4 * D * nb * 4].view(q4, D, nb, 4)[:, :, a:e].permute(2, 0, 3, 1).reshape(e - a, q4 * 4, D)[:, :M]
+                    m = msk.view(-1)[blk * q8 * 8:][:q8 * nb * 8].view(q8, nb, 8)[:, a:e].permute(1, 0, 2).reshape(e - a, q8 * 8)[:, :M]
+                else:
+                    r, m = rec[blk + a:blk + e], msk[blk + a:blk + e]
+                idx = batch_source_index(torch.arange(blk + a, blk + e, device=dev), k, shift, B, nd, sb)
+                okk = ok[idx]
+                exact = exact and bool(torch.equal(st[blk + a:blk + e], d_ost[idx])) and bool(torch.equal(r[okk], d_orec[idx][okk])) \
+                    and bool(torch.equal(m[okk], d_omsk[idx][okk]))
+                rows += int(d_len[idx].sum())
+                strings += e - a
+                del idx, okk, r, m
+    return {"strings": strings, "strings_per_set": int(B), "buffer_sets": len(sets), "rows": rows, "bit_exact": exact, "distinct_strings": int(nd),
+            "against": "oracle/hrx_oracle.c (%d threads) on the %d distinct strings of the batch: status words, records and masked rows of EVERY string of every buffer set, "
+                       "as written by one more replay of the timed graph over outputs poisoned after the timed region" % (cores, nd)}
 
 
 def mix_ceiling(dev_index):
@@ -261,7 +281,7 @@ def measured_traffic(argv, dev_index):
                         vals.append(float(row["Counter_Value"]))
             shutil.rmtree(tmp, ignore_errors=True)
             if r.returncode != 0 or not vals:
-                sys.stderr.write("rocprofv3 --pmc %s pass failed (rc %d): traffic falls back to the committed profile\n" % (counter, r.returncode))
+                sys.stderr.write("rocprofv3 --pmc %s pass failed (rc %d): roofline.traffic is null in this line\n" % (counter, r.returncode))
                 return None
             out[counter] = sum(vals) / len(vals)
     except Exception as e:                                   # a probe must never break the bench line
@@ -378,11 +398,18 @@ def run_rank(args, rank, world, device_index, barrier):
     defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in names]
     cfg = hra.RegexVerifyConfig.configure(M, defs, device=device_index)
 
-    # this rank's shard of the job: independent strings, seeded per rank (strong scaling: per shard start)
-    chars, lens = gen(B, n, seed=rank if args.scaling == "weak" else 7919 * b_begin + world, stride=stride)
+    # this rank's shard of the job: independent strings, seeded per rank (strong scaling: per shard start).  --distinct nd: nd generated strings,
+    # the batch = ceil(B / nd) blocks of them, block j rotated by j * sb strings (built on the device)
+    nd = min(B, args.distinct) if args.distinct > 0 else B
+    sb = (nd // 7 + 11) % nd if nd < B else 0
+    chars, lens = gen(nd, n, seed=rank if args.scaling == "weak" else 7919 * b_begin + world, stride=stride)
     d_lens0 = torch.from_numpy(lens.astype(np.int32)).to(dev)
-    rows_per_step = int(lens.sum())
     d_chars0 = torch.from_numpy(chars).to(dev)
+    if nd < B:
+        nblk = (B + nd - 1) // nd
+        d_chars0 = torch.cat([torch.roll(d_chars0, shifts=j * sb, dims=0) if j else d_chars0 for j in range(nblk)])[:B].contiguous()
+        d_lens0 = torch.cat([torch.roll(d_lens0, shifts=j * sb, dims=0) if j else d_lens0 for j in range(nblk)])[:B].contiguous()
+    rows_per_step = int(d_lens0.sum(dtype=torch.int64))
     q4, q8 = (M + 3) // 4, (M + 7) // 8
     foot = B * stride + B * rec_pitch * 4 * D + B * msk_pitch * 2
     nsets = pick_sets(args, foot)
@@ -391,7 +418,7 @@ def run_rank(args, rank, world, device_index, barrier):
     # are the rotated oracle rows of set 0.
     shift = (B // nsets + 37) % B if nsets > 1 else 0
     sets, placement, sm_sets = [], [], []
-    keep_sm = pm and world == 1 and not args.no_spread and nsets * B * stride <= (4 << 30)
+    keep_sm = pm and world == 1 and not args.no_spread and not args.leg and nsets * B * stride <= (4 << 30)
     for r in range(world):        # one rank at a time: the placement search times memory traffic
         if r == rank:
             for k in range(nsets):
@@ -531,7 +558,7 @@ def run_rank(args, rank, world, device_index, barrier):
         if o is None:
             res["verified"] = {"bit_exact": None, "skipped": "under a profiler and the oracle library is not built: no helper process may be started here"}
         else:
-            res["verified"] = verify_timed_buffers(o, hra, sets[:written], shift, chars, lens, M, D, pm, dev)
+            res["verified"] = verify_timed_buffers(o, hra, sets[:written], shift, chars, lens, M, D, pm, dev, B, sb)
             if not res["verified"]["bit_exact"]:
                 raise SystemExit("bench.py: the timed output buffers differ from the oracle")
     if rank != 0:
@@ -605,7 +632,8 @@ def run_rank(args, rank, world, device_index, barrier):
     res["library"] = os.path.realpath(hra.LIB_PATH)
     res["nsets"] = nsets
     res["config"] = {"workload": "%s DFA (D=%d), %d x %d-byte strings per GPU (n=%d chars, M=%d witness rows), %s"
-                                 % (label, D, B, stride, n, M, "uniform noise over the %s%s" % (alphabet, " + planted match" if planted else "")),
+                                 % (label, D, B, stride, n, M, "uniform noise over the %s%s%s" % (alphabet, " + planted match" if planted else "",
+                                    "" if nd == B else "; %d distinct strings, the batch = %d blocks of them, block j rotated by %d j strings" % (nd, (B + nd - 1) // nd, sb))),
                      "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
                      "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of 65536 strings): chars [%d/16][B][16], records "
                                  "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h); outputs from hrx_alloc_outputs_position_major (placement-aware "
@@ -684,7 +712,7 @@ def aggregate(per_rank, args):
             "ref_gbs": [round(p.get("ref_gbs", 0)) for p in srch], "first_gbs": [round(p.get("first_gbs", 0)) for p in srch],
             "best_gbs": [round(p.get("best_gbs", 0)) for p in srch], "search_ms": [round(p.get("search_ms", 0), 1) for p in srch],
             "what": "hrx_alloc_outputs_position_major per buffer set: two-stream probe rates (GB/s written, device clock) of the same-block reference, the first candidate "
-                    "(= two plain allocations) and the kept masked-row buffer; accepted = kept one >= 10 % above the reference (DESIGN.md §4.3)"}
+                    "(= two plain allocations) and the kept masked-row buffer; accepted = kept one >= 10 % above the reference (DESIGN.md §6)"}
     if r0.get("one_buffer_set"):
         ob = r0["one_buffer_set"]
         gbs = algo_bytes / (ob["ms_per_step_median"] * 1e-3) / 1e9
@@ -806,6 +834,63 @@ def spawn_children(args, argv, timeout_s=3600):
     return aggregate(results, args)
 
 
+# The BASELINE configs other than the one the metric is quoted on, at their per-GPU sizes: each runs as a child of the default single-GPU run AFTER the headline's
+# timed region, verification and probes, through the same code path (rotating buffer sets, the K steps replayed as one HIP graph, every string of every
+# set compared with the oracle, hrx_traffic_pass_device over the same buffers), and is condensed into the line's `other_configs`.
+OTHER_CONFIGS = [
+    ("configs[2]: regex2_test + regex3_test with substr extraction, 2^20 x 2048-byte strings, 1 MI355X",
+     ["--config", "regex23", "--batch", "1048576", "--len", "2047", "--rows", "2048", "--steps", "5", "--warmup", "2", "--distinct", "65536"]),
+    ("configs[3]: 32-KiB header regexes (D = 3 stand-ins, BASELINE.md), 256K strings over 8 GPUs = 32768 strings per GPU",
+     ["--config", "headers3", "--batch", "32768", "--len", "32767", "--rows", "32768", "--steps", "5", "--warmup", "2", "--distinct", "4096"]),
+    ("configs[4]: synthetic 256-state dense DFA, 4096-byte inputs, >= 1M strings over 8 GPUs = 131072 strings per GPU",
+     ["--config", "dfa256", "--batch", "131072", "--len", "4095", "--rows", "4096", "--steps", "10", "--warmup", "3", "--distinct", "65536"]),
+]
+
+
+def is_default_workload(args):
+    return (args.config == "regex1" and args.batch == 65536 and args.n == 1023 and args.rows == 1024 and args.layout == "position-major" and args.gpus == 1
+            and args.scaling == "weak" and args.dist == "planted" and not args.eager and not args.leg and args.distinct == 0)
+
+
+def condense_leg(name, line, wall_s):
+    r = line["roofline"]
+    mc = r.get("mix_ceiling") or {}
+    pl = r.get("placement") or {}
+    v = line.get("verified") or {}
+    return {"baseline_config": name, "workload": line["config"]["workload"], "value": line["value"], "unit": line["unit"], "steps": line["steps"], "warmup": line["warmup"],
+            "ms_per_step": line["ms_per_step"], "avg_launch_ms": r["avg_launch_ms"], "frac": r["frac"], "achieved": r["achieved"], "peak": r["peak"],
+            "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "bytes_per_row": r["bytes_per_row"], "kernel": r["kernel"], "launch": r["launch"],
+            "traffic_pass_us": mc.get("traffic_pass_us"), "kernel_over_traffic_pass": mc.get("kernel_over_best_probe"),
+            "spread_ms_per_step": (line.get("spread") or {}).get("ms_per_step_median"),
+            "verified": {"bit_exact": v.get("bit_exact"), "strings": v.get("strings"), "buffer_sets": v.get("buffer_sets"), "distinct_strings": v.get("distinct_strings")},
+            "placement": {"best_gbs": pl.get("best_gbs"), "ref_gbs": pl.get("ref_gbs"), "steps": pl.get("steps"), "sets_accepted": pl.get("sets_accepted")},
+            "buffer_sets": line["config"]["buffer_sets"].split(":")[0], "launch_mode": line["config"]["launch_mode"].split(" (")[0], "wall_s": wall_s}
+
+
+def other_config_legs(dev_index, timeout_s=600):
+    """Runs OTHER_CONFIGS one after the other, each in a fresh child process on the same device (this process keeps its context: the children are started,
+    not exec'ed into).  A leg that fails, times out or does not fit the free device memory is reported as skipped with the reason; it never breaks the line."""
+    legs = []
+    if under_profiler():
+        return [{"baseline_config": name, "skipped": "under a profiler: no child process may be started"} for name, _ in OTHER_CONFIGS]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=physical_device(dev_index))
+    for name, argv in OTHER_CONFIGS:
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--leg", "--no-cpu-baseline", "--no-pmc"], capture_output=True, text=True,
+                               timeout=timeout_s, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                legs.append({"baseline_config": name, "skipped": "leg failed (rc %d): %s" % (r.returncode, (r.stderr or "").strip().splitlines()[-1:] or "")})
+                continue
+            legs.append(condense_leg(name, json.loads(lines[-1]), time.time() - t0))
+        except subprocess.TimeoutExpired:
+            legs.append({"baseline_config": name, "skipped": "timed out after %d s" % timeout_s})
+        except Exception as e:
+            legs.append({"baseline_config": name, "skipped": "leg failed: %s" % e})
+    return legs
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -848,7 +933,10 @@ def main(argv=None):
         print(json.dumps(spawn_children(args, argv)), flush=True)
         return
     res = run_rank(args, 0, 1, 0, lambda: None)
-    print(json.dumps(aggregate([res], args)), flush=True)
+    line = aggregate([res], args)
+    if is_default_workload(args) and not args.no_other_configs:
+        line["other_configs"] = other_config_legs(0)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -13,7 +13,14 @@ pub struct hrx_place_report {
     pub ref_us: f64, pub first_us: f64, pub best_us: f64,
     pub ref_gbs: f64, pub first_gbs: f64, pub best_gbs: f64,
     pub probe_bytes: usize, pub peak_candidate_bytes: usize, pub search_ms: f64,
+    pub capped: c_int,   // HRX_PLACE_CAPPED_* or-ed: which bound ended the walk (0: the acceptance rule itself)
 }
+pub const HRX_PLACE_OFF: c_int = 0;
+pub const HRX_PLACE_WALK: c_int = 1;
+pub const HRX_PLACE_CAPPED_STEPS: c_int = 1;
+pub const HRX_PLACE_CAPPED_BYTES: c_int = 2;
+pub const HRX_PLACE_CAPPED_TIME: c_int = 4;
+pub const HRX_PLACE_CAPPED_ALLOC: c_int = 8;
 
 pub const HRX_DEVICE_NONE: c_int = -1;
 pub const HRX_MAX_DEFS: usize = 32;   // RegexDefs per config (more than three are walked in passes)
@@ -63,6 +70,8 @@ extern "C" {
     pub fn hrx_chars_to_position_major_device(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, chars_pm: *mut u8, stream: *mut c_void) -> c_int;
     /// what the context's last placement-aware allocation did (steps measured, reference / first / kept probe times, memory held)
     pub fn hrx_alloc_last_report(ctx: *const hrx_ctx, out: *mut hrx_place_report) -> c_int;
+    /// placement per context: HRX_PLACE_OFF = two plain allocations; max_bytes / max_ms bound one walk (0 = the defaults)
+    pub fn hrx_ctx_set_placement(ctx: *mut hrx_ctx, mode: c_int, max_bytes: usize, max_ms: f64) -> c_int;
     /// roofline diagnostic: the memory traffic of one position-major launch over these buffers, no DFA work (overwrites the outputs)
     pub fn hrx_traffic_pass_device(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, m: usize, records: *mut u32,
                                    masked: *mut u16, stream: *mut c_void) -> c_int;

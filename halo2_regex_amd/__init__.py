@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
     "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_chars_to_position_major_device", "hrx_device_free",
-    "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
+    "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_ctx_set_placement", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
     "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_shard_device", "hrx_multi_shard_stream", "hrx_multi_witness_batch_host",
@@ -56,7 +56,7 @@ class _PlaceReportC(C.Structure):    # hrx_place_report of include/hrx.h
     _fields_ = [("searched", C.c_int), ("steps", C.c_int), ("accepted", C.c_int), ("chosen_step", C.c_int),
                 ("ref_us", C.c_double), ("first_us", C.c_double), ("best_us", C.c_double),
                 ("ref_gbs", C.c_double), ("first_gbs", C.c_double), ("best_gbs", C.c_double), ("probe_bytes", C.c_size_t),
-                ("peak_candidate_bytes", C.c_size_t), ("search_ms", C.c_double)]
+                ("peak_candidate_bytes", C.c_size_t), ("search_ms", C.c_double), ("capped", C.c_int)]
 
 
 class HrxError(RuntimeError):
@@ -98,6 +98,7 @@ def _load():
         "hrx_ctx_device": (i, [vp]),
         "hrx_ctx_set_host_threshold": (i, [vp, sz]),
         "hrx_ctx_host_threshold": (sz, [vp]),
+        "hrx_ctx_set_placement": (i, [vp, i, sz, C.c_double]),
         "hrx_last_error": (C.c_char_p, []),
         "hrx_witness_batch_device": (i, [vp, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_witness_batch_device_pitched": (i, [vp, vp, sz, vp, sz, sz, vp, sz, vp, sz, vp, vp]),
@@ -153,7 +154,7 @@ lib = _load()
 
 class DeviceBuffer:
     """TOOLS ONLY (needs libhrx_ablation.so): `nbytes` of device memory from csrc/hrx_alloc.cpp — a virtual range over 2-MiB
-    physical chunks, for the placement probes of DESIGN.md §4.3 — exposed through __cuda_array_interface__; freed with the object."""
+    physical chunks, for the placement probes of DESIGN.md §6 — exposed through __cuda_array_interface__; freed with the object."""
 
     def __init__(self, nbytes, device=0):
         if not hasattr(lib, "hrx_chunked_alloc"):
@@ -424,6 +425,8 @@ def recommended_pitches(M):
 LAYOUT_STRING_MAJOR, LAYOUT_POSITION_MAJOR, LAYOUT_INPUT_POSITION_MAJOR = 0, 1, 2
 
 
+PLACE_OFF, PLACE_WALK = 0, 1     # hrx_ctx_set_placement modes
+PLACE_CAPPED_STEPS, PLACE_CAPPED_BYTES, PLACE_CAPPED_TIME, PLACE_CAPPED_ALLOC = 1, 2, 4, 8      # hrx_place_report.capped
 PLACED_FROM = 128 << 20    # alloc_outputs*: records of this many bytes or more come from the library's placement-aware allocator (kPlaceFromBytes)
 PM_BLOCK = 65536          # kPmBlock of csrc/hrx_lane.h: position-major buffers are blocked by this many strings
 
@@ -527,6 +530,10 @@ class RegexVerifyConfig:
     def host_threshold(self):
         return lib.hrx_ctx_host_threshold(self._need_ctx())
 
+    def set_placement(self, walk=True, max_bytes=0, max_ms=0.0):
+        """hrx_ctx_set_placement: placement-aware output allocation of this config's context off / on, and the memory / time budget of one walk (0 = default)."""
+        _check(lib.hrx_ctx_set_placement(self._need_ctx(), PLACE_WALK if walk else PLACE_OFF, int(max_bytes), float(max_ms)))
+
     # -- lookup tables: RegexVerifyConfig::load (lib.rs:779-785) ---------------------------------
     def load(self):
         """Returns per def (transition_rows, endpoint_rows) in table.rs assignment order."""
@@ -618,7 +625,7 @@ class RegexVerifyConfig:
         M, D = self.max_chars_size, self.num_defs
         rp, mp = (recommended_pitches(M)[:2] if pitched else (M, M))
         st = torch.empty((B,), dtype=torch.int64, device=dev)
-        if B * rp * D * 4 >= PLACED_FROM and dev.index in (None, self.device) and not torch.cuda.is_current_stream_capturing():     # several GB: a pair that does not collide (DESIGN.md §4.3)
+        if B * rp * D * 4 >= PLACED_FROM and dev.index in (None, self.device) and not torch.cuda.is_current_stream_capturing():     # several GB: a pair that does not collide (DESIGN.md §6)
             pr, pmk = C.c_void_p(), C.c_void_p()
             _check(lib.hrx_alloc_output_pair(self._ctx, B * rp * D * 4, B * mp * 2, C.byref(pr), C.byref(pmk)))
             d = torch.device("cuda", self.device)
@@ -639,7 +646,7 @@ class RegexVerifyConfig:
         st = torch.empty((B,), dtype=torch.int64, device=dev)
         if nr.value * 4 < PLACED_FROM or dev.index not in (None, self.device) or torch.cuda.is_current_stream_capturing():     # (the search allocates and measures: not inside a stream capture)
             return torch.empty((nr.value,), dtype=torch.int32, device=dev), torch.empty((nm.value,), dtype=torch.int16, device=dev), st
-        # several GB: the library allocates the pair and keeps the masked-row buffer that does not collide with the records (DESIGN.md §4.3)
+        # several GB: the library allocates the pair and keeps the masked-row buffer that does not collide with the records (DESIGN.md §6)
         pr, pmk = C.c_void_p(), C.c_void_p()
         _check(lib.hrx_alloc_outputs_position_major(self._ctx, B, self.max_chars_size, C.byref(pr), C.byref(pmk)))
         d = torch.device("cuda", self.device)

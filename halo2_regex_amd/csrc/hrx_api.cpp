@@ -134,7 +134,9 @@ struct hrx_ctx {
     bool place_enabled = true, place_trace = false;
     int place_max_steps = 48;
     bool place_max_steps_set = false;   // HRX_PLACE_MAX_STEPS given: it bounds arena walks too (their own cap is kPlaceArenaHardSteps)
-    double place_seen_rate = 0.0;     // bytes per microsecond of the best candidate any placement walk of this context has probed
+    double place_seen_rate = 0.0;     // bytes per microsecond of the best candidate any DIRECT walk (records >= 1 GiB) of this context has probed; arena walks keep theirs per device (hrx_place_pool)
+    size_t place_max_bytes = 0;       // hrx_ctx_set_placement: the most device memory a walk may hold at once (0: 70 % of what is free)
+    double place_max_ms = 0.0;        // ... and the wall-clock time a walk may take (0: the rule's own bounds, hrx_place_rule.hpp)
     hrx_place_report last_place{};
     struct hrx_place_pool *pool = nullptr;   // bench-sized outputs: the device's measured arena pair, shared by every context of that device in this process
 #ifdef HRX_STAMPS
@@ -332,7 +334,7 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     c->debug = debug_flags_from_env();
-    // tuning knobs of the placement search (DESIGN.md §4.3): HRX_PLACE=0 switches it off, HRX_PLACE_MAX_STEPS bounds the walk, HRX_PLACE_TRACE=1 prints every measured step to stderr
+    // tuning knobs of the placement search (DESIGN.md §6): HRX_PLACE=0 switches it off, HRX_PLACE_MAX_STEPS bounds the walk, HRX_PLACE_TRACE=1 prints every measured step to stderr
     if (const char *v = std::getenv("HRX_PLACE")) c->place_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_MP_COMBINE")) c->mp_combine = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_PLACE_TRACE")) c->place_trace = std::atoi(v) != 0;
@@ -839,7 +841,7 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
     return HRX_OK;
 }
 
-// Placement-aware allocation of the two output buffers (DESIGN.md §4.3, hrx_place.hip).
+// Placement-aware allocation of the two output buffers (DESIGN.md §6, hrx_place.hip).
 //
 // Device memory is handed out top-down, so whatever a process allocates next lands right below what it allocated last — in
 // the same class of the physical address space, where the launch's two write streams collide.  The search WALKS down the
@@ -865,6 +867,7 @@ constexpr double kPlaceBudgetFrac = 0.70;   // (the acceptance rule and its marg
 
 struct hrx_place_arena {
     void *base = nullptr;
+    int device = 0;
     hrx::ArenaRanges ranges;   // which offsets are handed out (first fit, freed ranges merge: hrx_arena_alloc.hpp) — an alloc / free churn is served from one pair for ever
     bool retired = false;      // no context serves requests from it any more: released with its last sub-buffer
 };
@@ -891,11 +894,26 @@ static void arena_retire(hrx_place_arena *a) {
     a->retired = true;
     if (a->ranges.live() == 0) { (void)hipFree(a->base); delete a; }
 }
-// true if ptr was a sub-buffer of an arena (and has been returned to it)
+// true if ptr was a sub-buffer of an arena (and has been returned to it).  hipFree waits for the device before it releases memory, and callers rely on that
+// (a buffer may be freed while the launch that writes it is still in flight; the Python wrapper's finalizers do).  A range handed back to an arena is reusable at
+// once — by another context, thread and stream — so the release waits for the arena's device first, exactly like the plain allocations' hipFree below 128 MiB:
+// the same caller code is safe whatever the buffer size (tests: test_arena_free_waits_for_the_device).
 static bool arena_release(void *ptr) {
+    int device = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        auto it = g_arena_of.find((uintptr_t)ptr);
+        if (it == g_arena_of.end()) return false;
+        device = it->second->device;
+    }
+    {   // (outside the arena mutex: other threads keep allocating while this one waits; ptr is the caller's until the give below)
+        DeviceGuard guard;
+        if (guard.set(device) == hipSuccess) (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
     std::lock_guard<std::mutex> lk(g_arena_mu);
     auto it = g_arena_of.find((uintptr_t)ptr);
-    if (it == g_arena_of.end()) return false;
+    if (it == g_arena_of.end()) return true;    // (released by a concurrent call with the same pointer: a double free; nothing left to do)
     hrx_place_arena *a = it->second;
     g_arena_of.erase(it);
     a->ranges.give((size_t)((unsigned char *)ptr - (unsigned char *)a->base));
@@ -943,17 +961,20 @@ static void place_trace(const hrx_ctx *ctx, const char *fmt, ...) {
 
 // The walk.  A: the block everything is measured against (a_bytes), cand_bytes: the size of the blocks to walk with.  Returns the
 // kept candidate (NULL: none could be allocated); everything else it allocated is freed.
-static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes, hrx_place_report &rep) {
+static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes, const bool arena_walk, const double seen_before, hrx_place_report &rep, double *best_rate_out) {
     const uint32_t D = (uint32_t)ctx->s.defs.size();
     unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);   // 16 bytes of the context's 64-byte scratch word area
     size_t free_b = 0, total_b = 0;
+    *best_rate_out = 0.0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     // never more than kPlaceBudgetFrac of what is free NOW.  The 2-GiB arena candidates of bench-sized outputs: 24 of them (48 GiB) as a rule — several contexts
     // or ranks on one device walk at the same time without pushing each other out of memory — and on only while NOTHING clearly above the same-block reference
     // has turned up (one lease of round 4: 24 candidates between 5.6 and 6.07 TB/s against a reference of 5.9, the bench line at 0.722 instead of 0.76; round 3's
     // unbounded walk had found a clear partner on every lease, up to ~100 candidates down), re-reading the free memory at every further step.
-    const bool arena_walk = cand_bytes == kPlaceArenaBytes;
-    const size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
+    // (arena_walk is the caller's statement, not inferred from the size: a direct walk whose masked buffer happens to measure 2 GiB — 1048576 x 1024 rows — keeps
+    // the direct walk's caps.)  hrx_ctx_set_placement narrows the budget and adds a time cap; rep.capped says which bound ended the walk.
+    size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
+    if (ctx->place_max_bytes) budget = std::min(budget, ctx->place_max_bytes);
     const int max_steps = arena_walk && !ctx->place_max_steps_set ? std::max(ctx->place_max_steps, hrx::kPlaceArenaHardSteps) : ctx->place_max_steps;
     rep.searched = 1;
     double ref_rate = 0.0;   // bytes per microsecond
@@ -970,18 +991,21 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
     double best_us = -1.0;
     hrx::PlaceWalk walk;               // the rates measured and when to stop: hrx_place_rule.hpp
     walk.ref_rate = ref_rate;
-    walk.seen_before = ctx->place_seen_rate;   // the fastest pairing earlier walks of this context measured
+    walk.seen_before = seen_before;    // the fastest pairing earlier walks of the same kind measured (direct: this context's; arena: this device's)
     walk.arena = arena_walk;
     const auto t_walk = std::chrono::steady_clock::now();
-    for (int i = 0; i < max_steps && spent + cand_bytes <= budget; ++i) {
-        if (!walk.may_take_another()) break;                    // the arena soft cap: something clear of the reference is in hand
+    int i = 0;
+    bool ended_by_rule = false;
+    for (; i < max_steps; ++i) {
+        if (spent + cand_bytes > budget) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
+        if (!walk.may_take_another()) { ended_by_rule = true; break; }   // the arena soft cap: something clear of the reference is in hand
         if (arena_walk && i >= hrx::kPlaceArenaSoftSteps) {     // beyond it: leave other walkers / contexts of this device their share
             size_t f2 = 0, t2 = 0;
-            if (hipMemGetInfo(&f2, &t2) != hipSuccess) { (void)hipGetLastError(); break; }
-            if ((double)f2 < (1.0 - kPlaceBudgetFrac) * (double)t2) break;
+            if (hipMemGetInfo(&f2, &t2) != hipSuccess) { (void)hipGetLastError(); rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
+            if ((double)f2 < (1.0 - kPlaceBudgetFrac) * (double)t2) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
         }
         void *cand = nullptr;
-        if (hipMalloc(&cand, cand_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (hipMalloc(&cand, cand_bytes) != hipSuccess) { (void)hipGetLastError(); rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
         spent += cand_bytes;
         rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
         const double us = hrx::placement_probe_us(A, a_bytes, cand, cand_bytes, D, ctx->stream, clk, &rep.probe_bytes);
@@ -994,12 +1018,19 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
         if (better) { best = cand; best_us = us; rep.chosen_step = i; }
         if (loser) spacers.push_back(loser);
         walk.rates.push_back(rate);
-        ctx->place_seen_rate = std::max(ctx->place_seen_rate, rate);
-        const hrx::PlaceVerdict v = walk.decide(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count());
-        if (v == hrx::PlaceVerdict::accept) { rep.accepted = 1; break; }
-        if (v == hrx::PlaceVerdict::settle) { rep.accepted = walk.clear_of_reference() ? 1 : 0; break; }
+        const double elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count();
+        const hrx::PlaceVerdict v = walk.decide(elapsed_ms);
+        if (v == hrx::PlaceVerdict::accept) { rep.accepted = 1; ended_by_rule = true; break; }
+        if (v == hrx::PlaceVerdict::settle) {
+            rep.accepted = walk.clear_of_reference() ? 1 : 0; ended_by_rule = true;
+            if (elapsed_ms > (arena_walk ? hrx::kPlaceArenaHardMs : hrx::kPlaceHardMs)) rep.capped |= HRX_PLACE_CAPPED_TIME;   // the rule's own hard bound: whatever it holds
+            break;
+        }
+        if (ctx->place_max_ms > 0 && elapsed_ms > ctx->place_max_ms) { rep.capped |= HRX_PLACE_CAPPED_TIME; break; }   // the caller's bound (hrx_ctx_set_placement)
     }
+    if (i >= max_steps && !ended_by_rule) rep.capped |= HRX_PLACE_CAPPED_STEPS;
     const double best_rate = walk.best();
+    *best_rate_out = best_rate;
     if (!rep.accepted && walk.clear_of_reference()) rep.accepted = 1;   // (a walk that ran into a cap with a pairing >= 10 % above the reference in hand)
     for (void *p : spacers) (void)hipFree(p);
     rep.best_us = best_us;
@@ -1035,7 +1066,9 @@ int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_byte
         // ---- large outputs: candidates measured against the records buffer itself
         void *rec = nullptr;
         if (hipMalloc(&rec, records_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
-        void *best = place_walk(ctx, rec, records_bytes, masked_bytes, rep);
+        double walked_best = 0.0;
+        void *best = place_walk(ctx, rec, records_bytes, masked_bytes, /*arena_walk=*/false, ctx->place_seen_rate, rep, &walked_best);
+        ctx->place_seen_rate = std::max(ctx->place_seen_rate, walked_best);
         if (!best && hipMalloc(&best, masked_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
         return done(rec, best);
     }
@@ -1055,16 +1088,29 @@ int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_byte
         }
         void *A = nullptr;
         if (hipMalloc(&A, kPlaceArenaBytes) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+        // (the arena walks' own best rate per device and D: a direct walk's rate over other buffer sizes is not comparable — copied in here it could keep the accept
+        // rule `b >= 0.96 seen()` from ever firing and every replacement pair walking to its caps with the pool mutex held)
         double &pool_seen = pool->seen_rate[std::min<size_t>(ctx->s.defs.size(), HRX_MAX_DEFS)];
-        ctx->place_seen_rate = std::max(ctx->place_seen_rate, pool_seen);
-        void *X = place_walk(ctx, A, kPlaceArenaBytes, kPlaceArenaBytes, rep);
-        pool_seen = std::max(pool_seen, ctx->place_seen_rate);
+        double walked_best = 0.0;
+        void *X = place_walk(ctx, A, kPlaceArenaBytes, kPlaceArenaBytes, /*arena_walk=*/true, pool_seen, rep, &walked_best);
+        pool_seen = std::max(pool_seen, walked_best);
         if (!X) { (void)hipFree(A); rep = hrx_place_report{}; return plain(); }
-        pool->rec = new hrx_place_arena(); pool->rec->base = A; pool->rec->ranges.reset(kPlaceArenaBytes);
-        pool->msk = new hrx_place_arena(); pool->msk->base = X; pool->msk->ranges.reset(kPlaceArenaBytes);
+        pool->rec = new hrx_place_arena(); pool->rec->base = A; pool->rec->device = ctx->device; pool->rec->ranges.reset(kPlaceArenaBytes);
+        pool->msk = new hrx_place_arena(); pool->msk->base = X; pool->msk->device = ctx->device; pool->msk->ranges.reset(kPlaceArenaBytes);
         pool->report = rep;
     }
     return plain();
+}
+
+int hrx_ctx_set_placement(hrx_ctx *ctx, int mode, size_t max_bytes, double max_ms) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (mode != HRX_PLACE_OFF && mode != HRX_PLACE_WALK) return fail(HRX_ERR_ARG, "hrx_ctx_set_placement: mode must be HRX_PLACE_OFF or HRX_PLACE_WALK");
+    if (max_ms < 0) return fail(HRX_ERR_ARG, "hrx_ctx_set_placement: max_ms < 0");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->place_enabled = mode == HRX_PLACE_WALK;
+    ctx->place_max_bytes = max_bytes;
+    ctx->place_max_ms = max_ms;
+    return HRX_OK;
 }
 
 int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out) {
@@ -1187,7 +1233,7 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
         for (size_t b = 0; b < B; ++b)
             if (lens[b] <= M && lens[b] > stride) return fail(HRX_ERR_ARG, "a string is longer than the stride");
         // one host thread per ~8192 witness rows (~100 us of walk; a thread costs ~30 us to start), up to the machine's cores: a host-only
-        // context walks 4096 x 1024 rows on a 256-core host in ~0.3 ms instead of 15
+        // context walks 4096 x 1024 rows on a 256-core host in ~0.3 ms instead of 15 (NOTES_MEASUREMENTS.md §7c)
         const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
         const size_t want = std::max<size_t>(1, B * M / 8192);
         host_witness_batch(ctx->s, chars, stride, lens, B, M, records, masked, status, (int)std::min(want, hw));

@@ -122,13 +122,13 @@ struct Parser {
             if (raw(i, '(')) {                                   // atom: a bracketed scope, up to where the depth is back at this bracket's
                 size_t j = i + 1;
                 while (j < hi && depth[j + 1] != depth[i]) ++j;
-                if (j >= hi) return fail("missing right bracket for", i + 1);
+                if (j >= hi) { err = "Error: missing right bracket for " + std::to_string(i + 1) + "."; return -1; }   // (the reference's text has no " at ", regex.js:289)
                 const int sub = alternation(i + 1, j, nest + 1);
                 if (sub < 0) return -1;
                 parts.push_back(sub);
                 i = j;
             } else if (raw(i, '*') || raw(i, '+') || raw(i, '?')) {   // postfix: on the factor in front of it
-                if (parts.empty()) return fail(std::string("unexpected ") + (char)k.ch, i);
+                if (parts.empty()) return fail(std::string("unexpected ") + (raw(i, '*') ? '*' : '+'), i);   // (a leading '?' reports "unexpected +" in the reference, regex.js:315)
                 const int x = parts.back();
                 if (raw(i, '*')) {
                     Ast n; n.type = N_STAR; n.sub = x;

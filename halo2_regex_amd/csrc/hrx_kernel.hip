@@ -11,7 +11,7 @@ namespace hrx {
 
 // Which of the position-major kernel's stores are write-back instead of streaming.  All-streaming output is not the best this
 // memory system does with a launch that writes more than the 256-MB Infinity Cache holds: with about 128 MiB of the records
-// stored write-back (every k-th tile's) the bench line runs at 63-67 us in every process instead of 70 or 78 (DESIGN.md §4.1:
+// stored write-back (every k-th tile's) the bench line runs at 63-67 us in every process instead of 70 or 78 (NOTES_MEASUREMENTS.md §4.1:
 // same-process and fresh-process A/Bs, tools/nt_mix_sweep.sh) and D = 3 at 65536 x 1024 B goes 0.72 -> 0.84.  Part of that is the
 // cache absorbing lines that the NEXT launch overwrites (the bench re-writes its buffers every step); with outputs rotating over
 // 4-8 buffer sets the policy is neutral (81-83 us either way, tools/rotating_outputs.py), and whoever consumes the rows next
@@ -50,7 +50,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
     const size_t min_stage = (a.layout & 1u) ? pm_pair_bytes(2, false, true) : wave_stage_bytes((int)a.D, 16);
     if (a.table_bytes + min_stage > kLdsLimit || (a.debug & kDbgForceGlobalTable)) out.gtab = 1;
     // position-major loader/walker kernel: from EIGHT groups per walker pair on, the pairs take their groups from a counter
-    // instead of a fixed stride — the walkers of odd XCDs run 8-17 % slower than those of even ones, and with a
+    // instead of a fixed stride — the walkers of odd XCDs run 8-17 % slower than those of even ones (NOTES_MEASUREMENTS.md §4.1), and with a
     // fixed split the launch waits for them.  A group is the unit, so this only pays with many groups per pair: 2^20 x 2048 B
     // (D = 2, 16 groups per pair) 4.68 -> 4.45 ms; with 4 groups per pair the last groups are drawn long before the fast pairs
     // run dry (262144 x 2048 B: 1.188 vs 1.184 ms), and with 16-tile groups the loader's counter access — it waits for its loads
@@ -233,7 +233,7 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         }
     }
     // string-major D = 3 (no walker/storer kernel: its string-tiles are 128 bytes = 32 / 16 rows of 1 / 2 defs): the
-    // loader/walker kernel with the lane's own string-major strides, 5x the one-wave kernel
+    // loader/walker kernel with the lane's own string-major strides, 5x the one-wave kernel (NOTES_MEASUREMENTS.md §3.4)
     const bool sm3 = !(a.layout & 1u) && a.D == 3 && a.M % 8u == 0 && !out.gtab && !(a.debug & kDbgForceOneWave);
     if ((a.layout & 1u) || sm3) {
         // ---- loader/walker kernel: table + per pair a ring of up to 4 input tiles (4 KiB each)

@@ -1,4 +1,4 @@
-// hrx_kernel_pm.hip — gfx950 kernel for the POSITION-MAJOR buffers (the headline path; DESIGN.md §3.3).
+// hrx_kernel_pm.hip — gfx950 kernel for the POSITION-MAJOR buffers (the headline path; DESIGN.md §3.2).
 #include <hip/hip_runtime.h>
 
 #include "hrx_device.h"
@@ -46,7 +46,7 @@ __device__ __forceinline__ TileBits byte_tile_bits(uint32_t (&sidq)[16], uint32_
 // 64 consecutive strings: every store is a full, contiguous 1-KiB (D=1) run written straight from the walker's
 // registers — no LDS transpose, no mover wave — and at any moment the whole chip writes into one compact slab of the
 // output (rows 4q..4q+3 of all strings = 1 MiB at B = 65536).  A compact write window is what the HBM write path
-// rewards: 6.5 TB/s vs 4.3-5.2 TB/s for the string-major comb (tools/fillprobe, tools/wpattern2).
+// rewards: 6.5 TB/s vs 4.3-5.2 TB/s for the string-major comb (tools/fillprobe, tools/wpattern2; NOTES_MEASUREMENTS.md §4).
 //
 // The walker's in-order vmcnt would make any wait for an input load also wait for every store issued before it, so
 // the walker issues no loads at all: a LOADER wave per walker streams the strings' bytes through its own registers (RT tiles

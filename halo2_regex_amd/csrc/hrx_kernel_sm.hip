@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
     constexpr uint32_t CSB = 80u;             // bytes per staged string-tile of chars
     // A wave owns a group of GS strings (lanes >= GS idle in the walk, all 64 lanes move data in the store phase).
     // GS = 32 when the batch is too small to give every SIMD two waves of 64: with a single wave per SIMD nothing
-    // can walk while that wave sits in its store burst behind HBM back-pressure.
+    // can walk while that wave sits in its store burst behind HBM back-pressure (NOTES_MEASUREMENTS.md §4).
     const uint32_t GS = a.gs;
     const uint32_t rec_base = lds_tab + wave * (uint32_t)wave_stage_bytes(D, GS);
     const uint32_t chr_base = rec_base + (GS + 1u) * RSB;  // row GS of each area: scratch for the idle lanes
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(512) void witness_kernel(const WitnessArgs a) {
 // =============================================================================================
 // Walker / storer kernel (the production path for D = 1 and D = 2, M % 8 == 0).
 //
-// Measured on MI355X (profiles/): with one wave doing everything, each tile's store burst
+// Measured on MI355X (profiles/, NOTES_MEASUREMENTS.md §4): with one wave doing everything, each tile's store burst
 // sits behind HBM back-pressure for 5-12k cycles (868 when the chip is idle) while the wave cannot walk, and
 // the walk leaves HBM idle — compute time and memory time ADD.  Here each CU runs 4 pairs of waves:
 //   walker  (wave i)   : everything that is per-string and sequential — the dependent table walk, record

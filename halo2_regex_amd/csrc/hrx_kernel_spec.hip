@@ -1,4 +1,4 @@
-// hrx_kernel_spec.hip — CHUNKED walk for batches that leave most walker slots empty (DESIGN.md §3.8).
+// hrx_kernel_spec.hip — CHUNKED walk for batches that leave most walker slots empty (DESIGN.md §3.5).
 //
 // derive_states is strictly sequential per string (src/lib.rs:808-819): a batch of fewer strings than the chip has lanes runs
 // for as long as ONE string's dependent chain, n x ~50 ns (8192 x 32768-byte strings: 0.94 ms with the pair-step table, a

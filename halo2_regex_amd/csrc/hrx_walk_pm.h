@@ -45,7 +45,7 @@ __device__ __forceinline__ uint4 masked_octet(const uint32_t c0, const uint32_t 
 // rows to a third "storer" wave through an LDS out-ring, so that the walker issued no vector-memory instruction at all, was
 // built and measured in round 1 — every global store does cost the issuing wave 75-125 cycles, but the ds_write_b128 +
 // hand-over cost the walker as much, and where all walker slots are busy the launch is bound by the memory system's mixed
-// read/write rate anyway: 97 vs 89 us on the headline workload, 3.41 vs 3.39 ms on cfg 4.  Dropped)
+// read/write rate anyway: 97 vs 89 us on the headline workload, 3.41 vs 3.39 ms on cfg 4.  Dropped; NOTES_MEASUREMENTS.md §4.)
 template <int D, bool SM = false>
 struct GlobalSink {
     static constexpr bool kSidq = true;

@@ -120,7 +120,7 @@ void hrx_ctx_destroy(hrx_ctx *ctx);
 int hrx_ctx_device(const hrx_ctx *ctx);
 /* Host-buffer batches (hrx_witness_batch_host, hrx_multi_witness_batch_host) of fewer than `rows` witness rows (B x M)
  * are walked on the calling host thread instead of being staged to the device; default HRX_DEFAULT_HOST_THRESHOLD
- * (the measured crossover); 0 = always the device.  The single-string entry points below always take the
+ * (the measured crossover, NOTES_MEASUREMENTS.md §7c); 0 = always the device.  The single-string entry points below always take the
  * host walk (one GPU lane needs ~50 ns per row, a host core ~3).  Results are identical either way. */
 #define HRX_DEFAULT_HOST_THRESHOLD 32768
 int hrx_ctx_set_host_threshold(hrx_ctx *ctx, size_t rows);
@@ -154,7 +154,7 @@ int hrx_witness_batch_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
                              size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream);
 /* Same with pitched outputs: string b's rows start at records + b*rec_pitch*D and masked + b*msk_pitch (pitches in rows,
  * >= M, multiples of 8 when M is).  A pitch that is not a power of two keeps the chip-wide write front off a subset of the
- * HBM channels; hrx_recommended_pitches gives values for a given M (and an input stride). */
+ * HBM channels (NOTES_MEASUREMENTS.md §4); hrx_recommended_pitches gives values for a given M (and an input stride). */
 int hrx_witness_batch_device_pitched(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
                                      size_t M, uint32_t *records, size_t rec_pitch, uint16_t *masked, size_t msk_pitch,
                                      uint64_t *status, void *stream);
@@ -165,7 +165,7 @@ void hrx_recommended_pitches(size_t M, size_t *rec_pitch, size_t *msk_pitch, siz
  *       record of (string b, row r, def d) at ((r/4*D + d)*B + b)*4 + r%4;  masked of (b, r) at (r/8*B + b)*8 + r%8.
  *       Four rows of one string and def are 16 contiguous bytes and consecutive strings are adjacent, so with one GPU
  *       lane per string every store instruction writes one contiguous 1-KiB run of full lines, and the whole device
- *       writes into one compact slab at a time — the layout the HBM write path rewards; rows >= M of
+ *       writes into one compact slab at a time — the layout the HBM write path rewards (NOTES_MEASUREMENTS.md §4); rows >= M of
  *       the last quad/octet are unspecified.
  *       Larger batches are BLOCKED: strings [k*HRX_PM_BLOCK, (k+1)*HRX_PM_BLOCK) form block k, each block is a complete
  *       array of the above shape over its own nb = min(HRX_PM_BLOCK, B - k*HRX_PM_BLOCK) strings, blocks back to back:
@@ -203,9 +203,10 @@ void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32,
  *     last context is destroyed.  A process therefore holds up to 4 GiB per device for its small
  *     output buffers, however many contexts it keeps.
  * 262144 x 2048 B at D = 2 runs at 0.97-1.03 ms with such a pair against 1.12-1.19 ms in a fresh process with two plain
- * allocations (DESIGN.md §4.3, csrc/hrx_place.hip).  The call takes the context's lock, launches on the context's own stream
- * and waits for it: not inside a stream capture.  Environment, read by hrx_ctx_create: HRX_PLACE=0 (plain allocations),
- * HRX_PLACE_MAX_STEPS, HRX_PLACE_TRACE=1.  The reference has no counterpart: its witness lives in host Vecs. */
+ * allocations (DESIGN.md §6, csrc/hrx_place.hip).  The call takes the context's lock, launches on the context's own stream
+ * and waits for it: not inside a stream capture.  Per context: hrx_ctx_set_placement (off / on, memory and time budget of a walk).
+ * Environment, read by hrx_ctx_create (the defaults of a new context): HRX_PLACE=0 (plain allocations), HRX_PLACE_MAX_STEPS,
+ * HRX_PLACE_TRACE=1.  The reference has no counterpart: its witness lives in host Vecs. */
 int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked);
 /* The same for any pair of output buffers given in bytes (string-major outputs: B * rec_pitch * D * 4 and B * msk_pitch * 2). */
 int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_bytes, void **records, void **masked);
@@ -214,8 +215,9 @@ typedef struct hrx_place_report {
     int searched;                /* 0: two plain allocations (small buffers, HRX_PLACE=0, or no memory to walk with); 1: this call walked;
                                     2: served from the arena pair an earlier call measured (the numbers below are that walk's) */
     int steps;                   /* candidates measured */
-    int accepted;                /* 1: the kept candidate is >= 10 % above both the same-neighbourhood reference and the slowest candidate of the
-                                    walk (and within 7 % of the best pairing the context has measured); 0: simply the fastest measured */
+    int accepted;                /* 1: the kept candidate is >= 10 % above both the same-neighbourhood reference and the MEDIAN candidate of the walk (at
+                                    least four candidates) and within 4 % of the best pairing earlier walks of the same kind measured — or a walk that ran
+                                    into a bound with a candidate >= 10 % above the reference in hand; 0: simply the fastest measured (csrc/hrx_place_rule.hpp) */
     int chosen_step;
     double ref_us;               /* the reference: both probe streams inside one neighbourhood (device clock) */
     double first_us, best_us;    /* the first candidate (what two plain allocations would have been) and the kept one */
@@ -225,8 +227,24 @@ typedef struct hrx_place_report {
     size_t peak_candidate_bytes; /* most memory the walk held at once: rejected candidates stay allocated, as the spacers that push the
                                     next candidate further, until the walk ends */
     double search_ms;            /* host time of the whole call */
+    int capped;                  /* which bound ended the walk, if one did (0: the acceptance rule itself): HRX_PLACE_CAPPED_* or-ed */
 } hrx_place_report;
+enum {
+    HRX_PLACE_CAPPED_STEPS = 1,  /* the candidate count (48; 2-GiB arena candidates 96; HRX_PLACE_MAX_STEPS) */
+    HRX_PLACE_CAPPED_BYTES = 2,  /* the memory budget: 70 % of the free memory, hrx_ctx_set_placement's max_bytes, or — arena walks past their 24th
+                                    candidate — less than 30 % of the device left free */
+    HRX_PLACE_CAPPED_TIME = 4,   /* hrx_ctx_set_placement's max_ms, or the rule's own hard bound (2 s; arena walks 8 s) */
+    HRX_PLACE_CAPPED_ALLOC = 8   /* a candidate could not be allocated */
+};
 int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out);
+/* Placement per context (a prover that links the library decides per context, not through the environment):
+ *   mode       HRX_PLACE_OFF: hrx_alloc_output_pair / hrx_alloc_outputs_position_major are two plain allocations, nothing is measured, no arena is held
+ *              on this context's behalf; HRX_PLACE_WALK (the default unless HRX_PLACE=0 was set when the context was created): as described above.
+ *   max_bytes  the most device memory one walk may hold at a time in candidates (0: 70 % of what is free when the walk begins; never more than that)
+ *   max_ms     wall-clock bound of one walk in milliseconds (0: the rule's own bounds); the walk keeps the fastest candidate measured until then
+ * A walk that ends on a bound says so in hrx_place_report.capped.  Applies to later calls; buffers already handed out are not touched. */
+enum { HRX_PLACE_OFF = 0, HRX_PLACE_WALK = 1 };
+int hrx_ctx_set_placement(hrx_ctx *ctx, int mode, size_t max_bytes, double max_ms);
 /* Roofline diagnostic: the memory traffic of ONE position-major witness launch of B strings x M rows of this context's
  * config (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR) and nothing else — the input read in 16-byte chunks
  * per lane, every record plane and the masked rows written at the launch's own addresses with the launch's store policy, by
@@ -239,10 +257,14 @@ int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, s
  * HRX_LAYOUT_INPUT_POSITION_MAJOR.  Pure streaming (2 * stride bytes of traffic per string; measured beside the bench line: bench.py
  * roofline.from_string_major_input).  Asynchronous on `stream`; no context state is touched. */
 int hrx_chars_to_position_major_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, uint8_t *chars_pm, void *stream);
+/* Releases a buffer of hrx_alloc_output_pair / hrx_alloc_outputs_position_major (NULL: nothing).  Like hipFree it WAITS for the buffer's device to
+ * finish everything in flight before the memory can be handed out again — a sub-buffer of the shared arena pair included (its range is reusable by
+ * any context of the device right after the call) — so a buffer may be freed while the launch that writes it is still running.  Not inside a
+ * stream capture. */
 int hrx_device_free(void *ptr);
 /* Which kernel and launch geometry the planner picks for a batch of B strings x M rows in `layout` on a gfx950 device
- * with `num_cus` compute units (MI355X: 256), as text: "hrx::witness_pm_kernel<1, false, false, true> grid=256 waves=8
- * ring=1 lds=147520" — the kernel name a profiler will show (bench.py's roofline.kernel).  Host-only: nothing is
+ * with `num_cus` compute units (MI355X: 256), as text: "hrx::witness_pm_kernel<1, false, false, false, false, false> grid=256
+ * waves=12 ring=4 lds=..." — the kernel name a profiler will show, every template argument spelled out (bench.py's roofline.kernel).  Host-only: nothing is
  * launched and no device is touched.  Returns HRX_OK, HRX_ERR_BOUNDS if nothing fits. */
 int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap);
 /* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers, or — below the

@@ -26,12 +26,19 @@ function allstrText(graph) {
     return text;
 }
 
+// the parser's own message for a malformed pattern: parseRegex returns it as a string ("Error: unexpected * at 0.", regex.js:236-367); regexToDfa then throws on it
+function errorOf(regex) {
+    let text = null;
+    try { const p = ctx.parseRegex(regex); if (typeof p === "string") text = p; } catch (e) { text = null; }
+    return text === null ? { regex: regex, error: true } : { regex: regex, error: true, error_text: text };
+}
+
 function run(regex, full) {
     let json;
-    try { json = ctx.regexToDfa(regex); } catch (e) { return { regex: regex, error: true }; }
+    try { json = ctx.regexToDfa(regex); } catch (e) { return errorOf(regex); }
     let graph;
-    try { graph = JSON.parse(json); } catch (e) { return { regex: regex, error: true }; }
-    if (!Array.isArray(graph) || graph.some(n => n === null)) return { regex: regex, error: true };
+    try { graph = JSON.parse(json); } catch (e) { return errorOf(regex); }
+    if (!Array.isArray(graph) || graph.some(n => n === null)) return errorOf(regex);
     const text = allstrText(graph), sha = t => crypto.createHash("sha256").update(t, "utf8").digest("hex");
     if (!full && json.length + text.length > 1500)   // keep the fixture small: big results are pinned by their digests
         return { regex: regex, states: graph.length, dfa_json_sha256: sha(json), allstr_sha256: sha(text) };

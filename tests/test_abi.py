@@ -129,6 +129,19 @@ def test_compute_fails_loudly_without_a_device():
         cfg.witness_batch_host(np.zeros((1, 16), np.uint8), np.zeros(1, np.uint32))
 
 
+def test_placement_switches_check_their_arguments():
+    """hrx_ctx_set_placement (per-context opt-out and budget of the placement walk): argument checks, on a host-only context — no device needed"""
+    import ctypes as C
+    cfg = RegexVerifyConfig.configure(64, _defs(CFG_3), device=hra.HRX_DEVICE_NONE)
+    cfg.set_placement(walk=False)
+    cfg.set_placement(walk=True, max_bytes=1 << 30, max_ms=50.0)
+    assert hra.lib.hrx_ctx_set_placement(cfg._ctx, 2, 0, C.c_double(0.0)) == hra.HRX_ERR_ARG
+    assert hra.lib.hrx_ctx_set_placement(cfg._ctx, hra.PLACE_WALK, 0, C.c_double(-0.5)) == hra.HRX_ERR_ARG
+    assert hra.lib.hrx_ctx_set_placement(None, hra.PLACE_OFF, 0, C.c_double(0.0)) == hra.HRX_ERR_ARG
+    rep = cfg.last_placement_report()
+    assert rep["searched"] == 0 and rep["capped"] == 0
+
+
 def test_planner_thresholds_of_round_3():
     """Where the chunked launch stops (below 2 / up to 1.75 / up to 1.5 groups of 64 strings per CU at D = 1 / 2 / 3, either input layout,
     position-major outputs, 4096 rows or more) and the one-round rule for small batches (profiles/r03_probes/spec_threshold.txt)."""

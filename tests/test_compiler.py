@@ -21,6 +21,7 @@ def test_small_regexes_json_and_text_are_byte_identical():
             with pytest.raises(hra.HrxError) as e:
                 hra.regex_to_allstr_text(c["regex"])
             assert e.value.code == hra.HRX_ERR_PARSE and str(e.value).startswith("Error:")
+            assert str(e.value) == c["error_text"], c["regex"]     # the parser's own message, text and position (regex.js:236-367)
             n_err += 1
             continue
         js, text = hra.regex_to_dfa_json_text(c["regex"]), hra.regex_to_allstr_text(c["regex"])

@@ -1159,6 +1159,81 @@ def test_placement_arenas_are_shared_by_the_contexts_of_a_device(hra, oracle):
     assert free0 - torch.cuda.mem_get_info()[0] < (256 << 20)                                          # the last context of the device is gone: so is the pair
 
 
+def test_arena_free_waits_for_the_device(hra, oracle):
+    """hrx_device_free on a sub-buffer of the shared arena pair waits for the device like hipFree does (include/hrx.h): the range is reusable by any
+    context right after the call, so a buffer freed while its launch is still in flight must not be handed to a second context that writes it on
+    another stream.  Context a queues launches into arena buffers on its own stream and frees them WITHOUT syncing; when the free returns that stream
+    has drained; context b then gets the very same ranges (first fit) and its rows — written on another stream — are the oracle's."""
+    import gc
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    M, B = 1024, 65536
+    chars, lens = synth.reveal_stress(B, M - 1, seed=31)
+    d_c, d_l = hra.chars_to_position_major(torch.from_numpy(chars).to(dev)), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    a, b = _cfg(hra, CFG_1, M), _cfg(hra, CFG_1, M)
+    keep = a.alloc_outputs_position_major(B, dev)                      # (keeps the arena pair alive and a's context busy below)
+    out_a = a.alloc_outputs_position_major(B, dev)
+    assert a.last_placement_report()["searched"] in (1, 2)
+    ptr_a = (out_a[0].data_ptr(), out_a[1].data_ptr())
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        for _ in range(40):                                             # ~3 ms of queued work writing out_a
+            a.witness_batch_position_major(d_c, d_l, out=out_a, chars_pm_stride=chars.shape[1])
+    assert not s1.query()                                               # still in flight
+    del out_a
+    gc.collect()                                                        # -> hrx_device_free of both sub-buffers, no sync by the caller
+    assert s1.query(), "hrx_device_free returned while launches into the freed arena range were still running"
+    out_b = b.alloc_outputs_position_major(B, dev)
+    assert (out_b[0].data_ptr(), out_b[1].data_ptr()) == ptr_a          # the freed ranges, handed to another context at once
+    with torch.cuda.stream(s2):
+        rec, msk, st = b.witness_batch_position_major(d_c, d_l, out=out_b, chars_pm_stride=chars.shape[1])
+    torch.cuda.synchronize()
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_1).witness_batch(chars, lens, M, threads=os.cpu_count() or 8)
+    r2, m2 = hra.position_major_to_string_major(rec, msk, B, M, 1)
+    ok = torch.from_numpy((ost & np.uint64(0xff)) == 0).to(dev)
+    assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+    assert torch.equal(r2[ok], torch.from_numpy(orec.view(np.int32)).to(dev)[ok]) and torch.equal(m2[ok], torch.from_numpy(omsk.view(np.int16)).to(dev)[ok])
+    del keep
+
+
+def test_placement_switches_per_context(hra):
+    """hrx_ctx_set_placement: off / on and the budget of a walk per context, through the C ABI (not only HRX_PLACE=0 in the environment), and
+    hrx_place_report.capped saying which bound ended a walk."""
+    import gc
+    import torch
+    dev = torch.device("cuda", 0)
+    M = 2048
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    cfg = _cfg(hra, CFG_23, M)
+    B = 131072                                                          # records 2 GiB: a direct walk (candidates = 512-MiB masked-row buffers)
+    cfg.set_placement(walk=False)
+    out = cfg.alloc_outputs_position_major(B, dev)
+    rep = cfg.last_placement_report()
+    assert rep["searched"] == 0 and rep["steps"] == 0 and rep["capped"] == 0           # two plain allocations, nothing measured
+    del out; gc.collect()
+    cfg.set_placement(walk=True, max_bytes=3 * (512 << 20) + 1)                         # room for three candidates at a time
+    out = cfg.alloc_outputs_position_major(B, dev)
+    rep = cfg.last_placement_report()
+    assert rep["searched"] == 1 and 1 <= rep["steps"] <= 3 and rep["peak_candidate_bytes"] <= 3 * (512 << 20) + 1
+    assert rep["steps"] < 3 or rep["accepted"] or (rep["capped"] & hra.PLACE_CAPPED_BYTES)
+    del out; gc.collect()
+    cfg.set_placement(walk=True, max_ms=0.001)                                          # the time bound ends the walk behind its first candidate
+    out = cfg.alloc_outputs_position_major(B, dev)
+    rep = cfg.last_placement_report()
+    assert rep["searched"] == 1 and rep["steps"] == 1 and (rep["capped"] & hra.PLACE_CAPPED_TIME) and rep["best_us"] > 0
+    del out; gc.collect()
+    cfg.set_placement(walk=True)                                                        # defaults again: an uncapped walk reports no bound
+    out = cfg.alloc_outputs_position_major(B, dev)
+    rep = cfg.last_placement_report()
+    assert rep["searched"] == 1 and rep["steps"] >= 1 and (rep["capped"] == 0 or not rep["accepted"] or rep["steps"] >= 8)
+    import ctypes as C
+    assert hra.lib.hrx_ctx_set_placement(cfg._ctx, 7, 0, C.c_double(0.0)) == hra.HRX_ERR_ARG
+    assert hra.lib.hrx_ctx_set_placement(cfg._ctx, 1, 0, C.c_double(-1.0)) == hra.HRX_ERR_ARG
+    assert hra.lib.hrx_ctx_set_placement(None, 1, 0, C.c_double(0.0)) == hra.HRX_ERR_ARG
+
+
 def test_one_context_per_thread_on_one_device(hra, oracle):
     """How a multi-threaded prover uses the library (a context serves one stream at a time; halo2 synthesizes from several threads): four threads, each with a context
     and a stream of its own, allocate bench-sized outputs (the device's shared arena pair: pool mutex, arena mutex), launch, free and allocate again, concurrently —

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """In-process A/B of the masked rows' store policy (hrx_kernel_pm.hip octets_out, hrx_kernel_pmd.hip): the SAME buffers, the same placement, modes alternating launch
-block by launch block.  Needs the ablation build (HRX_NT_FLAGS is read there only):
-    HRX_LIB_PATH=halo2_regex_amd/csrc/libhrx_ablation.so python3 tools/ab_policy.py --config dfa256 --batch 131072 --len 4095 --rows 4096
-modes: streamed (0x200: the round-3 behaviour: always non-temporal), gated (0: written back per tile once the wave has repaired rows in memory), open-span (0x400: written
-back whenever a span is open)."""
+block by launch block.  Needs the ntenv build (make -C halo2_regex_amd/csrc ntenv: the release kernels, HRX_NT_MIX / HRX_NT_FLAGS read at every launch):
+    HRX_LIB_PATH=halo2_regex_amd/csrc/libhrx_ntenv.so python3 tools/ab_policy.py --config dfa256 --batch 131072 --len 4095 --rows 4096
+modes (kNtMix* of csrc/hrx_kernel.hpp): streamed (0x200 = kNtMixNoOpenSpan: every masked row non-temporal, round 3's behaviour), open-span (0: the shipped rule — the masked
+rows of a tile into which an open optimistic span reaches are written back), all-wb (0x100 = kNtMixMaskedWb: every masked row written back)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -35,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     launch = lambda i: cfg.witness_batch_position_major(sets[i % nsets][0], sets[i % nsets][1], out=sets[i % nsets][2], chars_pm_stride=stride)
     K = args.steps
-    modes = [("streamed", "0x200"), ("gated", "0"), ("open-span", "0x400")]
+    modes = [("streamed", "0x200"), ("open-span", "0"), ("all-wb", "0x100")]
     if os.environ.get("AB_MODES"):      # name=flags,name=flags (0x100: every masked row written back; 0x800: those of odd tiles)
         modes = [tuple(x.split("=")) for x in os.environ["AB_MODES"].split(",")]
     res = {m: [] for m, _ in modes}

@@ -2,7 +2,7 @@
 """Where the native host walk (csrc/hrx_host_walk.cpp, one host thread) and the device path (H2D + batch kernel + D2H +
 synchronise) of hrx_witness_batch_host cross over: microseconds per call against the batch size, regex1 + substr1, M = 1024
 (and D = 2, regex1 + regex2).  The library's default threshold (HRX_DEFAULT_HOST_THRESHOLD rows) is read off this table
-(DESIGN.md §7c).  Run on the GPU box."""
+(NOTES_MEASUREMENTS.md §7c).  Run on the GPU box."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,4 @@
-"""PCIe-inclusive rate of the host-buffer entry point (hrx_witness_batch_host) on the bench workload: DESIGN.md §4.
+"""PCIe-inclusive rate of the host-buffer entry point (hrx_witness_batch_host) on the bench workload: NOTES_MEASUREMENTS.md §4.4.
 Never the bench's `value`."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

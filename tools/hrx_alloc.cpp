@@ -1,6 +1,6 @@
 // hrx_alloc.cpp — TOOLS ONLY (linked into libhrx_ablation.so, not into libhrx.so; not declared in include/hrx.h):
 // hrx_chunked_alloc / hrx_chunked_free, device buffers assembled from 2-MiB physical chunks, for the placement probes
-// (tools/alloc_policy_probe.py, tools/set_probe3.py; DESIGN.md §4.3).
+// (tools/alloc_policy_probe.py, tools/set_probe3.py; DESIGN.md §6).
 //
 // Background.  On an MI355X the bandwidth of concurrent write streams depends on where the streams lie in the PHYSICAL
 // address space: 6.3 TB/s for two streams inside one region, 7.4-7.5 TB/s across two (tools/halves_probe.cpp on one
