@@ -135,7 +135,6 @@ struct hrx_ctx {
     int place_max_steps = 48;
     bool place_max_steps_set = false;   // HRX_PLACE_MAX_STEPS given: it bounds arena walks too (their own cap is kPlaceArenaHardSteps)
     double place_seen_rate = 0.0;     // bytes per microsecond of the best candidate any DIRECT walk (records >= 1 GiB) of this context has probed; arena walks keep theirs per device (hrx_place_pool)
-    uint32_t gate_w = 24;             // def-parallel kernel: slack of the write-front gate in tiles (0: no gate; HRX_GATE_W read at context creation)
     size_t place_max_bytes = 0;       // hrx_ctx_set_placement: the most device memory a walk may hold at once (0: 70 % of what is free)
     double place_max_ms = 0.0;        // ... and the wall-clock time a walk may take (0: the rule's own bounds, hrx_place_rule.hpp)
     hrx_place_report last_place{};
@@ -339,7 +338,6 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     if (const char *v = std::getenv("HRX_PLACE")) c->place_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_MP_COMBINE")) c->mp_combine = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_PLACE_TRACE")) c->place_trace = std::atoi(v) != 0;
-    if (const char *v = std::getenv("HRX_GATE_W")) { const int n = std::atoi(v); if (n >= 0 && n <= 4096) c->gate_w = (uint32_t)n; }
     if (const char *v = std::getenv("HRX_PLACE_MAX_STEPS")) { const int n = std::atoi(v); if (n >= 1 && n <= 256) { c->place_max_steps = n; c->place_max_steps_set = true; } }
     c->pool = pool_acquire(device);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -566,18 +564,6 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
             a.group_base = 0;
             a.group_first_dyn = slots;
         }
-        if (li.split == 5 && ctx->gate_w && a.n_groups <= (uint32_t)li.grid * (uint32_t)(li.waves_per_wg / ((int)a.D + 1)) && (a.M + 63u) / 64u >= 4u * ctx->gate_w) {
-            // the def-parallel kernel's write-front gate (hrx_kernel_pmd.hip): one group per loader, the progress counter in the context's scratch words
-            if (ctx->scratch_used && ctx->scratch_stream != st && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) {
-                (void)hipGetLastError();
-                return fail(HRX_ERR_STATE, "the context's launch scratch is in use on another stream and that stream cannot be waited for here (stream capture?): one context serves one stream / graph at a time");
-            }
-            ctx->scratch_stream = st; ctx->scratch_used = true;
-            HIP_TRY(launch_zero_u32(ctx->d_group_counter + 1, st));
-            a.gate = ctx->d_group_counter + 1; a.gate_w = ctx->gate_w; a.gate_n = a.n_groups;
-        }
-        if (std::getenv("HRX_PMD_ROLES_OLD")) a.gate_w |= 0x80000000u;   // TEMP A/B
-        if (const char *v = std::getenv("HRX_PMD_PRIO")) a.gate_w |= ((uint32_t)std::atoi(v) & 3u) << 28;   // TEMP A/B
         a.nt_mix = plan_nt_mix(a, li);
 #if defined(HRX_STAMPS) || defined(HRX_ABLATION) || defined(HRX_NT_ENV)
         if (const char *nm = std::getenv("HRX_NT_MIX")) a.nt_mix = (uint32_t)std::strtoul(nm, nullptr, 0);

@@ -62,10 +62,6 @@ struct WitnessArgs {
     uint2 *vs_info;               // [chunk][B]: pend | fwd << 1 | sm << 2 | dec << 3, pend_start (hrx_lane.h TileMasks)
     uint32_t sm_no_touch;         // walker/storer kernel: 1 = the storer does not warm L2 for the walker (set by plan_witness_launch; hrx_kernel_sm.hip)
     uint32_t nt_mix;              // position-major kernels: which stores are write-back instead of streaming (kNtMix*, hrx_kernel_pm.hip)
-    // write-front gate (def-parallel kernel, hrx_kernel_pmd.hip): every group's combiner adds its finished tiles to *gate; a loader stalls (bounded) while its group is
-    // more than gate_w tiles ahead of the chip's average.  NULL / 0: no gate.
-    uint32_t *gate;
-    uint32_t gate_w, gate_n;      // slack in tiles; groups that add to the counter
     uint32_t pace_even;           // profiling only (HRX_PACE, stamps / ablation builds): x 64 idle cycles per tile for the walkers of even workgroups; 0 in the product
     DefConsts dc[kMaxDefsPerLaunch];
 };

@@ -27,24 +27,14 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t G = (blockDim.x >> 6) / (D + 1u);      // groups a workgroup walks at a time
-    // Which wave does what.  The waves of a workgroup go to the CU's four SIMDs round-robin (wave w -> SIMD w % 4) and two waves of one SIMD share its issue slots.
-    // Round 4 dealt the roles in order — group 0's D walkers, group 1's, then the loaders — which at D = 3, G = 2 put group 0's combiner (the heaviest wave: walk + sums +
-    // reveal mask + masked rows) beside a loader and group 1's beside another walker: group 0 of EVERY workgroup finished at 2435 us, group 1 at 2918 us of a 2957-us
-    // launch (tools/front_width.py, profiles/r05_probes/cfg4_front_width.txt) — a fifth of the launch ran with half the groups gone.  Now, at G = 2, both groups get
-    // the same company: SIMD 0 {combiner 0, loader 0}, SIMD 1 {combiner 1, loader 1}, SIMD 2 {walker d0 of group 0, of group 1}, SIMD 3 {walker d1 of group 0, of group 1}
-    // (D = 2: SIMDs 2 and 3 hold one d0 walker each).
-    bool is_walker;
-    uint32_t lg, d;                                       // local group; the def this walker walks
-    if (G == 2u && !(a.gate_w >> 31)) {
-        if (wave < 2u) { is_walker = true; lg = wave; d = D - 1u; }
-        else if (wave == 4u || wave == 5u) { is_walker = false; lg = wave - 4u; d = 0u; }
-        else if (D == 2) { is_walker = true; lg = wave - 2u; d = 0u; }
-        else { is_walker = true; lg = wave >= 6u ? 1u : 0u; d = wave >= 6u ? wave - 6u : wave - 2u; }
-    } else {
-        is_walker = wave < G * D;
-        lg = is_walker ? wave / D : wave - G * D;
-        d = is_walker ? wave % D : 0u;
-    }
+    // Roles in wave order: group 0's D walkers, group 1's, then the loaders.  The waves of a workgroup go to the CU's four SIMDs round-robin, so at D = 3, G = 2
+    // group 0's combiner shares its SIMD with a loader and group 1's with another walker: group 0 of EVERY workgroup finishes at ~2435 us, group 1 at ~2918 us of a
+    // 2957-us launch over 32768 rows (tools/front_width.py) — and that is the faster arrangement.  Round 5 dealt the roles so that both groups get the same company
+    // (both finish together, the chip-wide write front 4-18 tiles wide instead of 110): 11 % SLOWER in a same-lease A/B (3.245 against 2.914 ms), and a gate that holds
+    // loaders back once they are W tiles ahead of the chip's average moved the launch by -2 .. +2 %: profiles/r05_probes/cfg4_front_width.txt.
+    const bool is_walker = wave < G * D;
+    const uint32_t lg = is_walker ? wave / D : wave - G * D;
+    const uint32_t d = is_walker ? wave % D : 0u;         // the def this walker walks
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
     // LDS per group: ring | (D - 1) x (2 summaries + piece) | counters: ready, freed[D], per publishing walker sum_prod, sum_cons, piece_prod; merged
@@ -77,8 +67,6 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
         const uint32_t row_cap = (uint32_t)a.stride - 16u;
         const size_t cmul = in_pm ? (size_t)B : (size_t)1;
         uint4 buf[RT * 4u];
-        bool gate_off = false;
-        uint32_t gate_avg = 0;
         auto issue = [&](const uint32_t q, const uint32_t r) {
             const uint32_t g = g_first + (q / ntiles) * g_stride, t = q % ntiles;
             const uint32_t bl = min(g * 64u + lane, B - 1u);
@@ -108,27 +96,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
                         *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
                     }
                     ring_post(ready_off, sq + 1u);
-                    if (sq + RT < total) {
-                        // ---- write-front gate: the groups of a launch drift apart by ~20 % of their rows (tools/front_width.py: 110 tiles of 512 at 32768 rows), the fast
-                        // ones finish early and the launch ends with a tail of slow groups that cannot use the memory system alone.  A loader that is more than gate_w
-                        // tiles ahead of the chip's AVERAGE waits for it — bounded: a launch whose workgroups are not all resident (another launch holds CUs) must not
-                        // hang on the ones that have not started; after one timeout the loader stops looking.
-                        // The counter is ONE address: the memory side serves ~30 atomics per microsecond on it (a poll per tile and loader — 100 per microsecond — slowed the
-                        // launch threefold), so the combiners add every 16 tiles and a loader looks only every 16 tiles, and only when the average it knows does not let it pass
-                        // (the average only grows: a remembered value is on the safe side).  Read with an atomic RMW: a plain agent-scope load may hit a stale line in this XCD's L2.
-                        if (a.gate && !gate_off && ((sq + RT) & 15u) == 0u) {
-                            const uint32_t ahead = sq + RT;
-                            uint32_t spins = 0;
-                            while (ahead > (a.gate_w & 0xffffu) + gate_avg) {
-                                gate_avg = __hip_atomic_fetch_add(a.gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / a.gate_n;
-                                if (ahead <= (a.gate_w & 0xffffu) + gate_avg) break;
-                                if (++spins > 64u) { gate_off = true; break; }
-                                __builtin_amdgcn_s_sleep(127);
-                                __builtin_amdgcn_s_sleep(127);
-                            }
-                        }
-                        issue(sq + RT, r);
-                    }
+                    if (sq + RT < total) issue(sq + RT, r);
                 }
             }
         }
@@ -174,11 +142,6 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             if (a.stamps && combiner && lane == 0u && gi == 0u && (t % max(ntiles >> 3, 1u)) == 0u && t / max(ntiles >> 3, 1u) < 8u)
                 a.stamps[(size_t)(blockIdx.x * G + lg) * 16u + t / max(ntiles >> 3, 1u)] = wall_clock64();
 #endif
-            if (a.gate_w & 0x30000000u) {   // TEMP experiment: issue priority flips between the two groups of a workgroup
-                const uint32_t period = (a.gate_w & 0x10000000u) ? ntiles / 2u : 32u;
-                const bool second = ((t / max(period, 1u)) & 1u) != 0u;
-                if (second == (lg == 1u)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            }
             ring_wait(ready_off, seq + 1u);
             uint4 cq[4];
 #pragma unroll
@@ -300,7 +263,6 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
                 }
                 mp += 8u * mstep;
             }
-            if (a.gate && (t & 15u) == 15u && lane == 0u) __hip_atomic_fetch_add(a.gate, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (tiles finished: the loaders' gate)
         }
 #ifdef HRX_STAMPS
         if (a.stamps && combiner && lane == 0u && gi == 0u) a.stamps[(size_t)(blockIdx.x * G + lg) * 16u + 8u] = wall_clock64();
