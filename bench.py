@@ -243,6 +243,10 @@ def mix_ceiling(dev_index):
         return None
 
 
+def profiled_now():
+    return under_profiler()
+
+
 def under_profiler():
     """True when this process itself runs under rocprofv3 (its tool library is preloaded): no nested profiler runs then, and no
     other helper processes either — a process forked from a profiled one must not exec."""
@@ -627,6 +631,47 @@ def run_rank(args, rank, world, device_index, barrier):
         except Exception as e:
             sys.stderr.write("string-major-input probe failed: %s\n" % e)
     del sm_sets
+    # The path an UNMODIFIED caller of the seam takes: host Vecs in, host Vecs out (lib.rs:311-318) through hrx_witness_batch_host — PCIe-inclusive, never `value` —
+    # and what a host consumer pays to pull ONE circuit's rows out of position-major buffers copied to the host as they are.
+    if is_default_workload(args) and world == 1 and not args.no_spread and not profiled_now():
+        try:
+            import ctypes as C
+            hrec, hmsk, hst = np.empty((B, M, D), np.uint32), np.empty((B, M), np.uint16), np.empty(B, np.uint64)
+            hc = np.ascontiguousarray(chars[:, :stride])
+            cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))          # (first call: the context's staging buffers, first touch of the output pages)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))
+                ts.append(time.perf_counter() - t0)
+            ms = statistics.median(ts) * 1e3
+            e2e = {"ms_per_call": ms, "ms_min": min(ts) * 1e3, "rows_per_s": rows_per_step / (ms * 1e-3), "calls": 5,
+                   "bytes_out": int(hrec.nbytes + hmsk.nbytes + hst.nbytes), "bytes_in": int(hc.nbytes + 4 * B),
+                   "gbs_out": (hrec.nbytes + hmsk.nbytes + hst.nbytes) / (ms * 1e-3) / 1e9,
+                   "status_ok": bool(((hst & np.uint64(0xff)) == 0).all()),
+                   "what": "hrx_witness_batch_host on the same batch: pageable host arrays in (string-major, %d B apart) and out (records [B][M][D] u32, masked [B][M] u16, status), "
+                           "output arrays reused; staged, walked and copied out chunk by chunk (two streams, a staging thread); the call lasts as long as the copy out over the "
+                           "PCIe link (gbs_out)" % stride}
+            rp, mp = sets[0][2][0].cpu().numpy().view(np.uint32), sets[0][2][1].cpu().numpy().view(np.uint16)
+            r1, m1 = np.empty((M, D), np.uint32), np.empty(M, np.uint16)
+            fn = hra.lib.hrx_rows_of_string_position_major
+            picks = np.random.default_rng(0).integers(0, B, 4000)
+            args_c = (rp.ctypes.data, mp.ctypes.data, B, M, D)
+            same = True
+            for b in picks[:64]:
+                fn(*args_c, int(b), r1.ctypes.data, m1.ctypes.data)
+                same = same and np.array_equal(r1, hrec[int(b)]) and np.array_equal(m1, hmsk[int(b)])    # (set 0 holds the batch unrotated)
+            t0 = time.perf_counter()
+            for b in picks:
+                fn(*args_c, int(b), r1.ctypes.data, m1.ctypes.data)
+            e2e["gather_us_per_string"] = (time.perf_counter() - t0) / len(picks) * 1e6
+            e2e["gather_equals_host_path_rows"] = bool(same)
+            e2e["gather_what"] = ("hrx_rows_of_string_position_major: one circuit's [M][D] records + [M] masked rows gathered on one host core out of position-major HOST "
+                                  "buffers (the device buffers copied out as they are), random strings, through ctypes")
+            res["end_to_end_host"] = e2e
+            del hrec, hmsk, hst, rp, mp
+        except Exception as e:
+            sys.stderr.write("end-to-end host probe failed: %s\n" % e)
     res["desc"] = desc
     res["placement"] = placement
     res["library"] = os.path.realpath(hra.LIB_PATH)
@@ -750,6 +795,8 @@ def aggregate(per_rank, args):
         line["cpu_baseline"] = r0["cpu_baseline"]
     if r0.get("single_string"):
         line["single_string"] = r0["single_string"]
+    if r0.get("end_to_end_host"):
+        line["end_to_end_host"] = r0["end_to_end_host"]
     if r0.get("warmup_effective"):
         line["warmup_effective"] = r0["warmup_effective"]
     return line

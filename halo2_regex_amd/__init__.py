@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
     "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_chars_to_position_major_device", "hrx_device_free",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_ctx_set_placement", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
-    "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_describe_launch",
+    "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_rows_of_string_position_major", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
     "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_shard_device", "hrx_multi_shard_stream", "hrx_multi_witness_batch_host",
     "hrx_multi_witness_batch_device", "hrx_multi_synchronize",
@@ -105,6 +105,7 @@ def _load():
         "hrx_recommended_pitches": (None, [sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "hrx_witness_batch_device_layout": (i, [vp, i, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "hrx_rows_of_string_position_major": (i, [vp, vp, sz, sz, sz, sz, vp, vp]),
         "hrx_describe_launch": (i, [vp, i, sz, sz, i, C.c_char_p, sz]),
         "hrx_alloc_outputs_position_major": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
         "hrx_alloc_output_pair": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
@@ -470,6 +471,17 @@ def position_major_to_string_major(records_pm, masked_pm, B, M, D):
         recs.append(r.reshape(nb, -1, D)[:, :M])
         msks.append(m.reshape(nb, -1)[:, :M])
     return _cat(recs), _cat(msks)
+
+
+def rows_of_string_position_major(records_pm, masked_pm, B, M, D, b, out=None):
+    """hrx_rows_of_string_position_major: one circuit's rows — (M, D) uint32 records and (M,) uint16 masked rows of string b — gathered on the host out of
+    position-major HOST arrays (numpy; e.g. the device buffers copied out as they are)."""
+    rec = np.empty((M, D), np.uint32) if out is None else out[0]
+    msk = np.empty(M, np.uint16) if out is None else out[1]
+    rp = np.ascontiguousarray(records_pm).view(np.uint32)
+    mp = np.ascontiguousarray(masked_pm).view(np.uint16)
+    _check(lib.hrx_rows_of_string_position_major(rp.ctypes.data, mp.ctypes.data, B, M, D, b, rec.ctypes.data, msk.ctypes.data))
+    return rec, msk
 
 
 def shard_range(B, world, rank):

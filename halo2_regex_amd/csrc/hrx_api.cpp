@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -95,6 +96,7 @@ struct hrx_ctx {
     uint32_t debug = 0;      // HRX_DEBUG_FLAGS, read once at creation (hrx_kernel.hpp)
     size_t host_threshold = HRX_DEFAULT_HOST_THRESHOLD;   // rows (B x M) below which host-buffer batches take the host walk
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // host-buffer batches: the device-to-host copies of finished chunks run here while the next chunks are staged and walked on `stream`
     uint32_t *d_table = nullptr;
     uint64_t *d_wide = nullptr;
     uint16_t *d_half = nullptr;
@@ -341,6 +343,7 @@ int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     if (const char *v = std::getenv("HRX_PLACE_MAX_STEPS")) { const int n = std::atoi(v); if (n >= 1 && n <= 256) { c->place_max_steps = n; c->place_max_steps_set = true; } }
     c->pool = pool_acquire(device);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_group_counter, 64);
     if (e == hipSuccess) e = hipMemset(c->d_group_counter, 0, 64);
 
@@ -393,6 +396,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     DeviceGuard guard;
     if (c->device != HRX_DEVICE_NONE) (void)guard.set(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_half) (void)hipFree(c->d_half);
@@ -1169,6 +1173,29 @@ int hrx_device_free(void *ptr) {
     return HRX_OK;
 }
 
+int hrx_rows_of_string_position_major(const uint32_t *records_pm, const uint16_t *masked_pm, size_t B, size_t M, size_t D, size_t b, uint32_t *records, uint16_t *masked) {
+    if (!records_pm && !masked_pm) return fail(HRX_ERR_ARG, "NULL buffer");
+    if ((records_pm && !records) || (masked_pm && !masked)) return fail(HRX_ERR_ARG, "NULL output");
+    if (b >= B || M == 0 || D == 0 || D > HRX_MAX_DEFS) return fail(HRX_ERR_ARG, "string index or shape out of range");
+    const size_t k = b / HRX_PM_BLOCK, bl = b % HRX_PM_BLOCK, nb = std::min<size_t>(HRX_PM_BLOCK, B - k * HRX_PM_BLOCK);
+    const size_t q4 = (M + 3) / 4, q8 = (M + 7) / 8;
+    if (records_pm) {
+        const uint32_t *base = records_pm + k * HRX_PM_BLOCK * q4 * D * 4 + bl * 4;       // quad q of def d: base + (q * D + d) * nb * 4
+        for (size_t q = 0; q < q4; ++q) {
+            const size_t rows = std::min<size_t>(4, M - 4 * q);
+            for (size_t d = 0; d < D; ++d) {
+                const uint32_t *src = base + (q * D + d) * nb * 4;
+                for (size_t i = 0; i < rows; ++i) records[(4 * q + i) * D + d] = src[i];
+            }
+        }
+    }
+    if (masked_pm) {
+        const uint16_t *base = masked_pm + k * HRX_PM_BLOCK * q8 * 8 + bl * 8;
+        for (size_t o = 0; o < q8; ++o) std::memcpy(masked + 8 * o, base + o * nb * 8, 2 * std::min<size_t>(8, M - 8 * o));
+    }
+    return HRX_OK;
+}
+
 void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16) {
     if (records_u32) *records_u32 = (M + 3) / 4 * B * 4 * D;
     if (masked_u16) *masked_u16 = (M + 7) / 8 * B * 8;
@@ -1196,17 +1223,81 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
     HIP_TRY(ctx->masked.reserve(2 * B * M));
     HIP_TRY(ctx->status.reserve(8 * B));
     hipStream_t st = ctx->stream;
-    if (dstride != stride) HIP_TRY(hipMemsetAsync(ctx->chars.p, 0, dstride * B, st));
-    if (stride) HIP_TRY(hipMemcpy2DAsync(ctx->chars.p, dstride, chars, stride, stride, B, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->lens.p, lens, 4 * B, hipMemcpyHostToDevice, st));
-    if (int rc = launch_batch(ctx, (const uint8_t *)ctx->chars.p, dstride, (const uint32_t *)ctx->lens.p, B, M,
-                              (uint32_t *)ctx->records.p, (uint16_t *)ctx->masked.p, (uint64_t *)ctx->status.p, st))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(records, ctx->records.p, 4 * B * M * D, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(masked, ctx->masked.p, 2 * B * M, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(status, ctx->status.p, 8 * B, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return HRX_OK;
+    // Large batches go CHUNK BY CHUNK, two host threads: a producer stages chunk c (host-to-device) and launches its walk on `stream`, the calling thread copies chunk
+    // c - 1's finished rows out on `copy_stream` — the link is full duplex and a copy from or to pageable memory holds its host thread until it has landed, so one thread
+    // cannot have both directions busy.  The rows leave 6 D' bytes per byte that comes in (448 MiB out, 64 MiB in at 65536 x 1024, D = 1): the copy out IS the call
+    // (8.1 of round 4's 8.7 ms: ~55 GB/s, the link's rate in one direction); what the pipeline removes is the staging and the walk in front of it.
+    const size_t out_per_string = M * (4 * D + 2);
+    size_t cb = out_per_string ? ((size_t)48 << 20) / out_per_string / 64 * 64 : B;   // ~48 MiB of rows per chunk
+    if (cb < 1024) cb = 1024;
+    const size_t nchunk = (B + cb - 1) / cb;
+    if (nchunk < 3 || ctx->copy_stream == nullptr) {
+        if (dstride != stride) HIP_TRY(hipMemsetAsync(ctx->chars.p, 0, dstride * B, st));
+        if (stride) HIP_TRY(hipMemcpy2DAsync(ctx->chars.p, dstride, chars, stride, stride, B, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->lens.p, lens, 4 * B, hipMemcpyHostToDevice, st));
+        if (int rc = launch_batch(ctx, (const uint8_t *)ctx->chars.p, dstride, (const uint32_t *)ctx->lens.p, B, M,
+                                  (uint32_t *)ctx->records.p, (uint16_t *)ctx->masked.p, (uint64_t *)ctx->status.p, st))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(records, ctx->records.p, 4 * B * M * D, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(masked, ctx->masked.p, 2 * B * M, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(status, ctx->status.p, 8 * B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return HRX_OK;
+    }
+    std::vector<hipEvent_t> done(nchunk, nullptr);
+    for (size_t c = 0; c < nchunk; ++c)
+        if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+            return fail(HRX_ERR_HIP, "hipEventCreate failed");
+        }
+    std::atomic<size_t> staged{0};
+    std::atomic<int> prc{HRX_OK};
+    std::string pmsg;
+    const int device = ctx->device;
+    std::thread producer([&] {
+        DeviceGuard g2;
+        if (g2.set(device) != hipSuccess) { pmsg = "hipSetDevice failed in the staging thread"; prc = HRX_ERR_HIP; staged = nchunk; return; }
+        for (size_t c = 0; c < nchunk; ++c) {
+            const size_t b0 = c * cb, n = std::min(cb, B - b0);
+            unsigned char *dch = (unsigned char *)ctx->chars.p + b0 * dstride;
+            hipError_t e = hipSuccess;
+            if (dstride != stride) e = hipMemsetAsync(dch, 0, dstride * n, st);
+            if (e == hipSuccess && stride) e = hipMemcpy2DAsync(dch, dstride, chars + b0 * stride, stride, stride, n, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync((uint32_t *)ctx->lens.p + b0, lens + b0, 4 * n, hipMemcpyHostToDevice, st);
+            int rc = HRX_OK;
+            if (e == hipSuccess)
+                rc = launch_batch(ctx, dch, dstride, (const uint32_t *)ctx->lens.p + b0, n, M, (uint32_t *)ctx->records.p + b0 * M * D,
+                                  (uint16_t *)ctx->masked.p + b0 * M, (uint64_t *)ctx->status.p + b0, st);
+            if (e == hipSuccess && rc == HRX_OK) e = hipEventRecord(done[c], st);
+            if (e != hipSuccess || rc != HRX_OK) {
+                pmsg = e != hipSuccess ? std::string("HIP error while staging a chunk: ") + hipGetErrorString(e) : std::string(hrx_last_error());
+                (void)hipGetLastError();
+                prc = e != hipSuccess ? HRX_ERR_HIP : rc;
+                staged = nchunk;      // release the consumer
+                return;
+            }
+            staged = c + 1;
+        }
+    });
+    int rc = HRX_OK;
+    hipError_t ce = hipSuccess;
+    for (size_t c = 0; c < nchunk && ce == hipSuccess; ++c) {
+        while (staged.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+        if (prc.load() != HRX_OK) break;
+        const size_t b0 = c * cb, n = std::min(cb, B - b0);
+        ce = hipStreamWaitEvent(ctx->copy_stream, done[c], 0);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(records + b0 * M * D, (uint32_t *)ctx->records.p + b0 * M * D, 4 * n * M * D, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(masked + b0 * M, (uint16_t *)ctx->masked.p + b0 * M, 2 * n * M, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(status + b0, (uint64_t *)ctx->status.p + b0, 8 * n, hipMemcpyDeviceToHost, ctx->copy_stream);
+    }
+    producer.join();
+    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(st);
+    for (hipEvent_t e : done) (void)hipEventDestroy(e);
+    if (prc.load() != HRX_OK) return fail(prc.load(), pmsg);
+    if (ce != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, std::string("HIP error while copying a chunk out: ") + hipGetErrorString(ce)); }
+    return rc;
 }
 
 // host-buffer batches below the context's threshold (and every batch of a host-only context) take the native host walk

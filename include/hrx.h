@@ -183,6 +183,13 @@ enum { HRX_LAYOUT_STRING_MAJOR = 0, HRX_LAYOUT_POSITION_MAJOR = 1, HRX_LAYOUT_IN
 int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,
                                     size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream);
 void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16);
+/* One circuit's view of a position-major batch, on the HOST: the rows of string b of a batch of B strings x M rows x D defs that lies in host memory in
+ * HRX_LAYOUT_POSITION_MAJOR (e.g. copied from the device as it is) -> records [M][D] u32 and masked [M] u16, the string-major values the fill loops of
+ * match_substrs index per string (src/lib.rs:387-519).  A string's consecutive quads are nb*16*D bytes apart, so this is M/4*D + M/8 gathers of 16 bytes:
+ * ~10 us per 1024-row string on one core (bench.py: end_to_end_host.gather_us_per_string) against the ~(14 D + 21) gate calls per row that consume
+ * them.  Either buffer pair may be NULL (records_pm with records, masked_pm with masked).  No context, no device, re-entrant. */
+int hrx_rows_of_string_position_major(const uint32_t *records_pm, const uint16_t *masked_pm, size_t B, size_t M, size_t D, size_t b,
+                                      uint32_t *records, uint16_t *masked);
 /* Allocates the records and masked-row buffers of a position-major batch of B strings x M rows (sizes as
  * hrx_position_major_sizes) on ctx's device; each is released with hrx_device_free.  Optional — every entry point takes any
  * device pointer — and for records below 128 MiB (a launch that lives in the 256-MB Infinity Cache) just two hipMalloc calls.
@@ -268,7 +275,10 @@ int hrx_device_free(void *ptr);
  * launched and no device is touched.  Returns HRX_OK, HRX_ERR_BOUNDS if nothing fits. */
 int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap);
 /* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers, or — below the
- * context's host threshold, and always on a host-only context — walked on the host; synchronous. */
+ * context's host threshold, and always on a host-only context — walked on the host; synchronous.  This is what an unmodified caller of
+ * match_substrs' seam gets (host Vecs in, host Vecs out, src/lib.rs:311-318).  Batches of more than ~100 MiB of rows are pipelined chunk by chunk:
+ * a staging thread copies chunk c in and launches its walk while the calling thread copies chunk c - 1's rows out on a second stream; the call lasts
+ * as long as the copy out — (4 D + 2) bytes per row over the PCIe link in one direction (bench.py: end_to_end_host). */
 int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
                            size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);
 

@@ -142,6 +142,27 @@ def test_placement_switches_check_their_arguments():
     assert rep["searched"] == 0 and rep["capped"] == 0
 
 
+def test_rows_of_one_string_out_of_position_major_host_buffers():
+    """hrx_rows_of_string_position_major against the layout's definition (include/hrx.h): blocked by 65536 strings, partial last quad / octet, D up to 5"""
+    rng = np.random.default_rng(0)
+    for (B, M, D) in [(5, 7, 1), (70000, 9, 2), (130, 64, 3), (65537, 8, 5)]:
+        q4, q8 = (M + 3) // 4, (M + 7) // 8
+        rec_sm = rng.integers(0, 2 ** 32, size=(B, M, D), dtype=np.uint32)
+        msk_sm = rng.integers(0, 2 ** 16, size=(B, M), dtype=np.uint16)
+        rp, mp = np.zeros(q4 * B * 4 * D, np.uint32), np.zeros(q8 * B * 8, np.uint16)
+        for b in range(0, B, max(1, B // 997)):            # scatter a sample of strings by the formula of include/hrx.h
+            k, bl = b // hra.PM_BLOCK, b % hra.PM_BLOCK
+            nb = min(hra.PM_BLOCK, B - k * hra.PM_BLOCK)
+            for r in range(M):
+                for d in range(D):
+                    rp[k * hra.PM_BLOCK * q4 * D * 4 + ((r // 4 * D + d) * nb + bl) * 4 + r % 4] = rec_sm[b, r, d]
+                mp[k * hra.PM_BLOCK * q8 * 8 + (r // 8 * nb + bl) * 8 + r % 8] = msk_sm[b, r]
+            r1, m1 = hra.rows_of_string_position_major(rp, mp, B, M, D, b)
+            assert np.array_equal(r1, rec_sm[b]) and np.array_equal(m1, msk_sm[b]), (B, M, D, b)
+        with pytest.raises(hra.HrxError):
+            hra.rows_of_string_position_major(rp, mp, B, M, D, B)
+
+
 def test_planner_thresholds_of_round_3():
     """Where the chunked launch stops (below 2 / up to 1.75 / up to 1.5 groups of 64 strings per CU at D = 1 / 2 / 3, either input layout,
     position-major outputs, 4096 rows or more) and the one-round rule for small batches (profiles/r03_probes/spec_threshold.txt)."""

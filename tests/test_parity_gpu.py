@@ -1159,6 +1159,44 @@ def test_placement_arenas_are_shared_by_the_contexts_of_a_device(hra, oracle):
     assert free0 - torch.cuda.mem_get_info()[0] < (256 << 20)                                          # the last context of the device is gone: so is the pair
 
 
+def test_host_buffer_batches_are_pipelined_chunk_by_chunk(hra, oracle):
+    """hrx_witness_batch_host — what an unmodified caller of the seam gets (host Vecs in, host Vecs out, lib.rs:311-318) — stages, walks and copies a large batch out
+    chunk by chunk on two streams and two host threads.  Every string against the oracle: a batch of several chunks with a last partial one, ragged strings, strings
+    with undefined transitions in several chunks, a stride that is not a multiple of 16 (the staging pads it), two defs; and the same rows gathered per circuit out of
+    the position-major device buffers copied to the host as they are (hrx_rows_of_string_position_major)."""
+    import torch
+    from halo2_regex_amd import synth
+    M = 1024
+    for names, B, stride in ((CFG_1, 40000, 1024), (CFG_A, 21001, 1023)):
+        D = len(names)
+        chars, lens = synth.regex1_planted(B, min(stride, M - 1), seed=41, stride=stride) if stride % 16 == 0 else synth.regex1_planted(B, 1008, seed=41, stride=1008)
+        if chars.shape[1] != stride:                       # an odd stride: re-pack the strings 1023 bytes apart
+            wide = np.zeros((B, stride), np.uint8); wide[:, :chars.shape[1]] = chars; chars = wide
+        rng = np.random.default_rng(3)
+        idx = rng.choice(B, 300, replace=False)
+        lens[idx[:200]] = rng.integers(0, lens[idx[:200]] + 1)
+        chars[idx[200:], rng.integers(0, 900, 100)] = 200   # a byte no definition has a transition for: lib.rs:817 in chunks all over the batch
+        cfg = _cfg(hra, names, M)
+        grec, gmsk, gst = cfg.witness_batch_host(chars, lens)
+        o = OracleDefs.from_files(oracle, names)
+        orec, omsk, ost = o.witness_batch(chars, lens, M, threads=os.cpu_count() or 8)
+        ok = (ost & np.uint64(0xff)) == 0
+        assert np.array_equal(gst, ost) and (~ok).sum() >= 90
+        assert np.array_equal(grec[ok], orec[ok]) and np.array_equal(gmsk[ok], omsk[ok])
+        # per-circuit view of the position-major buffers, on the host
+        dev = torch.device("cuda", 0)
+        padded = chars if stride % 16 == 0 else np.pad(chars, ((0, 0), (0, 16 - stride % 16)))
+        d_c = hra.chars_to_position_major(torch.from_numpy(padded).to(dev))
+        rec, msk, st = cfg.witness_batch_position_major(d_c, torch.from_numpy(lens.astype(np.int32)).to(dev), chars_pm_stride=padded.shape[1])
+        torch.cuda.synchronize()
+        rp, mp = rec.cpu().numpy().view(np.uint32), msk.cpu().numpy().view(np.uint16)
+        for b in [0, B - 1] + [int(x) for x in rng.choice(np.nonzero(ok)[0], 40)]:
+            if not ok[b]:
+                continue
+            r1, m1 = hra.rows_of_string_position_major(rp, mp, B, M, D, b)
+            assert np.array_equal(r1, orec[b]) and np.array_equal(m1, omsk[b]), b
+
+
 def test_arena_free_waits_for_the_device(hra, oracle):
     """hrx_device_free on a sub-buffer of the shared arena pair waits for the device like hipFree does (include/hrx.h): the range is reusable by any
     context right after the call, so a buffer freed while its launch is still in flight must not be handed to a second context that writes it on
