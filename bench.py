@@ -47,6 +47,7 @@ def parse_args(argv=None):
                     "reference's three DFAs; headers3: configs[3] shape (D=3 from/to/subject header definitions, 5 substrs); dfa256: configs[4] shape (synthetic total 256-state DFA over all 256 byte values)")
     ap.add_argument("--untimed-replays", type=int, default=0, help="untimed replays of the K-step graph before the timed one (default: ~100 ms of them)")
     ap.add_argument("--substr-pairs", type=int, default=200, help="dfa256: transitions in the random substring definition")
+    ap.add_argument("--substr-defs", type=int, default=1, help="dfa256: substring definitions of the random DFA (SURVEY §8d cfg 5: 1-2), --substr-pairs tagged pairs each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed buffers with the oracle")
     ap.add_argument("--no-spread", action="store_true", help="skip the extra replays that give the per-step spread")
@@ -326,8 +327,13 @@ def workload(args):
         gen = synth.headers_planted if args.dist == "planted" else synth.noise
     else:
         allb = np.arange(256, dtype=np.uint8)
-        a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=args.substr_pairs)
-        names, label, alphabet = [(a_txt.encode(), [sub_txt.encode()])], "synthetic total DFA 256 states x 256 symbols (seed 2), one substring definition of %d random tagged (state, next) pairs" % args.substr_pairs, "all 256 byte values"
+        if args.substr_defs > 1:
+            a_txt, subs = synth.random_dfa_multi(256, seed=2, alphabet=allb, n_substr_pairs=args.substr_pairs, n_substrs=args.substr_defs)
+        else:
+            a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=args.substr_pairs)
+            subs = [sub_txt]
+        names, label, alphabet = [(a_txt.encode(), [t.encode() for t in subs])], "synthetic total DFA 256 states x 256 symbols (seed 2), %d substring definition%s of %d random tagged (state, next) pairs%s" % (
+            len(subs), "" if len(subs) == 1 else "s", args.substr_pairs, "" if len(subs) == 1 else " each"), "all 256 byte values"
         gen = lambda B, n, seed=0, stride=None: synth.noise(B, n, seed=seed, alphabet=allb, stride=stride)
     planted = gen in (synth.regex1_planted, synth.regex23_planted, synth.headers_planted)
     return names, label, alphabet, gen, planted

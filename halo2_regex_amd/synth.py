@@ -124,6 +124,23 @@ def reveal_stress(B, n, seed=7):
     return chars, lens
 
 
+def random_dfa_multi(n_states, seed=2, alphabet=ALPHABET98, n_substr_pairs=40, n_substrs=2):
+    """The total DFA of random_dfa(n_states, seed, alphabet) with `n_substrs` substring definitions instead of one (SURVEY §8d cfg 5: "1-2 substr defs drawn as
+    random transition subsets"): n_substr_pairs tagged (state, next) pairs EACH, disjoint, so that every definition's id turns up in the rows.
+    Returns (allstr_text, [substr_text, ...])."""
+    allstr, _ = random_dfa(n_states, seed=seed, alphabet=alphabet, n_substr_pairs=1)
+    pairs = sorted({(int(l.split()[0]), int(l.split()[1])) for l in allstr.splitlines()[3:]})
+    rng = _rng(seed, 10)
+    order = rng.permutation(len(pairs))
+    subs = []
+    for j in range(n_substrs):
+        pick = [pairs[i] for i in order[j * n_substr_pairs:(j + 1) * n_substr_pairs]]
+        starts = sorted({a for a, _ in pick[: max(1, len(pick) // 4)]})
+        ends = sorted({b for _, b in pick[len(pick) // 2:]})
+        subs.append("\n".join(["16", "0", "1023", " ".join(map(str, starts)) + " ", " ".join(map(str, ends)) + " "] + ["%d %d" % p for p in sorted(pick)]) + "\n")
+    return allstr, subs
+
+
 def random_dfa(n_states, seed=2, alphabet=ALPHABET98, n_substr_pairs=40, total=True):
     """A synthetic total (or, with total=False, 90%-dense) DFA over `alphabet` in the reference's text format
     (src/defs.rs:60-68) plus one substring definition (defs.rs:165-177) drawn from its transitions.

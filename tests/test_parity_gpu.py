@@ -1536,6 +1536,28 @@ def test_full_size_cfg4_share_32768_strings_of_32768_bytes(hra, oracle):
     assert (st & np.uint64(0xff) == 0).all()
 
 
+def test_full_size_cfg5_two_substr_defs_131072_strings_of_4096_bytes(hra, oracle):
+    """BASELINE configs[4] with TWO substring definitions (SURVEY §8d cfg 5: "1-2 substr defs drawn as random transition subsets"): 100 tagged pairs each — ids 1 and 2 in
+    one def, so the BYTE kernel's finisher holds two tiles of id bytes instead of three of bits (no byte_one_id) — at full size, every string, both layouts' kernels."""
+    from halo2_regex_amd import synth
+    allb = np.arange(256, dtype=np.uint8)
+    allstr, subs = synth.random_dfa_multi(256, seed=2, alphabet=allb, n_substr_pairs=100, n_substrs=2)
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(allstr), [hra.SubstrRegexDef(t) for t in subs])]
+    n, M = 4095, 4096
+    base_c, base_l = synth.noise(hra.PM_BLOCK, n, seed=4, alphabet=allb, stride=4096)
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    assert "witness_pm_kernel<1, false, false, false, false, true>" in cfg.describe_launch(131072, layout=3)     # the BYTE table (200 tagged pairs in all)
+    o = OracleDefs(oracle, [(allstr, subs)])
+    st = _full_check(hra, o, cfg, _rolled_blocks(base_c, base_l, 2, seed=9), M, 1)
+    assert (st & np.uint64(0xff) == 0).all()
+    # both ids turn up in the masked rows of the batch (the oracle's view of the first strings)
+    orec, omsk, _ = o.witness_batch(base_c[:256], base_l[:256], M, threads=os.cpu_count() or 8)
+    assert set(np.unique(orec[..., 0] >> 16 & 0xff)) >= {0, 1, 2} and set(np.unique(omsk >> 8)) >= {1, 2}
+    # string-major: the walker/storer kernel on the BYTE table
+    assert "witness_split_kernel<1, 32, true>" in cfg.describe_launch(8192, layout=0)
+    _full_check(hra, o, cfg, [(base_c[:8192], base_l[:8192])], M, 1, position_major=False)
+
+
 def test_full_size_cfg5_dfa256_131072_strings_of_4096_bytes(hra, oracle):
     """BASELINE configs[4] shape: 256-state x 256-symbol DFA (HALF table in LDS), 131072 x 4096-byte strings = 2 blocks; the random
     substring definition makes the optimistic end-mask protocol repair rows every few tiles."""
