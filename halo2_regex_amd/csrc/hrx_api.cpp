@@ -123,6 +123,8 @@ struct hrx_ctx {
     DevBuf tp_records, tp_masked;   // string-major callers served by the position-major path + transpose_pm_to_sm_kernel (hrx_kernel_tp.hip)
     DevBuf spec_cls, spec_ends, spec_fail, spec_init, spec_vstatus, spec_vinfo, spec_work;
     bool spec_qabs_ready = false;
+    DevBuf spec_cimage;            // the scout's compact tables (class LUTs + class-indexed u16 tables), built with spec_qabs
+    uint32_t spec_cimage_bytes = 0, spec_c_lut[kMaxDefsPerPass] = {}, spec_c_tab[kMaxDefsPerPass] = {}, spec_c_rowb[kMaxDefsPerPass] = {}, spec_c_inv[kMaxDefsPerPass] = {};
     uint32_t spec_qabs[kMaxDefsPerPass][8];   // chunked launches (hrx_kernel_spec.hip)
     // dynamic group assignment (hrx_kernel_pm.hip): a device counter, zeroed on the launch's stream right before the launch
     // (a memset node when the launches are captured into a HIP graph: replay-safe)
@@ -412,6 +414,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     }
     c->mp_masked.release(); c->mp_ov.release();
     c->tp_records.release(); c->tp_masked.release();
+    c->spec_cimage.release();
     c->spec_cls.release(); c->spec_ends.release(); c->spec_fail.release(); c->spec_init.release(); c->spec_vstatus.release(); c->spec_vinfo.release(); c->spec_work.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
     pool_release(c->pool);   // the device's arena pair goes with its last context (now, or with its last sub-buffer)
@@ -537,9 +540,52 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
                         if (q) ctx->spec_qabs[d][t >> 5] |= 1u << (t & 31);
                     }
                 }
+                // ---- the scout's compact tables: per def, bytes with the same column in every row (real states, dummy row, dead row) are one CLASS
+                std::vector<uint8_t> img;
+                bool compact = true;
+                for (uint32_t d = 0; d < Dn && compact; ++d) {
+                    const uint32_t S = sp.n_states[d], R = S + 2u, base = set.consts[d].row_base;
+                    const uint32_t *T = set.table_image.data() + (size_t)base * 256;
+                    auto rel = [&](uint32_t r, uint32_t c) { const uint32_t e = T[(size_t)r * 256 + c]; const uint32_t x = (e >> kNextShift) - base; return e >= set.consts[d].dead_entry || x > S + 1u ? S + 1u : x; };
+                    std::map<std::vector<uint16_t>, uint32_t> cls_of;
+                    std::vector<std::vector<uint16_t>> cols;
+                    uint8_t lut[256];
+                    for (uint32_t c = 0; c < 256 && compact; ++c) {
+                        std::vector<uint16_t> col(R);
+                        for (uint32_t r = 0; r < R; ++r) col[r] = (uint16_t)rel(r, c);
+                        auto it = cls_of.find(col);
+                        if (it == cls_of.end()) {
+                            if (cols.size() >= 127) { compact = false; break; }
+                            it = cls_of.emplace(col, (uint32_t)cols.size()).first;
+                            cols.push_back(col);
+                        }
+                        lut[c] = (uint8_t)(it->second * 2u);
+                    }
+                    if (!compact) break;
+                    const uint32_t Cn = (uint32_t)cols.size(), rowb = Cn * 2u;
+                    const uint32_t lut_off = (uint32_t)img.size();
+                    img.insert(img.end(), lut, lut + 256);
+                    const uint32_t tab_off = (uint32_t)img.size();
+                    if ((size_t)tab_off + (size_t)R * rowb > 0xfff0u) { compact = false; break; }      // row addresses are u16
+                    img.resize((size_t)tab_off + (((size_t)R * rowb + 15) & ~(size_t)15), 0);
+                    for (uint32_t r = 0; r < R; ++r)
+                        for (uint32_t k = 0; k < Cn; ++k) {
+                            const uint16_t addr = (uint16_t)(tab_off + (uint32_t)cols[k][r] * rowb);
+                            std::memcpy(&img[(size_t)tab_off + (size_t)r * rowb + 2u * k], &addr, 2);
+                        }
+                    ctx->spec_c_lut[d] = lut_off; ctx->spec_c_tab[d] = tab_off; ctx->spec_c_rowb[d] = rowb; ctx->spec_c_inv[d] = (65536u + rowb - 1u) / rowb;
+                }
+                ctx->spec_cimage_bytes = 0;
+                if (compact && !img.empty() && !std::getenv("HRX_SPEC_NO_COMPACT")) {
+                    HIP_TRY(ctx->spec_cimage.reserve(img.size()));
+                    HIP_TRY(hipMemcpy(ctx->spec_cimage.p, img.data(), img.size(), hipMemcpyHostToDevice));       // (once per context, like the allocations above)
+                    ctx->spec_cimage_bytes = (uint32_t)img.size();
+                }
                 ctx->spec_qabs_ready = true;
             }
             std::memcpy(sp.qabs, ctx->spec_qabs, sizeof sp.qabs);
+            sp.cimage = ctx->spec_cimage_bytes ? (const uint8_t *)ctx->spec_cimage.p : nullptr; sp.cimage_bytes = ctx->spec_cimage_bytes;
+            for (uint32_t d = 0; d < Dn && d < kMaxDefsPerPass; ++d) { sp.c_lut[d] = ctx->spec_c_lut[d]; sp.c_tab[d] = ctx->spec_c_tab[d]; sp.c_rowb[d] = ctx->spec_c_rowb[d]; sp.c_inv[d] = ctx->spec_c_inv[d]; }
             sp.rows = (uint8_t *)ctx->spec_cls.p; sp.row_bytes = row_bytes;
 #ifdef HRX_ABLATION
             if (const char *v = std::getenv("HRX_SPEC_DBG")) sp.dbg = (uint32_t)std::strtoul(v, nullptr, 0);

@@ -224,6 +224,13 @@ struct SpecArgs {
     uint32_t qabs[kMaxDefsPerPass][8];       // bit s: real state s is quasi-absorbing — every byte keeps it where it is, except bytes that NO real state
                                              // of the def has a transition for (those send it to the dead row, like everybody else)
     uint32_t smax;                           // >= every n_states
+    // COMPACT scout tables (hrx_api.cpp build_scout_image): per def a 256-byte class LUT (byte -> 2 x its column class) and the transition table over
+    // CLASSES, u16 entries holding the LDS byte address of the next state's row: a row is a few dozen bytes, so the lanes of a wave — different strings, mostly the
+    // same few states — read a handful of dwords instead of 64 random ones (the 4-byte [state][byte] table costs ~4.5 bank-conflict passes per wave read).
+    // cimage == NULL: some def has more than 127 classes (or the image passes 64 KiB): the scout walks the narrow table.
+    const uint8_t *cimage;
+    uint32_t cimage_bytes;
+    uint32_t c_lut[kMaxDefsPerPass], c_tab[kMaxDefsPerPass], c_rowb[kMaxDefsPerPass], c_inv[kMaxDefsPerPass];   // LDS offsets of LUT and table, bytes per row, ceil(2^16 / rowb)
     const uint16_t *pair_tags[kMaxDefsPerLaunch];   // device (state, next) -> tag tables (hrx_defs.hpp pair_tags)
     // scratch: one row per (chunk, def, string), [chunk][def][n_groups * 64][row_bytes]: smax bytes "the state start state s reached after
     // the scout's stage A" + a 32-byte record (8 keys | where each key ends | where it is before the chunk's last byte | fail flag)

@@ -41,11 +41,12 @@ constexpr uint32_t kSpecSlots = 4;     // survivors walked to the chunk's end; m
 // ---------------------------------------------------------------------------------------------
 // scout: lane = (chunk, string); the narrow fused table in LDS
 // ---------------------------------------------------------------------------------------------
+template <bool COMPACT>
 __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.table_image);
+        const uint4 *src = reinterpret_cast<const uint4 *>(COMPACT ? (const void *)a.cimage : (const void *)a.table_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (COMPACT ? a.cimage_bytes : a.table_bytes) / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
     const uint32_t Bpad = a.n_groups * 64u;
@@ -71,6 +72,21 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
         const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
         for (uint32_t d = 0; d < a.D; ++d) {
             const uint32_t S = a.n_states[d], base = a.dc[d].row_base;
+            // A chain word `e` names a state.  Narrow table: the table entry (next row << kNextShift | tags), one v_and_or + ds_read_b32 per step at a random one of 64
+            // banks (column = byte).  COMPACT: the LDS byte address of the state's row in the class-indexed u16 table, one v_add + ds_read_u16 per step at one of the
+            // row's few dwords, and per byte (shared by the chains of the def) one ds_read_u8 of the 256-byte class LUT, which lies in 64 different banks.
+            const uint32_t c_lut = COMPACT ? a.c_lut[d] : 0u, c_tab = COMPACT ? a.c_tab[d] : 0u, c_rowb = COMPACT ? a.c_rowb[d] : 0u, c_inv = COMPACT ? a.c_inv[d] : 0u;
+            auto e_of = [&](const uint32_t s) -> uint32_t { return COMPACT ? c_tab + s * c_rowb : (base + s) << kNextShift; };
+            auto st_of = [&](const uint32_t e) -> uint32_t { return COMPACT ? ((e - c_tab) * c_inv) >> 16 : (e >> kNextShift) - base; };
+            auto name_of = [&](const uint32_t e) -> uint32_t { return COMPACT ? e : e & ~kTagMask; };
+            auto col_of = [&](const uint32_t byte) -> uint32_t { return COMPACT ? (uint32_t)*(__attribute__((address_space(3))) const uint8_t *)(uintptr_t)(c_lut + byte) : byte << 2; };
+            auto step = [&](const uint32_t e, const uint32_t col) -> uint32_t {
+                if (COMPACT) return (uint32_t)*(__attribute__((address_space(3))) const uint16_t *)(uintptr_t)(e + col);
+                return lds_u32((e & ~kTagMask) | col);
+            };
+            uint32_t pcol[kSpecPrefix];      // the prefix bytes' columns (COMPACT: their classes, looked up once for all chains of this def)
+#pragma unroll
+            for (uint32_t i = 0; i < kSpecPrefix; ++i) pcol[i] = col_of((pw[i >> 2] >> (8u * (i & 3u))) & 0xffu);
             uint32_t key[kSpecKeys], NK = 0, fail = 0;
 #pragma unroll
             for (uint32_t j = 0; j < kSpecKeys; ++j) key[j] = 0xffffffffu;
@@ -83,18 +99,17 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
             for (uint32_t s0 = s_begin; s0 < s_end; s0 += 4u) {
                 uint32_t e[4];
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) e[j] = (base + min(s0 + j, S - 1u)) << kNextShift;
+                for (uint32_t j = 0; j < 4u; ++j) e[j] = e_of(min(s0 + j, S - 1u));
 #pragma unroll
                 for (uint32_t i = 0; i < kSpecStageA; ++i) {
-                    const uint32_t c4 = ((pw[i >> 2] >> (8u * (i & 3u))) & 0xffu) << 2;
 #pragma unroll
-                    for (uint32_t j = 0; j < 4u; ++j) e[j] = lds_u32((e[j] & ~kTagMask) | c4);
+                    for (uint32_t j = 0; j < 4u; ++j) e[j] = step(e[j], pcol[i]);
                 }
                 uint32_t clsw = 0;        // the four candidates' states after stage A, one byte each
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; ++j) {
                     if (s0 + j < s_end && (only == 0xffffffffu || s0 + j == only)) {
-                        const uint32_t v = e[j] & ~kTagMask;
+                        const uint32_t v = name_of(e[j]);
                         bool have = false;
 #pragma unroll
                         for (uint32_t q = 0; q < kSpecKeys; ++q) have = have || key[q] == v;
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
                                 fail = 1;
                             }
                         }
-                        clsw |= (((v >> kNextShift) - base) & 0xffu) << (8u * j);
+                        clsw |= (st_of(v) & 0xffu) << (8u * j);
                     }
                 }
                 if (b < a.B) *reinterpret_cast<uint32_t *>(rowp + s0) = clsw;
@@ -120,15 +135,14 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
             NKw = (uint32_t)__builtin_amdgcn_readfirstlane((int)NKw);
             uint32_t kb[kSpecKeys];
 #pragma unroll
-            for (uint32_t j = 0; j < kSpecKeys; ++j) kb[j] = key[j] == 0xffffffffu ? (base << kNextShift) : key[j];
+            for (uint32_t j = 0; j < kSpecKeys; ++j) kb[j] = key[j] == 0xffffffffu ? e_of(0u) : key[j];
 #pragma unroll
             for (uint32_t h = 0; h < kSpecKeys; h += 4u) {
                 if (h < NKw) {
 #pragma unroll
                     for (uint32_t i = kSpecStageA; i < kSpecPrefix; ++i) {
-                        const uint32_t c4 = ((pw[i >> 2] >> (8u * (i & 3u))) & 0xffu) << 2;
 #pragma unroll
-                        for (uint32_t j = 0; j < 4u; ++j) kb[h + j] = lds_u32((kb[h + j] & ~kTagMask) | c4);
+                        for (uint32_t j = 0; j < 4u; ++j) kb[h + j] = step(kb[h + j], pcol[i]);
                     }
                 }
             }
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
             for (uint32_t j = 0; j < kSpecKeys; ++j) {
                 kslot[j] = 0;
                 if (j < NK) {
-                    const uint32_t v = kb[j] & ~kTagMask;
+                    const uint32_t v = name_of(kb[j]);
                     uint32_t idx = 0xffu;
 #pragma unroll
                     for (uint32_t q = 0; q < kSpecSlots; ++q) if (idx == 0xffu && slot[q] == v) idx = q;
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
 #pragma unroll
             for (uint32_t j = 0; j < kSpecSlots; ++j) {
                 if (j < K) {
-                    const uint32_t stt = (slot[j] >> kNextShift) - base;
+                    const uint32_t stt = st_of(slot[j]);
                     const bool q = stt < S && ((a.qabs[d][stt >> 5] >> (stt & 31u)) & 1u);
 #pragma unroll
                     for (uint32_t t = 0; t < kSpecSlots; ++t) {
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
             uint32_t e[kSpecSlots], em1[kSpecSlots];
 #pragma unroll
             for (uint32_t j = 0; j < kSpecSlots; ++j) {
-                uint32_t v = base << kNextShift;
+                uint32_t v = e_of(0u);
 #pragma unroll
                 for (uint32_t t = 0; t < kSpecSlots; ++t) if (j < nw && walk[j] == t && slot[t] != 0xffffffffu) v = slot[t];
                 e[j] = v; em1[j] = v;
@@ -206,15 +220,17 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
                         if (i + u < npieces) {
                             const uint32_t w[4] = {pc[u].x, pc[u].y, pc[u].z, pc[u].w};
                             pc[u] = piece(min(i + u + kAhead, npieces - 1u));
+                            uint32_t col[16];
+#pragma unroll
+                            for (uint32_t q = 0; q < 16u; ++q) col[q] = col_of((w[q >> 2] >> (8u * (q & 3u))) & 0xffu);    // (COMPACT: 16 LUT reads off the chain)
 #pragma unroll
                             for (uint32_t q = 0; q < 16u; ++q) {
-                                const uint32_t c4 = ((w[q >> 2] >> (8u * (q & 3u))) & 0xffu) << 2;
                                 if (q == 15u) {
 #pragma unroll
                                     for (uint32_t j = 0; j < KC; ++j) em1[j] = e[j];    // the state BEFORE the piece's last byte (kept for the chunk's last piece)
                                 }
 #pragma unroll
-                                for (uint32_t j = 0; j < KC; ++j) e[j] = lds_u32((e[j] & ~kTagMask) | c4);
+                                for (uint32_t j = 0; j < KC; ++j) e[j] = step(e[j], col[q]);
                             }
                         }
                     }
@@ -236,8 +252,8 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
 #pragma unroll
                 for (uint32_t j = 0; j < kSpecSlots; ++j) {
                     if (j < nw) {
-                        died = died || (e[j] >> kNextShift) - base == dead_row;
-                        died_m1 = died_m1 || (em1[j] >> kNextShift) - base == dead_row;
+                        died = died || st_of(e[j]) == dead_row;
+                        died_m1 = died_m1 || st_of(em1[j]) == dead_row;
                     }
                 }
                 // A walked survivor that died says nothing about the derived ones unless the byte that killed it has no column at all: in a
@@ -248,11 +264,11 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
                 uint32_t s_end_v[kSpecSlots], s_endm1_v[kSpecSlots];
 #pragma unroll
                 for (uint32_t t = 0; t < kSpecSlots; ++t) {          // slot t: walked as chain j, or derived
-                    uint32_t end = (slot[t] >> kNextShift) - base, endm1 = end;
+                    uint32_t end = st_of(slot[t]), endm1 = end;
                     bool walked = false;
 #pragma unroll
                     for (uint32_t j = 0; j < kSpecSlots; ++j)
-                        if (j < nw && walk[j] == t) { end = (e[j] >> kNextShift) - base; endm1 = (em1[j] >> kNextShift) - base; walked = true; }
+                        if (j < nw && walk[j] == t) { end = st_of(e[j]); endm1 = st_of(em1[j]); walked = true; }
                     if (!walked) { if (died) end = dead_row; if (died_m1) endm1 = dead_row; }
                     s_end_v[t] = end; s_endm1_v[t] = endm1;
                 }
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(1024) void spec_scout_kernel(const SpecArgs a) {
                     uint32_t end = 0, endm1 = 0;
 #pragma unroll
                     for (uint32_t t = 0; t < kSpecSlots; ++t) if (kslot[j] == t) { end = s_end_v[t]; endm1 = s_endm1_v[t]; }
-                    const uint32_t kv = j < NK ? ((key[j] >> kNextShift) - base) & 0xffu : 0xffu;     // (0xff: no such key; states are <= 254 here)
+                    const uint32_t kv = j < NK ? st_of(key[j]) & 0xffu : 0xffu;     // (0xff: no such key; states are <= 254 here)
                     rw[j >> 2] |= kv << (8u * (j & 3u));
                     rw[2u + (j >> 2)] |= (end & 0xffu) << (8u * (j & 3u));
                     rw[4u + (j >> 2)] |= (endm1 & 0xffu) << (8u * (j & 3u));
@@ -593,14 +609,17 @@ hipError_t launch_spec_scout(const SpecArgs &a, int num_cus, hipStream_t stream)
     static std::atomic<size_t> granted[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    hipError_t e = ensure_lds(spec_scout_kernel, granted[dev & 63], a.table_bytes);
+    const bool compact = a.cimage != nullptr;
+    const uint32_t lds = compact ? a.cimage_bytes : a.table_bytes;
+    hipError_t e = compact ? ensure_lds(spec_scout_kernel<true>, granted[(dev & 31) + 32], lds) : ensure_lds(spec_scout_kernel<false>, granted[dev & 31], lds);
     if (e != hipSuccess) return e;
     // 16 waves per CU (the lookups saturate the LDS pipe from there): workgroups of 4 waves while four copies of the table fit LDS, of 8 while two do, of 16 above
     const size_t waves = (size_t)a.n_groups * a.C;
-    const size_t copies = std::max<size_t>(1, kLdsLimit / std::max<uint32_t>(a.table_bytes, 1u));
+    const size_t copies = std::max<size_t>(1, kLdsLimit / std::max<uint32_t>(lds, 1u));
     const size_t wpw = copies >= 4 ? 4 : copies >= 2 ? 8 : 16, per_cu = std::min<size_t>(copies, 16 / wpw);
     const size_t grid = std::min<size_t>((waves + wpw - 1) / wpw, (size_t)num_cus * per_cu);
-    hipLaunchKernelGGL(spec_scout_kernel, dim3((unsigned)std::max<size_t>(grid, 1)), dim3((unsigned)(64 * wpw)), a.table_bytes, stream, a);
+    if (compact) hipLaunchKernelGGL(spec_scout_kernel<true>, dim3((unsigned)std::max<size_t>(grid, 1)), dim3((unsigned)(64 * wpw)), lds, stream, a);
+    else hipLaunchKernelGGL(spec_scout_kernel<false>, dim3((unsigned)std::max<size_t>(grid, 1)), dim3((unsigned)(64 * wpw)), lds, stream, a);
     return hipGetLastError();
 }
 
