@@ -595,16 +595,17 @@ def run_rank(args, rank, world, device_index, barrier):
             sys.stderr.write("one-buffer-set probe failed: %s\n" % e)
     # No-compute ceiling on THESE buffers (after the verification: it overwrites the outputs): hrx_traffic_pass_device moves the bytes
     # of one launch — same addresses, same instructions, same store policy — and does no DFA work.
-    if not args.no_spread and world == 1 and pm:
+    if not args.no_spread and world == 1 and (pm or M % 8 == 0):
         try:
-            tp = lambda i: cfg.traffic_pass(sets[i % nsets][0], B, sets[i % nsets][2], stride)
+            tp = (lambda i: cfg.traffic_pass(sets[i % nsets][0], B, sets[i % nsets][2], stride)) if pm else \
+                 (lambda i: cfg.traffic_pass_string_major(sets[i % nsets][0], sets[i % nsets][2]))
             gt = graph_of(tp, args.steps) if not args.eager else None
             runt = gt.replay if gt is not None else (lambda: [tp(i) for i in range(args.steps)])
             runt(); torch.cuda.synchronize()
             per = timed_replays(runt, 5, args.steps)
             mc = {"rotating_us": statistics.median(per) * 1e3}
             if nsets > 1:
-                tp1 = lambda i: cfg.traffic_pass(sets[0][0], B, sets[0][2], stride)
+                tp1 = (lambda i: cfg.traffic_pass(sets[0][0], B, sets[0][2], stride)) if pm else (lambda i: cfg.traffic_pass_string_major(sets[0][0], sets[0][2]))
                 gt1 = graph_of(tp1, args.steps) if not args.eager else None
                 runt1 = gt1.replay if gt1 is not None else (lambda: [tp1(i) for i in range(args.steps)])
                 runt1(); torch.cuda.synchronize()
@@ -779,7 +780,8 @@ def aggregate(per_rank, args):
             ceil["traffic_pass_gbs"] = algo_bytes / (tp["rotating_us"] * 1e-6) / 1e9
             ceil["kernel_over_best_probe"] = kern_ms * 1e3 / tp["rotating_us"]
             ceil["what"] = ("hrx_traffic_pass_device over the SAME buffer sets in the same rotation, replayed as the same kind of graph: the bytes of one launch — "
-                            "same addresses, same 16-byte-per-lane instructions, same store policy, 4 reader + 4 writer waves per CU — with no DFA work")
+                            "same addresses, same 16-byte-per-lane instructions, same store policy, 4 reader + 4 writer waves per CU — with no DFA work"
+                            " (string-major lines: hrx_traffic_pass_device_layout, the walker/storer kernel's 128-byte lines of eight strings per store instruction)")
             if "one_set_us" in tp:
                 ceil["one_set_us"] = tp["one_set_us"]
                 if r0.get("one_buffer_set"):

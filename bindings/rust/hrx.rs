@@ -75,6 +75,11 @@ extern "C" {
     /// roofline diagnostic: the memory traffic of one position-major launch over these buffers, no DFA work (overwrites the outputs)
     pub fn hrx_traffic_pass_device(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, m: usize, records: *mut u32,
                                    masked: *mut u16, stream: *mut c_void) -> c_int;
+    pub fn hrx_traffic_pass_device_layout(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, b: usize, m: usize, records: *mut u32, rec_pitch: usize,
+                                          masked: *mut u16, msk_pitch: usize, stream: *mut c_void) -> c_int;
+    /// one circuit's rows out of position-major HOST buffers: records [M][D], masked [M] (either pair may be null)
+    pub fn hrx_rows_of_string_position_major(records_pm: *const u32, masked_pm: *const u16, b_total: usize, m: usize, d: usize, b: usize,
+                                             records: *mut u32, masked: *mut u16) -> c_int;
     /// device = HRX_DEVICE_NONE (-1): a host-only context (the native small-batch walk; no GPU needed)
     pub fn hrx_device_count(count: *mut c_int) -> c_int;
     pub fn hrx_ctx_device(ctx: *const hrx_ctx) -> c_int;

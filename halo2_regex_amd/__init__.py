@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hrx_defs_push_substr_text", "hrx_defs_push_substr_file", "hrx_defs_push_allstr", "hrx_defs_push_substr",
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
-    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_chars_to_position_major_device", "hrx_device_free",
+    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_traffic_pass_device_layout", "hrx_chars_to_position_major_device", "hrx_device_free",
     "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_ctx_set_placement", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_rows_of_string_position_major", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
@@ -112,6 +112,7 @@ def _load():
         "hrx_device_free": (i, [vp]),
         "hrx_alloc_last_report": (i, [vp, C.POINTER(_PlaceReportC)]),
         "hrx_traffic_pass_device": (i, [vp, vp, sz, sz, sz, vp, vp, vp]),
+        "hrx_traffic_pass_device_layout": (i, [vp, i, vp, sz, sz, sz, vp, sz, vp, sz, vp]),
         "hrx_chars_to_position_major_device": (i, [vp, vp, sz, sz, vp, vp]),
         "hrx_multi_create": (i, [vp, C.POINTER(i), i, C.POINTER(vp)]),
         "hrx_multi_destroy": (None, [vp]),
@@ -678,6 +679,16 @@ class RegexVerifyConfig:
         s = torch.cuda.current_stream(chars_pm.device) if stream is None else stream
         _check(lib.hrx_traffic_pass_device(self._need_device(chars_pm, rec, msk), chars_pm.data_ptr(), int(chars_pm_stride), int(B), self.max_chars_size,
                                            rec.data_ptr(), msk.data_ptr(), s.cuda_stream))
+
+    def traffic_pass_string_major(self, chars, out, stream=None):
+        """hrx_traffic_pass_device_layout(HRX_LAYOUT_STRING_MAJOR): the memory traffic of one string-major launch over these buffers (chars (B, stride) uint8;
+        out = (records (B, M, D) view, masked (B, M) view, status) as alloc_outputs gives them, pitched or not), no DFA work; OVERWRITES out."""
+        rec, msk, _ = out
+        B, stride = chars.shape
+        D = self.num_defs
+        s = torch.cuda.current_stream(chars.device) if stream is None else stream
+        _check(lib.hrx_traffic_pass_device_layout(self._need_device(chars, rec, msk), 0, chars.data_ptr(), int(stride), int(B), self.max_chars_size,
+                                                  rec.data_ptr(), rec.stride(0) // D, msk.data_ptr(), msk.stride(0), s.cuda_stream))
 
     def chars_to_position_major_device(self, chars, out=None, stream=None):
         """hrx_chars_to_position_major_device: (B, stride) string-major bytes on the device (stride % 16 == 0, one contiguous string per row: the reference's

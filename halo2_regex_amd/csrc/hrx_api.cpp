@@ -1190,6 +1190,34 @@ int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, s
     return HRX_OK;
 }
 
+int hrx_traffic_pass_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, size_t rec_pitch,
+                                   uint16_t *masked, size_t msk_pitch, void *stream) {
+    if (layout == (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR)) return hrx_traffic_pass_device(ctx, chars, stride, B, M, records, masked, stream);
+    if (layout != HRX_LAYOUT_STRING_MAJOR) return fail(HRX_ERR_ARG, "hrx_traffic_pass_device_layout: HRX_LAYOUT_STRING_MAJOR or HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR");
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
+    if (B == 0) return HRX_OK;
+    if (!chars || !records || !masked) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
+    if (rec_pitch == 0) rec_pitch = M;
+    if (msk_pitch == 0) msk_pitch = M;
+    const size_t D = ctx->s.defs.size();
+    if (rec_pitch < M || msk_pitch < M || (M % 8) || (rec_pitch % 4) || (msk_pitch % 8) || rec_pitch > 0xffffffffull || msk_pitch > 0xffffffffull)
+        return fail(HRX_ERR_ARG, "string-major traffic pass: M % 8 == 0, pitches >= M in multiples of 4 / 8 rows");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)records & 15) || ((uintptr_t)masked & 15))
+        return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    WitnessArgs a{};
+    a.layout = HRX_LAYOUT_STRING_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)D;
+    LaunchInfo li{};
+    li.split = 1;
+    const uint32_t nt_mix = plan_nt_mix(a, li);
+    HIP_TRY(launch_traffic_pass_sm(chars, stride, B, M, (uint32_t)D, records, rec_pitch, masked, msk_pitch, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream));
+    return HRX_OK;
+}
+
 int hrx_chars_to_position_major_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, uint8_t *chars_pm, void *stream) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");

@@ -167,6 +167,8 @@ constexpr uint32_t kNtMixMaskedWb = 0x100u, kNtMixNoOpenSpan = 0x200u;
 // hrx_place.hip: microseconds (device clock) of a time-aligned two-stream write over two regions (both are overwritten); clk: 16 bytes of device scratch
 double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, unsigned long long *clk, size_t *bytes_written);
 // hrx_place.hip: the memory traffic of one position-major witness launch of this shape and nothing else (roofline diagnostics)
+hipError_t launch_traffic_pass_sm(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, size_t rec_pitch, uint16_t *masked,
+                                  size_t msk_pitch, uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream);
 hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
                                uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream);
 uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li);

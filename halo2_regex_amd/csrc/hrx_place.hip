@@ -119,6 +119,73 @@ __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) 
     }
 }
 
+// The same for STRING-MAJOR outputs, the way the walker/storer kernel (hrx_kernel_sm.hip) moves them: a store instruction writes the 128-byte lines of EIGHT strings
+// (lane = string it * 8 + lane / 8, 16-byte piece lane % 8 of the line), 2 D lines of records and one line of masked rows per string and 64 rows; the input is read
+// one string per lane, 16 bytes at a time, a stride apart.  rec_pitch / msk_pitch in rows.
+struct TrafficSmArgs {
+    const unsigned char *chars;
+    uint64_t stride;
+    uint32_t B, M, D, rec_pitch, msk_pitch;
+    unsigned char *records, *masked;
+    uint32_t nt_mix;
+    uint32_t *sink;
+};
+
+__global__ __launch_bounds__(512) void traffic_pass_sm_kernel(const TrafficSmArgs a) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_groups = (a.B + 63u) / 64u;
+    const uint32_t nblk = (a.M + 63u) / 64u;
+    for (uint32_t g = blockIdx.x * 4u + (wave & 3u); g < n_groups; g += gridDim.x * 4u) {
+        const uint32_t b0 = g * 64u;
+        if (wave >= 4u) {   // reader: every 16-byte chunk of the lane's string
+            const unsigned char *cp = a.chars + (size_t)min(b0 + lane, a.B - 1u) * a.stride;
+            uint4 acc = make_uint4(0, 0, 0, 0);
+            const uint32_t nchunk = (uint32_t)(a.stride / 16u);
+#pragma unroll 8
+            for (uint32_t c = 0; c < nchunk; ++c) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(cp + (size_t)c * 16u);
+                acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+            }
+            if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) a.sink[0] = acc.z ^ acc.w;
+            continue;
+        }
+        const uint32_t js0 = lane >> 3, w = lane & 7u;
+        const uint32_t wb_k = a.nt_mix & 0xffu;
+        const size_t rec_row = (size_t)a.rec_pitch * a.D * 4u, msk_row = (size_t)a.msk_pitch * 2u;
+        for (uint32_t t = 0; t < nblk; ++t) {
+            const uint32_t rows = min(64u, a.M - t * 64u);
+            const uint32_t rec_bytes = rows * a.D * 4u, msk_bytes = rows * 2u;      // of this block, per string
+            const bool wb = wb_k != 0u && (t % wb_k) == wb_k - 1u;
+            const uint4 v = make_uint4(t, 1, 2, 3);
+            for (uint32_t j = 0; j * 128u < rec_bytes; ++j) {
+                const uint32_t off = j * 128u + w * 16u;
+#pragma unroll
+                for (uint32_t it = 0; it < 8u; ++it) {
+                    const uint32_t b = b0 + it * 8u + js0;
+                    if (b < a.B && off < rec_bytes) {
+                        unsigned char *p = a.records + (size_t)b * rec_row + (size_t)t * 64u * a.D * 4u + off;
+                        if (wb) *reinterpret_cast<uint4 *>(p) = v; else store16_nt(p, v);
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t it = 0; it < 8u; ++it) {
+                const uint32_t b = b0 + it * 8u + js0;
+                if (b < a.B && w * 16u < msk_bytes) store16_nt(a.masked + (size_t)b * msk_row + (size_t)t * 128u + w * 16u, v);
+            }
+        }
+    }
+}
+
+hipError_t launch_traffic_pass_sm(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, size_t rec_pitch, uint16_t *masked,
+                                  size_t msk_pitch, uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream) {
+    TrafficSmArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (uint32_t)rec_pitch, (uint32_t)msk_pitch, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink};
+    const size_t n_groups = (B + 63) / 64, need = (n_groups + 3) / 4;
+    const int grid = (int)std::min<size_t>(need, (size_t)num_cus);
+    hipLaunchKernelGGL(traffic_pass_sm_kernel, dim3(grid < 1 ? 1 : grid), dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
                                uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream) {
     TrafficArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink};

@@ -259,6 +259,12 @@ int hrx_ctx_set_placement(hrx_ctx *ctx, int mode, size_t max_bytes, double max_m
  * box's ceiling for the launch's byte mix on these very buffers (bench.py: roofline.mix_ceiling).  Asynchronous on `stream`. */
 int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records,
                             uint16_t *masked, void *stream);
+/* The same diagnostic for either layout: HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR is the call above (pitches ignored);
+ * HRX_LAYOUT_STRING_MAJOR moves the bytes of a string-major launch (M % 8 == 0) the way the walker/storer kernel does — a store instruction writes the 128-byte
+ * lines of eight strings, 2 D lines of records and one of masked rows per string and 64 rows, the input read one string per lane — rec_pitch / msk_pitch in rows
+ * (0 = M).  What the string-major lines of a sweep are measured against (the reference's fill loops index one string: src/lib.rs:387-519). */
+int hrx_traffic_pass_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, size_t rec_pitch,
+                                   uint16_t *masked, size_t msk_pitch, void *stream);
 /* From the reference's input shape to the coalesced one, on the device: `chars` = B strings of `stride` bytes each, back to back — one contiguous
  * &[u8] per string is what RegexVerifyConfig::match_substrs is handed (src/lib.rs:311-315) — -> `chars_pm` (B * stride bytes, another buffer) in
  * HRX_LAYOUT_INPUT_POSITION_MAJOR.  Pure streaming (2 * stride bytes of traffic per string; measured beside the bench line: bench.py
