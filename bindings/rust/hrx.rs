@@ -83,6 +83,8 @@ extern "C" {
     /// device = HRX_DEVICE_NONE (-1): a host-only context (the native small-batch walk; no GPU needed)
     pub fn hrx_device_count(count: *mut c_int) -> c_int;
     pub fn hrx_ctx_device(ctx: *const hrx_ctx) -> c_int;
+    /// a second context of the same config (own stream / scratch / lock): what `impl Clone for RegexVerifyConfig` calls; device -2 = the source's
+    pub fn hrx_ctx_clone(ctx: *const hrx_ctx, device: c_int, out: *mut *mut hrx_ctx) -> c_int;
     /// host-buffer batches of fewer than `rows` witness rows (B x M) take the native host walk (default 32768)
     pub fn hrx_ctx_set_host_threshold(ctx: *mut hrx_ctx, rows: usize) -> c_int;
     pub fn hrx_ctx_host_threshold(ctx: *const hrx_ctx) -> usize;

@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("HRX_LIB_PATH") or os.path.join(_HERE, "csrc", "libhrx
 HRX_OK = 0
 HRX_ERR_PARSE, HRX_ERR_BOUNDS, HRX_ERR_ARG, HRX_ERR_HIP, HRX_ERR_STATE = 1, 2, 3, 4, 5
 HRX_ERR_INVALID_TRANSITION, HRX_ERR_OUT_OF_CONTRACT, HRX_ERR_IO = 6, 7, 8
+HRX_DEVICE_SAME = -2                 # hrx_ctx_clone: the source context's device
 HRX_DEVICE_NONE = -1                 # hrx_ctx_create: host-only context (the native small-batch host walk)
 HRX_DEFAULT_HOST_THRESHOLD = 32768   # rows (B x M) below which host-buffer batches are walked on the host
 
@@ -31,7 +32,7 @@ ABI_SYMBOLS = [
     "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
     "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
     "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_traffic_pass_device_layout", "hrx_chars_to_position_major_device", "hrx_device_free",
-    "hrx_ctx_create", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_ctx_set_placement", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
+    "hrx_ctx_create", "hrx_ctx_clone", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_ctx_set_placement", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
     "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_rows_of_string_position_major", "hrx_describe_launch",
     "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
     "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_shard_device", "hrx_multi_shard_stream", "hrx_multi_witness_batch_host",
@@ -96,6 +97,7 @@ def _load():
         "hrx_ctx_create": (i, [vp, i, C.POINTER(vp)]),
         "hrx_ctx_destroy": (None, [vp]),
         "hrx_ctx_device": (i, [vp]),
+        "hrx_ctx_clone": (i, [vp, i, C.POINTER(vp)]),
         "hrx_ctx_set_host_threshold": (i, [vp, sz]),
         "hrx_ctx_host_threshold": (sz, [vp]),
         "hrx_ctx_set_placement": (i, [vp, i, sz, C.c_double]),
@@ -522,6 +524,16 @@ class RegexVerifyConfig:
         if getattr(self, "_ctx", None) and lib is not None:
             lib.hrx_ctx_destroy(self._ctx)
             self._ctx = None
+
+    def clone(self, device=HRX_DEVICE_SAME):
+        """hrx_ctx_clone: RegexVerifyConfig derives Clone (lib.rs:96) — the same config with a context (stream, scratch, lock) of its own, e.g. one per prover thread."""
+        import copy
+        c = copy.copy(self)
+        ctx = C.c_void_p()
+        _check(lib.hrx_ctx_clone(self._need_ctx(), int(device), C.byref(ctx)))
+        c._ctx = ctx
+        c.device = self.device if device == HRX_DEVICE_SAME else device
+        return c
 
     def _need_ctx(self):
         if not self._ctx:

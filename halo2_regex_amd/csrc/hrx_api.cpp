@@ -313,9 +313,28 @@ void hrx_shard_range(size_t B, int world, int rank, size_t *begin, size_t *count
     if (count) *count = e - b;
 }
 
+static int ctx_create_from(const DefsSet &set, int device, hrx_ctx **out);
+
 int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out) {
     if (!defs || !out) return fail(HRX_ERR_ARG, "NULL argument");
     if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
+    return ctx_create_from(defs->s, device, out);
+}
+
+int hrx_ctx_clone(const hrx_ctx *ctx, int device, hrx_ctx **out) {
+    if (!ctx || !out) return fail(HRX_ERR_ARG, "NULL argument");
+    hrx_ctx *c = nullptr;
+    const int rc = ctx_create_from(ctx->s, device == HRX_DEVICE_SAME ? ctx->device : device, &c);
+    if (rc != HRX_OK) return rc;
+    c->host_threshold = ctx->host_threshold;      // the per-context switches travel with the clone
+    c->place_enabled = ctx->place_enabled; c->place_max_bytes = ctx->place_max_bytes; c->place_max_ms = ctx->place_max_ms;
+    *out = c;
+    return HRX_OK;
+}
+
+static int ctx_create_from(const DefsSet &set, int device, hrx_ctx **out) {
+    struct { const DefsSet &s; } defs_view{set};
+    const auto *defs = &defs_view;
     if (device == HRX_DEVICE_NONE) {   // host-only context: single strings and host-buffer batches through the native host walk
         hrx_ctx *c = new hrx_ctx();
         c->s = defs->s;

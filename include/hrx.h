@@ -116,6 +116,12 @@ int hrx_device_count(int *count);
  * HRX_DEBUG_FLAGS (environment; kernel-selection bits for the tests, csrc/hrx_kernel.hpp) is read here, once. */
 #define HRX_DEVICE_NONE (-1)
 int hrx_ctx_create(const hrx_defs *defs, int device, hrx_ctx **out);
+/* A second context of the same config: its own stream, scratch and lock, the same tables (uploaded again: ~100 KiB) and the source's per-context switches
+ * (host threshold, placement).  RegexVerifyConfig derives Clone (src/lib.rs:96) and halo2 clones the config per synthesize pass / worker thread: a context
+ * serves one stream at a time, so a prover that wants its threads to overlap gives every clone a context of its own (they share the device's measured arena pair,
+ * hrx_alloc_output_pair).  device: a GPU index, HRX_DEVICE_NONE, or HRX_DEVICE_SAME (the source's).  The hrx_defs handle the source was made from need not exist any more. */
+#define HRX_DEVICE_SAME (-2)
+int hrx_ctx_clone(const hrx_ctx *ctx, int device, hrx_ctx **out);
 void hrx_ctx_destroy(hrx_ctx *ctx);
 int hrx_ctx_device(const hrx_ctx *ctx);
 /* Host-buffer batches (hrx_witness_batch_host, hrx_multi_witness_batch_host) of fewer than `rows` witness rows (B x M)

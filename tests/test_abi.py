@@ -163,6 +163,28 @@ def test_rows_of_one_string_out_of_position_major_host_buffers():
             hra.rows_of_string_position_major(rp, mp, B, M, D, B)
 
 
+def test_context_clone_is_an_independent_context_of_the_same_config(oracle):
+    """hrx_ctx_clone (RegexVerifyConfig derives Clone, lib.rs:96): the clone outlives its source and the defs handle, carries the per-context switches, computes the same rows"""
+    cfg = RegexVerifyConfig.configure(64, _defs(CFG_3), device=hra.HRX_DEVICE_NONE)
+    cfg.set_host_threshold(12345)
+    c2 = cfg.clone()
+    assert c2._ctx.value != cfg._ctx.value and c2.host_threshold() == 12345
+    s = b"from:alice@gmail.com\r\n"
+    want = cfg.match_substrs(s)
+    del cfg
+    import gc
+    gc.collect()
+    got = c2.match_substrs(s)
+    assert want.status == got.status and want.status & 0xff == 0 and (want.status >> 8) & 1 == 1     # ok, accept bit of def 0
+    for k in ("all_enable_flags", "all_characters", "all_substr_ids", "masked_characters", "states", "substr_ids", "start_enables", "end_enables"):
+        assert np.array_equal(getattr(want, k), getattr(got, k)), k
+    assert bytes(got.masked_characters[5:20].astype(np.uint8)) == b"alice@gmail.com"        # lib.rs:1318-1331
+    import ctypes as C
+    out = C.c_void_p()
+    assert hra.lib.hrx_ctx_clone(None, hra.HRX_DEVICE_SAME, C.byref(out)) == hra.HRX_ERR_ARG
+    assert hra.lib.hrx_ctx_clone(c2._ctx, hra.HRX_DEVICE_SAME, None) == hra.HRX_ERR_ARG
+
+
 def test_planner_thresholds_of_round_3():
     """Where the chunked launch stops (below 2 / up to 1.75 / up to 1.5 groups of 64 strings per CU at D = 1 / 2 / 3, either input layout,
     position-major outputs, 4096 rows or more) and the one-round rule for small batches (profiles/r03_probes/spec_threshold.txt)."""

@@ -1197,6 +1197,49 @@ def test_host_buffer_batches_are_pipelined_chunk_by_chunk(hra, oracle):
             assert np.array_equal(r1, orec[b]) and np.array_equal(m1, omsk[b]), b
 
 
+def test_context_clones_run_side_by_side(hra, oracle):
+    """hrx_ctx_clone: what `impl Clone for RegexVerifyConfig` maps to — two clones of one config launch on two streams from two threads at the same time (a context serves
+    one stream at a time; its clones have their own scratch and lock) and write the oracle's rows; a host-only clone of a device context serves the single-string seam."""
+    import threading
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    M, B = 2048, 70000
+    chars, lens = synth.regex23_planted(4096, M - 1, seed=5, stride=M)
+    chars, lens = np.tile(chars, (18, 1))[:B], np.tile(lens, 18)[:B]
+    cfg = _cfg(hra, CFG_23, M)
+    clones = [cfg.clone(), cfg.clone()]
+    d_c = hra.chars_to_position_major(torch.from_numpy(chars).to(dev))
+    d_l = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    outs, errs = [None, None], []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                for _ in range(3):
+                    outs[k] = clones[k].witness_batch_position_major(d_c, d_l, chars_pm_stride=M)      # multi-round: dynamic groups, the context's counter
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    ref = cfg.witness_batch_position_major(d_c, d_l, chars_pm_stride=M)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert all(torch.equal(x, y) for x, y in zip(outs[k], ref))
+    o = OracleDefs.from_files(oracle, CFG_23)
+    orec, omsk, ost = o.witness_batch(chars[:4096], lens[:4096], M, threads=os.cpu_count() or 8)
+    r2, m2 = hra.position_major_to_string_major(ref[0], ref[1], B, M, 2)
+    assert np.array_equal(ref[2][:4096].cpu().numpy().view(np.uint64), ost)
+    assert np.array_equal(r2[:4096].cpu().numpy().view(np.uint32), orec) and np.array_equal(m2[:4096].cpu().numpy().view(np.uint16), omsk)
+    host = cfg.clone(device=hra.HRX_DEVICE_NONE)
+    one = host.match_substrs(bytes(chars[0, :lens[0]]))
+    assert np.array_equal(one.masked_characters.astype(np.uint16) | (one.all_substr_ids.astype(np.uint16) << 8), omsk[0])
+
+
 def test_arena_free_waits_for_the_device(hra, oracle):
     """hrx_device_free on a sub-buffer of the shared arena pair waits for the device like hipFree does (include/hrx.h): the range is reusable by any
     context right after the call, so a buffer freed while its launch is still in flight must not be handed to a second context that writes it on
