@@ -659,6 +659,21 @@ def run_rank(args, rank, world, device_index, barrier):
                    "what": "hrx_witness_batch_host on the same batch: pageable host arrays in (string-major, %d B apart) and out (records [B][M][D] u32, masked [B][M] u16, status), "
                            "output arrays reused; staged, walked and copied out chunk by chunk (two streams, a staging thread); the call lasts as long as the copy out over the "
                            "PCIe link (gbs_out)" % stride}
+            # what the link gives a plain device-to-host copy of the same bytes into the same (pageable, already touched) arrays on THIS box
+            try:
+                tr_, tm_ = torch.from_numpy(hrec.view(np.int32).reshape(-1)), torch.from_numpy(hmsk.view(np.int16).reshape(-1))
+                dr_, dm_ = sets[0][2][0].view(-1)[:tr_.numel()], sets[0][2][1].view(-1)[:tm_.numel()]
+                tc = []
+                for _ in range(3):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    tr_.copy_(dr_); tm_.copy_(dm_)
+                    torch.cuda.synchronize(); tc.append(time.perf_counter() - t0)
+                e2e["copy_out_alone_ms"] = min(tc) * 1e3
+                e2e["copy_out_alone_gbs"] = (tr_.numel() * 4 + tm_.numel() * 2) / min(tc) / 1e9
+                e2e["copy_out_alone_what"] = "a plain device-to-host copy of as many bytes (records + masked rows) into the same host arrays, nothing else: the link's rate for this process on this box"
+                cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))      # (the arrays hold the host path's rows again: compared with the gather below)
+            except Exception as e:
+                sys.stderr.write("copy-out probe failed: %s\n" % e)
             rp, mp = sets[0][2][0].cpu().numpy().view(np.uint32), sets[0][2][1].cpu().numpy().view(np.uint16)
             r1, m1 = np.empty((M, D), np.uint32), np.empty(M, np.uint16)
             fn = hra.lib.hrx_rows_of_string_position_major

@@ -1321,7 +1321,8 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
     // cannot have both directions busy.  The rows leave 6 D' bytes per byte that comes in (448 MiB out, 64 MiB in at 65536 x 1024, D = 1): the copy out IS the call
     // (8.1 of round 4's 8.7 ms: ~55 GB/s, the link's rate in one direction); what the pipeline removes is the staging and the walk in front of it.
     const size_t out_per_string = M * (4 * D + 2);
-    size_t cb = out_per_string ? ((size_t)48 << 20) / out_per_string / 64 * 64 : B;   // ~48 MiB of rows per chunk
+    static const size_t chunk_mib = [] { const char *v = std::getenv("HRX_HOST_CHUNK_MIB"); const long n = v ? std::atol(v) : 0; return (size_t)(n >= 4 && n <= 4096 ? n : 48); }();
+    size_t cb = out_per_string ? (chunk_mib << 20) / out_per_string / 64 * 64 : B;   // ~48 MiB of rows per chunk (HRX_HOST_CHUNK_MIB)
     if (cb < 1024) cb = 1024;
     const size_t nchunk = (B + cb - 1) / cb;
     if (nchunk < 3 || ctx->copy_stream == nullptr) {
