@@ -231,7 +231,26 @@ impl HrxHandle {
 }
 
 impl Drop for HrxHandle {
-    fn drop(&mut self) { unsafe { hrx_ctx_destroy(self.ctx); hrx_defs_destroy(self.defs); } }
+    fn drop(&mut self) { unsafe { hrx_ctx_destroy(self.ctx); if !self.defs.is_null() { hrx_defs_destroy(self.defs); } } }
+}
+
+impl HrxHandle {
+    /// A second context of the same config on the same device — own stream, scratch and lock (hrx_ctx_clone): what `impl Clone for RegexVerifyConfig` calls when the
+    /// prover's threads should overlap on the device instead of sharing one handle behind its mutex.  The clone needs neither the source nor its hrx_defs afterwards.
+    pub fn clone_ctx(&self) -> HrxHandle {
+        let mut ctx = std::ptr::null_mut();
+        let rc = unsafe { hrx_ctx_clone(self.ctx, -2 /* HRX_DEVICE_SAME */, &mut ctx) };
+        assert_eq!(rc, 0, "{}", last_error());
+        HrxHandle { defs: std::ptr::null_mut(), ctx }
+    }
+
+    /// One circuit's rows out of position-major HOST buffers (the device buffers copied out as they are): records [m][d], masked [m].
+    pub fn rows_of_string(records_pm: &[u32], masked_pm: &[u16], batch: usize, m: usize, d: usize, b: usize) -> (Vec<u32>, Vec<u16>) {
+        let (mut rec, mut msk) = (vec![0u32; m * d], vec![0u16; m]);
+        let rc = unsafe { hrx_rows_of_string_position_major(records_pm.as_ptr(), masked_pm.as_ptr(), batch, m, d, b, rec.as_mut_ptr(), msk.as_mut_ptr()) };
+        assert_eq!(rc, 0, "{}", last_error());
+        (rec, msk)
+    }
 }
 
 /// The integer columns of one circuit (hrx_match_substrs).  state / substr_id / start_enable / end_enable are [def][row].

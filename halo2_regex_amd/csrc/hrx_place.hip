@@ -80,13 +80,17 @@ struct TrafficArgs {
     unsigned char *records, *masked;
     uint32_t nt_mix;
     uint32_t *sink;
+    uint32_t spread;
 };
 
 __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n_groups = (a.B + 63u) / 64u;
     const size_t q4 = (a.M + 3u) / 4u, q8 = (a.M + 7u) / 8u;
-    for (uint32_t g = blockIdx.x * 4u + (wave & 3u); g < n_groups; g += gridDim.x * 4u) {
+    // groups per workgroup: four adjacent ones (the loader / walker / finisher kernel's dealing) when the batch has at least four per CU; a smaller batch is SPREAD
+    // over the CUs like the def-parallel kernel's two groups per workgroup (cfg 4's 512 groups ran on 128 of the 256 CUs here until round 5: its "ceiling" was slower than the kernel)
+    const bool spread = a.spread != 0u;
+    for (uint32_t g = spread ? blockIdx.x + (wave & 3u) * gridDim.x : blockIdx.x * 4u + (wave & 3u); g < n_groups; g += gridDim.x * 4u) {
         const uint32_t b = min(g * 64u + lane, a.B - 1u);
         const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0), bl = b - blk0;
         if (wave >= 4u) {   // reader: every 16-byte chunk of the string
@@ -188,8 +192,10 @@ hipError_t launch_traffic_pass_sm(const uint8_t *chars, size_t stride, size_t B,
 
 hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
                                uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream) {
-    TrafficArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink};
-    const size_t n_groups = (B + 63) / 64, need = (n_groups + 3) / 4;
+    TrafficArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink, 0u};
+    const size_t n_groups = (B + 63) / 64;
+    a.spread = n_groups < (size_t)num_cus * 4 ? 1u : 0u;
+    const size_t need = a.spread ? n_groups : (n_groups + 3) / 4;
     const int grid = (int)std::min<size_t>(need, (size_t)num_cus);
     hipLaunchKernelGGL(traffic_pass_kernel, dim3(grid < 1 ? 1 : grid), dim3(512), 0, stream, a);
     return hipGetLastError();
