@@ -778,6 +778,7 @@ def aggregate(per_rank, args):
             "steps": [p.get("steps") for p in srch], "chosen_step": [p.get("chosen_step") for p in srch],
             "ref_gbs": [round(p.get("ref_gbs", 0)) for p in srch], "first_gbs": [round(p.get("first_gbs", 0)) for p in srch],
             "best_gbs": [round(p.get("best_gbs", 0)) for p in srch], "search_ms": [round(p.get("search_ms", 0), 1) for p in srch],
+            "capped": [p.get("capped", 0) for p in srch],
             "what": "hrx_alloc_outputs_position_major per buffer set: two-stream probe rates (GB/s written, device clock) of the same-block reference, the first candidate "
                     "(= two plain allocations) and the kept masked-row buffer; accepted = kept one >= 10 % above the reference (DESIGN.md §6)"}
     if r0.get("one_buffer_set"):
@@ -933,7 +934,8 @@ def condense_leg(name, line, wall_s):
             "traffic_pass_us": mc.get("traffic_pass_us"), "kernel_over_traffic_pass": mc.get("kernel_over_best_probe"),
             "spread_ms_per_step": (line.get("spread") or {}).get("ms_per_step_median"),
             "verified": {"bit_exact": v.get("bit_exact"), "strings": v.get("strings"), "buffer_sets": v.get("buffer_sets"), "distinct_strings": v.get("distinct_strings")},
-            "placement": {"best_gbs": pl.get("best_gbs"), "ref_gbs": pl.get("ref_gbs"), "steps": pl.get("steps"), "sets_accepted": pl.get("sets_accepted")},
+            "placement": {"best_gbs": pl.get("best_gbs"), "ref_gbs": pl.get("ref_gbs"), "steps": pl.get("steps"), "sets_accepted": pl.get("sets_accepted"), "capped": pl.get("capped"),
+                          "search_ms": pl.get("search_ms")},
             "buffer_sets": line["config"]["buffer_sets"].split(":")[0], "launch_mode": line["config"]["launch_mode"].split(" (")[0], "wall_s": wall_s}
 
 

@@ -1079,7 +1079,8 @@ static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes
         rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
         const double us = hrx::placement_probe_us(A, a_bytes, cand, cand_bytes, D, ctx->stream, clk, &rep.probe_bytes);
         const double rate = us > 0 ? (double)rep.probe_bytes / us : 0.0;
-        place_trace(ctx, "hrx placement: step %d candidate %p: %.1f us = %.2f TB/s, reference %.2f TB/s\n", i, cand, us, rate * 1e-6, ref_rate * 1e-6);
+        place_trace(ctx, "hrx placement: step %d candidate %p: %.1f us = %.2f TB/s, reference %.2f TB/s, %.1f ms into the walk\n", i, cand, us, rate * 1e-6, ref_rate * 1e-6,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count());
         ++rep.steps;
         if (i == 0) { rep.first_us = us; rep.first_gbs = rate * 1e-3; }
         const bool better = us >= 0 && (best_us < 0 || us < best_us);
@@ -1133,6 +1134,9 @@ int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_byte
     if (records_bytes < kPlaceFromBytes || !ctx->place_enabled) return plain();
     if (records_bytes >= kPlaceDirectFrom) {
         // ---- large outputs: candidates measured against the records buffer itself
+        // (Round 5 also walked the RECORDS side — against one 12-GiB records buffer of cfg 4 all 48 masked-row candidates measure 6.4-6.8 TB/s, against the next one 5.8-6.3: where the records
+        // lie sets the level — trying up to three records buffers and keeping the best pair: the allocation churn of 12-GiB spacers brought multi-second hipMalloc stalls (search_ms 3-4 s per
+        // buffer set) and the launches did not follow the probe level closely enough to pay for it — cfg 4 at 0.655 with all three sets at 6.6-6.75.  Not kept.)
         void *rec = nullptr;
         if (hipMalloc(&rec, records_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
         double walked_best = 0.0;

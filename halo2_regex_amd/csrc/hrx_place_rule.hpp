@@ -14,6 +14,9 @@ constexpr double kPlaceWalkMs = 250.0;     // a walk past its eighth candidate t
 constexpr double kPlaceHardMs = 2000.0, kPlaceArenaHardMs = 8000.0;   // ... and any walk after this, whatever it holds (one lease of round 4 took 66 ms per 2-GiB hipMalloc where the others take 2:
                                                                       // the one-second bound ended its arena walk at 17 colliding candidates and the bench line ran at 0.70 instead of 0.76)
 constexpr int kPlaceMinCandidates = 4;     // the median of fewer says nothing: clear pairings are about one in eight
+constexpr int kPlaceMinCandidatesFirst = 8;   // ... and the FIRST direct walk of a context (nothing seen before to hold a candidate against) looks at eight: against a same-block reference of the
+                                              // hard kind (4.3-4.7 TB/s) a middle-kind candidate (5.9-6.5) clears reference and median by 10 % as well as a clear one (6.8-7.2) does — round 5, lease b:
+                                              // cfg 3's first buffer set kept a 5.9 after four candidates, the second matched it, 0.697 where a process of its own on the same lease found 6.8 / 7.0 and ran at 0.736
 constexpr int kPlaceArenaSoftSteps = 24, kPlaceArenaHardSteps = 96;   // 2-GiB arena candidates: 24 as a rule, on only while nothing clear of the reference is in hand
 
 enum class PlaceVerdict { go_on, accept, settle };   // settle: stop with the fastest candidate measured (accepted only if it is clear of the reference)
@@ -50,7 +53,8 @@ struct PlaceWalk {
         // least four candidates, so that the median is a colliding one: round 3's rule (10 % above the SLOWEST of at least two) took a 6.1 for clear next to a 4.7
         // and cost cfg 5 at 393216 x 4096 a fifth of its rate — and within 4 % of the best pairing any walk of this context has measured (a later buffer set must
         // not settle for less than the first one found: cfg 5, 0.365 -> 0.417 ms per step on such a box).
-        if (i + 1 >= kPlaceMinCandidates && b >= kPlaceMargin * std::max(ref_rate, median()) && b >= kPlaceNearBest * seen()) return PlaceVerdict::accept;
+        const int min_cand = (!arena && seen_before <= 0.0) ? kPlaceMinCandidatesFirst : kPlaceMinCandidates;
+        if (i + 1 >= min_cand && b >= kPlaceMargin * std::max(ref_rate, median()) && b >= kPlaceNearBest * seen()) return PlaceVerdict::accept;
         // ... or as soon as it is as good as the pairing an EARLIER walk of this context kept (where most neighbours are clear the median rule never fires: 48 steps
         // and 1.6 s for one buffer set of cfg 5 seen)
         if (i >= 1 && seen_before > 0 && b >= kPlaceAsSeen * seen_before && clear_of_reference()) return PlaceVerdict::accept;

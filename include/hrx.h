@@ -229,7 +229,7 @@ typedef struct hrx_place_report {
                                     2: served from the arena pair an earlier call measured (the numbers below are that walk's) */
     int steps;                   /* candidates measured */
     int accepted;                /* 1: the kept candidate is >= 10 % above both the same-neighbourhood reference and the MEDIAN candidate of the walk (at
-                                    least four candidates) and within 4 % of the best pairing earlier walks of the same kind measured — or a walk that ran
+                                    least four candidates; eight in a context's first direct walk) and within 4 % of the best pairing earlier walks of the same kind measured — or a walk that ran
                                     into a bound with a candidate >= 10 % above the reference in hand; 0: simply the fastest measured (csrc/hrx_place_rule.hpp) */
     int chosen_step;
     double ref_us;               /* the reference: both probe streams inside one neighbourhood (device clock) */

@@ -32,18 +32,29 @@ int main() {
         Outcome o = run(w, {4730, 6118});
         CHECK(o.verdict == PlaceVerdict::go_on);
         // ... the walk goes on through the middle kind until a clear one comes
-        o = run(w, {4730, 6118, 5800, 5900, 6050, 6922, 5700});
-        CHECK(o.verdict == PlaceVerdict::accept && o.steps == 6 && o.kept == 6922);
+        o = run(w, {4730, 6118, 5800, 5900, 6050, 6922, 5700, 5750, 5800});
+        CHECK(o.verdict == PlaceVerdict::accept && o.steps == 8 && o.kept == 6922);      // (a context's first direct walk looks at eight candidates: round 5)
     }
-    {   // a clear candidate first still needs four candidates (the median must be a colliding one), then wins
+    {   // a clear candidate first still needs its company (the median must be a colliding one): eight candidates in a context's first direct walk, four later and in arena walks
         PlaceWalk w; w.ref_rate = 5412;
-        Outcome o = run(w, {7205, 4020, 5600, 5750, 5800});
+        Outcome o = run(w, {7205, 4020, 5600, 5750, 5800, 5700, 5650, 5600, 5900});
+        CHECK(o.verdict == PlaceVerdict::accept && o.steps == 8 && o.kept == 7205);
+        PlaceWalk a; a.ref_rate = 5412; a.arena = true;
+        o = run(a, {7205, 4020, 5600, 5750, 5800});
         CHECK(o.verdict == PlaceVerdict::accept && o.steps == 4 && o.kept == 7205);
     }
-    {   // two clear ones among the first four do not hide each other (lower median)
-        PlaceWalk w; w.ref_rate = 5400;
+    {   // two clear ones among the first candidates do not hide each other (lower median)
+        PlaceWalk w; w.ref_rate = 5400; w.arena = true;
         Outcome o = run(w, {7000, 5800, 7050, 5900});
         CHECK(o.verdict == PlaceVerdict::accept && o.steps == 4 && o.kept == 7050);
+    }
+    {   // round 5, lease b, cfg 3's first buffer set: a hard-kind reference, and after four candidates a middle-kind 5.9 clears reference and median by 10 % — four more candidates
+        // turn up what the lease has (the same lease's other process kept 6.8 / 7.0)
+        PlaceWalk w; w.ref_rate = 4660;
+        Outcome o = run(w, {4764, 4700, 4810, 5899});
+        CHECK(o.verdict == PlaceVerdict::go_on);
+        o = run(w, {4764, 4700, 4810, 5899, 5850, 6809, 4790, 5900});
+        CHECK(o.verdict == PlaceVerdict::accept && o.steps == 8 && o.kept == 6809);
     }
     {   // a later buffer set of the same context: as good as what an earlier walk kept ends the walk at its second candidate ...
         PlaceWalk w; w.ref_rate = 5412; w.seen_before = 7239;
