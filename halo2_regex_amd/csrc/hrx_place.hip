@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "hrx_device.h"
 
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) 
         unsigned char *rp = a.records + ((size_t)blk0 * q4 * a.D + bl) * 16u;
         unsigned char *mp = a.masked + ((size_t)blk0 * q8 + bl) * 16u;
         const uint32_t wb_k = a.nt_mix & 0xffu;
+        // (round 5 also split a group's stores over TWO writer waves — four storing waves per CU for cfg 4's two groups: 0.69-0.70 against 0.70-0.71, no gain: it is the memory
+        // system, not the number of storing waves — profiles/r05_probes/cfg4_front_width.txt)
         for (uint32_t q = 0; q < (uint32_t)q4; ++q) {
             const uint32_t t = q >> 4;
             const bool wb = wb_k != 0u && (t % wb_k) == wb_k - 1u;
