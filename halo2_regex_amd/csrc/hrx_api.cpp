@@ -143,6 +143,7 @@ struct hrx_ctx {
     double place_max_ms = 0.0;        // ... and the wall-clock time a walk may take (0: the rule's own bounds, hrx_place_rule.hpp)
     hrx_place_report last_place{};
     struct hrx_place_pool *pool = nullptr;   // bench-sized outputs: the device's measured arena pair, shared by every context of that device in this process
+    DevBuf d_cw;                    // CLASS-WIDE image of a config of 4 .. 7 defs (DefsSet::cw_image): the single-launch def-parallel path
 #ifdef HRX_STAMPS
     DevBuf stamps;                  // tools-only build: 8 u64 per walker pair of the position-major kernel (hrx_kernel_pm.hip)
 #endif
@@ -378,6 +379,10 @@ static int ctx_create_from(const DefsSet &set, int device, hrx_ctx **out) {
             if (e == hipSuccess) e = upload_blob(c->s.groups[g].byte.image, c->groups[g].d_bytetab);
         }
     }
+    if (e == hipSuccess && !c->s.cw_image.empty()) {
+        e = c->d_cw.reserve(c->s.cw_image.size());
+        if (e == hipSuccess) e = hipMemcpy(c->d_cw.p, c->s.cw_image.data(), c->s.cw_image.size(), hipMemcpyHostToDevice);
+    }
     for (size_t d = 0; e == hipSuccess && d < c->s.pair_tags.size(); ++d) {
         uint16_t *p = nullptr;
         e = hipMalloc((void **)&p, c->s.pair_tags[d].size() * 2);
@@ -433,7 +438,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     }
     c->mp_masked.release(); c->mp_ov.release();
     c->tp_records.release(); c->tp_masked.release();
-    c->spec_cimage.release();
+    c->spec_cimage.release(); c->d_cw.release();
     c->spec_cls.release(); c->spec_ends.release(); c->spec_fail.release(); c->spec_init.release(); c->spec_vstatus.release(); c->spec_vinfo.release(); c->spec_work.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
     pool_release(c->pool);   // the device's arena pair goes with its last context (now, or with its last sub-buffer)
@@ -702,6 +707,28 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         records = (uint32_t *)ctx->tp_records.p; masked = (uint16_t *)ctx->tp_masked.p;
         layout = HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR);
     }
+    // ---- 6 or 7 defs whose CLASS-WIDE tables exist (every def <= 32 byte classes; 4 and 5 when forced): ONE def-parallel launch walks all defs — one walker wave per def, the last one combining
+    // (hrx_kernel_pmd.hip CW) — instead of passes over groups of three with summaries in between: no second read of the input, no 80-byte tile summaries written and read back
+    if ((layout & HRX_LAYOUT_POSITION_MAJOR) && ctx->d_cw.p && !ctx->mp_combine) {
+        WitnessArgs a{};
+        a.layout = (uint32_t)layout; a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
+        a.rec_pitch = (uint32_t)M; a.msk_pitch = (uint32_t)M;
+        a.records = records; a.masked = masked; a.status = status;
+        a.D = (uint32_t)ctx->s.defs.size();
+        a.debug = ctx->debug;
+        a.cw_image = (const uint8_t *)ctx->d_cw.p; a.cw_lut_off = ctx->s.cw_lut_off; a.table_bytes = (uint32_t)ctx->s.cw_image.size();
+        for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = ctx->s.cw_consts[d];
+        LaunchInfo li{};
+        if (plan_pmd_cw(a, ctx->num_cus, li)) {
+            a.nt_mix = plan_nt_mix(a, li);
+            HIP_TRY(launch_witness(a, li, st));
+            if (via_tp) {
+                TransposeArgs ta{records, masked, (uint32_t)B, (uint32_t)M, (uint32_t)ctx->s.defs.size(), caller_records, caller_masked, (uint32_t)rec_pitch, (uint32_t)msk_pitch};
+                HIP_TRY(launch_transpose(ta, st));
+            }
+            return HRX_OK;
+        }
+    }
     const bool summary_mode = (layout & HRX_LAYOUT_POSITION_MAJOR) != 0;   // position-major outputs: the passes write the caller's record planes themselves
     if (!summary_mode) HIP_TRY(ctx->mp_masked.reserve(q8 * 8 * B * 2));
     // position-major outputs, up to kMaxMergeGroups + 1 groups: the LAST pass reads the earlier groups' summaries itself and writes the final
@@ -817,7 +844,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     const char *tf[2] = {"false", "true"};
     // the names rocprofv3 lists: every template argument spelled out, defaulted ones too (an exact-match join with a kernel_stats.csv works)
     if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
-    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u>", a.D);
+    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u, %s>", a.D, a.cw_image ? "true" : "false");
     else if (li.split == 2) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, %s, %s, %s, %s, %s>", a.D, tf[li.gtab], tf[li.wide], tf[li.half], tf[!(layout & 1)], tf[li.byte]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u, %s>", a.D, li.byte ? 32u : 32u / a.D, tf[li.byte]);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
@@ -843,6 +870,22 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
         const int rc = describe_set(s, via_tp ? HRX_LAYOUT_POSITION_MAJOR : layout, B, M, num_cus, text);
         if (rc != HRX_OK) return rc;
         if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
+    } else if ([&] {   // 6 or 7 defs with CLASS-WIDE tables: one def-parallel launch over the whole config (position-major; string-major rows in multiples of 8 through the transposer)
+                   const char *mpc = std::getenv("HRX_MP_COMBINE");
+                   const bool tp = !(layout & 1) && M % 8 == 0;
+                   if (s.cw_image.empty() || (mpc && std::atoi(mpc) != 0) || !((layout & 1) || tp)) return false;
+                   WitnessArgs a{};
+                   a.layout = HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR); a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)s.defs.size();
+                   a.debug = debug_flags_from_env();
+                   a.cw_image = s.cw_image.data(); a.table_bytes = (uint32_t)s.cw_image.size();
+                   LaunchInfo li{};
+                   if (!plan_pmd_cw(a, num_cus, li)) return false;
+                   char buf[256];
+                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true> grid=%d waves=%d ring=%d lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+                   text = buf;
+                   if (tp) text += " + hrx::transpose_pm_to_sm_kernel";
+                   return true;
+               }()) {
     } else {   // one launch per group of defs (position-major, the caller's input layout), then the combine kernel
         text = "multi-pass, " + std::to_string(s.groups.size()) + " groups: ";
         for (size_t g = 0; g < s.groups.size(); ++g) {

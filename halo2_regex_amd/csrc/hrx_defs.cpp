@@ -2,6 +2,7 @@
 #include "hrx_defs.hpp"
 
 #include <algorithm>
+#include <map>
 #include <cmath>
 #include <cstring>
 
@@ -349,6 +350,62 @@ int finalize_defs(DefsSet &s, std::string &err) {
     }
     build_pair_table(s);
     if (!passes) build_byte_table(s);
+    // CLASS-WIDE image of a whole config of 4 .. kMaxDefsPerLaunch defs (hrx_defs.hpp)
+    s.cw_image.clear(); s.cw_consts.clear(); s.cw_lut_off = 0;
+    if (passes && s.defs.size() <= 8 && total_rows <= kCwMaxRows) {
+        bool ok = true;
+        std::vector<uint8_t> luts(s.defs.size() * 256, 0);
+        std::vector<uint64_t> tab((size_t)total_rows * kCwClasses, 0);
+        for (size_t d = 0; d < s.defs.size() && ok; ++d) {
+            const RegexDefs &rd = s.defs[d];
+            const DefConsts &c = s.consts[d];
+            const uint64_t L = rd.allstr.largest_state_val;
+            const uint32_t *T = s.table_image.data() + (size_t)c.row_base * 256;
+            // bytes with the same column over the real states are one class (the dummy and dead rows do not tell bytes apart)
+            std::map<std::vector<uint32_t>, uint32_t> cls_of;
+            std::vector<int> rep;                  // a representative byte per class
+            for (int ch = 0; ch < 256 && ok; ++ch) {
+                std::vector<uint32_t> col(L + 1);
+                for (uint64_t st = 0; st <= L; ++st) col[st] = T[st * 256 + ch];
+                auto it = cls_of.find(col);
+                if (it == cls_of.end()) {
+                    if (rep.size() >= kCwClasses) { ok = false; break; }
+                    it = cls_of.emplace(std::move(col), (uint32_t)rep.size()).first;
+                    rep.push_back(ch);
+                }
+                luts[d * 256 + ch] = (uint8_t)(it->second * 8u);
+            }
+            if (!ok) break;
+            uint64_t *W = tab.data() + (size_t)c.row_base * kCwClasses;
+            const uint64_t dead_lo = (uint64_t)(c.row_base + L + 2) << kCwRowShift, dummy_lo = (uint64_t)(c.row_base + L + 1) << kCwRowShift;
+            for (uint64_t st = 0; st <= L + 2; ++st)
+                for (uint32_t k = 0; k < kCwClasses; ++k) {
+                    uint64_t w = st == L + 1 ? (dummy_lo | (L + 1) << 32) : (dead_lo | std::min<uint64_t>(st, L + 1) << 32);
+                    if (st <= L && k < rep.size()) {
+                        const uint32_t e = T[st * 256 + rep[k]];
+                        if (e < c.dead_entry) {     // a defined transition: as the WIDE entry, the row field at bit kCwRowShift
+                            const uint64_t next = (e >> kNextShift) - c.row_base, tag = e & kTagMask;
+                            const uint64_t sid = tag & 0xff, is_start = (tag >> 8) & 1, is_end = (tag >> 9) & 1;
+                            w = ((uint64_t)(c.row_base + next) << kCwRowShift | sid << kWideSidShift | is_start << kWideStartShift | is_end << kWideEndShift) | (st | tag << 16) << 32;
+                        }
+                    }
+                    W[st * kCwClasses + k] = w;
+                }
+            DefConsts cc = c;
+            cc.first_entry = (uint32_t)(c.row_base + rd.allstr.first_state_val) << kCwRowShift;
+            cc.dummy_entry = (uint32_t)(c.row_base + L + 1) << kCwRowShift;
+            cc.dead_entry = (uint32_t)(c.row_base + L + 2) << kCwRowShift;
+            s.cw_consts.push_back(cc);
+        }
+        if (ok) {
+            s.cw_lut_off = (uint32_t)(total_rows * 256);
+            s.cw_image.resize((size_t)s.cw_lut_off + luts.size());
+            std::memcpy(s.cw_image.data(), tab.data(), (size_t)s.cw_lut_off);
+            std::memcpy(s.cw_image.data() + s.cw_lut_off, luts.data(), luts.size());
+        } else {
+            s.cw_consts.clear();
+        }
+    }
     // more defs than one launch walks: consecutive groups, each finalized as a DefsSet of its own
     s.groups.clear();
     s.group_first.clear();

@@ -98,6 +98,13 @@ struct DefsSet {
     std::vector<DefsSet> groups;
     std::vector<uint32_t> group_first;   // index of each group's first def
     uint64_t sid_base = 1;               // substr_id_offset of def 0: 1 for a config (lib.rs:780), the running offset for a group
+    // CLASS-WIDE image (round 5; configs of kMaxDefsPerPass + 1 .. kMaxDefsPerLaunch defs, every def with at most kCwClasses byte classes): the WIDE entry format over byte CLASSES
+    // instead of bytes — 8-byte entries, kCwClasses columns, 256 B per state row, the chain word's row field at bit kCwRowShift (10 bits: all the config's rows, numbered like
+    // the narrow table's) — [rows x 256 B | one 256-byte class LUT per def (value = class x 8)].  A whole five-def config is a few dozen KiB of LDS, where its 1-KiB-per-row tables are ~120:
+    // the def-parallel kernel walks ALL the defs of a config of six or seven in one launch (hrx_kernel_pmd.hip, CW) instead of passes over groups of three.  Empty: not built.
+    std::vector<uint8_t> cw_image;
+    uint32_t cw_lut_off = 0;               // LDS byte offset of def 0's LUT (= rows x 256); def d's at + 256 d
+    std::vector<DefConsts> cw_consts;      // the consts the kernel sees: entries in the CW encoding (row << kCwRowShift)
     // dense image: for def d, n_rows x 256 u32 entries at table_base (see hrx_lane.h for the entry format)
     std::vector<uint32_t> table_image;
     // WIDE image (hrx_lane.h): n_rows x 128 u64 entries per def, same row numbering; empty unless every transition

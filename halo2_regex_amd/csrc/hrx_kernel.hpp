@@ -32,6 +32,8 @@ struct WitnessArgs {
     uint32_t byte_bytes, byte_ptab_off, byte_mul_a4, byte_mul_b4, byte_slot_mask4, byte_dead;   // (mul_a * 4, mul_b * 4, (slots - 1) * 4: byte offsets of the 4-byte pair slots)
     uint32_t byte_one_id;         // BYTE table, position-major: the def's ONE substring id (0: it has several, or none): the finisher then holds three tiles instead of two (hrx_kernel_pm.hip)
     uint32_t byte_rows_bytes, byte16_bytes, byte16_ptab_off;   // the walker/storer kernel's image: next-state bytes [0, byte_rows_bytes) + the 2-byte slots (byte_image + byte_bytes) at byte16_ptab_off
+    const uint8_t *cw_image;      // device copy of DefsSet::cw_image (CLASS-WIDE tables of a whole config of 4 .. 8 defs: hrx_kernel_pmd.hip CW; table_bytes = its size then), or NULL
+    uint32_t cw_lut_off;          // LDS offset of def 0's class LUT
     const uint8_t *pair_image;    // device copy of DefsSet::pair.image (the exact LDS image: blocks + class LUT), or NULL
     uint32_t pair_bytes, pair_classes, pair_blk_bytes, pair_lut_off;
     uint32_t n_groups;            // ceil(B / gs), set by plan_witness_launch
@@ -148,6 +150,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 
 // Picks the launch geometry for `a` on a device with `num_cus` CUs; returns false if nothing fits.
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out);
+bool plan_pmd_cw(WitnessArgs &a, int num_cus, LaunchInfo &out);   // a whole config of 4 .. 7 defs in one def-parallel launch on the CLASS-WIDE tables (a.cw_image set)
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 hipError_t launch_zero_u32(uint32_t *p, hipStream_t stream);   // *p = 0 as a kernel node (hrx_kernel.hip)
 // the two kernel translation units behind launch_witness: li.split == 2 -> hrx_kernel_pm.hip, else hrx_kernel_sm.hip

@@ -22,8 +22,13 @@ namespace hrx {
 constexpr uint32_t kSumBytes = 64u * 80u;     // per lane: st (8 B), en1 (8 B), 64 substr-id bytes
 constexpr uint32_t kPmdPiece = 64u * 32u;     // per lane: dead, err_pos, err_state, err_char, acc_state
 
-template <int D>
-__global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
+// CW: the CLASS-WIDE tables (hrx_lane.h) — a whole config of 6 or 7 defs in one launch (one group per workgroup: 7-8 waves; instantiated for 4 and 5 defs too — two groups per workgroup,
+// 12 waves at 168 VGPRs — which the planner only takes when forced: there the two passes are as fast, hrx_kernel.hip plan_pmd_cw): each def's walker looks its bytes' columns up in the def's 256-byte class LUT (four ds_read_u8 per quad,
+// off the chain, before the tile's walk) and walks 256-byte rows; everything else is the D = 2, 3 kernel.  Batches of any size: the buffers' blocks of 65536 strings are addressed per group.
+template <int D, bool CW>
+__global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
+    constexpr int RS = CW ? kCwRowShift : kWideRowShift;
+    constexpr uint32_t kRowField = CW ? 0x3ffu : 0xffu, kRowMaskT = kRowField << RS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t G = (blockDim.x >> 6) / (D + 1u);      // groups a workgroup walks at a time
@@ -39,17 +44,18 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
 
     // LDS per group: ring | (D - 1) x (2 summaries + piece) | counters: ready, freed[D], per publishing walker sum_prod, sum_cons, piece_prod; merged
     const uint32_t walker_bytes = 2u * kSumBytes + kPmdPiece;
-    const uint32_t group_bytes = nring * kPmTileBytes + (D - 1u) * walker_bytes + 64u;   // the combiner publishes nothing
+    const uint32_t group_bytes = nring * kPmTileBytes + (D - 1u) * walker_bytes + 128u;  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
     const uint32_t ring_base = a.table_bytes + lg * group_bytes;
     const uint32_t wbase = ring_base + nring * kPmTileBytes;                  // walker areas of this group
     const uint32_t cnt = wbase + (D - 1u) * walker_bytes;
     const uint32_t ready_off = cnt, freed0 = cnt + 4u;                        // freed0 + 4 d
-    auto sum_prod_off = [&](uint32_t dd) { return cnt + 16u + 12u * dd; };    // + 4: sum_cons, + 8: piece_prod
+    auto sum_prod_off = [&](uint32_t dd) { return cnt + 40u + 12u * dd; };    // + 4: sum_cons, + 8: piece_prod  (D <= 8: freed[] ends at 36, these at 124)
+    const uint32_t merged_off = cnt + 124u;
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.wide_image);
+        const uint4 *src = CW ? reinterpret_cast<const uint4 *>(a.cw_image) : reinterpret_cast<const uint4 *>(a.wide_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
-        if (!is_walker && lane < 16u) lds_store_u32(cnt + 4u * lane, 0);
+        if (!is_walker && lane < 32u) lds_store_u32(cnt + 4u * lane, 0);
     }
     __syncthreads();
 
@@ -65,12 +71,13 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
         const uint32_t my_groups = g_first < a.n_groups ? (a.n_groups - g_first + g_stride - 1u) / g_stride : 0u;
         const uint32_t total = my_groups * ntiles;
         const uint32_t row_cap = (uint32_t)a.stride - 16u;
-        const size_t cmul = in_pm ? (size_t)B : (size_t)1;
         uint4 buf[RT * 4u];
         auto issue = [&](const uint32_t q, const uint32_t r) {
             const uint32_t g = g_first + (q / ntiles) * g_stride, t = q % ntiles;
             const uint32_t bl = min(g * 64u + lane, B - 1u);
-            const uint8_t *cptr = in_pm ? a.chars + (size_t)bl * 16u : a.chars + (size_t)bl * a.stride;
+            const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);     // the position-major buffers' block of 65536 strings this group lies in
+            const size_t cmul = in_pm ? (size_t)nb : (size_t)1;
+            const uint8_t *cptr = in_pm ? a.chars + (size_t)blk0 * a.stride + (size_t)(bl - blk0) * 16u : a.chars + (size_t)bl * a.stride;
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) buf[r * 4u + i] = *reinterpret_cast<const uint4 *>(cptr + (size_t)min(t * 64u + 16u * i, row_cap) * cmul);
         };
@@ -125,10 +132,13 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
         uint32_t dead = 0, err_pos = 0, err_state = 0, err_char = 0;
         uint32_t acc_state[1] = {ad.dc[0].first_state};   // n == 0
         const uint32_t bc = active ? b : B - 1u;
-        unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * 16u + (size_t)d * B * 16u;   // this def's plane of [M/4][D][B][4]
-        const size_t rstep = (size_t)B * 16u * D;
-        unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * 16u;
-        const size_t mstep = (size_t)B * 16u;
+        const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);                  // this group's block of the position-major buffers
+        const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
+        unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * D + (size_t)d * nb + (bc - blk0)) * 16u;   // this def's plane of the block's [M/4][D][nb][4]
+        const size_t rstep = (size_t)nb * 16u * D;
+        unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
+        const size_t mstep = (size_t)nb * 16u;
+        const uint32_t lut = CW ? a.cw_lut_off + 256u * d : 0u;     // this def's class LUT
         // combiner state
         MaskCarry mc = {0, 0, 0, 0};
         uint32_t sum_prev = 0, ov_row = 0xffffffffu;
@@ -154,33 +164,47 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             GlobalSink<1> sink{rp, 0, rstep, !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
             const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                       cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
-            if (full) {
-                tb = walk_tile_pm_wide<1, true>(L, cq, ad, sink, 0, 0, tile_ov, sidq, acc_state);
+            uint4 ccol[4];      // CW: the bytes' columns (class x 8) of this def, packed like the bytes
+            if constexpr (CW) {
+                uint32_t cw2[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) hb |= cwl[q];
-                hb &= 0x80808080u;
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t x0 = lds_u8(lut + (cwl[q] & 0xffu)), x1 = lds_u8(lut + ((cwl[q] >> 8) & 0xffu)), x2 = lds_u8(lut + ((cwl[q] >> 16) & 0xffu)), x3 = lds_u8(lut + (cwl[q] >> 24));
+                    cw2[q] = x0 | x1 << 8 | x2 << 16 | x3 << 24;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ccol[i] = make_uint4(cw2[4 * i], cw2[4 * i + 1], cw2[4 * i + 2], cw2[4 * i + 3]);
+            }
+            const uint4 (&cwalk)[4] = CW ? ccol : cq;
+            if (full) {
+                tb = walk_tile_pm_wide<1, true, GlobalSink<1>, RS, CW>(L, cwalk, ad, sink, 0, 0, tile_ov, sidq, acc_state);
+                if constexpr (!CW) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) hb |= cwl[q];
+                    hb &= 0x80808080u;
+                }
             } else {
-                tb = walk_tile_pm_wide<1, false>(L, cq, ad, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, tile_ov, sidq, acc_state);
+                tb = walk_tile_pm_wide<1, false, GlobalSink<1>, RS, CW>(L, cwalk, ad, sink, (int)n - (int)t0, (int)M - 1 - (int)t0, tile_ov, sidq, acc_state);
                 const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {   // bytes at or beyond the string's length are not trusted
-                    const uint32_t nb = live_rows > 4u * q ? min(live_rows - 4u * q, 4u) : 0u;
-                    hb |= cwl[q] & (nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u));
+                    const uint32_t nby = live_rows > 4u * q ? min(live_rows - 4u * q, 4u) : 0u;
+                    hb |= cwl[q] & (nby >= 4u ? 0xffffffffu : ((1u << (8u * nby)) - 1u));
                 }
-                hb &= 0x80808080u;
+                hb &= CW ? 0u : 0x80808080u;      // (CW: every byte value has a column)
             }
             rp = sink.rp;
             // ---------------- undefined transition (lib.rs:817): rare slow path, re-walk the tile out of the ring slot ----------------
-            if (__any(!dead && ((L.mx[0] & kWideRowMask) == ad.dc[0].dead_entry || hb != 0))) {
-                if (!dead && ((L.mx[0] & kWideRowMask) == ad.dc[0].dead_entry || hb != 0)) {
+            if (__any(!dead && ((L.mx[0] & kRowMaskT) == ad.dc[0].dead_entry || hb != 0))) {
+                if (!dead && ((L.mx[0] & kRowMaskT) == ad.dc[0].dead_entry || hb != 0)) {
                     uint32_t e = e_start;
                     const uint32_t live_rows = n > t0 ? min(n - t0, 64u) : 0u;
                     for (uint32_t p = 0; p < live_rows; ++p) {
                         const uint32_t c = smem[slot + (p >> 4) * 1024u + lane * 16u + (p & 15u)];
-                        const uint32_t nx = c < 128u ? lds_u32((e & kWideRowMask) | (c << 3)) : ad.dc[0].dead_entry;
-                        if ((nx & kWideRowMask) == ad.dc[0].dead_entry) {
+                        const uint32_t nx = CW ? lds_u32((e & kRowMaskT) | lds_u8(lut + c)) : c < 128u ? lds_u32((e & kRowMaskT) | (c << 3)) : ad.dc[0].dead_entry;
+                        if ((nx & kRowMaskT) == ad.dc[0].dead_entry) {
                             err_pos = t0 + p;
-                            err_state = ((e >> kWideRowShift) & 0xffu) - ad.dc[0].row_base;
+                            err_state = ((e >> RS) & kRowField) - ad.dc[0].row_base;
                             err_char = c;
                             dead = 1;
                             break;
@@ -191,7 +215,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             }
             ring_post(freed0 + 4u * d, seq + 1u);   // done with the slot's bytes (the combiner keeps cq in registers)
             // ---------------- accept state when n == M: row n does not exist, s[n] is the live state ----------------
-            if (!full && n == t0 + 64u && t + 1 == ntiles) acc_state[0] = ((L.e[0] >> kWideRowShift) & 0xffu) - ad.dc[0].row_base;
+            if (!full && n == t0 + 64u && t + 1 == ntiles) acc_state[0] = ((L.e[0] >> RS) & kRowField) - ad.dc[0].row_base;
 
             if (!combiner) {
                 // ---- publish this def's share of the tile: start / end bitvectors and the byte-per-row substr ids
@@ -274,11 +298,11 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(pa + 16u) = v4u32{acc_state[0], 0u, 0u, 0u};
             ring_post(sum_prod_off(d) + 8u, gi + 1u);
             // wait until the combiner has merged before the next group's piece overwrites this one
-            ring_wait(cnt + 60u, gi + 1u);
+            ring_wait(merged_off, gi + 1u);
             continue;
         }
         uint32_t m_dead = 0, accept = 0;
-        uint32_t m_pos[D], m_state[D], m_char[D];
+        uint32_t m_def = 0, m_pos = 0, m_state = 0, m_char = 0;     // the LOWEST def's undefined transition: the reference walks the defs in order (lib.rs:806)
 #pragma unroll
         for (uint32_t dd = 0; dd < (uint32_t)D; ++dd) {
             uint32_t w_dead, w_pos, w_state, w_char, w_acc;
@@ -290,19 +314,16 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             } else {
                 w_dead = dead; w_pos = err_pos; w_state = err_state; w_char = err_char; w_acc = acc_state[0];
             }
-            m_dead |= (w_dead & 1u) << dd;
-            m_pos[dd] = w_pos; m_state[dd] = w_state; m_char[dd] = w_char;
+            if ((w_dead & 1u) && !m_dead) { m_def = dd; m_pos = w_pos; m_state = w_state; m_char = w_char; }
+            m_dead |= w_dead & 1u;
             accept |= (w_acc == a.dc[dd].accepted_state ? 1u : 0u) << dd;
         }
-        ring_post(cnt + 60u, gi + 1u);
+        ring_post(merged_off, gi + 1u);
         if (active) {
             uint64_t sw;
             if (badlen) sw = kStatusBadLength;
             else if (m_dead) {
-                sw = 0;
-#pragma unroll
-                for (int dd = D - 1; dd >= 0; --dd)  // lowest def wins: the reference walks defs in order (lib.rs:806)
-                    if ((m_dead >> dd) & 1u) sw = status_invalid((uint32_t)dd, m_pos[dd], m_state[dd], m_char[dd]);
+                sw = status_invalid(m_def, m_pos, m_state, m_char);
             } else if (ov_row != 0xffffffffu) sw = status_overlap(ov_row);
             else sw = status_ok(accept);
             a.status[b] = sw;
@@ -310,9 +331,9 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
     }
 }
 
-template <int D>
+template <int D, bool CW>
 static hipError_t launch_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto kern = witness_pmd_kernel<D>;
+    auto kern = witness_pmd_kernel<D, CW>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -323,7 +344,16 @@ static hipError_t launch_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStre
 }
 
 hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    return a.D == 2 ? launch_pmd<2>(a, li, stream) : a.D == 3 ? launch_pmd<3>(a, li, stream) : hipErrorInvalidValue;
+    if (a.cw_image) {
+        switch (a.D) {
+            case 4: return launch_pmd<4, true>(a, li, stream);
+            case 5: return launch_pmd<5, true>(a, li, stream);
+            case 6: return launch_pmd<6, true>(a, li, stream);
+            case 7: return launch_pmd<7, true>(a, li, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    return a.D == 2 ? launch_pmd<2, false>(a, li, stream) : a.D == 3 ? launch_pmd<3, false>(a, li, stream) : hipErrorInvalidValue;
 }
 
 }  // namespace hrx

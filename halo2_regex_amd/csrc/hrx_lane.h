@@ -45,6 +45,13 @@ constexpr int kWideRowShift = 10;
 constexpr uint32_t kWideRowMask = 0xffu << kWideRowShift;
 constexpr int kWideSidShift = 20, kWideStartShift = 28, kWideEndShift = 30;
 
+// CLASS-WIDE table (def-parallel kernel over more than three defs): the WIDE entry over byte classes — 32 columns x 8 B = 256 B per state row; lo: bits 3..7 zero (column),
+// 8..17 absolute table row of the next state (row x 256 = its LDS byte address: the table starts at LDS offset 0), 18..19 zero, 20.. as WIDE; hi as WIDE.  The column of a
+// byte comes from the def's 256-byte class LUT (class x 8).
+constexpr int kCwRowShift = 8;
+constexpr uint32_t kCwRowMask = 0x3ffu << kCwRowShift;
+constexpr uint32_t kCwClasses = 32u, kCwMaxRows = 1023u;
+
 // HALF table (position-major kernel; all defs together have at most 256 real states and substr ids <= 62): 2-byte
 // entries, so that a 256-state x 256-symbol DFA (cfg 5) is LDS-resident in 128 KiB instead of being walked out of L2.
 //   bits 0..7   absolute table row of the NEXT state (rows = real states only: no dummy row, no dead row)

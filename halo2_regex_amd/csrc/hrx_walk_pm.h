@@ -268,17 +268,20 @@ __device__ __forceinline__ uint2 lds_u64(uint32_t off) {
     return make_uint2(v.x, v.y);
 }
 
-template <int D, bool FULL, class Sink>
+// RS / CLS: the CLASS-WIDE table of the def-parallel kernel over more than three defs (hrx_lane.h kCwRowShift): the row field sits at bit RS, and `cq` holds the bytes'
+// columns already (class x 8, looked up in the def's LUT by the caller) instead of the bytes.
+template <int D, bool FULL, class Sink, int RS = kWideRowShift, bool CLS = false>
 __device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint4 (&cq)[4], const WitnessArgs &a, Sink &sink, int rem, int mrem,
                                                       uint32_t &tile_ov, uint32_t (&sidq)[16], uint32_t (&acc_state)[D]) {
+    constexpr uint32_t kRowField = RS == kWideRowShift ? 0xffu : 0x3ffu, kRowMaskT = kRowField << RS, kByteMask = CLS ? 0xffffffffu : 0x7f7f7f7fu;
     uint32_t st[2] = {0, 0}, en1[2] = {0, 0}, ch[2] = {0, 0};
     uint32_t rbuf[D][4];
     uint32_t ov = 0;
     // bytes >= 128 have no column: they are masked here and the tile is re-walked by the caller
-    const uint32_t cw[16] = {cq[0].x & 0x7f7f7f7fu, cq[0].y & 0x7f7f7f7fu, cq[0].z & 0x7f7f7f7fu, cq[0].w & 0x7f7f7f7fu,
-                             cq[1].x & 0x7f7f7f7fu, cq[1].y & 0x7f7f7f7fu, cq[1].z & 0x7f7f7f7fu, cq[1].w & 0x7f7f7f7fu,
-                             cq[2].x & 0x7f7f7f7fu, cq[2].y & 0x7f7f7f7fu, cq[2].z & 0x7f7f7f7fu, cq[2].w & 0x7f7f7f7fu,
-                             cq[3].x & 0x7f7f7f7fu, cq[3].y & 0x7f7f7f7fu, cq[3].z & 0x7f7f7f7fu, cq[3].w & 0x7f7f7f7fu};
+    const uint32_t cw[16] = {cq[0].x & kByteMask, cq[0].y & kByteMask, cq[0].z & kByteMask, cq[0].w & kByteMask,
+                             cq[1].x & kByteMask, cq[1].y & kByteMask, cq[1].z & kByteMask, cq[1].w & kByteMask,
+                             cq[2].x & kByteMask, cq[2].y & kByteMask, cq[2].z & kByteMask, cq[2].w & kByteMask,
+                             cq[3].x & kByteMask, cq[3].y & kByteMask, cq[3].z & kByteMask, cq[3].w & kByteMask};
     uint32_t lo[D], plo[D], phi[D];   // lo: chain word after the newest row; plo/phi: chain word and record of the row being posted
 #pragma unroll
     for (int d = 0; d < D; ++d) { lo[d] = plo[d] = L.e[d]; phi[d] = 0; }
@@ -319,10 +322,10 @@ __device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int p = q * 4 + k;
-            const uint32_t c8 = ((cw[q] >> (8 * k)) & 0xffu) << 3;
+            const uint32_t c8 = CLS ? ((cw[q] >> (8 * k)) & 0xffu) : ((cw[q] >> (8 * k)) & 0xffu) << 3;
             uint2 raw[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) raw[d] = lds_u64((lo[d] & kWideRowMask) | c8);   // delta(state, byte): lib.rs:810
+            for (int d = 0; d < D; ++d) raw[d] = lds_u64((lo[d] & kRowMaskT) | c8);   // delta(state, byte): lib.rs:810
             if (p > 0) {
                 post(p - 1);
                 asm volatile("" : "+v"(st[(p - 1) >> 5]), "+v"(en1[(p - 1) >> 5]), "+v"(L.sid_prev));
@@ -342,10 +345,10 @@ __device__ __forceinline__ TileBits walk_tile_pm_wide(LaneRegs<D> &L, const uint
                     phi[d] = raw[d].y;
                 } else {
                     const bool live = p < rem;
-                    const uint32_t state_here = ((prev >> kWideRowShift) & 0xffu) - a.dc[d].row_base;
+                    const uint32_t state_here = ((prev >> RS) & kRowField) - a.dc[d].row_base;
                     if (p == rem) acc_state[d] = state_here;                       // the state at row n (lib.rs:437-457)
                     lo[d] = live ? raw[d].x : a.dc[d].dummy_entry;                 // rows >= n: lib.rs:404-418
-                    phi[d] = live ? raw[d].y : (p == rem ? state_here : (a.dc[d].dummy_entry >> kWideRowShift) - a.dc[d].row_base);
+                    phi[d] = live ? raw[d].y : (p == rem ? state_here : (a.dc[d].dummy_entry >> RS) - a.dc[d].row_base);
                     L.mx[d] = live ? raw[d].x : L.mx[d];                           // last real chain word (dead-row check)
                 }
                 plo[d] = lo[d];
