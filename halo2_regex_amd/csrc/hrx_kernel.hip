@@ -30,32 +30,29 @@ uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li) {
 
 static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &out);
 
-// A whole config of 6 or 7 defs through the def-parallel kernel on the CLASS-WIDE tables (hrx_kernel_pmd.hip CW): position-major outputs, a.cw_image / a.table_bytes set.
-// One group per workgroup (7-8 waves, the 256-VGPR budget).  The launch is bound by its combiner wave — walk + D - 1 summaries merged + reveal mask + masked rows per tile — at 0.54-0.65 of
-// peak whatever D, so it pays where the passes over groups of three defs cost more than that: same-lease A/B at 65536 x 2048 / 1024 rows (tools/dn_bench.py): D = 7 0.806 against 0.974 ms /
-// 0.412 against 0.456; D = 6 0.752 against 0.834 / 0.388 against 0.381; D = 5 0.706-0.714 against 0.648-0.701, D = 4 0.586-0.626 against 0.574-0.613 with one or two groups per workgroup:
-// four and five defs keep their two passes (the kernel is instantiated for them: kDbgForceDefParallel takes it, the tests do).
+// A whole config of 4 .. 7 defs through the def-parallel kernel on the CLASS-WIDE tables (hrx_kernel_pmd.hip CW): position-major outputs, a.cw_image / a.table_bytes set.  One group per
+// workgroup: D walkers + a combiner wave + a loader (seven defs: the last def's walker combines — nine waves would leave 168 VGPRs).  Same-lease A/B against the passes over groups of three
+// defs, 65536 x 2048 / 1024 rows (tools/dn_bench.py, outputs equal bit for bit): D = 4 0.468 against 0.577 ms / 0.220 against 0.285; D = 5 0.581 against 0.637 / 0.293 against 0.319;
+// D = 6 0.644 against 0.763 / 0.317 against 0.371; D = 7 0.797 against 0.922 / 0.415 against 0.458.  (With the last def's walker combining — the first version — four and five defs ran no
+// faster than their two passes: the combiner, walk + D - 1 merges + reveal mask + masked rows per tile, set the pace of every group.)
 bool plan_pmd_cw(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     out = LaunchInfo{};
     a.gs = 64;
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
-    const bool forced = (a.debug & kDbgForceDefParallel) != 0;
-    if (!(a.layout & 1u) || !a.cw_image || a.D < (forced ? 4u : 6u) || a.D > 7u || (a.debug & kDbgNoDefParallel)) return false;
-    const int gmax = a.D <= 5u && (size_t)a.n_groups > (size_t)num_cus ? 2 : 1;
-    for (int G = gmax; G >= 1; --G)
-        for (int ns = 4; ns >= 2; --ns) {
-            const size_t lds = a.table_bytes + (size_t)G * pmd_group_bytes((int)a.D, ns);
-            if (lds > kLdsLimit) continue;
-            out.split = 5;
-            out.wide = 1;
-            out.waves_per_wg = G * ((int)a.D + 1);
-            out.nslots = ns;
-            out.lds_bytes = lds;
-            const size_t need = ((size_t)a.n_groups + G - 1) / G;
-            out.grid = (int)(need < (size_t)num_cus ? need : (size_t)num_cus);
-            if (out.grid < 1) out.grid = 1;
-            return true;
-        }
+    if (!(a.layout & 1u) || !a.cw_image || a.D < 4u || a.D > 7u || (a.debug & kDbgNoDefParallel)) return false;
+    const int fin = a.D <= 6u ? 1 : 0;      // a combiner wave of its own up to six defs (eight waves, the 256-VGPR budget); seven: the last def's walker combines
+    for (int ns = 4; ns >= 2; --ns) {
+        const size_t lds = a.table_bytes + pmd_group_bytes((int)a.D + fin, ns);     // the publishing walkers' areas
+        if (lds > kLdsLimit) continue;
+        out.split = 5;
+        out.wide = 1;
+        out.waves_per_wg = (int)a.D + 1 + fin;
+        out.nslots = ns;
+        out.lds_bytes = lds;
+        out.grid = (int)((size_t)a.n_groups < (size_t)num_cus ? (size_t)a.n_groups : (size_t)num_cus);
+        if (out.grid < 1) out.grid = 1;
+        return true;
+    }
     return false;
 }
 

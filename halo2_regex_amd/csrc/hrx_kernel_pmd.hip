@@ -25,29 +25,32 @@ constexpr uint32_t kPmdPiece = 64u * 32u;     // per lane: dead, err_pos, err_st
 // CW: the CLASS-WIDE tables (hrx_lane.h) — a whole config of 6 or 7 defs in one launch (one group per workgroup: 7-8 waves; instantiated for 4 and 5 defs too — two groups per workgroup,
 // 12 waves at 168 VGPRs — which the planner only takes when forced: there the two passes are as fast, hrx_kernel.hip plan_pmd_cw): each def's walker looks its bytes' columns up in the def's 256-byte class LUT (four ds_read_u8 per quad,
 // off the chain, before the tile's walk) and walks 256-byte rows; everything else is the D = 2, 3 kernel.  Batches of any size: the buffers' blocks of 65536 strings are addressed per group.
-template <int D, bool CW>
-__global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
+// FIN: the combiner is a wave of its own that walks nothing — W = D + 1 walker-like waves per group, all D walkers publish, the last wave merges, runs the reveal mask and stores the masked
+// rows: with the last def's walk on top of D - 1 merges the combiner was the slowest wave of every group and set the launch's pace (0.54-0.65 of peak at 4 .. 7 defs whatever D).
+template <int D, bool CW, bool FIN>
+__global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
     constexpr int RS = CW ? kCwRowShift : kWideRowShift;
+    constexpr uint32_t W = FIN ? D + 1u : D;              // walker-like waves per group: the defs' walkers, the last one (FIN: an extra one) combining
     constexpr uint32_t kRowField = CW ? 0x3ffu : 0xffu, kRowMaskT = kRowField << RS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t G = (blockDim.x >> 6) / (D + 1u);      // groups a workgroup walks at a time
+    const uint32_t G = (blockDim.x >> 6) / (W + 1u);      // groups a workgroup walks at a time
     // Roles in wave order: group 0's D walkers, group 1's, then the loaders.  The waves of a workgroup go to the CU's four SIMDs round-robin, so at D = 3, G = 2
     // group 0's combiner shares its SIMD with a loader and group 1's with another walker: group 0 of EVERY workgroup finishes at ~2435 us, group 1 at ~2918 us of a
     // 2957-us launch over 32768 rows (tools/front_width.py) — and that is the faster arrangement.  Round 5 dealt the roles so that both groups get the same company
     // (both finish together, the chip-wide write front 4-18 tiles wide instead of 110): 11 % SLOWER in a same-lease A/B (3.245 against 2.914 ms), and a gate that holds
     // loaders back once they are W tiles ahead of the chip's average moved the launch by -2 .. +2 %: profiles/r05_probes/cfg4_front_width.txt.
-    const bool is_walker = wave < G * D;
-    const uint32_t lg = is_walker ? wave / D : wave - G * D;
-    const uint32_t d = is_walker ? wave % D : 0u;         // the def this walker walks
+    const bool is_walker = wave < G * W;
+    const uint32_t lg = is_walker ? wave / W : wave - G * W;
+    const uint32_t d = is_walker ? wave % W : 0u;         // the def this walker walks (FIN: d == D is the combiner, which walks none)
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
     // LDS per group: ring | (D - 1) x (2 summaries + piece) | counters: ready, freed[D], per publishing walker sum_prod, sum_cons, piece_prod; merged
     const uint32_t walker_bytes = 2u * kSumBytes + kPmdPiece;
-    const uint32_t group_bytes = nring * kPmTileBytes + (D - 1u) * walker_bytes + 128u;  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
+    const uint32_t group_bytes = nring * kPmTileBytes + (W - 1u) * walker_bytes + 128u;  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
     const uint32_t ring_base = a.table_bytes + lg * group_bytes;
     const uint32_t wbase = ring_base + nring * kPmTileBytes;                  // walker areas of this group
-    const uint32_t cnt = wbase + (D - 1u) * walker_bytes;
+    const uint32_t cnt = wbase + (W - 1u) * walker_bytes;
     const uint32_t ready_off = cnt, freed0 = cnt + 4u;                        // freed0 + 4 d
     auto sum_prod_off = [&](uint32_t dd) { return cnt + 40u + 12u * dd; };    // + 4: sum_cons, + 8: piece_prod  (D <= 8: freed[] ends at 36, these at 124)
     const uint32_t merged_off = cnt + 124u;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
                 if (sq < total) {
                     if (sq >= nring) {
 #pragma unroll
-                        for (uint32_t dd = 0; dd < (uint32_t)D; ++dd) ring_wait(freed0 + 4u * dd, sq - nring + 1u);   // every walker is done with this slot
+                        for (uint32_t dd = 0; dd < W; ++dd) ring_wait(freed0 + 4u * dd, sq - nring + 1u);   // every walker (and the combiner) is done with this slot
                     }
                     const uint32_t slot = ring_base + (sq % nring) * kPmTileBytes;
                     if (sq + RT <= total) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // RT-1 younger tiles x 4 loads may be in flight
@@ -112,8 +115,8 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
 
     // ================================ walkers ================================
     WitnessArgs ad = a;           // the single-def view the D = 1 walk sees: its def's constants in slot 0
-    ad.dc[0] = a.dc[d];
-    const bool combiner = d == (uint32_t)D - 1u;
+    ad.dc[0] = a.dc[min(d, (uint32_t)D - 1u)];
+    const bool combiner = d == W - 1u;
     const uint32_t my_area = wbase + d * walker_bytes;
     uint32_t gi = 0;
     for (uint32_t g = g_first; g < a.n_groups; g += g_stride, ++gi) {
@@ -134,11 +137,11 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
         const uint32_t bc = active ? b : B - 1u;
         const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);                  // this group's block of the position-major buffers
         const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
-        unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * D + (size_t)d * nb + (bc - blk0)) * 16u;   // this def's plane of the block's [M/4][D][nb][4]
+        unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * D + (size_t)min(d, (uint32_t)D - 1u) * nb + (bc - blk0)) * 16u;   // this def's plane of the block's [M/4][D][nb][4]
         const size_t rstep = (size_t)nb * 16u * D;
         unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
         const size_t mstep = (size_t)nb * 16u;
-        const uint32_t lut = CW ? a.cw_lut_off + 256u * d : 0u;     // this def's class LUT
+        const uint32_t lut = CW ? a.cw_lut_off + 256u * min(d, (uint32_t)D - 1u) : 0u;     // this def's class LUT
         // combiner state
         MaskCarry mc = {0, 0, 0, 0};
         uint32_t sum_prev = 0, ov_row = 0xffffffffu;
@@ -164,7 +167,12 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
             GlobalSink<1> sink{rp, 0, rstep, !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
             const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                       cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
-            uint4 ccol[4];      // CW: the bytes' columns (class x 8) of this def, packed like the bytes
+            uint4 ccol[4] = {};  // CW: the bytes' columns (class x 8) of this def, packed like the bytes
+            if (FIN && combiner) {          // the combiner of the FIN variant walks nothing: its own share of the tile is empty
+                tb = TileBits{0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sidq[q] = 0;
+            } else {
             if constexpr (CW) {
                 uint32_t cw2[16];
 #pragma unroll
@@ -213,9 +221,10 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
                     }
                 }
             }
-            ring_post(freed0 + 4u * d, seq + 1u);   // done with the slot's bytes (the combiner keeps cq in registers)
             // ---------------- accept state when n == M: row n does not exist, s[n] is the live state ----------------
             if (!full && n == t0 + 64u && t + 1 == ntiles) acc_state[0] = ((L.e[0] >> RS) & kRowField) - ad.dc[0].row_base;
+            }   // (walks)
+            ring_post(freed0 + 4u * d, seq + 1u);   // done with the slot's bytes (the combiner keeps cq in registers)
 
             if (!combiner) {
                 // ---- publish this def's share of the tile: start / end bitvectors and the byte-per-row substr ids
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
             // ================= combiner (the last def's walker): sums over the defs, reveal mask, masked rows =================
             uint64_t st = tb.st, en1 = tb.en1, ov_st = 0, ov_en = 0;
 #pragma unroll
-            for (uint32_t dd = 0; dd + 1u < (uint32_t)D; ++dd) {
+            for (uint32_t dd = 0; dd + 1u < W; ++dd) {
                 ring_wait(sum_prod_off(dd), seq + 1u);
                 const uint32_t sa = wbase + dd * walker_bytes + (seq & 1u) * kSumBytes + lane * 80u;
                 const uint4 h = lds_u128(sa);
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
                 const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
                 const uint32_t bj = b0 + (uint32_t)j;
                 for (uint32_t r = fs + lane; r < t0; r += 64u)
-                    a.masked[((size_t)(r >> 3) * B + bj) * 8u + (r & 7u)] = 0;
+                    a.masked[((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;     // (in this group's block of the buffer)
             }
             {
                 // (streamed unless a string of the wave has an open optimistic span: rows that may be zeroed later stay in L2 for the repair — hrx_kernel_pm.hip octets_out)
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
 #pragma unroll
         for (uint32_t dd = 0; dd < (uint32_t)D; ++dd) {
             uint32_t w_dead, w_pos, w_state, w_char, w_acc;
-            if (dd + 1u < (uint32_t)D) {
+            if (dd + 1u < W) {
                 ring_wait(sum_prod_off(dd) + 8u, gi + 1u);
                 const uint32_t oa = wbase + dd * walker_bytes + 2u * kSumBytes + lane * 32u;
                 const uint4 x0 = lds_u128(oa), x1 = lds_u128(oa + 16u);
@@ -331,9 +340,9 @@ __global__ __launch_bounds__(CW && D <= 5 ? 768 : 512) void witness_pmd_kernel(c
     }
 }
 
-template <int D, bool CW>
+template <int D, bool CW, bool FIN>
 static hipError_t launch_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto kern = witness_pmd_kernel<D, CW>;
+    auto kern = witness_pmd_kernel<D, CW, FIN>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -344,16 +353,16 @@ static hipError_t launch_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStre
 }
 
 hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    if (a.cw_image) {
+    if (a.cw_image) {   // CLASS-WIDE tables: D walkers + a combiner wave + a loader per group
         switch (a.D) {
-            case 4: return launch_pmd<4, true>(a, li, stream);
-            case 5: return launch_pmd<5, true>(a, li, stream);
-            case 6: return launch_pmd<6, true>(a, li, stream);
-            case 7: return launch_pmd<7, true>(a, li, stream);
+            case 4: return launch_pmd<4, true, true>(a, li, stream);
+            case 5: return launch_pmd<5, true, true>(a, li, stream);
+            case 6: return launch_pmd<6, true, true>(a, li, stream);
+            case 7: return launch_pmd<7, true, false>(a, li, stream);      // (nine waves would leave 168 VGPRs: 84 spills; seven defs keep the last def's walker as the combiner)
             default: return hipErrorInvalidValue;
         }
     }
-    return a.D == 2 ? launch_pmd<2, false>(a, li, stream) : a.D == 3 ? launch_pmd<3, false>(a, li, stream) : hipErrorInvalidValue;
+    return a.D == 2 ? launch_pmd<2, false, false>(a, li, stream) : a.D == 3 ? launch_pmd<3, false, false>(a, li, stream) : hipErrorInvalidValue;
 }
 
 }  // namespace hrx

@@ -848,16 +848,15 @@ CFG_D6 = HDR + CFG_123
 
 @pytest.mark.parametrize("names", [CFG_D4, CFG_D5, CFG_D6, CFG_D7], ids=["D4", "D5", "D6", "D7"])
 def test_four_to_seven_defs_in_one_def_parallel_launch(hra, oracle, names, monkeypatch):
-    """Configs of six or seven defs whose defs have at most 32 byte classes each are walked by ONE def-parallel launch on the CLASS-WIDE tables (hrx_kernel_pmd.hip CW: a walker wave per def
-    over 256-byte rows behind the def's class LUT, the last def's walker combining) instead of passes over groups of three; four and five defs when kDbgForceDefParallel says so.  Every
+    """Configs of four to seven defs whose defs have at most 32 byte classes each are walked by ONE def-parallel launch on the CLASS-WIDE tables (hrx_kernel_pmd.hip CW: a walker wave per def
+    over 256-byte rows behind the def's class LUT, a combiner wave of its own up to six defs, the last def's walker combining at seven) instead of passes over groups of three.  Every
     string against the oracle: aligned and odd row counts, ragged and failing strings, n > M, both input layouts, string-major through the transposer — and a batch of 70000 strings, two
     blocks of the position-major buffers, in multi-round launches (the groups' block addressing)."""
     from halo2_regex_amd import synth
     D = len(names)
-    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(0x4000000))                    # kDbgForceDefParallel: D = 4, 5 take the kernel too
     for M in (328, 203):
         cfg = _cfg(hra, names, M)
-        assert cfg.describe_launch(700, layout=3).startswith("hrx::witness_pmd_kernel<%d, true>" % D)
+        assert cfg.describe_launch(700, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, %s>" % (D, "true" if D <= 6 else "false"))
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=37)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=5, stride=chars.shape[1])
         chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
@@ -872,7 +871,7 @@ def test_four_to_seven_defs_in_one_def_parallel_launch(hra, oracle, names, monke
     B = 70000
     chars, lens = synth.ragged(B, M, seed=29)
     cfg = _cfg(hra, names, M)
-    assert cfg.describe_launch(B, layout=3).startswith("hrx::witness_pmd_kernel<%d, true>" % D)
+    assert cfg.describe_launch(B, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, %s>" % (D, "true" if D <= 6 else "false"))
     blocks = [(chars[:hra.PM_BLOCK], lens[:hra.PM_BLOCK]), (np.ascontiguousarray(chars[hra.PM_BLOCK:]), lens[hra.PM_BLOCK:])]
     st = _full_check(hra, OracleDefs.from_files(oracle, names), cfg, blocks, M, D)
     assert len(st) == B and (names is CFG_D7 or (st & np.uint64(0xff) == 0).mean() > 0.5)      # (D7's partial example DFA fails on almost any noise: its status words are the oracle's too)
@@ -894,9 +893,10 @@ def test_more_than_three_regex_defs_multi_pass(hra, oracle, names, combine, monk
     for M in (328, 203):                                       # aligned and unaligned row counts
         cfg = _cfg(hra, names, M)
         d = cfg.describe_launch(700, layout=3)
-        # (six or seven defs of at most 32 byte classes each, without HRX_MP_COMBINE: ONE def-parallel launch on the CLASS-WIDE tables instead of passes — D7's partial example DFA included)
+        # (four to seven defs of at most 32 byte classes each, without HRX_MP_COMBINE: ONE def-parallel launch on the CLASS-WIDE tables instead of passes — D7's partial example DFA included;
+        # with HRX_MP_COMBINE=1, and for D8, the passes over groups of three defs)
         assert (d.startswith("multi-pass, ") and ("witness_combine_summary_kernel" if combine else "witness_merge_status_kernel") in d) or \
-            (not combine and D in (6, 7) and d.startswith("hrx::witness_pmd_kernel<%d, true>" % D))
+            (not combine and D in (4, 5, 6, 7) and d.startswith("hrx::witness_pmd_kernel<%d, true, %s>" % (D, "true" if D <= 6 else "false")))
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=31)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=3, stride=chars.shape[1])
         chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
