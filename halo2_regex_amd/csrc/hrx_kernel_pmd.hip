@@ -25,6 +25,7 @@ constexpr uint32_t kPmdPiece = 64u * 32u;     // per lane: dead, err_pos, err_st
 // CW: the CLASS-WIDE tables (hrx_lane.h) — a whole config of 6 or 7 defs in one launch (one group per workgroup: 7-8 waves; instantiated for 4 and 5 defs too — two groups per workgroup,
 // 12 waves at 168 VGPRs — which the planner only takes when forced: there the two passes are as fast, hrx_kernel.hip plan_pmd_cw): each def's walker looks its bytes' columns up in the def's 256-byte class LUT (four ds_read_u8 per quad,
 // off the chain, before the tile's walk) and walks 256-byte rows; everything else is the D = 2, 3 kernel.  Batches of any size: the buffers' blocks of 65536 strings are addressed per group.
+// (cfg 4 — three defs, two groups per workgroup — on these tables with a combiner wave: 3.03-3.23 ms against 2.89-2.94 for the WIDE kernel below; not taken.)
 // FIN: the combiner is a wave of its own that walks nothing — W = D + 1 walker-like waves per group, all D walkers publish, the last wave merges, runs the reveal mask and stores the masked
 // rows: with the last def's walk on top of D - 1 merges the combiner was the slowest wave of every group and set the launch's pace (0.54-0.65 of peak at 4 .. 7 defs whatever D).
 template <int D, bool CW, bool FIN>
