@@ -844,7 +844,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     const char *tf[2] = {"false", "true"};
     // the names rocprofv3 lists: every template argument spelled out, defaulted ones too (an exact-match join with a kernel_stats.csv works)
     if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
-    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u, %s>", a.D, a.cw_image ? (a.D <= 6 ? "true, true" : "true, false") : "false, false");
+    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u, %s>", a.D, a.cw_image ? "true, true" : "false, false");
     else if (li.split == 2) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, %s, %s, %s, %s, %s>", a.D, tf[li.gtab], tf[li.wide], tf[li.half], tf[!(layout & 1)], tf[li.byte]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u, %s>", a.D, li.byte ? 32u : 32u / a.D, tf[li.byte]);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
@@ -881,7 +881,7 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
                    LaunchInfo li{};
                    if (!plan_pmd_cw(a, num_cus, li)) return false;
                    char buf[256];
-                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, %s> grid=%d waves=%d ring=%d lds=%zu", a.D, a.D <= 6 ? "true" : "false", li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true> grid=%d waves=%d ring=%d lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
                    text = buf;
                    if (tp) text += " + hrx::transpose_pm_to_sm_kernel";
                    return true;

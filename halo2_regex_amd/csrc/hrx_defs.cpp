@@ -352,7 +352,7 @@ int finalize_defs(DefsSet &s, std::string &err) {
     if (!passes) build_byte_table(s);
     // CLASS-WIDE image of a whole config of 4 .. kMaxDefsPerLaunch defs (hrx_defs.hpp)
     s.cw_image.clear(); s.cw_consts.clear(); s.cw_lut_off = 0;
-    if (passes && s.defs.size() <= 7 && total_rows <= kCwMaxRows) {
+    if (passes && s.defs.size() <= 8 && total_rows <= kCwMaxRows) {
         bool ok = true;
         std::vector<uint8_t> luts(s.defs.size() * 256, 0);
         std::vector<uint64_t> tab((size_t)total_rows * kCwClasses, 0);

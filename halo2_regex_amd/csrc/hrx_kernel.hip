@@ -30,8 +30,8 @@ uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li) {
 
 static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &out);
 
-// A whole config of 4 .. 7 defs through the def-parallel kernel on the CLASS-WIDE tables (hrx_kernel_pmd.hip CW): position-major outputs, a.cw_image / a.table_bytes set.  One group per
-// workgroup: D walkers + a combiner wave + a loader (seven defs: the last def's walker combines — nine waves would leave 168 VGPRs).  Same-lease A/B against the passes over groups of three
+// A whole config of 4 .. 8 defs through the def-parallel kernel on the CLASS-WIDE tables (hrx_kernel_pmd.hip CW): position-major outputs, a.cw_image / a.table_bytes set.  One group per
+// workgroup: D walkers + a combiner wave + a loader.  Same-lease A/B against the passes over groups of three
 // defs, 65536 x 2048 / 1024 rows (tools/dn_bench.py, outputs equal bit for bit): D = 4 0.468 against 0.577 ms / 0.220 against 0.285; D = 5 0.581 against 0.637 / 0.293 against 0.319;
 // D = 6 0.644 against 0.763 / 0.317 against 0.371; D = 7 0.797 against 0.922 / 0.415 against 0.458.  (With the last def's walker combining — the first version — four and five defs ran no
 // faster than their two passes: the combiner, walk + D - 1 merges + reveal mask + masked rows per tile, set the pace of every group.)
@@ -39,8 +39,8 @@ bool plan_pmd_cw(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     out = LaunchInfo{};
     a.gs = 64;
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
-    if (!(a.layout & 1u) || !a.cw_image || a.D < 4u || a.D > 7u || (a.debug & kDbgNoDefParallel)) return false;
-    const int fin = a.D <= 6u ? 1 : 0;      // a combiner wave of its own up to six defs (eight waves, the 256-VGPR budget); seven: the last def's walker combines
+    if (!(a.layout & 1u) || !a.cw_image || a.D < 4u || a.D > 8u || (a.debug & kDbgNoDefParallel)) return false;
+    const int fin = 1;      // a combiner wave of its own: D + 2 waves (seven and eight defs: nine and ten waves at 168 VGPRs, the combiner's merge loop rolled)
     for (int ns = 4; ns >= 2; --ns) {
         const size_t lds = a.table_bytes + pmd_group_bytes((int)a.D + fin, ns);     // the publishing walkers' areas
         if (lds > kLdsLimit) continue;

@@ -183,7 +183,7 @@ constexpr size_t pm_pair_bytes(size_t nring, bool half, bool fin) { return nring
 constexpr size_t kPpSlotBytes = 8192;   // pair-step kernel: one ring slot = 4 KiB of pair indices + 4 KiB of raw bytes
 constexpr size_t pp_pair_bytes(size_t nring) { return nring * kPpSlotBytes + kPmSummaryBytes + kPmCounterBytes; }   // + the finisher's tile summary + counters
 // LDS bytes per group of the def-parallel kernel: input ring + (D - 1) x (2 summaries of 5 KiB + a 2-KiB status piece) + counters
-constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 128; }
+constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 192; }
 
 // Configs of more than kMaxDefsPerPass RegexDefs (hrx_defs.hpp): every group of defs is walked by an ordinary launch into a
 // group-private position-major records buffer [ceil(M/4)][D_g][nb][4] (blocked like every position-major buffer) and its own

@@ -22,14 +22,13 @@ namespace hrx {
 constexpr uint32_t kSumBytes = 64u * 80u;     // per lane: st (8 B), en1 (8 B), 64 substr-id bytes
 constexpr uint32_t kPmdPiece = 64u * 32u;     // per lane: dead, err_pos, err_state, err_char, acc_state
 
-// CW: the CLASS-WIDE tables (hrx_lane.h) — a whole config of 6 or 7 defs in one launch (one group per workgroup: 7-8 waves; instantiated for 4 and 5 defs too — two groups per workgroup,
-// 12 waves at 168 VGPRs — which the planner only takes when forced: there the two passes are as fast, hrx_kernel.hip plan_pmd_cw): each def's walker looks its bytes' columns up in the def's 256-byte class LUT (four ds_read_u8 per quad,
+// CW: the CLASS-WIDE tables (hrx_lane.h) — a whole config of 4 .. 8 defs in one launch, one group per workgroup: D walkers, a combiner wave (FIN), a loader — 6 .. 10 waves: each def's walker looks its bytes' columns up in the def's 256-byte class LUT (four ds_read_u8 per quad,
 // off the chain, before the tile's walk) and walks 256-byte rows; everything else is the D = 2, 3 kernel.  Batches of any size: the buffers' blocks of 65536 strings are addressed per group.
 // (cfg 4 — three defs, two groups per workgroup — on these tables with a combiner wave: 3.03-3.23 ms against 2.89-2.94 for the WIDE kernel below; not taken.)
 // FIN: the combiner is a wave of its own that walks nothing — W = D + 1 walker-like waves per group, all D walkers publish, the last wave merges, runs the reveal mask and stores the masked
 // rows: with the last def's walk on top of D - 1 merges the combiner was the slowest wave of every group and set the launch's pace (0.54-0.65 of peak at 4 .. 7 defs whatever D).
 template <int D, bool CW, bool FIN>
-__global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
+__global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
     constexpr int RS = CW ? kCwRowShift : kWideRowShift;
     constexpr uint32_t W = FIN ? D + 1u : D;              // walker-like waves per group: the defs' walkers, the last one (FIN: an extra one) combining
     constexpr uint32_t kRowField = CW ? 0x3ffu : 0xffu, kRowMaskT = kRowField << RS;
@@ -48,18 +47,18 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
 
     // LDS per group: ring | (D - 1) x (2 summaries + piece) | counters: ready, freed[D], per publishing walker sum_prod, sum_cons, piece_prod; merged
     const uint32_t walker_bytes = 2u * kSumBytes + kPmdPiece;
-    const uint32_t group_bytes = nring * kPmTileBytes + (W - 1u) * walker_bytes + 128u;  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
+    const uint32_t group_bytes = nring * kPmTileBytes + (W - 1u) * walker_bytes + 192u;  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
     const uint32_t ring_base = a.table_bytes + lg * group_bytes;
     const uint32_t wbase = ring_base + nring * kPmTileBytes;                  // walker areas of this group
     const uint32_t cnt = wbase + (W - 1u) * walker_bytes;
     const uint32_t ready_off = cnt, freed0 = cnt + 4u;                        // freed0 + 4 d
-    auto sum_prod_off = [&](uint32_t dd) { return cnt + 40u + 12u * dd; };    // + 4: sum_cons, + 8: piece_prod  (D <= 8: freed[] ends at 36, these at 124)
-    const uint32_t merged_off = cnt + 124u;
+    auto sum_prod_off = [&](uint32_t dd) { return cnt + 48u + 12u * dd; };    // + 4: sum_cons, + 8: piece_prod  (W <= 9: freed[] ends at 40, these at 144)
+    const uint32_t merged_off = cnt + 148u;
     {
         const uint4 *src = CW ? reinterpret_cast<const uint4 *>(a.cw_image) : reinterpret_cast<const uint4 *>(a.wide_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
-        if (!is_walker && lane < 32u) lds_store_u32(cnt + 4u * lane, 0);
+        if (!is_walker && lane < 48u) lds_store_u32(cnt + 4u * lane, 0);
     }
     __syncthreads();
 
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(512) void witness_pmd_kernel(const WitnessArgs a, c
             }
             // ================= combiner (the last def's walker): sums over the defs, reveal mask, masked rows =================
             uint64_t st = tb.st, en1 = tb.en1, ov_st = 0, ov_en = 0;
-#pragma unroll
+#pragma unroll(D >= 7 ? 1 : 8)      // (seven and eight defs: rolled — unrolled, the summaries' loads of all iterations are in flight at once and the nine / ten waves' 168 VGPRs spill)
             for (uint32_t dd = 0; dd + 1u < W; ++dd) {
                 ring_wait(sum_prod_off(dd), seq + 1u);
                 const uint32_t sa = wbase + dd * walker_bytes + (seq & 1u) * kSumBytes + lane * 80u;
@@ -359,7 +358,8 @@ hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStr
             case 4: return launch_pmd<4, true, true>(a, li, stream);
             case 5: return launch_pmd<5, true, true>(a, li, stream);
             case 6: return launch_pmd<6, true, true>(a, li, stream);
-            case 7: return launch_pmd<7, true, false>(a, li, stream);      // (nine waves would leave 168 VGPRs: 84 spills; seven defs keep the last def's walker as the combiner)
+            case 7: return launch_pmd<7, true, true>(a, li, stream);
+            case 8: return launch_pmd<8, true, true>(a, li, stream);
             default: return hipErrorInvalidValue;
         }
     }

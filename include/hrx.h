@@ -70,7 +70,8 @@ int hrx_defs_push_substr(hrx_defs *defs, size_t n_pairs, const uint64_t *pair_cu
                          size_t n_start, const uint64_t *start_states, size_t n_end, const uint64_t *end_states);
 /* Validate and build the dense fused (state,char) tables.  Required before any call below.
  * regex_defs is a Vec of any length in the reference (src/lib.rs:112; loops at :387, :806, :828, :855): up to HRX_MAX_DEFS
- * RegexDefs per config.  Up to three defs are walked side by side by one kernel launch; a larger config is walked in passes
+ * RegexDefs per config.  Up to three defs are walked side by side by one kernel launch; four to eight defs of at most 32 byte classes each (position-major
+ * outputs) by ONE def-parallel launch — a walker wave per def over class-indexed tables, a combiner wave — at 0.66-0.70 of the HBM peak; any larger config is walked in passes
  * over consecutive groups of defs (each group's tables LDS-resident); the per-row sums over all defs (reveal masks, flag
  * overlap) and the merged status are formed by the last pass itself from 80-byte tile summaries the earlier passes leave
  * (position-major outputs, up to four groups) or by a combine launch — same buffers, same results; with position-major outputs

@@ -846,17 +846,17 @@ CFG_D8 = CFG_123 + HDR + [CFG_1[0], CFG_A[1]]           # regex1 and regex2 a se
 CFG_D6 = HDR + CFG_123
 
 
-@pytest.mark.parametrize("names", [CFG_D4, CFG_D5, CFG_D6, CFG_D7], ids=["D4", "D5", "D6", "D7"])
-def test_four_to_seven_defs_in_one_def_parallel_launch(hra, oracle, names, monkeypatch):
-    """Configs of four to seven defs whose defs have at most 32 byte classes each are walked by ONE def-parallel launch on the CLASS-WIDE tables (hrx_kernel_pmd.hip CW: a walker wave per def
-    over 256-byte rows behind the def's class LUT, a combiner wave of its own up to six defs, the last def's walker combining at seven) instead of passes over groups of three.  Every
+@pytest.mark.parametrize("names", [CFG_D4, CFG_D5, CFG_D6, CFG_D7, CFG_D8], ids=["D4", "D5", "D6", "D7", "D8"])
+def test_four_to_eight_defs_in_one_def_parallel_launch(hra, oracle, names, monkeypatch):
+    """Configs of four to eight defs whose defs have at most 32 byte classes each are walked by ONE def-parallel launch on the CLASS-WIDE tables (hrx_kernel_pmd.hip CW: a walker wave per def
+    over 256-byte rows behind the def's class LUT, a combiner wave of its own) instead of passes over groups of three.  Every
     string against the oracle: aligned and odd row counts, ragged and failing strings, n > M, both input layouts, string-major through the transposer — and a batch of 70000 strings, two
     blocks of the position-major buffers, in multi-round launches (the groups' block addressing)."""
     from halo2_regex_amd import synth
     D = len(names)
     for M in (328, 203):
         cfg = _cfg(hra, names, M)
-        assert cfg.describe_launch(700, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, %s>" % (D, "true" if D <= 6 else "false"))
+        assert cfg.describe_launch(700, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, true>" % D)
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=37)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=5, stride=chars.shape[1])
         chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
@@ -871,10 +871,11 @@ def test_four_to_seven_defs_in_one_def_parallel_launch(hra, oracle, names, monke
     B = 70000
     chars, lens = synth.ragged(B, M, seed=29)
     cfg = _cfg(hra, names, M)
-    assert cfg.describe_launch(B, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, %s>" % (D, "true" if D <= 6 else "false"))
+    assert cfg.describe_launch(B, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, true>" % D)
     blocks = [(chars[:hra.PM_BLOCK], lens[:hra.PM_BLOCK]), (np.ascontiguousarray(chars[hra.PM_BLOCK:]), lens[hra.PM_BLOCK:])]
     st = _full_check(hra, OracleDefs.from_files(oracle, names), cfg, blocks, M, D)
-    assert len(st) == B and (names is CFG_D7 or (st & np.uint64(0xff) == 0).mean() > 0.5)      # (D7's partial example DFA fails on almost any noise: its status words are the oracle's too)
+    # (D7's partial example DFA fails on almost any noise, D8's two copies of regex1 / regex2 flag the same rows: out of contract — their status words are the oracle's too)
+    assert len(st) == B and (names is CFG_D7 or names is CFG_D8 or (st & np.uint64(0xff) == 0).mean() > 0.5)
 
 
 @pytest.mark.parametrize("combine", [False, True], ids=["merged-by-the-last-pass", "combine-launch"])
@@ -896,7 +897,7 @@ def test_more_than_three_regex_defs_multi_pass(hra, oracle, names, combine, monk
         # (four to seven defs of at most 32 byte classes each, without HRX_MP_COMBINE: ONE def-parallel launch on the CLASS-WIDE tables instead of passes — D7's partial example DFA included;
         # with HRX_MP_COMBINE=1, and for D8, the passes over groups of three defs)
         assert (d.startswith("multi-pass, ") and ("witness_combine_summary_kernel" if combine else "witness_merge_status_kernel") in d) or \
-            (not combine and D in (4, 5, 6, 7) and d.startswith("hrx::witness_pmd_kernel<%d, true, %s>" % (D, "true" if D <= 6 else "false")))
+            (not combine and D in (4, 5, 6, 7, 8) and d.startswith("hrx::witness_pmd_kernel<%d, true, true>" % D))
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=31)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=3, stride=chars.shape[1])
         chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])

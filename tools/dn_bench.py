@@ -15,7 +15,8 @@ rd = lambda f: open(os.path.join(DFA, f), "rb").read()
 pair = lambda k: (rd("regex%d_test_lookup.txt" % k), [rd("substr%d_test_lookup.txt" % k)])
 hdr = lambda n, ns: (rd(n + "_lookup.txt"), [rd("%s_substr%d.txt" % (n, k)) for k in range(ns)])
 H = [hdr("header_from", 1), hdr("header_to", 1), hdr("header_subject", 3)]
-cfgs = {4: H + [pair(1)], 5: H + [pair(1), pair(2)], 6: H + [pair(1), pair(2), pair(3)], 7: H + [pair(1), pair(2), pair(3), hdr("header_from", 1)]}
+cfgs = {4: H + [pair(1)], 5: H + [pair(1), pair(2)], 6: H + [pair(1), pair(2), pair(3)], 7: H + [pair(1), pair(2), pair(3), hdr("header_from", 1)],
+        8: H + [pair(1), pair(2), pair(3), hdr("header_from", 1), hdr("header_to", 1)]}
 base_c, base_l = synth.headers_planted(4096, M - 1, seed=3, stride=M)
 d_c = torch.from_numpy(base_c).to(dev)
 d_c = torch.cat([torch.roll(d_c, shifts=131 * j, dims=0) for j in range(B // 4096)])
