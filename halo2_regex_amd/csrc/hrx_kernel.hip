@@ -21,11 +21,15 @@ namespace hrx {
 uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li) {
     const bool pm = (a.layout & 1u) && li.split == 2 && !li.half, sm_split = !(a.layout & 1u) && li.split == 1;   // (the walker/storer kernel streams full lines too)
     if (!pm && !sm_split) return 0u;
+    // The finisher's open-span rule (masked rows of a tile into which an open optimistic span reaches are written back, so that a repair merges in L2) pays where repairs happen — one-def
+    // kernels: the bench line + 1.7 %, cfg 5 + 4-8 % — and costs where spans are long and DO end: headers3 65536 x 2048 0.687 with it against 0.721 without, regex2+3 0.745 against 0.749,
+    // regex123 0.751 against 0.753 (tools/ab_policy.py on the release kernels, two leases, profiles/r05_probes/ab_policy.txt).  From two defs on the masked rows are streamed.
+    const uint32_t flags = pm && a.D >= 2u ? kNtMixNoOpenSpan : 0u;
     const size_t rows = pm ? (size_t)a.M : (size_t)a.rec_pitch;   // string-major: the rows between consecutive strings
     const size_t rec_bytes = (size_t)a.B * rows * 4u * a.D, msk_bytes = (size_t)a.B * a.M * 2u;
-    if (rec_bytes + msk_bytes < ((size_t)256 << 20)) return 0u;
+    if (rec_bytes + msk_bytes < ((size_t)256 << 20)) return flags;
     const size_t k = (rec_bytes + ((size_t)128 << 20) - 1) / ((size_t)128 << 20);
-    return k < 2 ? 2u : k <= 8 ? (uint32_t)k : 0u;
+    return (k < 2 ? 2u : k <= 8 ? (uint32_t)k : 0u) | flags;
 }
 
 static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &out);

@@ -1,7 +1,7 @@
 #!/bin/bash
-# tools/ab_policy.py over the shapes whose finisher / combiner stores masked rows (ablation build)
+# tools/ab_policy.py over the shapes whose finisher / combiner stores masked rows (ntenv build)
 cd "$(dirname "$0")/.." || exit 1
-export HRX_LIB_PATH=halo2_regex_amd/csrc/libhrx_ablation.so
+export HRX_LIB_PATH=halo2_regex_amd/csrc/libhrx_ntenv.so    # (make -C halo2_regex_amd/csrc ntenv: the release kernels, the store-policy variables read per launch)
 T="timeout 400 python3 tools/ab_policy.py"
 $T --steps 100 2>/dev/null
 $T --dist noise --steps 100 2>/dev/null
