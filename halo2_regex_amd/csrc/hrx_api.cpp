@@ -117,6 +117,8 @@ struct hrx_ctx {
         DevBuf records, status, summary;
     };
     std::vector<GroupDev> groups;
+    struct CwGroupDev { DevBuf d_cw, status, summary; };
+    std::vector<CwGroupDev> cw_groups;   // more than eight defs: the CW groups of DefsSet::cw_groups (position-major passes of up to eight defs each)
     DevBuf mp_masked;
     DevBuf mp_ov;          // multi-pass configs whose last pass merges the summaries: its cross-group overlap rows (WitnessArgs::merge_ov)
     bool mp_combine = false;   // HRX_MP_COMBINE=1: always the separate combine launch
@@ -379,6 +381,11 @@ static int ctx_create_from(const DefsSet &set, int device, hrx_ctx **out) {
             if (e == hipSuccess) e = upload_blob(c->s.groups[g].byte.image, c->groups[g].d_bytetab);
         }
     }
+    c->cw_groups.resize(c->s.cw_groups.size());
+    for (size_t g = 0; e == hipSuccess && g < c->s.cw_groups.size(); ++g) {
+        e = c->cw_groups[g].d_cw.reserve(c->s.cw_groups[g].cw_image.size());
+        if (e == hipSuccess) e = hipMemcpy(c->cw_groups[g].d_cw.p, c->s.cw_groups[g].cw_image.data(), c->s.cw_groups[g].cw_image.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && !c->s.cw_image.empty()) {
         e = c->d_cw.reserve(c->s.cw_image.size());
         if (e == hipSuccess) e = hipMemcpy(c->d_cw.p, c->s.cw_image.data(), c->s.cw_image.size(), hipMemcpyHostToDevice);
@@ -439,6 +446,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
     c->mp_masked.release(); c->mp_ov.release();
     c->tp_records.release(); c->tp_masked.release();
     c->spec_cimage.release(); c->d_cw.release();
+    for (auto &g : c->cw_groups) { g.d_cw.release(); g.status.release(); g.summary.release(); }
     c->spec_cls.release(); c->spec_ends.release(); c->spec_fail.release(); c->spec_init.release(); c->spec_vstatus.release(); c->spec_vinfo.release(); c->spec_work.release();
     if (c->d_group_counter) (void)hipFree(c->d_group_counter);
     pool_release(c->pool);   // the device's arena pair goes with its last context (now, or with its last sub-buffer)
@@ -729,6 +737,54 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
             return HRX_OK;
         }
     }
+    // ---- more than eight defs, every def of at most 32 byte classes: passes over CW GROUPS of 4 .. 8 defs (DefsSet::cw_groups), each ONE def-parallel launch that writes its defs' planes of the
+    // caller's records and a tile summary; the combine launch forms what needs all defs of a row.  D = 16: two passes instead of six, D = 32: four instead of eleven.
+    if ((layout & HRX_LAYOUT_POSITION_MAJOR) && !ctx->cw_groups.empty() && !(ctx->debug & kDbgNoDefParallel)) {
+        const size_t GC = ctx->cw_groups.size();
+        CombineArgs cc{};
+        bool planned = true;
+        std::vector<LaunchInfo> lis(GC);
+        std::vector<WitnessArgs> was(GC);
+        for (size_t g = 0; g < GC && planned; ++g) {
+            const DefsSet &gs = ctx->s.cw_groups[g];
+            WitnessArgs &a = was[g];
+            a = WitnessArgs{};
+            a.layout = (uint32_t)layout; a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
+            a.rec_pitch = (uint32_t)M; a.msk_pitch = (uint32_t)M;
+            a.records = records; a.masked = masked;
+            a.D = (uint32_t)gs.defs.size();
+            a.rec_D = (uint32_t)ctx->s.defs.size(); a.rec_d0 = ctx->s.cw_group_first[g];
+            a.debug = ctx->debug;
+            a.cw_image = (const uint8_t *)ctx->cw_groups[g].d_cw.p; a.cw_lut_off = gs.cw_lut_off; a.table_bytes = (uint32_t)gs.cw_image.size();
+            for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = gs.cw_consts[d];
+            planned = plan_pmd_cw(a, ctx->num_cus, lis[g]);
+        }
+        if (planned) {
+            for (size_t g = 0; g < GC; ++g) {
+                hrx_ctx::CwGroupDev &gd = ctx->cw_groups[g];
+                HIP_TRY(gd.status.reserve(B * 8));
+                HIP_TRY(gd.summary.reserve(ntiles * 5 * B * 16));
+                was[g].status = (uint64_t *)gd.status.p;
+                was[g].summary = (uint32_t *)gd.summary.p;
+                was[g].nt_mix = plan_nt_mix(was[g], lis[g]);
+                HIP_TRY(launch_witness(was[g], lis[g], st));
+                cc.gsummary[g] = (const uint32_t *)gd.summary.p;
+                cc.gstatus[g] = (const uint64_t *)gd.status.p;
+                cc.gD[g] = (uint8_t)ctx->s.cw_groups[g].defs.size();
+                cc.gfirst[g] = (uint8_t)ctx->s.cw_group_first[g];
+            }
+            cc.chars = chars; cc.stride = stride; cc.lens = lens; cc.B = (uint32_t)B; cc.M = (uint32_t)M;
+            cc.D = (uint32_t)ctx->s.defs.size(); cc.G = (uint32_t)GC; cc.layout = (uint32_t)layout;
+            cc.rec_pitch = (uint32_t)rec_pitch; cc.msk_pitch = (uint32_t)msk_pitch;
+            cc.records = records; cc.masked = masked; cc.status = status;
+            HIP_TRY(launch_combine(cc, st));
+            if (via_tp) {
+                TransposeArgs ta{records, masked, (uint32_t)B, (uint32_t)M, (uint32_t)ctx->s.defs.size(), caller_records, caller_masked, (uint32_t)rec_pitch, (uint32_t)msk_pitch};
+                HIP_TRY(launch_transpose(ta, st));
+            }
+            return HRX_OK;
+        }
+    }
     const bool summary_mode = (layout & HRX_LAYOUT_POSITION_MAJOR) != 0;   // position-major outputs: the passes write the caller's record planes themselves
     if (!summary_mode) HIP_TRY(ctx->mp_masked.reserve(q8 * 8 * B * 2));
     // position-major outputs, up to kMaxMergeGroups + 1 groups: the LAST pass reads the earlier groups' summaries itself and writes the final
@@ -883,6 +939,25 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
                    char buf[256];
                    std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true> grid=%d waves=%d ring=%d lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
                    text = buf;
+                   if (tp) text += " + hrx::transpose_pm_to_sm_kernel";
+                   return true;
+               }()) {
+    } else if ([&] {   // more than eight defs with CW groups: one def-parallel launch per group of 4 .. 8 defs, then the combine launch
+                   const bool tp = !(layout & 1) && M % 8 == 0;
+                   if (s.cw_groups.empty() || !((layout & 1) || tp) || (debug_flags_from_env() & kDbgNoDefParallel)) return false;
+                   std::string t2 = "multi-pass, " + std::to_string(s.cw_groups.size()) + " groups: ";
+                   for (size_t g = 0; g < s.cw_groups.size(); ++g) {
+                       WitnessArgs a{};
+                       a.layout = HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR); a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)s.cw_groups[g].defs.size();
+                       a.cw_image = s.cw_groups[g].cw_image.data(); a.table_bytes = (uint32_t)s.cw_groups[g].cw_image.size();
+                       LaunchInfo li{};
+                       if (!plan_pmd_cw(a, num_cus, li)) return false;
+                       char buf[256];
+                       std::snprintf(buf, sizeof buf, "[defs %u..%zu: hrx::witness_pmd_kernel<%u, true, true> grid=%d waves=%d ring=%d lds=%zu] ", s.cw_group_first[g],
+                                     s.cw_group_first[g] + s.cw_groups[g].defs.size() - 1, a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+                       t2 += buf;
+                   }
+                   text = t2 + "+ hrx::witness_combine_summary_kernel";
                    if (tp) text += " + hrx::transpose_pm_to_sm_kernel";
                    return true;
                }()) {

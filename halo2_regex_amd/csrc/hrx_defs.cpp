@@ -352,7 +352,7 @@ int finalize_defs(DefsSet &s, std::string &err) {
     if (!passes) build_byte_table(s);
     // CLASS-WIDE image of a whole config of 4 .. kMaxDefsPerLaunch defs (hrx_defs.hpp)
     s.cw_image.clear(); s.cw_consts.clear(); s.cw_lut_off = 0;
-    if (passes && s.defs.size() <= 8 && total_rows <= kCwMaxRows) {
+    if ((passes || s.cw_group) && s.defs.size() <= 8 && total_rows <= kCwMaxRows) {
         bool ok = true;
         std::vector<uint8_t> luts(s.defs.size() * 256, 0);
         std::vector<uint64_t> tab((size_t)total_rows * kCwClasses, 0);
@@ -409,7 +409,28 @@ int finalize_defs(DefsSet &s, std::string &err) {
     // more defs than one launch walks: consecutive groups, each finalized as a DefsSet of its own
     s.groups.clear();
     s.group_first.clear();
-    if (passes) {
+    s.cw_groups.clear();
+    s.cw_group_first.clear();
+    if (passes && !s.cw_group && s.defs.size() > 8) {
+        // CW groups: ceil(D / 8) groups of nearly equal size (D = 13: 7 + 6; 16: 8 + 8; 9: 5 + 4), every one of at least four defs (the def-parallel CW kernel's range)
+        const size_t ng = (s.defs.size() + 7) / 8, base = s.defs.size() / ng, extra = s.defs.size() % ng;
+        bool ok = base >= 4;
+        size_t d = 0;
+        for (size_t g = 0; g < ng && ok; ++g) {
+            const size_t cnt = base + (g < extra ? 1 : 0);
+            DefsSet grp;
+            grp.defs.assign(s.defs.begin() + (long)d, s.defs.begin() + (long)(d + cnt));
+            grp.sid_base = s.consts[d].substr_id_offset;
+            grp.cw_group = true;
+            std::string e2;
+            if (finalize_defs(grp, e2) != HRX_OK || grp.cw_image.empty()) { ok = false; break; }
+            s.cw_group_first.push_back((uint32_t)d);
+            s.cw_groups.push_back(std::move(grp));
+            d += cnt;
+        }
+        if (!ok) { s.cw_groups.clear(); s.cw_group_first.clear(); }
+    }
+    if (passes && !s.cw_group) {
         // a group takes up to kMaxDefsPerPass defs while their fused 4-byte tables (1 KiB per row) still fit LDS next to the
         // input rings (96 KiB); a def that is larger than that on its own walks alone
         size_t d = 0;

@@ -102,6 +102,11 @@ struct DefsSet {
     // instead of bytes — 8-byte entries, kCwClasses columns, 256 B per state row, the chain word's row field at bit kCwRowShift (10 bits: all the config's rows, numbered like
     // the narrow table's) — [rows x 256 B | one 256-byte class LUT per def (value = class x 8)].  A whole five-def config is a few dozen KiB of LDS, where its 1-KiB-per-row tables are ~120:
     // the def-parallel kernel walks ALL the defs of a config of six or seven in one launch (hrx_kernel_pmd.hip, CW) instead of passes over groups of three.  Empty: not built.
+    // More than kMaxDefsPerLaunch defs: besides the groups of three (`groups`, every layout) the config is cut into CW GROUPS of 4 .. 8 consecutive defs, each with a CLASS-WIDE image of its own — the
+    // passes of position-major launches then walk eight defs at a time with the def-parallel kernel (D = 16: two passes instead of six).  Empty: a def has more than 32 byte classes, or <= 8 defs.
+    std::vector<DefsSet> cw_groups;
+    std::vector<uint32_t> cw_group_first;
+    bool cw_group = false;                 // this set IS such a group: finalize builds its CLASS-WIDE image and no groups of its own
     std::vector<uint8_t> cw_image;
     uint32_t cw_lut_off = 0;               // LDS byte offset of def 0's LUT (= rows x 256); def d's at + 256 d
     std::vector<DefConsts> cw_consts;      // the consts the kernel sees: entries in the CW encoding (row << kCwRowShift)

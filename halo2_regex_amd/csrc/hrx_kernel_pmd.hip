@@ -137,8 +137,10 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
         const uint32_t bc = active ? b : B - 1u;
         const uint32_t blk0 = (b0 / kPmBlock) * kPmBlock, nb = min(kPmBlock, B - blk0);                  // this group's block of the position-major buffers
         const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
-        unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * D + (size_t)min(d, (uint32_t)D - 1u) * nb + (bc - blk0)) * 16u;   // this def's plane of the block's [M/4][D][nb][4]
-        const size_t rstep = (size_t)nb * 16u * D;
+        // this def's plane of the block's [M/4][RD][nb][4]: a pass of a multi-pass config (CW groups of up to eight defs, hrx_defs.hpp) writes planes rec_d0 .. of the caller's rec_D
+        const uint32_t RD = a.rec_D ? a.rec_D : (uint32_t)D;
+        unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * RD + (size_t)(a.rec_d0 + min(d, (uint32_t)D - 1u)) * nb + (bc - blk0)) * 16u;
+        const size_t rstep = (size_t)nb * 16u * RD;
         unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
         const size_t mstep = (size_t)nb * 16u;
         const uint32_t lut = CW ? a.cw_lut_off + 256u * min(d, (uint32_t)D - 1u) : 0u;     // this def's class LUT
@@ -259,6 +261,15 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
             if (ov_row == 0xffffffffu) {
                 if (ov_st) ov_row = t0 + (uint32_t)ctz64(ov_st);
                 if (ov_en) ov_row = min(ov_row, t0 + (uint32_t)ctz64(ov_en) + 1u);
+            }
+            if (a.summary) {   // a pass of a multi-pass config: this group's share of the tile for the combine launch (hrx_kernel_mp.hip) — [tile][5][B][16 B], as the finisher of hrx_kernel_pm.hip writes it
+                if (active) {
+                    uint4 *sp = reinterpret_cast<uint4 *>(a.summary) + ((size_t)t * 5u * B + b);
+                    sp[0] = make_uint4((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)en1, (uint32_t)(en1 >> 32));
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) sp[(size_t)(i + 1u) * B] = make_uint4(sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]);
+                }
+                continue;
             }
             // id-changed bits: byte p of the sums against byte p - 1 (the previous tile's last byte for p = 0)
             uint64_t ch = 0;

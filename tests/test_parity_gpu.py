@@ -934,8 +934,8 @@ CFG_D32 = CFG_123 + NOSUB(HDR + CFG_123) * 4 + HDR + NOSUB(CFG_A)               
 @pytest.mark.parametrize("combine", [False, True], ids=["default", "combine-launch"])
 @pytest.mark.parametrize("names", [CFG_D13, CFG_D16, CFG_D32], ids=["D13", "D16", "D32"])
 def test_up_to_32_regex_defs(hra, oracle, names, combine, monkeypatch):
-    """HRX_MAX_DEFS = 32 RegexDefs per config (the status word's accept mask, bits 8..39; include/hrx.h): 13, 16 and 32 defs = 5 .. 11 groups — more than the last
-    pass merges itself, so the combine launch forms what needs all defs of a row whatever HRX_MP_COMBINE says — string-major outputs (through the position-major path
+    """HRX_MAX_DEFS = 32 RegexDefs per config (the status word's accept mask, bits 8..39; include/hrx.h): 13, 16 and 32 defs = 2 .. 4 CW groups of up to eight defs (position-major passes: one
+    def-parallel launch each) or 5 .. 11 groups of three — more than the last pass merges itself, so the combine launch forms what needs all defs of a row whatever HRX_MP_COMBINE says — string-major outputs (through the position-major path
     and the transpose kernel for row counts in multiples of 8: 16-row tiles from 10 defs on, hrx_kernel_tp.hip; the copy-mode combine otherwise), position-major outputs
     with both input layouts; accept masks with a bit per def, the lowest def's undefined transition, flags of defs in different groups on one row."""
     from halo2_regex_amd import synth
@@ -945,7 +945,9 @@ def test_up_to_32_regex_defs(hra, oracle, names, combine, monkeypatch):
     for M in (328, 203):                                       # aligned (transpose kernel) and unaligned (copy-mode combine) row counts
         cfg = _cfg(hra, names, M)
         d = cfg.describe_launch(700, layout=3)
-        assert d.startswith("multi-pass, ") and "witness_combine_summary_kernel" in d and d.count("[defs ") >= 5
+        # (every def of these configs has at most 32 byte classes: passes over CW groups of up to eight defs — 2, 2 and 4 def-parallel launches; the groups of three, 5 .. 11 passes, serve the
+        # unaligned string-major row counts below and kDbgNoDefParallel)
+        assert d.startswith("multi-pass, ") and "witness_combine_summary_kernel" in d and d.count("[defs ") >= 2 and "witness_pmd_kernel<" in d
         assert ("transpose_pm_to_sm_kernel" in cfg.describe_launch(700, layout=0)) == (M % 8 == 0)
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=41)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=5, stride=chars.shape[1])
