@@ -71,7 +71,7 @@ int hrx_defs_push_substr(hrx_defs *defs, size_t n_pairs, const uint64_t *pair_cu
 /* Validate and build the dense fused (state,char) tables.  Required before any call below.
  * regex_defs is a Vec of any length in the reference (src/lib.rs:112; loops at :387, :806, :828, :855): up to HRX_MAX_DEFS
  * RegexDefs per config.  Up to three defs are walked side by side by one kernel launch; four to eight defs of at most 32 byte classes each (position-major
- * outputs) by ONE def-parallel launch — a walker wave per def over class-indexed tables, a combiner wave — at 0.66-0.70 of the HBM peak; any larger config is walked in passes
+ * outputs) by ONE def-parallel launch — a walker wave per def over class-indexed tables, a combiner wave — at 0.66-0.70 of the HBM peak (nine defs and more: one such launch per group of up to eight defs + the combine launch, 0.58-0.65); a def of more than 32 byte classes puts its config into passes
  * over consecutive groups of defs (each group's tables LDS-resident); the per-row sums over all defs (reveal masks, flag
  * overlap) and the merged status are formed by the last pass itself from 80-byte tile summaries the earlier passes leave
  * (position-major outputs, up to four groups) or by a combine launch — same buffers, same results; with position-major outputs
