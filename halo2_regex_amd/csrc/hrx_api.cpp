@@ -706,6 +706,24 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     // string-major outputs (rows in multiples of 8): the passes and the combine run position-major into context scratch and
     // transpose_pm_to_sm_kernel turns the rows around (hrx_kernel_tp.hip: 3.7 -> ~1 ms at D = 5, 65536 x 1024 rows); other row counts keep the
     // copy-mode combine (per-lane 4-byte stores)
+    // ---- four and five defs, string-major outputs, rows in multiples of 16: the def-parallel launch writes the caller's [B][pitch][D] records and [B][pitch] masked rows itself — its walkers'
+    // quads meet in LDS sub-tiles, a storer wave writes each string's 16 rows x D records as one run (hrx_kernel_pmd.hip SMO) — instead of position-major scratch + the transposer
+    if (layout == HRX_LAYOUT_STRING_MAJOR && ctx->d_cw.p && !ctx->mp_combine) {
+        WitnessArgs a{};
+        a.layout = (uint32_t)layout; a.chars = chars; a.stride = stride; a.lens = lens; a.B = (uint32_t)B; a.M = (uint32_t)M;
+        a.rec_pitch = (uint32_t)rec_pitch; a.msk_pitch = (uint32_t)msk_pitch;
+        a.records = records; a.masked = masked; a.status = status;
+        a.D = (uint32_t)ctx->s.defs.size();
+        a.debug = ctx->debug;
+        a.cw_image = (const uint8_t *)ctx->d_cw.p; a.cw_lut_off = ctx->s.cw_lut_off; a.table_bytes = (uint32_t)ctx->s.cw_image.size();
+        for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = ctx->s.cw_consts[d];
+        LaunchInfo li{};
+        if (plan_pmd_cw_sm(a, ctx->num_cus, li)) {
+            a.nt_mix = plan_nt_mix(a, li);
+            HIP_TRY(launch_witness(a, li, st));
+            return HRX_OK;
+        }
+    }
     const bool via_tp = !(layout & HRX_LAYOUT_POSITION_MAJOR) && M % 8 == 0;
     uint32_t *const caller_records = records;
     uint16_t *const caller_masked = masked;
@@ -900,7 +918,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     const char *tf[2] = {"false", "true"};
     // the names rocprofv3 lists: every template argument spelled out, defaulted ones too (an exact-match join with a kernel_stats.csv works)
     if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
-    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u, %s>", a.D, a.cw_image ? "true, true" : "false, false");
+    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u, %s>", a.D, a.cw_image ? ((a.layout & 1u) ? "true, true, false" : "true, true, true") : "false, false, false");
     else if (li.split == 2) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, %s, %s, %s, %s, %s>", a.D, tf[li.gtab], tf[li.wide], tf[li.half], tf[!(layout & 1)], tf[li.byte]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u, %s>", a.D, li.byte ? 32u : 32u / a.D, tf[li.byte]);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
@@ -926,6 +944,20 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
         const int rc = describe_set(s, via_tp ? HRX_LAYOUT_POSITION_MAJOR : layout, B, M, num_cus, text);
         if (rc != HRX_OK) return rc;
         if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
+    } else if ([&] {   // four and five defs, string-major rows in multiples of 16: the def-parallel launch writes them itself
+                   const char *mpc = std::getenv("HRX_MP_COMBINE");
+                   if (s.cw_image.empty() || (mpc && std::atoi(mpc) != 0) || layout != HRX_LAYOUT_STRING_MAJOR) return false;
+                   WitnessArgs a{};
+                   a.layout = HRX_LAYOUT_STRING_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)s.defs.size();
+                   a.debug = debug_flags_from_env();
+                   a.cw_image = s.cw_image.data(); a.table_bytes = (uint32_t)s.cw_image.size();
+                   LaunchInfo li{};
+                   if (!plan_pmd_cw_sm(a, num_cus, li)) return false;
+                   char buf[256];
+                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true, true> grid=%d waves=%d ring=%d lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+                   text = buf;
+                   return true;
+               }()) {
     } else if ([&] {   // 6 or 7 defs with CLASS-WIDE tables: one def-parallel launch over the whole config (position-major; string-major rows in multiples of 8 through the transposer)
                    const char *mpc = std::getenv("HRX_MP_COMBINE");
                    const bool tp = !(layout & 1) && M % 8 == 0;
@@ -937,7 +969,7 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
                    LaunchInfo li{};
                    if (!plan_pmd_cw(a, num_cus, li)) return false;
                    char buf[256];
-                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true> grid=%d waves=%d ring=%d lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true, false> grid=%d waves=%d ring=%d lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
                    text = buf;
                    if (tp) text += " + hrx::transpose_pm_to_sm_kernel";
                    return true;
@@ -953,7 +985,7 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
                        LaunchInfo li{};
                        if (!plan_pmd_cw(a, num_cus, li)) return false;
                        char buf[256];
-                       std::snprintf(buf, sizeof buf, "[defs %u..%zu: hrx::witness_pmd_kernel<%u, true, true> grid=%d waves=%d ring=%d lds=%zu] ", s.cw_group_first[g],
+                       std::snprintf(buf, sizeof buf, "[defs %u..%zu: hrx::witness_pmd_kernel<%u, true, true, false> grid=%d waves=%d ring=%d lds=%zu] ", s.cw_group_first[g],
                                      s.cw_group_first[g] + s.cw_groups[g].defs.size() - 1, a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
                        t2 += buf;
                    }

@@ -90,6 +90,17 @@ __device__ __forceinline__ void ring_post(uint32_t off, uint32_t v) {
     lds_store_u32(off, v);
 }
 
+// ... for a counter that guards LDS data only: the LDS executes one wave's operations in the order they were issued, so the counter's store lands behind the wave's earlier
+// LDS writes (and reads) without the wave waiting for them.
+__device__ __forceinline__ void ring_post_lds(uint32_t off, uint32_t v) {
+    asm volatile("" ::: "memory");
+    lds_store_u32(off, v);
+}
+// ... 16 bytes per lane at an SGPR base + a 32-bit lane offset
+__device__ __forceinline__ void store16_nt_so(const void *sbase, uint32_t voff, const uint4 &v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v4u32{v.x, v.y, v.z, v.w}), "s"(sbase) : "memory");
+}
+
 // hipFuncSetAttribute costs several microseconds of host time: raise a kernel's dynamic-LDS limit only when a launch
 // needs more than every earlier launch of that kernel did (the launch path is otherwise one hipLaunchKernelGGL).
 // (Two shards of one device may race here — hrx_multi_* launches from one host thread per shard: the slow path is

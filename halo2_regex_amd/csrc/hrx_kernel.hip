@@ -60,6 +60,29 @@ bool plan_pmd_cw(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     return false;
 }
 
+// ... with STRING-MAJOR outputs straight out of the launch (four and five defs, rows in multiples of 16): + a storer wave per group, two LDS sub-tile buffers of [64 strings][D][16 rows]
+// and the masked rows' 8-KiB transpose buffer (hrx_kernel_pmd.hip SMO)
+bool plan_pmd_cw_sm(WitnessArgs &a, int num_cus, LaunchInfo &out) {
+    out = LaunchInfo{};
+    a.gs = 64;
+    a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
+    if ((a.layout & 1u) || !a.cw_image || a.D < 4u || a.D > 5u || (a.M % 16u) != 0u || (a.debug & kDbgNoDefParallel)) return false;
+    if ((size_t)a.rec_pitch * a.D * 4u * 64u > 0xffffffffull) return false;      // the storer's 32-bit lane offsets span 64 strings' records
+    for (int ns = 4; ns >= 2; --ns) {
+        const size_t lds = a.table_bytes + pmd_group_bytes((int)a.D + 1, ns) + 2 * 64 * (16 * (size_t)a.D + 4) * 4 + 8192;
+        if (lds > kLdsLimit) continue;
+        out.split = 5;
+        out.wide = 1;
+        out.waves_per_wg = (int)a.D + 3;
+        out.nslots = ns;
+        out.lds_bytes = lds;
+        out.grid = (int)((size_t)a.n_groups < (size_t)num_cus ? (size_t)a.n_groups : (size_t)num_cus);
+        if (out.grid < 1) out.grid = 1;
+        return true;
+    }
+    return false;
+}
+
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.gs = 64;
     a.sm_no_touch = 0;

@@ -150,7 +150,8 @@ constexpr size_t kLdsLimit = 160 * 1024;
 
 // Picks the launch geometry for `a` on a device with `num_cus` CUs; returns false if nothing fits.
 bool plan_witness_launch(WitnessArgs &a, int num_cus, LaunchInfo &out);
-bool plan_pmd_cw(WitnessArgs &a, int num_cus, LaunchInfo &out);   // a whole config of 4 .. 7 defs in one def-parallel launch on the CLASS-WIDE tables (a.cw_image set)
+bool plan_pmd_cw(WitnessArgs &a, int num_cus, LaunchInfo &out);
+bool plan_pmd_cw_sm(WitnessArgs &a, int num_cus, LaunchInfo &out);   // ... with string-major outputs straight out of the launch (four and five defs, rows in multiples of 16)   // a whole config of 4 .. 7 defs in one def-parallel launch on the CLASS-WIDE tables (a.cw_image set)
 hipError_t launch_witness(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream);
 hipError_t launch_zero_u32(uint32_t *p, hipStream_t stream);   // *p = 0 as a kernel node (hrx_kernel.hip)
 // the two kernel translation units behind launch_witness: li.split == 2 -> hrx_kernel_pm.hip, else hrx_kernel_sm.hip

@@ -19,6 +19,41 @@
 
 namespace hrx {
 
+// STRING-MAJOR outputs straight out of the def-parallel launch (SMO; four and five defs): a walker's quads — four rows of its def, 16 B per lane — go into an LDS SUB-TILE
+// [string][def][16 rows] (S = 16 D + 4 dwords per string: the lanes' b128 writes meet no bank twice) instead of its plane in memory, and a STORER wave per group moves a finished
+// sub-tile out: a string's 16 rows x D records are 64 D contiguous bytes of the caller's [B][pitch][D] buffer, 16 bytes per lane and store, 64 consecutive pieces per instruction (three
+// strings' runs at D = 5).  Two sub-tile buffers: the walkers fill one while the storer drains the other.  What the walkers pay is what bounds the launch (their table chain is LDS
+// latency, ~6400 cycles of a tile's ~10500): every blocking look at a counter is an LDS round trip on that chain (~90 cycles), every write an issue slot.  Measured per 65536 x 1024 at
+// D = 5 (the passes + transposer this replaces, which moved the records three times: 0.93 ms):
+//   1. b128 writes, a storer that read four dwords and stored, piece after piece (80 dependent round trips per sub-tile)                                 0.545 ms
+//   2. sub-tiles in OUTPUT order [string][16 rows][def] (four 4-byte writes per quad, 4-way bank conflicts), the storer a ds_read_b128 per piece         0.459 ms
+//   3. the same with the WALKERS storing a D-th of the sub-tile each, no storer wave (5 + 5 counter waits per sub-tile and walker)                        0.490 ms
+//      (ablation build, 3.: no stores 0.458, no sub-tile writes 0.462, neither 0.404 — against 0.28 ms for the position-major launch with everything)
+//   4. this: b128 writes; the storer reads ALL of a sub-tile's dwords before its first store (one round trip, offsets loop-invariant), looks at the walkers' counters
+//      with one round trip, stores through an SGPR base; the walkers post without waiting for their writes (LDS executes a wave's operations in order) and read the storer's
+//      counter one sub-tile ahead of needing it.
+template <int D>
+struct LdsQuadSink {
+    static constexpr bool kSidq = true;
+    uint32_t wbase, buf_stride;         // LDS: this lane's 16 rows of this walker's def in sub-tile buffer 0; the buffers' distance
+    uint32_t sub;                       // sub-tiles this walker has filled (four per tile, counted over all its groups)
+    uint32_t filled_off, drained_off;   // LDS counters: this walker's; the storer's
+    uint32_t seen;                      // the storer's counter as read right after the last sub-tile was posted: by the next sub-tile's first quad it has arrived with the walk's own reads
+    uint32_t dbg;                       // (ablation build: kDbgSplitNoWalk — no sub-tile writes)
+    unsigned char *rp;                  // (interface of GlobalSink: unused)
+    __device__ __forceinline__ void quad(const int, const int p, const bool, const int, const uint4 &v) {
+        const uint32_t j = (uint32_t)p >> 2;
+        if ((j & 3u) == 0u && sub >= 2u && (int32_t)(seen - (sub - 1u)) < 0) ring_wait(drained_off, sub - 1u);     // the buffer's previous sub-tile is out
+        if (!(dbg & kDbgSplitNoWalk))
+            *(volatile __attribute__((address_space(3))) v4u32 *)(uintptr_t)(wbase + (sub & 1u) * buf_stride + (j & 3u) * 16u) = v4u32{v.x, v.y, v.z, v.w};
+        if ((j & 3u) == 3u) {
+            ring_post_lds(filled_off, ++sub);
+            seen = lds_vol_u32(drained_off);
+        }
+    }
+    __device__ __forceinline__ void row(const int) {}
+};
+
 constexpr uint32_t kSumBytes = 64u * 80u;     // per lane: st (8 B), en1 (8 B), 64 substr-id bytes
 constexpr uint32_t kPmdPiece = 64u * 32u;     // per lane: dead, err_pos, err_state, err_char, acc_state
 
@@ -27,38 +62,44 @@ constexpr uint32_t kPmdPiece = 64u * 32u;     // per lane: dead, err_pos, err_st
 // (cfg 4 — three defs, two groups per workgroup — on these tables with a combiner wave: 3.03-3.23 ms against 2.89-2.94 for the WIDE kernel below; not taken.)
 // FIN: the combiner is a wave of its own that walks nothing — W = D + 1 walker-like waves per group, all D walkers publish, the last wave merges, runs the reveal mask and stores the masked
 // rows: with the last def's walk on top of D - 1 merges the combiner was the slowest wave of every group and set the launch's pace (0.54-0.65 of peak at 4 .. 7 defs whatever D).
-template <int D, bool CW, bool FIN>
+template <int D, bool CW, bool FIN, bool SMO = false>
 __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
+    static_assert(!SMO || (CW && FIN), "string-major outputs: the CLASS-WIDE kernel with a combiner wave");
+    constexpr uint32_t kSubS = 16u * D + 4u;              // SMO: dwords per string of a sub-tile buffer
+    constexpr uint32_t kSubBytes = 64u * kSubS * 4u;
     constexpr int RS = CW ? kCwRowShift : kWideRowShift;
     constexpr uint32_t W = FIN ? D + 1u : D;              // walker-like waves per group: the defs' walkers, the last one (FIN: an extra one) combining
     constexpr uint32_t kRowField = CW ? 0x3ffu : 0xffu, kRowMaskT = kRowField << RS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t G = (blockDim.x >> 6) / (W + 1u);      // groups a workgroup walks at a time
+    const uint32_t G = (blockDim.x >> 6) / (W + 1u + (SMO ? 1u : 0u));      // groups a workgroup walks at a time (SMO: + a storer wave per group, behind the loaders)
     // Roles in wave order: group 0's D walkers, group 1's, then the loaders.  The waves of a workgroup go to the CU's four SIMDs round-robin, so at D = 3, G = 2
     // group 0's combiner shares its SIMD with a loader and group 1's with another walker: group 0 of EVERY workgroup finishes at ~2435 us, group 1 at ~2918 us of a
     // 2957-us launch over 32768 rows (tools/front_width.py) — and that is the faster arrangement.  Round 5 dealt the roles so that both groups get the same company
     // (both finish together, the chip-wide write front 4-18 tiles wide instead of 110): 11 % SLOWER in a same-lease A/B (3.245 against 2.914 ms), and a gate that holds
     // loaders back once they are W tiles ahead of the chip's average moved the launch by -2 .. +2 %: profiles/r05_probes/cfg4_front_width.txt.
     const bool is_walker = wave < G * W;
-    const uint32_t lg = is_walker ? wave / W : wave - G * W;
+    const bool is_storer = SMO && wave >= G * (W + 1u);
+    const uint32_t lg = is_walker ? wave / W : is_storer ? wave - G * (W + 1u) : wave - G * W;
     const uint32_t d = is_walker ? wave % W : 0u;         // the def this walker walks (FIN: d == D is the combiner, which walks none)
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
     // LDS per group: ring | (D - 1) x (2 summaries + piece) | counters: ready, freed[D], per publishing walker sum_prod, sum_cons, piece_prod; merged
     const uint32_t walker_bytes = 2u * kSumBytes + kPmdPiece;
-    const uint32_t group_bytes = nring * kPmTileBytes + (W - 1u) * walker_bytes + 192u;  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
+    const uint32_t group_bytes = nring * kPmTileBytes + (W - 1u) * walker_bytes + 192u + (SMO ? 2u * kSubBytes + 8192u : 0u);  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
     const uint32_t ring_base = a.table_bytes + lg * group_bytes;
     const uint32_t wbase = ring_base + nring * kPmTileBytes;                  // walker areas of this group
     const uint32_t cnt = wbase + (W - 1u) * walker_bytes;
     const uint32_t ready_off = cnt, freed0 = cnt + 4u;                        // freed0 + 4 d
     auto sum_prod_off = [&](uint32_t dd) { return cnt + 48u + 12u * dd; };    // + 4: sum_cons, + 8: piece_prod  (W <= 9: freed[] ends at 40, these at 144)
     const uint32_t merged_off = cnt + 148u;
+    const uint32_t filled0 = cnt + 152u, drained_off = cnt + 188u;            // SMO: filled0 + 4 d per walker, the storer's counter
+    const uint32_t sub_base = cnt + 192u, mbuf = sub_base + 2u * kSubBytes;  // SMO: the two sub-tile buffers, the masked rows' 8-KiB transpose buffer
     {
         const uint4 *src = CW ? reinterpret_cast<const uint4 *>(a.cw_image) : reinterpret_cast<const uint4 *>(a.wide_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < a.table_bytes / 16u; i += blockDim.x) dst[i] = src[i];
-        if (!is_walker && lane < 48u) lds_store_u32(cnt + 4u * lane, 0);
+        if (!is_walker && !is_storer && lane < 48u) lds_store_u32(cnt + 4u * lane, 0);
     }
     __syncthreads();
 
@@ -67,6 +108,48 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
     const uint32_t g_first = blockIdx.x * G + lg, g_stride = gridDim.x * G;
     uint32_t seq = 0;
 
+    if constexpr (SMO) {
+        if (is_storer) {
+            // ================================ storer ================================  (SMO: LDS sub-tiles -> the caller's string-major records)
+            uint32_t sseq = 0;     // sub-tiles drained so far
+            const uint32_t run_bytes = a.rec_pitch * (uint32_t)D * 4u;      // a string's records (< 2^32 / 64: hrx_api.cpp checks the pitch)
+            for (uint32_t g = g_first; g < a.n_groups; g += g_stride) {
+                const uint32_t b0 = g * 64u;
+                for (uint32_t t = 0; t < ntiles; ++t) {
+#pragma unroll 1
+                    for (uint32_t sub = 0; sub < 4u; ++sub, ++sseq) {
+                        for (;;) {      // every walker has filled this sub-tile: the D counters in one round trip
+                            bool ok = true;
+#pragma unroll
+                            for (uint32_t dd = 0; dd < (uint32_t)D; ++dd) ok &= (int32_t)(lds_vol_u32(filled0 + 4u * dd) - (sseq + 1u)) >= 0;
+                            if (ok) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const uint32_t row0 = t * 64u + sub * 16u;
+                        const uint32_t buf = sub_base + (sseq & 1u) * kSubBytes;
+                        if (row0 < M) {     // (M % 16 == 0: a sub-tile lies below M entirely or not at all)
+                            uint32_t w[4u * D][4];
+#pragma unroll
+                            for (uint32_t k = 0; k < 4u * D; ++k) {      // piece u of the sub-tile's 256 D: string u / 4 D, bytes 16 (u % 4 D) .. of its run = dwords q = 4 (u % 4 D) + i: row q / D, def q % D
+                                const uint32_t u = k * 64u + lane, sidx = u / (4u * D), q0 = (u % (4u * D)) * 4u;
+#pragma unroll
+                                for (uint32_t i = 0; i < 4u; ++i) w[k][i] = lds_u32(buf + sidx * kSubS * 4u + ((q0 + i) % D) * 64u + ((q0 + i) / D) * 4u);
+                            }
+                            const unsigned char *base = reinterpret_cast<const unsigned char *>(a.records) + ((size_t)b0 * a.rec_pitch + row0) * D * 4u;
+#pragma unroll
+                            for (uint32_t k = 0; k < 4u * D; ++k) {
+                                const uint32_t u = k * 64u + lane, sidx = u / (4u * D), piece = u % (4u * D);
+                                if (b0 + sidx < B && !(a.debug & kDbgSkipRecords)) store16_nt_so(base, sidx * run_bytes + piece * 16u, make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]));
+                            }
+                        }
+                        ring_post_lds(drained_off, sseq + 1u);
+                    }
+                }
+            }
+            return;
+        }
+    }
     if (!is_walker) {
         // ================================ loader ================================  (one per group, D consumers)
         constexpr uint32_t RT = 8u;
@@ -119,6 +202,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
     const bool combiner = d == W - 1u;
     const uint32_t my_area = wbase + d * walker_bytes;
     uint32_t gi = 0;
+    LdsQuadSink<D> lsink{sub_base + lane * kSubS * 4u + min(d, (uint32_t)D - 1u) * 64u, kSubBytes, 0u, filled0 + 4u * min(d, (uint32_t)D - 1u), drained_off, 0u, a.debug, nullptr};
     for (uint32_t g = g_first; g < a.n_groups; g += g_stride, ++gi) {
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
@@ -186,7 +270,11 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
                 for (int i = 0; i < 4; ++i) ccol[i] = make_uint4(cw2[4 * i], cw2[4 * i + 1], cw2[4 * i + 2], cw2[4 * i + 3]);
             }
             const uint4 (&cwalk)[4] = CW ? ccol : cq;
-            if (full) {
+            if (SMO && full) {
+                tb = walk_tile_pm_wide<1, true, LdsQuadSink<D>, RS, CW>(L, cwalk, ad, lsink, 0, 0, tile_ov, sidq, acc_state);
+            } else if (SMO) {
+                tb = walk_tile_pm_wide<1, false, LdsQuadSink<D>, RS, CW>(L, cwalk, ad, lsink, (int)n - (int)t0, (int)M - 1 - (int)t0, tile_ov, sidq, acc_state);
+            } else if (full) {
                 tb = walk_tile_pm_wide<1, true, GlobalSink<1>, RS, CW>(L, cwalk, ad, sink, 0, 0, tile_ov, sidq, acc_state);
                 if constexpr (!CW) {
 #pragma unroll
@@ -291,8 +379,10 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
                 fixm &= fixm - 1;
                 const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)tm.fix_start, j);
                 const uint32_t bj = b0 + (uint32_t)j;
-                for (uint32_t r = fs + lane; r < t0; r += 64u)
-                    a.masked[((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;     // (in this group's block of the buffer)
+                for (uint32_t r = fs + lane; r < t0; r += 64u) {
+                    if (SMO) a.masked[(size_t)bj * a.msk_pitch + r] = 0;
+                    else a.masked[((size_t)blk0 * q8 + (size_t)(r >> 3) * nb + (bj - blk0)) * 8u + (r & 7u)] = 0;     // (in this group's block of the buffer)
+                }
             }
             {
                 // (streamed unless a string of the wave has an open optimistic span: rows that may be zeroed later stay in L2 for the repair — hrx_kernel_pm.hip octets_out)
@@ -303,7 +393,25 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
                     const uint32_t mbyte = ((q < 4 ? mlo : mhi) >> (8 * (q & 3))) & 0xffu;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (mbyte) v = masked_octet(cwl[2 * q], cwl[2 * q + 1], sidq[2 * q], sidq[2 * q + 1], mbyte);  // lib.rs:752-761
-                    if (t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, nt_tile);
+                    if constexpr (SMO) {   // string-major masked rows [B][pitch]: a string's 64 rows are one 128-byte line — through LDS, so that a store instruction writes the full lines of eight strings
+                        *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(mbuf + (lane * 8u + ((uint32_t)q ^ (lane & 7u))) * 16u) = v4u32{v.x, v.y, v.z, v.w};
+                    } else {
+                        if (t0 + (uint32_t)q * 8u < M && !(a.debug & kDbgSkipMasked)) store16(mp + (size_t)q * mstep, v, nt_tile);
+                    }
+                }
+                if constexpr (SMO) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t js0 = lane >> 3, w8 = lane & 7u;
+#pragma unroll
+                    for (uint32_t it = 0; it < 8u; ++it) {
+                        const uint32_t js = it * 8u + js0;
+                        const uint4 v = lds_u128(mbuf + (js * 8u + (w8 ^ (js & 7u))) * 16u);
+                        if (b0 + js < B && t0 + w8 * 8u < M && !(a.debug & kDbgSkipMasked))
+                            store16(reinterpret_cast<unsigned char *>(a.masked) + ((size_t)(b0 + js) * a.msk_pitch + t0) * 2u + (size_t)w8 * 16u, v, nt_tile);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
                 mp += 8u * mstep;
             }
@@ -351,9 +459,9 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
     }
 }
 
-template <int D, bool CW, bool FIN>
+template <int D, bool CW, bool FIN, bool SMO = false>
 static hipError_t launch_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
-    auto kern = witness_pmd_kernel<D, CW, FIN>;
+    auto kern = witness_pmd_kernel<D, CW, FIN, SMO>;
     static std::atomic<size_t> granted[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -364,6 +472,9 @@ static hipError_t launch_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStre
 }
 
 hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStream_t stream) {
+    if (a.cw_image && !(a.layout & 1u)) {   // ... with string-major outputs: + a storer wave (four and five defs)
+        return a.D == 4 ? launch_pmd<4, true, true, true>(a, li, stream) : a.D == 5 ? launch_pmd<5, true, true, true>(a, li, stream) : hipErrorInvalidValue;
+    }
     if (a.cw_image) {   // CLASS-WIDE tables: D walkers + a combiner wave + a loader per group
         switch (a.D) {
             case 4: return launch_pmd<4, true, true>(a, li, stream);

@@ -213,7 +213,7 @@ def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     assert cfg.describe_launch(32768, layout=3).startswith("hrx::witness_pp_kernel grid=256 waves=6 ")     # walker slots left empty: one def, 18 byte classes -> the pair-step table (76 KiB), two bytes per lookup
     assert cfg.describe_launch(65536, layout=0).startswith("hrx::witness_split_kernel<1, 32, false> ")
     cfg = RegexVerifyConfig.configure(2048, _defs(CFG_A), device=None)
-    assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pmd_kernel<2, false, false> grid=256 waves=6 ")       # <= 2 groups per CU: one walker per def
+    assert cfg.describe_launch(32768, layout=1).startswith("hrx::witness_pmd_kernel<2, false, false, false> grid=256 waves=6 ")       # <= 2 groups per CU: one walker per def
     assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<2, false, true, false, false, false> ")     # D >= 2: the WIDE table
     d = cfg.describe_launch(1 << 20, layout=1)
     assert d.startswith("hrx::witness_pm_kernel<2, false, true, false, false, false> grid=256 waves=12 ") and d.endswith(" groups=dynamic")   # >= 3 groups per walker pair: drawn from a counter

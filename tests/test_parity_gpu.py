@@ -856,7 +856,7 @@ def test_four_to_eight_defs_in_one_def_parallel_launch(hra, oracle, names, monke
     D = len(names)
     for M in (328, 203):
         cfg = _cfg(hra, names, M)
-        assert cfg.describe_launch(700, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, true>" % D)
+        assert cfg.describe_launch(700, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, true, false>" % D)
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=37)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=5, stride=chars.shape[1])
         chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
@@ -867,11 +867,37 @@ def test_four_to_eight_defs_in_one_def_parallel_launch(hra, oracle, names, monke
         _check_batch_pm(hra, oracle, names, chars, lens, M)                   # position-major outputs, both input layouts
         if M % 8 == 0:
             _check_batch(hra, oracle, names, chars, lens, M)                  # string-major: the same launch into scratch + the transposer
+    # string-major rows in multiples of 16, four and five defs: the launch writes the caller's [B][pitch][D] records and [B][pitch] masked rows itself (storer wave, LDS sub-tiles)
+    for M in (336, 64, 1024):
+        cfg = _cfg(hra, names, M)
+        d0 = cfg.describe_launch(700, layout=0)
+        assert d0.startswith("hrx::witness_pmd_kernel<%d, true, true, true>" % D) == (D <= 5) and ("transpose_pm_to_sm_kernel" in d0) == (D > 5)
+        chars, lens = synth.reveal_stress(700, M - 1, seed=43)
+        h_c, h_l = synth.headers_planted(200, min(chars.shape[1] - 3, M - 1), seed=7, stride=chars.shape[1])
+        chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
+        chars[5, 20] = 250
+        lens[11] = M + 72
+        lens[12], lens[13] = 0, min(M, chars.shape[1])
+        _check_batch(hra, oracle, names, chars, lens, M)
+        if M == 1024:          # device-resident, pitched string-major buffers (hrx_recommended_pitches), several rounds of groups
+            import torch
+            dev = torch.device("cuda", 0)
+            big_c, big_l = np.tile(chars, (20, 1)), np.tile(lens, 20)
+            o = OracleDefs.from_files(oracle, names)
+            orec, omsk, ost = o.witness_batch(big_c, big_l, M, threads=os.cpu_count() or 8)
+            wide = torch.zeros((len(big_l), (big_c.shape[1] + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+            wide[:, :big_c.shape[1]] = torch.from_numpy(big_c).to(dev)
+            out = cfg.alloc_outputs(len(big_l), dev, pitched=True)
+            rec, msk, st = cfg.witness_batch(wide, torch.from_numpy(big_l.astype(np.int32)).to(dev), out=out)
+            torch.cuda.synchronize()
+            ok = (ost & np.uint64(0xff)) == 0
+            assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+            assert np.array_equal(rec.cpu().numpy().view(np.uint32)[ok], orec[ok]) and np.array_equal(msk.cpu().numpy().view(np.uint16)[ok], omsk[ok])
     M = 136
     B = 70000
     chars, lens = synth.ragged(B, M, seed=29)
     cfg = _cfg(hra, names, M)
-    assert cfg.describe_launch(B, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, true>" % D)
+    assert cfg.describe_launch(B, layout=3).startswith("hrx::witness_pmd_kernel<%d, true, true, false>" % D)
     blocks = [(chars[:hra.PM_BLOCK], lens[:hra.PM_BLOCK]), (np.ascontiguousarray(chars[hra.PM_BLOCK:]), lens[hra.PM_BLOCK:])]
     st = _full_check(hra, OracleDefs.from_files(oracle, names), cfg, blocks, M, D)
     # (D7's partial example DFA fails on almost any noise, D8's two copies of regex1 / regex2 flag the same rows: out of contract — their status words are the oracle's too)
@@ -897,7 +923,7 @@ def test_more_than_three_regex_defs_multi_pass(hra, oracle, names, combine, monk
         # (four to seven defs of at most 32 byte classes each, without HRX_MP_COMBINE: ONE def-parallel launch on the CLASS-WIDE tables instead of passes — D7's partial example DFA included;
         # with HRX_MP_COMBINE=1, and for D8, the passes over groups of three defs)
         assert (d.startswith("multi-pass, ") and ("witness_combine_summary_kernel" if combine else "witness_merge_status_kernel") in d) or \
-            (not combine and D in (4, 5, 6, 7, 8) and d.startswith("hrx::witness_pmd_kernel<%d, true, true>" % D))
+            (not combine and D in (4, 5, 6, 7, 8) and d.startswith("hrx::witness_pmd_kernel<%d, true, true, false>" % D))
         chars, lens = synth.reveal_stress(500, min(M - 8, 320), seed=31)
         h_c, h_l = synth.headers_planted(200, chars.shape[1] - 3, seed=3, stride=chars.shape[1])
         chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
