@@ -42,7 +42,7 @@ def parse_args(argv=None):
     ap.add_argument("--len", type=int, default=1023, dest="n", help="bytes per string (n); rows M = --rows")
     ap.add_argument("--rows", type=int, default=1024, help="max_chars_size M (witness rows per string)")
     ap.add_argument("--dist", choices=["planted", "noise"], default="planted")
-    ap.add_argument("--config", choices=["regex1", "regex23", "regex123", "headers3", "headers5", "dfa256"], default="regex1",
+    ap.add_argument("--config", choices=["regex1", "regex23", "regex123", "headers3", "headers4", "headers5", "dfa256"], default="regex1",
                     help="regex1: BASELINE configs[1] (the metric's workload); regex23: configs[2] shape (D=2); regex123: D=3 with the "
                     "reference's three DFAs; headers3: configs[3] shape (D=3 from/to/subject header definitions, 5 substrs); dfa256: configs[4] shape (synthetic total 256-state DFA over all 256 byte values)")
     ap.add_argument("--untimed-replays", type=int, default=0, help="untimed replays of the K-step graph before the timed one (default: ~100 ms of them)")
@@ -320,6 +320,10 @@ def workload(args):
     elif args.config == "headers3":
         hdr = lambda n, ns: (rd(n + "_lookup.txt"), [rd("%s_substr%d.txt" % (n, k)) for k in range(ns)])
         names, label = [hdr("header_from", 1), hdr("header_to", 1), hdr("header_subject", 3)], "from/to/subject header definitions (5 substrs)"
+        gen = synth.headers_planted if args.dist == "planted" else synth.noise
+    elif args.config == "headers4":     # D = 4: the smallest config of the def-parallel launch over CLASS-WIDE tables
+        hdr = lambda n, ns: (rd(n + "_lookup.txt"), [rd("%s_substr%d.txt" % (n, k)) for k in range(ns)])
+        names, label = [hdr("header_from", 1), hdr("header_to", 1), hdr("header_subject", 3), pair(1)], "from/to/subject header definitions + regex1 (6 substrs)"
         gen = synth.headers_planted if args.dist == "planted" else synth.noise
     elif args.config == "headers5":     # D = 5: more than one launch walks side by side -> passes over groups of defs + combine
         hdr = lambda n, ns: (rd(n + "_lookup.txt"), [rd("%s_substr%d.txt" % (n, k)) for k in range(ns)])

@@ -954,7 +954,7 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
                    LaunchInfo li{};
                    if (!plan_pmd_cw_sm(a, num_cus, li)) return false;
                    char buf[256];
-                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true, true> grid=%d waves=%d ring=%d lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
+                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true, true> grid=%d waves=%d ring=%d sub-tiles=%u lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, a.sm_bufs, li.lds_bytes);
                    text = buf;
                    return true;
                }()) {

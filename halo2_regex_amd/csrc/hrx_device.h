@@ -96,6 +96,11 @@ __device__ __forceinline__ void ring_post_lds(uint32_t off, uint32_t v) {
     asm volatile("" ::: "memory");
     lds_store_u32(off, v);
 }
+// ... when the counter was read ahead of time (`seen`, a volatile read some instructions back): no round trip if it had got there already
+__device__ __forceinline__ void ring_wait_seen(uint32_t off, uint32_t want, uint32_t seen) {
+    if ((int32_t)(seen - want) < 0) ring_wait(off, want);
+    asm volatile("" ::: "memory");
+}
 // ... 16 bytes per lane at an SGPR base + a 32-bit lane offset
 __device__ __forceinline__ void store16_nt_so(const void *sbase, uint32_t voff, const uint4 &v) {
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v4u32{v.x, v.y, v.z, v.w}), "s"(sbase) : "memory");

@@ -68,18 +68,20 @@ bool plan_pmd_cw_sm(WitnessArgs &a, int num_cus, LaunchInfo &out) {
     a.n_groups = (uint32_t)(((size_t)a.B + 63) / 64);
     if ((a.layout & 1u) || !a.cw_image || a.D < 4u || a.D > 5u || (a.M % 16u) != 0u || (a.debug & kDbgNoDefParallel)) return false;
     if ((size_t)a.rec_pitch * a.D * 4u * 64u > 0xffffffffull) return false;      // the storer's 32-bit lane offsets span 64 strings' records
-    for (int ns = 4; ns >= 2; --ns) {
-        const size_t lds = a.table_bytes + pmd_group_bytes((int)a.D + 1, ns) + 2 * 64 * (16 * (size_t)a.D + 4) * 4 + 8192;
-        if (lds > kLdsLimit) continue;
-        out.split = 5;
-        out.wide = 1;
-        out.waves_per_wg = (int)a.D + 3;
-        out.nslots = ns;
-        out.lds_bytes = lds;
-        out.grid = (int)((size_t)a.n_groups < (size_t)num_cus ? (size_t)a.n_groups : (size_t)num_cus);
-        if (out.grid < 1) out.grid = 1;
-        return true;
-    }
+    for (int nbuf = 3; nbuf >= 2; --nbuf)      // three sub-tile buffers where LDS has room (four defs): 0.691 against 0.712 ms per 65536 x 2048, the same at x 1024 (profiles/r05_probes/sm_out_of_the_launch.txt)
+        for (int ns = 4; ns >= (nbuf == 3 ? 3 : 2); --ns) {
+            const size_t lds = a.table_bytes + pmd_group_bytes((int)a.D + 1, ns) + (size_t)nbuf * 64 * (16 * (size_t)a.D + 4) * 4 + 8192;
+            if (lds > kLdsLimit) continue;
+            a.sm_bufs = (uint32_t)nbuf;
+            out.split = 5;
+            out.wide = 1;
+            out.waves_per_wg = (int)a.D + 3;
+            out.nslots = ns;
+            out.lds_bytes = lds;
+            out.grid = (int)((size_t)a.n_groups < (size_t)num_cus ? (size_t)a.n_groups : (size_t)num_cus);
+            if (out.grid < 1) out.grid = 1;
+            return true;
+        }
     return false;
 }
 

@@ -63,6 +63,7 @@ struct WitnessArgs {
     uint64_t *vs_status;          // [chunk][B]: every chunk's status word
     uint2 *vs_info;               // [chunk][B]: pend | fwd << 1 | sm << 2 | dec << 3, pend_start (hrx_lane.h TileMasks)
     uint32_t sm_no_touch;         // walker/storer kernel: 1 = the storer does not warm L2 for the walker (set by plan_witness_launch; hrx_kernel_sm.hip)
+    uint32_t sm_bufs;             // def-parallel kernel, string-major outputs: LDS sub-tile buffers per group, 2 or 3 (set by plan_pmd_cw_sm; hrx_kernel_pmd.hip SMO)
     uint32_t nt_mix;              // position-major kernels: which stores are write-back instead of streaming (kNtMix*, hrx_kernel_pm.hip)
     uint32_t pace_even;           // profiling only (HRX_PACE, stamps / ablation builds): x 64 idle cycles per tile for the walkers of even workgroups; 0 in the product
     DefConsts dc[kMaxDefsPerLaunch];

@@ -22,7 +22,7 @@ namespace hrx {
 // STRING-MAJOR outputs straight out of the def-parallel launch (SMO; four and five defs): a walker's quads — four rows of its def, 16 B per lane — go into an LDS SUB-TILE
 // [string][def][16 rows] (S = 16 D + 4 dwords per string: the lanes' b128 writes meet no bank twice) instead of its plane in memory, and a STORER wave per group moves a finished
 // sub-tile out: a string's 16 rows x D records are 64 D contiguous bytes of the caller's [B][pitch][D] buffer, 16 bytes per lane and store, 64 consecutive pieces per instruction (three
-// strings' runs at D = 5).  Two sub-tile buffers: the walkers fill one while the storer drains the other.  What the walkers pay is what bounds the launch (their table chain is LDS
+// strings' runs at D = 5).  Two or three sub-tile buffers (what LDS has room for): the walkers fill one while the storer drains another.  What the walkers pay is what bounds the launch (their table chain is LDS
 // latency, ~6400 cycles of a tile's ~10500): every blocking look at a counter is an LDS round trip on that chain (~90 cycles), every write an issue slot.  Measured per 65536 x 1024 at
 // D = 5 (the passes + transposer this replaces, which moved the records three times: 0.93 ms):
 //   1. b128 writes, a storer that read four dwords and stored, piece after piece (80 dependent round trips per sub-tile)                                 0.545 ms
@@ -36,18 +36,19 @@ template <int D>
 struct LdsQuadSink {
     static constexpr bool kSidq = true;
     uint32_t wbase, buf_stride;         // LDS: this lane's 16 rows of this walker's def in sub-tile buffer 0; the buffers' distance
-    uint32_t sub;                       // sub-tiles this walker has filled (four per tile, counted over all its groups)
+    uint32_t sub, bi, nbuf;             // sub-tiles this walker has filled (four per tile, counted over all its groups); the buffer sub-tile `sub` goes to; the buffers (2 or 3)
     uint32_t filled_off, drained_off;   // LDS counters: this walker's; the storer's
     uint32_t seen;                      // the storer's counter as read right after the last sub-tile was posted: by the next sub-tile's first quad it has arrived with the walk's own reads
     uint32_t dbg;                       // (ablation build: kDbgSplitNoWalk — no sub-tile writes)
     unsigned char *rp;                  // (interface of GlobalSink: unused)
     __device__ __forceinline__ void quad(const int, const int p, const bool, const int, const uint4 &v) {
         const uint32_t j = (uint32_t)p >> 2;
-        if ((j & 3u) == 0u && sub >= 2u && (int32_t)(seen - (sub - 1u)) < 0) ring_wait(drained_off, sub - 1u);     // the buffer's previous sub-tile is out
+        if ((j & 3u) == 0u && sub >= nbuf && (int32_t)(seen - (sub - nbuf + 1u)) < 0) ring_wait(drained_off, sub - nbuf + 1u);     // the buffer's previous sub-tile is out
         if (!(dbg & kDbgSplitNoWalk))
-            *(volatile __attribute__((address_space(3))) v4u32 *)(uintptr_t)(wbase + (sub & 1u) * buf_stride + (j & 3u) * 16u) = v4u32{v.x, v.y, v.z, v.w};
+            *(volatile __attribute__((address_space(3))) v4u32 *)(uintptr_t)(wbase + bi * buf_stride + (j & 3u) * 16u) = v4u32{v.x, v.y, v.z, v.w};
         if ((j & 3u) == 3u) {
             ring_post_lds(filled_off, ++sub);
+            bi = bi + 1u == nbuf ? 0u : bi + 1u;
             seen = lds_vol_u32(drained_off);
         }
     }
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
 
     // LDS per group: ring | (D - 1) x (2 summaries + piece) | counters: ready, freed[D], per publishing walker sum_prod, sum_cons, piece_prod; merged
     const uint32_t walker_bytes = 2u * kSumBytes + kPmdPiece;
-    const uint32_t group_bytes = nring * kPmTileBytes + (W - 1u) * walker_bytes + 192u + (SMO ? 2u * kSubBytes + 8192u : 0u);  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
+    const uint32_t group_bytes = nring * kPmTileBytes + (W - 1u) * walker_bytes + 192u + (SMO ? a.sm_bufs * kSubBytes + 8192u : 0u);  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
     const uint32_t ring_base = a.table_bytes + lg * group_bytes;
     const uint32_t wbase = ring_base + nring * kPmTileBytes;                  // walker areas of this group
     const uint32_t cnt = wbase + (W - 1u) * walker_bytes;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
     auto sum_prod_off = [&](uint32_t dd) { return cnt + 48u + 12u * dd; };    // + 4: sum_cons, + 8: piece_prod  (W <= 9: freed[] ends at 40, these at 144)
     const uint32_t merged_off = cnt + 148u;
     const uint32_t filled0 = cnt + 152u, drained_off = cnt + 188u;            // SMO: filled0 + 4 d per walker, the storer's counter
-    const uint32_t sub_base = cnt + 192u, mbuf = sub_base + 2u * kSubBytes;  // SMO: the two sub-tile buffers, the masked rows' 8-KiB transpose buffer
+    const uint32_t sub_base = cnt + 192u, mbuf = sub_base + a.sm_bufs * kSubBytes;  // SMO: the two sub-tile buffers, the masked rows' 8-KiB transpose buffer
     {
         const uint4 *src = CW ? reinterpret_cast<const uint4 *>(a.cw_image) : reinterpret_cast<const uint4 *>(a.wide_image);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
     if constexpr (SMO) {
         if (is_storer) {
             // ================================ storer ================================  (SMO: LDS sub-tiles -> the caller's string-major records)
-            uint32_t sseq = 0;     // sub-tiles drained so far
+            uint32_t sseq = 0, sbi = 0;     // sub-tiles drained so far; the buffer the next one is in
             const uint32_t run_bytes = a.rec_pitch * (uint32_t)D * 4u;      // a string's records (< 2^32 / 64: hrx_api.cpp checks the pitch)
             for (uint32_t g = g_first; g < a.n_groups; g += g_stride) {
                 const uint32_t b0 = g * 64u;
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         const uint32_t row0 = t * 64u + sub * 16u;
-                        const uint32_t buf = sub_base + (sseq & 1u) * kSubBytes;
+                        const uint32_t buf = sub_base + sbi * kSubBytes;
+                        sbi = sbi + 1u == a.sm_bufs ? 0u : sbi + 1u;
                         if (row0 < M) {     // (M % 16 == 0: a sub-tile lies below M entirely or not at all)
                             uint32_t w[4u * D][4];
 #pragma unroll
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
 #pragma unroll
                                 for (uint32_t i = 0; i < 4u; ++i) w[k][i] = lds_u32(buf + sidx * kSubS * 4u + ((q0 + i) % D) * 64u + ((q0 + i) / D) * 4u);
                             }
-                            const unsigned char *base = reinterpret_cast<const unsigned char *>(a.records) + ((size_t)b0 * a.rec_pitch + row0) * D * 4u;
+                            const unsigned char *base = reinterpret_cast<const unsigned char *>(a.records) + ((size_t)b0 * a.rec_pitch + ((a.debug & kDbgFixedLines) ? 0u : row0)) * D * 4u;   // (ablation: every sub-tile onto the strings' first rows)
 #pragma unroll
                             for (uint32_t k = 0; k < 4u * D; ++k) {
                                 const uint32_t u = k * 64u + lane, sidx = u / (4u * D), piece = u % (4u * D);
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
                         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
                         *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
                     }
-                    ring_post(ready_off, sq + 1u);
+                    ring_post_lds(ready_off, sq + 1u);
                     if (sq + RT < total) issue(sq + RT, r);
                 }
             }
@@ -201,8 +203,8 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
     ad.dc[0] = a.dc[min(d, (uint32_t)D - 1u)];
     const bool combiner = d == W - 1u;
     const uint32_t my_area = wbase + d * walker_bytes;
-    uint32_t gi = 0;
-    LdsQuadSink<D> lsink{sub_base + lane * kSubS * 4u + min(d, (uint32_t)D - 1u) * 64u, kSubBytes, 0u, filled0 + 4u * min(d, (uint32_t)D - 1u), drained_off, 0u, a.debug, nullptr};
+    uint32_t gi = 0, ready_seen = 0;     // the loader's counter as read at the end of the previous tile
+    LdsQuadSink<D> lsink{sub_base + lane * kSubS * 4u + min(d, (uint32_t)D - 1u) * 64u, kSubBytes, 0u, 0u, a.sm_bufs, filled0 + 4u * min(d, (uint32_t)D - 1u), drained_off, 0u, a.debug, nullptr};
     for (uint32_t g = g_first; g < a.n_groups; g += g_stride, ++gi) {
         const uint32_t b0 = g * 64u;
         const uint32_t b = b0 + lane;
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
             if (a.stamps && combiner && lane == 0u && gi == 0u && (t % max(ntiles >> 3, 1u)) == 0u && t / max(ntiles >> 3, 1u) < 8u)
                 a.stamps[(size_t)(blockIdx.x * G + lg) * 16u + t / max(ntiles >> 3, 1u)] = wall_clock64();
 #endif
-            ring_wait(ready_off, seq + 1u);
+            ring_wait_seen(ready_off, seq + 1u, ready_seen);
+            const uint32_t cons_seen = (!combiner && seq >= 2u) ? lds_vol_u32(sum_prod_off(d) + 4u) : 0u;    // (looked at again when the tile is walked: it arrives with the tile's bytes)
             uint4 cq[4];
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) cq[i] = lds_u128(slot + i * 1024u + lane * 16u);
@@ -314,24 +317,33 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
             // ---------------- accept state when n == M: row n does not exist, s[n] is the live state ----------------
             if (!full && n == t0 + 64u && t + 1 == ntiles) acc_state[0] = ((L.e[0] >> RS) & kRowField) - ad.dc[0].row_base;
             }   // (walks)
-            ring_post(freed0 + 4u * d, seq + 1u);   // done with the slot's bytes (the combiner keeps cq in registers)
+            ring_post_lds(freed0 + 4u * d, seq + 1u);   // done with the slot's bytes (the combiner keeps cq in registers)
 
             if (!combiner) {
                 // ---- publish this def's share of the tile: start / end bitvectors and the byte-per-row substr ids
                 const uint32_t sa = my_area + (seq & 1u) * kSumBytes + lane * 80u;
-                if (seq >= 2u) ring_wait(sum_prod_off(d) + 4u, seq - 1u);   // the combiner has read the summary that used this slot
+                if (seq >= 2u) ring_wait_seen(sum_prod_off(d) + 4u, seq - 1u, cons_seen);   // the combiner has read the summary that used this slot
                 *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)sa = v4u32{(uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32)};
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i)
                     *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(sa + 16u + 16u * i) = v4u32{sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]};
-                ring_post(sum_prod_off(d), seq + 1u);
+                ring_post_lds(sum_prod_off(d), seq + 1u);
+                ready_seen = lds_vol_u32(ready_off);
                 continue;
             }
             // ================= combiner (the last def's walker): sums over the defs, reveal mask, masked rows =================
             uint64_t st = tb.st, en1 = tb.en1, ov_st = 0, ov_en = 0;
-#pragma unroll(D >= 7 ? 1 : 8)      // (seven and eight defs: rolled — unrolled, the summaries' loads of all iterations are in flight at once and the nine / ten waves' 168 VGPRs spill)
+            // (the merge loop below, seven and eight defs: rolled — unrolled, the summaries' loads of all iterations are in flight at once and the nine / ten waves' 168 VGPRs spill)
+            for (;;) {      // every walker has published this tile: the counters in one round trip
+                bool ok = true;
+#pragma unroll
+                for (uint32_t dd = 0; dd + 1u < W; ++dd) ok &= (int32_t)(lds_vol_u32(sum_prod_off(dd)) - (seq + 1u)) >= 0;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll(D >= 7 ? 1 : 8)
             for (uint32_t dd = 0; dd + 1u < W; ++dd) {
-                ring_wait(sum_prod_off(dd), seq + 1u);
                 const uint32_t sa = wbase + dd * walker_bytes + (seq & 1u) * kSumBytes + lane * 80u;
                 const uint4 h = lds_u128(sa);
                 const uint64_t ost = (uint64_t)h.x | ((uint64_t)h.y << 32), oen = (uint64_t)h.z | ((uint64_t)h.w << 32);
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
                     const uint4 v = lds_u128(sa + 16u + 16u * i);
                     sidq[4 * i] += v.x; sidq[4 * i + 1] += v.y; sidq[4 * i + 2] += v.z; sidq[4 * i + 3] += v.w;   // byte sums <= 255 (finalize_defs)
                 }
-                ring_post(sum_prod_off(dd) + 4u, seq + 1u);
+                ring_post_lds(sum_prod_off(dd) + 4u, seq + 1u);
             }
             if (ov_row == 0xffffffffu) {
                 if (ov_st) ov_row = t0 + (uint32_t)ctz64(ov_st);
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
         if (!combiner) {
             *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)pa = v4u32{dead, err_pos, err_state, err_char};
             *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(pa + 16u) = v4u32{acc_state[0], 0u, 0u, 0u};
-            ring_post(sum_prod_off(d) + 8u, gi + 1u);
+            ring_post_lds(sum_prod_off(d) + 8u, gi + 1u);
             // wait until the combiner has merged before the next group's piece overwrites this one
             ring_wait(merged_off, gi + 1u);
             continue;
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
             m_dead |= w_dead & 1u;
             accept |= (w_acc == a.dc[dd].accepted_state ? 1u : 0u) << dd;
         }
-        ring_post(merged_off, gi + 1u);
+        ring_post_lds(merged_off, gi + 1u);
         if (active) {
             uint64_t sw;
             if (badlen) sw = kStatusBadLength;
