@@ -102,7 +102,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
     const uint32_t gt = vs ? a.vs_tiles : ntiles;                     // tiles per (virtual) group
     auto vg_real = [&](const uint32_t vg) -> uint32_t { return vs ? vg % a.vs_groups : vg; };
     auto vg_tile0 = [&](const uint32_t vg) -> uint32_t { return vs ? (vg / a.vs_groups) * a.vs_tiles : 0u; };
-    uint32_t seq = 0;
+    uint32_t seq = 0, ready_seen = 0;
 #if defined(HRX_STAMPS) || defined(HRX_ABLATION)
     // profiling only (HRX_PACE's high half): rotate which 4-KiB class of every slab an XCD's walkers write
     const uint32_t wg_rot = (blockIdx.x & ~7u) | ((blockIdx.x + (a.pace_even >> 16)) & 7u);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 const uint4 c = lds_u128(ring_base + (f % nring) * kPmTileBytes + i * 1024u + lane * 16u);
                 cw[4 * i] = c.x; cw[4 * i + 1] = c.y; cw[4 * i + 2] = c.z; cw[4 * i + 3] = c.w;
             }
-            ring_post(sum_freed_off, f + 1u);   // (its release fence waits for the reads above)
+            ring_post_lds(sum_freed_off, f + 1u);   // (the LDS executes it behind the reads above)
             lds_store_u32(freed2_off, f + 1u);
             TileBits tb;
             if constexpr (BYTE) {
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
                 *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(ring_base + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
             }
-            ring_post(ready_off, 1u);
+            ring_post_lds(ready_off, 1u);
         }
 #pragma unroll
         for (uint32_t k = 1; k < RT; ++k) try_issue(k, k);
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));  // after the counted wait, not before
                         *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + i * 1024u + lane * 16u) = v4u32{v.x, v.y, v.z, v.w};
                     }
-                    ring_post(ready_off, sq + 1u);
+                    ring_post_lds(ready_off, sq + 1u);
                     try_issue(sq + RT, k);
                 }
             }
@@ -612,11 +612,12 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
 #ifdef HRX_STAMPS
                 const unsigned long long tk_a = clock64();
 #endif
-                ring_wait(ready_off, seq + 1u);
+                ring_wait_seen(ready_off, seq + 1u, ready_seen);
+                const uint32_t sf_seen = FIN ? lds_vol_u32(sum_freed_off) : 0u;     // (looked at when the tile is walked: it arrives with the tile's bytes)
                 uint4 cq[4];
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) cq[i] = lds_u128(slot + i * 1024u + lane * 16u);
-                ring_post(freed_off, seq + 1u);
+                ring_post_lds(freed_off, seq + 1u);
 #ifdef HRX_STAMPS
                 const unsigned long long tk_b = clock64();
 #endif
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 }
                 if constexpr (FIN) {
                     // ---------------- hand the tile over to the finisher wave: bitvectors, substr-id bytes, the string's length ----------------
-                    ring_wait(sum_freed_off, seq);   // it has consumed the previous tile's summary (one summary area per pair)
+                    ring_wait_seen(sum_freed_off, seq, sf_seen);   // it has consumed the previous tile's summary (one summary area per pair)
                     typedef __attribute__((address_space(3))) v4u32 lds_v4u32;
                     if constexpr (BYTE) {   // tag bytes instead of bitvectors; word 0: the substr id of the row before the group's first tile
                         *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{byte_sid0, 0u, n, vs_en};
@@ -799,7 +800,8 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i)
                         *(lds_v4u32 *)(uintptr_t)(sum_off + 2048u + i * 1024u + lane * 16u) = v4u32{sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]};
-                    ring_post(sum_ready_off, seq + 1u);
+                    ring_post_lds(sum_ready_off, seq + 1u);
+                    ready_seen = lds_vol_u32(ready_off);      // the next tile's look at the loader's counter
                 } else {
                 // ---------------- reveal masks: lib.rs:598-764 ----------------
                 TileMasks tm = tile_masks<64>(tb, mc, t0, tile_is_exact(t0, n, M), rows_below(t0, n));

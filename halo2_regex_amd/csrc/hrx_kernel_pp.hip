@@ -138,7 +138,7 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
     const uint32_t freed2_off = ready_off + 8u, sum_ready_off = ready_off + 12u, sum_freed_off = ready_off + 16u;
     const uint32_t M = a.M, B = a.B;
     const uint32_t ntiles = (M + 63u) >> 6;
-    uint32_t seq = 0;
+    uint32_t seq = 0, ready_seen = 0;
     const uint32_t g_first = xcd_slot(blockIdx.x, gridDim.x, (a.debug & kDbgXcdRemap) != 0) * pairs + pair, g_stride = gridDim.x * pairs;
     // the loaders request their pair's first input tile, the walkers their first lengths, BEFORE the table is staged
     uint32_t first_len = M;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
                     const uint4 c = lds_u128(ring_base + (f % nring) * kSlot + kRaw + i * 1024u + lane * 16u);
                     cw[4 * i] = c.x; cw[4 * i + 1] = c.y; cw[4 * i + 2] = c.z; cw[4 * i + 3] = c.w;
                 }
-                ring_post(sum_freed_off, f + 1u);   // (its release fence waits for the reads above)
+                ring_post_lds(sum_freed_off, f + 1u);   // (the LDS executes it behind the reads above)
                 lds_store_u32(freed2_off, f + 1u);
                 TileBits tb;
                 tb.st = (uint64_t)s0.x | ((uint64_t)s0.y << 32);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) emit(ring_base, first_tile[i], i);
-            ring_post(ready_off, 1u);
+            ring_post_lds(ready_off, 1u);
         }
 #pragma unroll
         for (uint32_t k = 1; k < RT; ++k)
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail of the sequence: nothing younger is being issued
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) emit(slot, buf[k * 4u + i], i);
-                    ring_post(ready_off, sq + 1u);
+                    ring_post_lds(ready_off, sq + 1u);
                     if (sq + RT < total) issue(sq + RT, k);
                 }
             }
@@ -324,7 +324,8 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
         for (uint32_t t = 0; t < ntiles; ++t, ++seq) {
             const uint32_t t0 = t << 6;
             const uint32_t slot = ring_base + (seq % nring) * kSlot;
-            ring_wait(ready_off, seq + 1u);
+            ring_wait_seen(ready_off, seq + 1u, ready_seen);
+            const uint32_t sf_seen = lds_vol_u32(sum_freed_off);     // (looked at when the tile is walked: it arrives with the tile's pair indices)
             uint32_t iw[16];
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
@@ -367,16 +368,17 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
             }
             // ---------------- accept state when n == M: row n does not exist, s[n] is the live state ----------------
             if (!full && n == t0 + 64u && t + 1 == ntiles) acc_state = lds_u32((L.lo & 0xffffu) * 8u + 4u) & 0xffu;
-            ring_post(freed_off, seq + 1u);   // done with the slot's pair indices and (slow path) raw bytes; the finisher frees its own view
+            ring_post_lds(freed_off, seq + 1u);   // done with the slot's pair indices and (slow path) raw bytes; the finisher frees its own view
             // ---------------- hand the tile over to the finisher wave: bitvectors, substr-id bytes, the string's length ----------------
-            ring_wait(sum_freed_off, seq);   // it has consumed the previous tile's summary (one summary area per pair)
+            ring_wait_seen(sum_freed_off, seq, sf_seen);   // it has consumed the previous tile's summary (one summary area per pair)
             typedef __attribute__((address_space(3))) v4u32 lds_v4u32;
             *(lds_v4u32 *)(uintptr_t)(sum_off + lane * 16u) = v4u32{(uint32_t)tb.st, (uint32_t)(tb.st >> 32), (uint32_t)tb.en1, (uint32_t)(tb.en1 >> 32)};
             *(lds_v4u32 *)(uintptr_t)(sum_off + 1024u + lane * 16u) = v4u32{(uint32_t)tb.ch, (uint32_t)(tb.ch >> 32), n, 0u};
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i)
                 *(lds_v4u32 *)(uintptr_t)(sum_off + 2048u + i * 1024u + lane * 16u) = v4u32{sidq[4 * i], sidq[4 * i + 1], sidq[4 * i + 2], sidq[4 * i + 3]};
-            ring_post(sum_ready_off, seq + 1u);
+            ring_post_lds(sum_ready_off, seq + 1u);
+            ready_seen = lds_vol_u32(ready_off);      // the next tile's look at the loader's counter
         }
         // ---------------- per-string status ----------------
         if (active) {
