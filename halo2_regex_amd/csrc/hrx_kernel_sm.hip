@@ -565,7 +565,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
     const uint32_t M = a.M;
     const uint32_t ntiles = (M + T - 1u) / T;
     const uint32_t l7 = lane & 7u;
-    uint32_t seq = 0;  // tiles handed over by this pair so far
+    uint32_t seq = 0, cons_seen = 0;  // tiles handed over by this pair so far
 
     for (uint32_t g = blockIdx.x * pairs + pair; g < a.n_groups; g += gridDim.x * pairs) {
         const uint32_t b0 = g * 64u;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 for (uint32_t c = 0; c < 8u; ++c) chunks.addr[c] = slot + lane * 128u + ((c ^ l7) << 4);
                 unsigned long long *stamp = a.stamps ? a.stamps + ((size_t)(blockIdx.x * pairs + pair) * ntiles + t) * 8u : nullptr;
                 if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memtime();
-                if (seq >= nslots) ring_wait(cons_off, seq - nslots + 1u);  // the storer has drained this slot
+                if (seq >= nslots) ring_wait_seen(cons_off, seq - nslots + 1u, cons_seen);  // the storer has drained this slot
                 if (stamp && lane == 0) stamp[1] = __builtin_amdgcn_s_memtime();
 
                 // ---------------- walk + tag: lib.rs:804-888 ----------------
@@ -687,7 +687,8 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                         *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(slot + G::kSlotChr + lane * T + 16u * i) =
                             v4u32{act[i].x, act[i].y, act[i].z, act[i].w};
                 }
-                ring_post(prod_off, seq + 1u);
+                ring_post_lds(prod_off, seq + 1u);
+                cons_seen = lds_vol_u32(cons_off);      // the next tile's look at the storer's counter (hrx_device.h ring_wait_seen)
                 if (stamp && lane == 0) stamp[2] = __builtin_amdgcn_s_memtime();
 
                 // next tile's bytes move to the front; every kSuper tiles the pending batch takes over
@@ -767,8 +768,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                 if (__ballot(hdr.y != kNoFix)) {  // an earlier optimistic end_mask = 1 turned out wrong: zero those masked rows
                     // rows already in memory (everything below this 64-row block): one string at a time, behind the stores that wrote them
                     uint64_t memfix = __ballot(hdr.y < blk0);          // (kNoFix = 0xffffffff)
-                    if (memfix) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (memfix) {      // (this wave's own earlier stores to these rows are performed before these: one wave's stores to one address keep their order, as in the position-major kernels' repairs)
                         while (memfix) {
                             const int j = __ffsll((unsigned long long)memfix) - 1;
                             memfix &= memfix - 1;
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                         }
                     }
                 }
-                ring_post(cons_off, seq + 1u);  // every LDS read of the slot has returned; the stores may still be in flight
+                ring_post_lds(cons_off, seq + 1u);  // behind every LDS read of the slot; the stores may still be in flight
                 if (t0 % kTouchRows == 0) touch(t0 + kTouchAhead + kTouchRows);
                 if (blk_last && !(a.debug & kDbgSkipMasked)) {
                     unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked + (size_t)(b0 + mj0) * a.msk_pitch + blk0 + mw * 8u);

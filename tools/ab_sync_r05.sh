@@ -5,8 +5,7 @@ for r in 1 2 3; do
 for lib in libhrx_prev.so libhrx.so; do
 export HRX_LIB_PATH=$PWD/halo2_regex_amd/csrc/$lib
 echo "== $lib"
-echo -n "regex1 65536 x 1024 (headline): "; STEPS=200 one
-echo -n "regex23 1048576 x 2048: "; one --config regex23 --batch 1048576 --rows 2048 --len 2047 --distinct 65536
-echo -n "dfa256 131072 x 4096: "; one --config dfa256 --batch 131072 --rows 4096 --len 4095 --distinct 65536
-echo -n "regex1 string-major: "; one --layout string-major
+
+
+echo -n "dfa256 65536 x 4096 string-major: "; one --config dfa256 --batch 65536 --rows 4096 --len 4095 --layout string-major
 done; done
