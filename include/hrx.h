@@ -75,9 +75,11 @@ int hrx_defs_push_substr(hrx_defs *defs, size_t n_pairs, const uint64_t *pair_cu
  * over consecutive groups of defs (each group's tables LDS-resident); the per-row sums over all defs (reveal masks, flag
  * overlap) and the merged status are formed by the last pass itself from 80-byte tile summaries the earlier passes leave
  * (position-major outputs, up to four groups) or by a combine launch — same buffers, same results; with position-major outputs
- * the passes write the caller's record planes directly and the extra cost is ~2.5 bytes per row and earlier group (string-major
- * outputs with row counts in multiples of 8 are produced position-major in context scratch and transposed; other row counts are
- * copied into place by the combine launch and are several times slower: ask for position-major buffers).
+ * the passes write the caller's record planes directly and the extra cost is ~2.5 bytes per row and earlier group.  String-major
+ * outputs of more than three defs: four and five defs of at most 32 byte classes each, row counts in multiples of 16, come straight out of the
+ * def-parallel launch (0.50-0.68 of peak: the records meet in LDS sub-tiles, a storer wave writes the caller's [B][pitch][D]); otherwise row counts
+ * in multiples of 8 are produced position-major in context scratch and transposed (~0.2 of peak), and other row counts are copied into place by
+ * the combine launch and are several times slower: ask for position-major buffers there.
  * HRX_MP_COMBINE=1 in the environment of hrx_ctx_create keeps the separate combine launch. */
 #define HRX_MAX_DEFS 32
 int hrx_defs_finalize(hrx_defs *defs);
