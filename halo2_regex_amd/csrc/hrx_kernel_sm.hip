@@ -774,8 +774,16 @@ __global__ __launch_bounds__(512) void witness_split_kernel(const WitnessArgs a,
                             memfix &= memfix - 1;
                             const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)hdr.y, j);
                             uint16_t *mrow = a.masked + (size_t)(b0 + j) * a.msk_pitch;
-                            for (uint32_t r = (fs & ~63u) + lane; r < blk0; r += 64u)
-                                if (r >= fs) mrow[r] = 0;
+                            if (((a.msk_pitch & 7u) | ((uint32_t)(uintptr_t)a.masked & 15u)) == 0u) {
+                                // the rows up to the next octet border two bytes at a time (lanes 0 .. 6), then 16 bytes per lane: 512 rows per store instruction (blk0 is a multiple of 64) —
+                                // a random DFA's repairs reach back hundreds of rows (hrx_kernel_pm.hip does the same on its layout)
+                                const uint32_t o0 = (fs + 7u) >> 3, o1 = blk0 >> 3;
+                                if (fs + lane < (o0 << 3)) mrow[fs + lane] = 0;
+                                for (uint32_t o = o0 + lane; o < o1; o += 64u) *reinterpret_cast<uint4 *>(mrow + (size_t)o * 8u) = make_uint4(0, 0, 0, 0);
+                            } else {
+                                for (uint32_t r = (fs & ~63u) + lane; r < blk0; r += 64u)
+                                    if (r >= fs) mrow[r] = 0;
+                            }
                         }
                     }
                     // rows of this block still held in mk (earlier tiles of the block): every lane looks at its own eight strings' fix starts —
