@@ -484,6 +484,17 @@ constexpr uint32_t kFrRowsPerBlock = 4u * 32u * kFrJ;
 __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
     // thread = (row, half of the 32-byte cell): both lanes of a pair compute the cell, each stores its 16 bytes, so that a
     // store instruction writes 1 KiB of full lines (one lane per row stored half of every 32 bytes per instruction)
+    // Every value a row holds is small — bytes, states, ids, flags — and F::from(v) costs ~200 VALU operations: the cells of v < 256 come out of an LDS table the block's 256 threads
+    // build first (one entry each; 8 KiB), anything larger (states of DFAs beyond 256 states) is computed in place.  Computed per cell by both lanes of a pair the launch was VALU-bound
+    // at 0.68 of the HBM peak.
+    __shared__ uint4 frtab[512];
+    {
+        uint32_t w[8];
+        fr_from_u32(threadIdx.x, w, a.canonical != 0);
+        frtab[2u * threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
+        frtab[2u * threadIdx.x + 1u] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    __syncthreads();
     const uint32_t half = threadIdx.x & 1u;
     const uint32_t bi = blockIdx.y;              // index inside the requested range
     const uint32_t b = a.b_begin + bi;
@@ -501,10 +512,16 @@ __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
 #pragma unroll
         for (uint32_t j = 0; j < kFrJ; ++j) {
             if (rbase + j * 32u < a.M) {
-                uint32_t w[8];
-                fr_from_u32(v[j], w, a.canonical != 0);
+                uint4 cell;
+                if (v[j] < 256u) {
+                    cell = frtab[2u * v[j] + half];
+                } else {
+                    uint32_t w[8];
+                    fr_from_u32(v[j], w, a.canonical != 0);
+                    cell = half ? make_uint4(w[4], w[5], w[6], w[7]) : make_uint4(w[0], w[1], w[2], w[3]);
+                }
                 unsigned char *p = reinterpret_cast<unsigned char *>(out0 + (size_t)col * col_cells * 4u + (size_t)j * 32u * 4u);
-                store16_nt(p, half ? make_uint4(w[4], w[5], w[6], w[7]) : make_uint4(w[0], w[1], w[2], w[3]));    // streaming: nothing reads the cells back here
+                store16_nt(p, cell);    // streaming: nothing reads the cells back here
             }
         }
     };

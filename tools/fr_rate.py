@@ -14,21 +14,28 @@ defs = [hra.RegexDefs(hra.AllstrRegexDef(rd("regex1_test_lookup.txt")), [hra.Sub
 cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
 dev = torch.device("cuda", 0)
 chars, lens = synth.regex1_planted(B, n, seed=0, stride=1024)
-d_chars = hra.chars_to_position_major(torch.from_numpy(chars).to(dev))
+SM = len(sys.argv) > 1 and sys.argv[1] == "sm"      # the compact witness in string-major buffers instead of position-major ones
+d_chars = torch.from_numpy(chars).to(dev)
 d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
-out = cfg.witness_batch_position_major(d_chars, d_lens, chars_pm_stride=1024)
+if SM:
+    out = cfg.witness_batch(d_chars, d_lens)
+    kw = dict()
+else:
+    d_chars = hra.chars_to_position_major(d_chars)
+    out = cfg.witness_batch_position_major(d_chars, d_lens, chars_pm_stride=1024)
+    kw = dict(position_major=True, chars_pm_stride=1024)
 for _ in range(2):
-    cells = cfg.fr_columns(d_chars, d_lens, out, b_begin=0, b_count=NB, position_major=True, chars_pm_stride=1024)
+    cells = cfg.fr_columns(d_chars, d_lens, out, b_begin=0, b_count=NB, **kw)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 steps = 10
 e0.record()
 for i in range(steps):
-    cells = cfg.fr_columns(d_chars, d_lens, out, b_begin=(i * NB) % B, b_count=NB, position_major=True, chars_pm_stride=1024)
+    cells = cfg.fr_columns(d_chars, d_lens, out, b_begin=(i * NB) % B, b_count=NB, **kw)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / steps
 rows = NB * M
 cells_per_row = 8
-print(json.dumps({"what": "hrx_fr_columns_device, regex1 (D=1), %d strings x %d rows per call" % (NB, M), "ms_per_call": ms,
+print(json.dumps({"what": "hrx_fr_columns_device, regex1 (D=1), %d strings x %d rows per call, %s witness" % (NB, M, "string-major" if SM else "position-major"), "ms_per_call": ms,
                   "rows_per_s": rows / (ms * 1e-3), "cells_per_s": rows * cells_per_row / (ms * 1e-3),
                   "written_GBps": rows * cells_per_row * 32 / (ms * 1e-3) / 1e9, "frac_of_8TBps": rows * (cells_per_row * 32 + 7) / (ms * 1e-3) / 8e12}))
