@@ -13,6 +13,10 @@ $B --config headers3 --batch 32768 --len 32767 --rows 32768 --steps 5 --warmup 2
 $B --config headers3 --batch 65536 --len 2047 --rows 2048 --steps 20 --warmup 3      > $O/headers3_65536x2048.json
 $B --config headers5 --batch 65536 --len 2047 --rows 2048 --steps 20 --warmup 3      > $O/headers5_65536x2048.json
 $B --config headers5 --batch 65536 --len 1023 --rows 1024 --steps 20 --warmup 3 --layout string-major > $O/headers5_65536x1024_string_major.json
+$B --config headers5 --batch 65536 --len 1023 --rows 1024 --steps 20 --warmup 3 --layout string-major --dense > $O/headers5_65536x1024_string_major_dense_pitches.json
+$B --config headers5 --batch 65536 --len 2047 --rows 2048 --steps 20 --warmup 3 --layout string-major > $O/headers5_65536x2048_string_major.json
+$B --config headers4 --batch 65536 --len 1023 --rows 1024 --steps 20 --warmup 3 --layout string-major > $O/headers4_65536x1024_string_major.json
+$B --config headers4 --batch 65536 --len 2047 --rows 2048 --steps 20 --warmup 3                      > $O/headers4_65536x2048.json
 $B --config regex123 --steps 50                                                      > $O/regex123_65536x1024.json
 $B --config dfa256 --len 4095 --rows 4096 --steps 20 --warmup 3                      > $O/cfg5_dfa256_65536x4096.json
 $B --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 10 --warmup 3 --distinct 65536 > $O/cfg5_dfa256_131072x4096.json
