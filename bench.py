@@ -650,6 +650,11 @@ def run_rank(args, rank, world, device_index, barrier):
             hrec, hmsk, hst = np.empty((B, M, D), np.uint32), np.empty((B, M), np.uint16), np.empty(B, np.uint64)
             hc = np.ascontiguousarray(chars[:, :stride])
             cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))          # (first call: the context's staging buffers, first touch of the output pages)
+            explore = []
+            for _ in range(4):        # the context's own comparison: pipelined, one stream, pipelined, one stream (hrx_api.cpp batch_host_locked) — timed, reported apart
+                t0 = time.perf_counter()
+                cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))
+                explore.append((time.perf_counter() - t0) * 1e3)
             ts = []
             for _ in range(5):
                 t0 = time.perf_counter()
@@ -660,9 +665,11 @@ def run_rank(args, rank, world, device_index, barrier):
                    "bytes_out": int(hrec.nbytes + hmsk.nbytes + hst.nbytes), "bytes_in": int(hc.nbytes + 4 * B),
                    "gbs_out": (hrec.nbytes + hmsk.nbytes + hst.nbytes) / (ms * 1e-3) / 1e9,
                    "status_ok": bool(((hst & np.uint64(0xff)) == 0).all()),
+                   "comparison_calls_ms": {"pipelined": [explore[0], explore[2]], "one_stream": [explore[1], explore[3]]},
                    "what": "hrx_witness_batch_host on the same batch: pageable host arrays in (string-major, %d B apart) and out (records [B][M][D] u32, masked [B][M] u16, status), "
-                           "output arrays reused; staged, walked and copied out chunk by chunk (two streams, a staging thread); the call lasts as long as the copy out over the "
-                           "PCIe link (gbs_out)" % stride}
+                           "output arrays reused; the five timed calls go the way the context's own comparison (comparison_calls_ms: its calls 2-5) found faster on this box: staged, walked and "
+                           "copied out chunk by chunk on two streams (8.0 ms where the box lets both directions run at once, 16.5 where it does not), or in, walk, out on one stream (8.6 ms "
+                           "everywhere); the call lasts about as long as the copy out over the PCIe link (gbs_out)" % stride}
             # what the link gives a plain device-to-host copy of the same bytes into the same (pageable, already touched) arrays on THIS box
             try:
                 tr_, tm_ = torch.from_numpy(hrec.view(np.int32).reshape(-1)), torch.from_numpy(hmsk.view(np.int16).reshape(-1))

@@ -96,6 +96,8 @@ struct hrx_ctx {
     uint32_t debug = 0;      // HRX_DEBUG_FLAGS, read once at creation (hrx_kernel.hpp)
     size_t host_threshold = HRX_DEFAULT_HOST_THRESHOLD;   // rows (B x M) below which host-buffer batches take the host walk
     hipStream_t stream = nullptr;
+    // host-buffer batches of three chunks and more: pipelined (two streams) or one stream, whichever the last comparison on this box found faster (batch_host_locked)
+    struct HostMode { unsigned calls = 0, until_probe = 0; bool sequential = false; double piped_ns_per_byte = 0.0, seq_ns_per_byte = 0.0; } host_mode;
     hipStream_t copy_stream = nullptr;   // host-buffer batches: the device-to-host copies of finished chunks run here while the next chunks are staged and walked on `stream`
     uint32_t *d_table = nullptr;
     uint64_t *d_wide = nullptr;
@@ -1479,7 +1481,44 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
     size_t cb = out_per_string ? (chunk_mib << 20) / out_per_string / 64 * 64 : B;   // ~48 MiB of rows per chunk (HRX_HOST_CHUNK_MIB)
     if (cb < 1024) cb = 1024;
     const size_t nchunk = (B + cb - 1) / cb;
-    if (nchunk < 3 || ctx->copy_stream == nullptr) {
+    // HRX_HOST_TRACE=1: one line per call on stderr — which way the call went, how long it took, per chunk when its input was on its way / its walk launched / its copy out began and ended
+    static const bool trace = [] { const char *v = std::getenv("HRX_HOST_TRACE"); return v && std::atoi(v) != 0; }();
+    const auto t_call = std::chrono::steady_clock::now();
+    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    // Pipelined or not.  On about every second box of this pool the pipelined call's device-to-host copies run at 25 GB/s instead of 55 for as long as the same call (or process) also
+    // copies host-to-device on the other stream — 16.5 ms per 65536 x 1024 call instead of 8.0, while one stream doing in, walk, out takes 8.6 on every box and a plain copy of the same
+    // bytes 7.2 (per-chunk traces, the variants tried: profiles/r05_probes/host_path_modes.txt).  So a context MEASURES: after its first big call (allocations, first touches) two calls go
+    // pipelined and two on one stream, alternating; the faster way (the better of its two calls, per byte sent back; the pipeline unless the single stream is 10 % faster) takes the next
+    // 62 calls, then the other way gets one call again; a pipelined call a quarter slower than the single stream's figure switches at once.  HRX_HOST_PIPELINE=1 / 0: always / never pipelined.
+    static const int force_pipe = [] { const char *v = std::getenv("HRX_HOST_PIPELINE"); return v ? (std::atoi(v) != 0 ? 1 : 0) : -1; }();
+    hrx_ctx::HostMode &hm = ctx->host_mode;
+    const bool big = nchunk >= 3 && ctx->copy_stream != nullptr;
+    bool sequential = !big, timed = false;
+    if (big) {
+        if (force_pipe >= 0) sequential = force_pipe == 0;
+        else if (hm.calls == 0) sequential = false;                                      // not timed
+        else if (hm.calls <= 4) { sequential = (hm.calls & 1u) == 0u; timed = true; }    // pipelined, one stream, pipelined, one stream
+        else if (hm.until_probe == 0) { sequential = !hm.sequential; timed = true; }     // the other way's turn
+        else { sequential = hm.sequential; timed = true; --hm.until_probe; }
+    }
+    auto account = [&](const bool was_sequential) {
+        if (!big || force_pipe >= 0) return;
+        const double ns_per_byte = ms_now() * 1e6 / (double)(B * out_per_string);
+        const unsigned k = hm.calls++;
+        if (!timed) return;
+        double &fig = was_sequential ? hm.seq_ns_per_byte : hm.piped_ns_per_byte;
+        fig = (k <= 4 && fig > 0.0) ? std::min(fig, ns_per_byte) : ns_per_byte;
+        if (k < 4) return;
+        if (k == 4 || was_sequential != hm.sequential) {       // a comparison is complete: decide
+            hm.sequential = hm.seq_ns_per_byte < 0.9 * hm.piped_ns_per_byte;
+            hm.until_probe = 62;
+        } else if (!was_sequential && ns_per_byte > 1.25 * hm.seq_ns_per_byte) {     // the box has changed its mind
+            hm.sequential = true;
+            hm.until_probe = 62;
+        }
+        if (trace) std::fprintf(stderr, "[hrx host] per byte sent back: pipelined %.4f ns, one stream %.4f ns -> %s\n", hm.piped_ns_per_byte, hm.seq_ns_per_byte, hm.sequential ? "one stream" : "pipelined");
+    };
+    if (sequential) {
         if (dstride != stride) HIP_TRY(hipMemsetAsync(ctx->chars.p, 0, dstride * B, st));
         if (stride) HIP_TRY(hipMemcpy2DAsync(ctx->chars.p, dstride, chars, stride, stride, B, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ctx->lens.p, lens, 4 * B, hipMemcpyHostToDevice, st));
@@ -1490,8 +1529,11 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
         HIP_TRY(hipMemcpyAsync(masked, ctx->masked.p, 2 * B * M, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(status, ctx->status.p, 8 * B, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (trace) std::fprintf(stderr, "[hrx host] %zu strings on one stream: %.2f ms\n", B, ms_now());
+        account(true);
         return HRX_OK;
     }
+    std::vector<double> t_in(trace ? nchunk : 0), t_launch(trace ? nchunk : 0), t_out0(trace ? nchunk : 0), t_out1(trace ? nchunk : 0);
     std::vector<hipEvent_t> done(nchunk, nullptr);
     for (size_t c = 0; c < nchunk; ++c)
         if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess) {
@@ -1513,11 +1555,13 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
             if (dstride != stride) e = hipMemsetAsync(dch, 0, dstride * n, st);
             if (e == hipSuccess && stride) e = hipMemcpy2DAsync(dch, dstride, chars + b0 * stride, stride, stride, n, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync((uint32_t *)ctx->lens.p + b0, lens + b0, 4 * n, hipMemcpyHostToDevice, st);
+            if (trace) t_in[c] = ms_now();
             int rc = HRX_OK;
             if (e == hipSuccess)
                 rc = launch_batch(ctx, dch, dstride, (const uint32_t *)ctx->lens.p + b0, n, M, (uint32_t *)ctx->records.p + b0 * M * D,
                                   (uint16_t *)ctx->masked.p + b0 * M, (uint64_t *)ctx->status.p + b0, st);
             if (e == hipSuccess && rc == HRX_OK) e = hipEventRecord(done[c], st);
+            if (trace) t_launch[c] = ms_now();
             if (e != hipSuccess || rc != HRX_OK) {
                 pmsg = e != hipSuccess ? std::string("HIP error while staging a chunk: ") + hipGetErrorString(e) : std::string(hrx_last_error());
                 (void)hipGetLastError();
@@ -1534,15 +1578,26 @@ static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, 
         while (staged.load(std::memory_order_acquire) <= c) std::this_thread::yield();
         if (prc.load() != HRX_OK) break;
         const size_t b0 = c * cb, n = std::min(cb, B - b0);
+        if (trace) t_out0[c] = ms_now();
         ce = hipStreamWaitEvent(ctx->copy_stream, done[c], 0);
         if (ce == hipSuccess) ce = hipMemcpyAsync(records + b0 * M * D, (uint32_t *)ctx->records.p + b0 * M * D, 4 * n * M * D, hipMemcpyDeviceToHost, ctx->copy_stream);
         if (ce == hipSuccess) ce = hipMemcpyAsync(masked + b0 * M, (uint16_t *)ctx->masked.p + b0 * M, 2 * n * M, hipMemcpyDeviceToHost, ctx->copy_stream);
         if (ce == hipSuccess) ce = hipMemcpyAsync(status + b0, (uint64_t *)ctx->status.p + b0, 8 * n, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (trace) t_out1[c] = ms_now();
     }
     producer.join();
     if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamSynchronize(st);
     for (hipEvent_t e : done) (void)hipEventDestroy(e);
+    if (trace) {
+        std::string line = "[hrx host] " + std::to_string(nchunk) + " chunks of " + std::to_string(cb) + " strings, pipelined, ms: in/launched/out from-to";
+        char buf[96];
+        for (size_t c = 0; c < nchunk; ++c) { std::snprintf(buf, sizeof buf, " | %.2f/%.2f/%.2f-%.2f", t_in[c], t_launch[c], t_out0[c], t_out1[c]); line += buf; }
+        std::snprintf(buf, sizeof buf, " | end %.2f\n", ms_now());
+        line += buf;
+        std::fputs(line.c_str(), stderr);
+    }
+    if (prc.load() == HRX_OK && ce == hipSuccess) account(false);
     if (prc.load() != HRX_OK) return fail(prc.load(), pmsg);
     if (ce != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, std::string("HIP error while copying a chunk out: ") + hipGetErrorString(ce)); }
     return rc;

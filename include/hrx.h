@@ -291,9 +291,11 @@ int hrx_device_free(void *ptr);
 int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap);
 /* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers, or — below the
  * context's host threshold, and always on a host-only context — walked on the host; synchronous.  This is what an unmodified caller of
- * match_substrs' seam gets (host Vecs in, host Vecs out, src/lib.rs:311-318).  Batches of more than ~100 MiB of rows are pipelined chunk by chunk:
- * a staging thread copies chunk c in and launches its walk while the calling thread copies chunk c - 1's rows out on a second stream; the call lasts
- * as long as the copy out — (4 D + 2) bytes per row over the PCIe link in one direction (bench.py: end_to_end_host). */
+ * match_substrs' seam gets (host Vecs in, host Vecs out, src/lib.rs:311-318).  Batches of more than ~100 MiB of rows go one of two ways: pipelined chunk by chunk
+ * (a staging thread copies chunk c in and launches its walk while the calling thread copies chunk c - 1's rows out on a second stream), or in, walk, out on one stream —
+ * the context times both over its first calls and keeps the faster one for this process on this box (the pipeline's copies out run at half rate on some hosts), looking again
+ * every 64 calls; the call lasts about as long as the copy out — (4 D + 2) bytes per row over the PCIe link in one direction (bench.py: end_to_end_host).
+ * Environment: HRX_HOST_PIPELINE=1 / 0 forces a way, HRX_HOST_TRACE=1 prints a line per call on stderr, HRX_HOST_CHUNK_MIB the pipeline's chunk size. */
 int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B,
                            size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);
 

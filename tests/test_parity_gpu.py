@@ -1227,7 +1227,7 @@ def test_placement_arenas_are_shared_by_the_contexts_of_a_device(hra, oracle):
 
 def test_host_buffer_batches_are_pipelined_chunk_by_chunk(hra, oracle):
     """hrx_witness_batch_host — what an unmodified caller of the seam gets (host Vecs in, host Vecs out, lib.rs:311-318) — stages, walks and copies a large batch out
-    chunk by chunk on two streams and two host threads.  Every string against the oracle: a batch of several chunks with a last partial one, ragged strings, strings
+    chunk by chunk on two streams and two host threads, or in one piece on one stream, whichever the context finds faster on the box.  Every string against the oracle: a batch of several chunks with a last partial one, ragged strings, strings
     with undefined transitions in several chunks, a stride that is not a multiple of 16 (the staging pads it), two defs; and the same rows gathered per circuit out of
     the position-major device buffers copied to the host as they are (hrx_rows_of_string_position_major)."""
     import torch
@@ -1249,6 +1249,10 @@ def test_host_buffer_batches_are_pipelined_chunk_by_chunk(hra, oracle):
         ok = (ost & np.uint64(0xff)) == 0
         assert np.array_equal(gst, ost) and (~ok).sum() >= 90
         assert np.array_equal(grec[ok], orec[ok]) and np.array_equal(gmsk[ok], omsk[ok])
+        # the context compares its two ways over its next calls (pipelined, one stream, pipelined, one stream: hrx_api.cpp batch_host_locked) and then keeps the faster one: the same rows every time
+        for call in range(5):
+            r2, m2, s2 = cfg.witness_batch_host(chars, lens)
+            assert np.array_equal(s2, ost) and np.array_equal(r2[ok], orec[ok]) and np.array_equal(m2[ok], omsk[ok]), call
         # per-circuit view of the position-major buffers, on the host
         dev = torch.device("cuda", 0)
         padded = chars if stride % 16 == 0 else np.pad(chars, ((0, 0), (0, 16 - stride % 16)))
