@@ -879,6 +879,9 @@ def test_four_to_eight_defs_in_one_def_parallel_launch(hra, oracle, names, monke
         lens[11] = M + 72
         lens[12], lens[13] = 0, min(M, chars.shape[1])
         _check_batch(hra, oracle, names, chars, lens, M)
+        if M == 64:            # batches smaller than a group, and a group plus one string
+            for Bs in (1, 65):
+                _check_batch(hra, oracle, names, np.ascontiguousarray(chars[100:100 + Bs]), lens[100:100 + Bs].copy(), M)
         if M == 1024:          # device-resident, pitched string-major buffers (hrx_recommended_pitches), several rounds of groups
             import torch
             dev = torch.device("cuda", 0)
