@@ -110,7 +110,52 @@ extern "C" {
     pub fn hrx_regex_files_allstr(files: *const hrx_regex_files, len: *mut usize) -> *const c_char;
     pub fn hrx_regex_files_substr(files: *const hrx_regex_files, idx: usize, len: *mut usize) -> *const c_char;
     pub fn hrx_regex_files_destroy(files: *mut hrx_regex_files);
+    // ---- the rest of include/hrx.h (tests/test_abi.py diffs these names against the header) ----
+    /// the text parsers of src/defs.rs (read_from_text / read_from_reader) for callers that hold files or strings instead of the structs
+    pub fn hrx_defs_push_allstr_text(defs: *mut hrx_defs, text: *const c_char, len: usize) -> c_int;
+    pub fn hrx_defs_push_allstr_file(defs: *mut hrx_defs, path: *const c_char) -> c_int;
+    pub fn hrx_defs_push_substr_text(defs: *mut hrx_defs, text: *const c_char, len: usize) -> c_int;
+    pub fn hrx_defs_push_substr_file(defs: *mut hrx_defs, path: *const c_char) -> c_int;
+    pub fn hrx_defs_num_defs(defs: *const hrx_defs) -> usize;
+    pub fn hrx_defs_num_substrs(defs: *const hrx_defs, def: usize) -> usize;
+    pub fn hrx_defs_first_state(defs: *const hrx_defs, def: usize) -> u64;
+    pub fn hrx_defs_accepted_state(defs: *const hrx_defs, def: usize) -> u64;
+    pub fn hrx_defs_largest_state(defs: *const hrx_defs, def: usize) -> u64;
+    pub fn hrx_defs_num_transitions(defs: *const hrx_defs, def: usize) -> usize;
+    pub fn hrx_defs_substr_id_offset(defs: *const hrx_defs, def: usize) -> u64;
+    pub fn hrx_defs_table_bytes(defs: *const hrx_defs) -> usize;
+    pub fn hrx_witness_batch_device_pitched(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, lens: *const u32, b: usize, m: usize, records: *mut u32, rec_pitch: usize,
+                                            masked: *mut u16, msk_pitch: usize, status: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn hrx_recommended_pitches(m: usize, rec_pitch: *mut usize, msk_pitch: *mut usize, chars_stride: *mut usize);
+    /// RECORD PLANES: every def's records in a buffer of its own (the D + 1 write streams of a launch spread over the classes of the device memory)
+    pub fn hrx_witness_batch_device_planes(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, lens: *const u32, b: usize, m: usize,
+                                           record_planes: *const *mut u32, n_planes: usize, masked: *mut u16, status: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn hrx_probe_write_pair(ctx: *mut hrx_ctx, a: *mut c_void, b: *mut c_void, bytes: usize, gbs: *mut f64) -> c_int;
+    pub fn hrx_position_major_plane_sizes(b: usize, m: usize, plane_u32: *mut usize, masked_u16: *mut usize);
+    pub fn hrx_alloc_output_planes(ctx: *mut hrx_ctx, b: usize, m: usize, record_planes: *mut *mut u32, masked: *mut *mut u16) -> c_int;
+    pub fn hrx_rows_of_string_planes(record_planes: *const *const u32, masked_pm: *const u16, b_total: usize, m: usize, d: usize, b: usize,
+                                     records: *mut u32, masked: *mut u16) -> c_int;
+    pub fn hrx_traffic_pass_device_planes(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, m: usize, record_planes: *const *mut u32, n_planes: usize,
+                                          masked: *mut u16, stream: *mut c_void) -> c_int;
+    /// per-context choices between variants that compute the same rows (HRX_OPT_*)
+    pub fn hrx_ctx_set_option(ctx: *mut hrx_ctx, option: c_int, value: std::ffi::c_long) -> c_int;
+    pub fn hrx_ctx_get_option(ctx: *const hrx_ctx, option: c_int) -> std::ffi::c_long;
+    pub fn hrx_describe_launch(defs: *const hrx_defs, layout: c_int, b: usize, m: usize, num_cus: c_int, out: *mut c_char, cap: usize) -> c_int;
+    pub fn hrx_ctx_describe_launch(ctx: *const hrx_ctx, layout: c_int, b: usize, m: usize, out: *mut c_char, cap: usize) -> c_int;
+    /// the Vecs of lib.rs:316-318 out of one string's compact records; the integer advice columns of all circuits of a batch, column-major
+    pub fn hrx_witness_of_string(records: *const u32, d: usize, n: usize, m: usize, states: *mut u64, substr_ids: *mut usize, is_start: *mut bool, is_end: *mut bool) -> c_int;
+    pub fn hrx_witness_num_columns(d: usize) -> usize;
+    pub fn hrx_witness_columns_host(layout: c_int, chars: *const u8, stride: usize, lens: *const u32, records: *const u32, rec_pitch: usize, masked: *const u16,
+                                    msk_pitch: usize, b: usize, m: usize, d: usize, b_begin: usize, b_count: usize, columns: *mut u64) -> c_int;
+    pub fn hrx_fr_num_columns(d: usize) -> usize;
+    pub fn hrx_fr_from_u64(v: u64, flags: c_int, limbs: *mut u64);
+    /// what src/vrm/js_caller.rs:36-48, 127-157 obtain from V8: regexToDfa's JSON, the AllstrRegexDef text, formatRegexPrintable; and the part search of vrm/mod.rs:540-600
+    pub fn hrx_regex_to_allstr_text(regex: *const c_char, regex_len: usize, out: *mut c_char, cap: usize, needed: *mut usize) -> c_int;
+    pub fn hrx_regex_to_dfa_json(regex: *const c_char, regex_len: usize, out: *mut c_char, cap: usize, needed: *mut usize) -> c_int;
+    pub fn hrx_format_regex_str(regex: *const c_char, regex_len: usize, out: *mut c_char, cap: usize, needed: *mut usize) -> c_int;
+    pub fn hrx_regex_find(pattern: *const c_char, pattern_len: usize, text: *const c_char, text_len: usize, found: *mut c_int, start: *mut usize, end: *mut usize) -> c_int;
 }
+pub const HRX_OPT_PMD_COMBINER_WAVE: c_int = 1;
 
 #[repr(C)] pub struct hrx_regex_part { regex_def: *const c_char, regex_len: usize, is_public: c_int, max_size: usize }
 #[repr(C)] pub struct hrx_regex_files { _private: [u8; 0] }
@@ -289,30 +334,26 @@ impl WitnessOf {
     /// `n` = characters.len() <= m.  Row n of the records holds the state after the last character (lib.rs:404-411); when n == m that row does not
     /// exist and the state after the last character is not part of any cell either (the reference's states[d][m] is computed and never assigned).
     pub fn new(rec: &[u32], d: usize, n: usize, m: usize) -> Self {
-        let mut w = WitnessOf { states: vec![vec![0; n + 1]; d], substr_ids: vec![vec![0; n]; d], is_starts: vec![vec![false; n + 1]; d], is_ends: vec![vec![false; n + 1]; d] };
-        for di in 0..d {
-            for idx in 0..n.min(m) {
-                let r = rec[idx * d + di];
-                w.states[di][idx] = (r & 0xffff) as u64;
-                w.substr_ids[di][idx] = ((r >> 16) & 0xff) as usize;
-                w.is_starts[di][idx] = (r >> 24) & 1 != 0;
-                w.is_ends[di][idx + 1] = (r >> 25) & 1 != 0;
-            }
-            if n < m { w.states[di][n] = (rec[n * d + di] & 0xffff) as u64; }
-            // n == m: states[di][m] stays 0 — match_substrs never reads it (lib.rs:388-418 stop at max_chars_size) — and is_ends[di][m], the flag of the last
-            // transition, is dropped by the reference as well (lib.rs:501: the loop ends at max_chars_size - 2)
+        assert!(rec.len() >= m * d && n <= m);
+        // hrx_witness_of_string (csrc/hrx_fill.cpp) writes [def][..] row-major; Vec<bool> is one 0 / 1 byte per element
+        let (mut states, mut ids) = (vec![0u64; d * (n + 1)], vec![0usize; d * n]);
+        let (mut st, mut en) = (vec![false; d * (n + 1)], vec![false; d * (n + 1)]);
+        let rc = unsafe { hrx_witness_of_string(rec.as_ptr(), d, n, m, states.as_mut_ptr(), ids.as_mut_ptr(), st.as_mut_ptr(), en.as_mut_ptr()) };
+        if rc != 0 { panic!("{}", last_error()); }
+        WitnessOf {
+            states: states.chunks(n + 1).map(|c| c.to_vec()).collect(),
+            substr_ids: if n == 0 { vec![vec![]; d] } else { ids.chunks(n).map(|c| c.to_vec()).collect() },
+            is_starts: st.chunks(n + 1).map(|c| c.to_vec()).collect(),
+            is_ends: en.chunks(n + 1).map(|c| c.to_vec()).collect(),
         }
-        w
+        // (n == m: states[di][m] is 0 and is_ends[di][m] false — the two values match_substrs computes and never assigns: lib.rs:388-418, 501)
     }
 
     /// The same view out of HRX_LAYOUT_POSITION_MAJOR records ([ceil(m/4)][d][nb][4] per block of 65536 strings): string `b` of a batch of `batch` strings.
     pub fn from_position_major(rec_pm: &[u32], batch: usize, b: usize, d: usize, n: usize, m: usize) -> Self {
-        const BLOCK: usize = 65536;
-        let (blk0, q4) = (b / BLOCK * BLOCK, (m + 3) / 4);
-        let nb = BLOCK.min(batch - blk0);
-        let base = blk0 * q4 * d * 4;
-        let at = |row: usize, di: usize| rec_pm[base + ((row / 4 * d + di) * nb + (b - blk0)) * 4 + row % 4];
-        let flat: Vec<u32> = (0..m).flat_map(|row| (0..d).map(move |di| (row, di))).map(|(row, di)| at(row, di)).collect();
+        let mut flat = vec![0u32; m * d];
+        let rc = unsafe { hrx_rows_of_string_position_major(rec_pm.as_ptr(), std::ptr::null(), batch, m, d, b, flat.as_mut_ptr(), std::ptr::null_mut()) };
+        if rc != 0 { panic!("{}", last_error()); }
         Self::new(&flat, d, n, m)
     }
 }

@@ -25,23 +25,6 @@ HRX_DEVICE_SAME = -2                 # hrx_ctx_clone: the source context's devic
 HRX_DEVICE_NONE = -1                 # hrx_ctx_create: host-only context (the native small-batch host walk)
 HRX_DEFAULT_HOST_THRESHOLD = 32768   # rows (B x M) below which host-buffer batches are walked on the host
 
-#: every symbol include/hrx.h declares (tests check the library exports exactly these)
-ABI_SYMBOLS = [
-    "hrx_defs_create", "hrx_defs_destroy", "hrx_defs_push_allstr_text", "hrx_defs_push_allstr_file",
-    "hrx_defs_push_substr_text", "hrx_defs_push_substr_file", "hrx_defs_push_allstr", "hrx_defs_push_substr",
-    "hrx_defs_finalize", "hrx_defs_num_defs", "hrx_defs_num_substrs", "hrx_defs_first_state",
-    "hrx_defs_accepted_state", "hrx_defs_largest_state", "hrx_defs_num_transitions", "hrx_defs_substr_id_offset",
-    "hrx_defs_table_bytes", "hrx_table_transition_rows", "hrx_table_endpoint_rows", "hrx_device_count", "hrx_alloc_outputs_position_major", "hrx_alloc_output_pair", "hrx_alloc_last_report", "hrx_traffic_pass_device", "hrx_traffic_pass_device_layout", "hrx_chars_to_position_major_device", "hrx_device_free",
-    "hrx_ctx_create", "hrx_ctx_clone", "hrx_ctx_destroy", "hrx_ctx_device", "hrx_ctx_set_host_threshold", "hrx_ctx_host_threshold", "hrx_ctx_set_placement", "hrx_last_error", "hrx_witness_batch_device", "hrx_witness_batch_device_pitched",
-    "hrx_recommended_pitches", "hrx_witness_batch_device_layout", "hrx_position_major_sizes", "hrx_rows_of_string_position_major", "hrx_describe_launch",
-    "hrx_fr_num_columns", "hrx_fr_columns_device", "hrx_fr_from_u64",
-    "hrx_multi_create", "hrx_multi_destroy", "hrx_multi_num_shards", "hrx_multi_shard_device", "hrx_multi_shard_stream", "hrx_multi_witness_batch_host",
-    "hrx_multi_witness_batch_device", "hrx_multi_synchronize",
-    "hrx_witness_batch_host",
-    "hrx_shard_range", "hrx_derive_states", "hrx_derive_substr_ids", "hrx_derive_is_start_end", "hrx_match_substrs",
-    "hrx_regex_to_allstr_text", "hrx_regex_to_dfa_json", "hrx_gen_regex_files", "hrx_regex_files_num_substrs",
-    "hrx_regex_files_allstr", "hrx_regex_files_substr", "hrx_regex_files_destroy", "hrx_format_regex_str", "hrx_regex_find",
-]
 
 _u64p = C.POINTER(C.c_uint64)
 _u32p = C.POINTER(C.c_uint32)
@@ -107,8 +90,20 @@ def _load():
         "hrx_recommended_pitches": (None, [sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "hrx_witness_batch_device_layout": (i, [vp, i, vp, sz, vp, sz, sz, vp, vp, vp, vp]),
         "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "hrx_witness_batch_device_planes": (i, [vp, i, vp, sz, vp, sz, sz, C.POINTER(vp), sz, vp, vp, vp]),
+        "hrx_position_major_plane_sizes": (None, [sz, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "hrx_alloc_output_planes": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
+        "hrx_rows_of_string_planes": (i, [C.POINTER(vp), vp, sz, sz, sz, sz, vp, vp]),
+        "hrx_probe_write_pair": (i, [vp, vp, vp, sz, C.POINTER(C.c_double)]),
+        "hrx_traffic_pass_device_planes": (i, [vp, vp, sz, sz, sz, C.POINTER(vp), sz, vp, vp]),
+        "hrx_witness_of_string": (i, [vp, sz, sz, sz, vp, vp, vp, vp]),
+        "hrx_witness_num_columns": (sz, [sz]),
+        "hrx_witness_columns_host": (i, [i, vp, sz, vp, vp, sz, vp, sz, sz, sz, sz, sz, sz, vp]),
+        "hrx_ctx_set_option": (i, [vp, i, C.c_long]),
+        "hrx_ctx_get_option": (C.c_long, [vp, i]),
         "hrx_rows_of_string_position_major": (i, [vp, vp, sz, sz, sz, sz, vp, vp]),
         "hrx_describe_launch": (i, [vp, i, sz, sz, i, C.c_char_p, sz]),
+        "hrx_ctx_describe_launch": (i, [vp, i, sz, sz, C.c_char_p, sz]),
         "hrx_alloc_outputs_position_major": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
         "hrx_alloc_output_pair": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
         "hrx_device_free": (i, [vp]),
@@ -143,6 +138,7 @@ def _load():
         "hrx_format_regex_str": (i, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]),
         "hrx_regex_find": (i, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(i), C.POINTER(sz), C.POINTER(sz)]),
     }
+    _load.symbols = list(sig)
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
         f.restype = res
@@ -154,6 +150,8 @@ def _load():
 
 
 lib = _load()
+#: every symbol include/hrx.h declares = every symbol bound above (tests check that the header, this list and the library's exports agree)
+ABI_SYMBOLS = list(_load.symbols)
 
 
 class DeviceBuffer:
@@ -427,9 +425,11 @@ def recommended_pitches(M):
 
 
 LAYOUT_STRING_MAJOR, LAYOUT_POSITION_MAJOR, LAYOUT_INPUT_POSITION_MAJOR = 0, 1, 2
+LAYOUT_RECORD_PLANES = 4      # describe_launch only: the launch witness_batch_planes makes
 
 
 PLACE_OFF, PLACE_WALK = 0, 1     # hrx_ctx_set_placement modes
+OPT_PMD_COMBINER_WAVE = 1        # hrx_ctx_set_option: 0 default, 1 on, 2 off
 PLACE_CAPPED_STEPS, PLACE_CAPPED_BYTES, PLACE_CAPPED_TIME, PLACE_CAPPED_ALLOC = 1, 2, 4, 8      # hrx_place_report.capped
 PLACED_FROM = 128 << 20    # alloc_outputs*: records of this many bytes or more come from the library's placement-aware allocator (kPlaceFromBytes)
 PM_BLOCK = 65536          # kPmBlock of csrc/hrx_lane.h: position-major buffers are blocked by this many strings
@@ -487,6 +487,58 @@ def rows_of_string_position_major(records_pm, masked_pm, B, M, D, b, out=None):
     return rec, msk
 
 
+def planes_to_string_major(planes, masked_pm, B, M):
+    """Inverse of the record-planes layout (include/hrx.h hrx_witness_batch_device_planes): D planes, each per block of PM_BLOCK strings [ceil(M/4)][nb][4], and the
+    position-major masked rows -> (B, M, D) and (B, M); torch tensors or numpy arrays."""
+    D = len(planes)
+    recs = [position_major_to_string_major(p, masked_pm, B, M, 1)[0] for p in planes]
+    msk = position_major_to_string_major(planes[0], masked_pm, B, M, 1)[1]
+    if hasattr(recs[0], "permute"):
+        return torch.cat(recs, dim=2) if D > 1 else recs[0], msk
+    return (np.concatenate(recs, axis=2) if D > 1 else recs[0]), msk
+
+
+def rows_of_string_planes(planes, masked_pm, B, M, b, out=None):
+    """hrx_rows_of_string_planes: one circuit's rows out of record planes in HOST memory (numpy arrays, each plane copied from the device as it is)."""
+    D = len(planes)
+    rec = np.empty((M, D), np.uint32) if out is None else out[0]
+    msk = np.empty(M, np.uint16) if out is None else out[1]
+    ps = [np.ascontiguousarray(p).view(np.uint32) for p in planes]
+    arr = (C.c_void_p * D)(*[p.ctypes.data for p in ps])
+    mp = np.ascontiguousarray(masked_pm).view(np.uint16)
+    _check(lib.hrx_rows_of_string_planes(arr, mp.ctypes.data, B, M, D, b, rec.ctypes.data, msk.ctypes.data))
+    return rec, msk
+
+
+def witness_of_string(records, n):
+    """hrx_witness_of_string: (states (D, n+1) uint64, substr_ids (D, n) uint64, is_starts (D, n+1) bool, is_ends (D, n+1) bool) — what lib.rs:316-318 derive —
+    out of one string's compact records, a (M, D) uint32 array."""
+    rec = np.ascontiguousarray(records).view(np.uint32)
+    M, D = rec.shape
+    states, sids = np.zeros((D, n + 1), np.uint64), np.zeros((D, n), np.uint64)      # (usize == u64 on every target of this library)
+    st, en = np.zeros((D, n + 1), np.uint8), np.zeros((D, n + 1), np.uint8)
+    _check(lib.hrx_witness_of_string(rec.ctypes.data, D, n, M, states.ctypes.data, sids.ctypes.data, st.ctypes.data, en.ctypes.data))
+    return states, sids, st.astype(bool), en.astype(bool)
+
+
+def witness_columns_host(chars, lens, records, masked, M, D, b_begin=0, b_count=None, position_major=False, chars_pm_stride=None, B=None):
+    """hrx_witness_columns_host: (4 + 4 D, b_count, M) uint64 — the integer content of every advice column of circuits [b_begin, b_begin + b_count) out of a finished batch
+    in host memory (numpy): string-major records (B, M, D) / masked (B, M) / chars (B, stride), or the flat position-major buffers with position_major=True."""
+    lens = np.ascontiguousarray(lens, np.uint32)
+    B = len(lens) if B is None else B
+    b_count = B - b_begin if b_count is None else b_count
+    cols = np.empty((4 + 4 * D, b_count, M), np.uint64)
+    rec, msk, ch = np.ascontiguousarray(records).view(np.uint32), np.ascontiguousarray(masked).view(np.uint16), np.ascontiguousarray(chars)
+    if position_major:
+        layout = LAYOUT_POSITION_MAJOR | (LAYOUT_INPUT_POSITION_MAJOR if chars_pm_stride else 0)
+        stride = int(chars_pm_stride) if chars_pm_stride else ch.shape[1]
+        rp = mp = 0
+    else:
+        layout, stride, rp, mp = LAYOUT_STRING_MAJOR, ch.shape[1], rec.strides[0] // (4 * D), msk.strides[0] // 2
+    _check(lib.hrx_witness_columns_host(layout, ch.ctypes.data, stride, lens.ctypes.data, rec.ctypes.data, rp, msk.ctypes.data, mp, B, M, D, b_begin, b_count, cols.ctypes.data))
+    return cols
+
+
 def shard_range(B, world, rank):
     b, c = C.c_size_t(0), C.c_size_t(0)
     lib.hrx_shard_range(B, world, rank, C.byref(b), C.byref(c))
@@ -528,9 +580,9 @@ class RegexVerifyConfig:
     def clone(self, device=HRX_DEVICE_SAME):
         """hrx_ctx_clone: RegexVerifyConfig derives Clone (lib.rs:96) — the same config with a context (stream, scratch, lock) of its own, e.g. one per prover thread."""
         import copy
-        c = copy.copy(self)
         ctx = C.c_void_p()
-        _check(lib.hrx_ctx_clone(self._need_ctx(), int(device), C.byref(ctx)))
+        _check(lib.hrx_ctx_clone(self._need_ctx(), int(device), C.byref(ctx)))   # first: a failed clone must leave nothing behind that owns the source's context
+        c = copy.copy(self)
         c._ctx = ctx
         c.device = self.device if device == HRX_DEVICE_SAME else device
         return c
@@ -580,7 +632,10 @@ class RegexVerifyConfig:
         """Kernel name and launch geometry the planner picks for B strings in `layout` (include/hrx.h: 0 string-major, 1 position-major
         outputs, 3 position-major input and outputs); host-only; MI355X has 256 CUs."""
         buf = C.create_string_buffer(4096)
-        _check(lib.hrx_describe_launch(self._defs.h, layout, B, self.max_chars_size, num_cus, buf, 4096))
+        if self._ctx and num_cus == 256:    # the context's own view: its device's CUs, the flags it was created with, its set_option choices
+            _check(lib.hrx_ctx_describe_launch(self._ctx, layout, B, self.max_chars_size, buf, 4096))
+        else:
+            _check(lib.hrx_describe_launch(self._defs.h, layout, B, self.max_chars_size, num_cus, buf, 4096))
         return buf.value.decode()
 
     # -- the three derive_* of lib.rs:804-888 -----------------------------------------------------
@@ -678,6 +733,65 @@ class RegexVerifyConfig:
         rec = torch.as_tensor(_LibraryOwned(pr.value, nr.value * 4), device=d).view(torch.int32)
         msk = torch.as_tensor(_LibraryOwned(pmk.value, nm.value * 2), device=d).view(torch.int16)
         return rec, msk, st
+
+    def alloc_output_planes(self, B, device=None):
+        """hrx_alloc_output_planes: ([plane_0 .. plane_{D-1}] int32, masked int16, status int64) — every def's records in a buffer of its own, each placed in a neighbourhood
+        of the device memory of its own (include/hrx.h: the launch's D + 1 write streams spread over the classes of the physical address space)."""
+        dev = torch.device("cuda", self.device) if device is None else device
+        D = self.num_defs
+        npl, nm = C.c_size_t(0), C.c_size_t(0)
+        lib.hrx_position_major_plane_sizes(B, self.max_chars_size, C.byref(npl), C.byref(nm))
+        st = torch.empty((B,), dtype=torch.int64, device=dev)
+        if npl.value * 4 < PLACED_FROM or dev.index not in (None, self.device) or torch.cuda.is_current_stream_capturing():
+            return [torch.empty((npl.value,), dtype=torch.int32, device=dev) for _ in range(D)], torch.empty((nm.value,), dtype=torch.int16, device=dev), st
+        arr, pmk = (C.c_void_p * D)(), C.c_void_p()
+        _check(lib.hrx_alloc_output_planes(self._ctx, B, self.max_chars_size, arr, C.byref(pmk)))
+        d = torch.device("cuda", self.device)
+        planes = [torch.as_tensor(_LibraryOwned(arr[k], npl.value * 4), device=d).view(torch.int32) for k in range(D)]
+        msk = torch.as_tensor(_LibraryOwned(pmk.value, nm.value * 2), device=d).view(torch.int16)
+        return planes, msk, st
+
+    def witness_batch_planes(self, chars, lens, out=None, stream=None, chars_pm_stride=None):
+        """hrx_witness_batch_device_planes: like witness_batch_position_major with the record planes in D buffers (out = (planes, masked, status) as alloc_output_planes gives them)."""
+        assert chars.is_cuda and lens.is_cuda and chars.dtype == torch.uint8 and lens.dtype == torch.int32
+        layout = LAYOUT_POSITION_MAJOR
+        if chars_pm_stride is None:
+            assert chars.stride(1) == 1 and lens.is_contiguous()
+            B, stride = chars.shape[0], chars.stride(0)
+        else:
+            assert chars.is_contiguous() and chars.numel() == lens.numel() * chars_pm_stride
+            B, stride = lens.numel(), int(chars_pm_stride)
+            layout |= LAYOUT_INPUT_POSITION_MAJOR
+        if out is None:
+            out = self.alloc_output_planes(B, chars.device)
+        planes, msk, st = out
+        arr = (C.c_void_p * len(planes))(*[p.data_ptr() for p in planes])
+        s = torch.cuda.current_stream(chars.device) if stream is None else stream
+        _check(lib.hrx_witness_batch_device_planes(self._need_device(chars, lens, msk, st, *planes), layout, chars.data_ptr(), stride, lens.data_ptr(), B, self.max_chars_size,
+                                                   arr, len(planes), msk.data_ptr(), st.data_ptr(), s.cuda_stream))
+        return planes, msk, st
+
+    def traffic_pass_planes(self, chars_pm, B, out, chars_pm_stride, stream=None):
+        """hrx_traffic_pass_device_planes: the memory traffic of one record-planes launch over these buffers, no DFA work; OVERWRITES out."""
+        planes, msk, _ = out
+        arr = (C.c_void_p * len(planes))(*[p.data_ptr() for p in planes])
+        s = torch.cuda.current_stream(chars_pm.device) if stream is None else stream
+        _check(lib.hrx_traffic_pass_device_planes(self._need_device(chars_pm, msk, *planes), chars_pm.data_ptr(), int(chars_pm_stride), int(B), self.max_chars_size,
+                                                  arr, len(planes), msk.data_ptr(), s.cuda_stream))
+
+    def probe_write_pair(self, a, b, nbytes=None):
+        """hrx_probe_write_pair: GB/s of two equal write streams over device tensors a and b (OVERWRITTEN): do they lie in colliding neighbourhoods of the device memory?"""
+        nbytes = min(a.numel() * a.element_size(), b.numel() * b.element_size()) if nbytes is None else nbytes
+        g = C.c_double(0.0)
+        _check(lib.hrx_probe_write_pair(self._need_device(a, b), a.data_ptr(), b.data_ptr(), int(nbytes), C.byref(g)))
+        return g.value
+
+    def set_option(self, option, value):
+        """hrx_ctx_set_option (include/hrx.h HRX_OPT_*)."""
+        _check(lib.hrx_ctx_set_option(self._need_ctx(), int(option), int(value)))
+
+    def get_option(self, option):
+        return lib.hrx_ctx_get_option(self._need_ctx(), int(option))
 
     def last_placement_report(self):
         """hrx_alloc_last_report: what the last placement-aware allocation of this config's context did (a dict)."""

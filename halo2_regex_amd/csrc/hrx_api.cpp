@@ -24,6 +24,7 @@
 #include "hrx_fr.h"
 #include "hrx_host_walk.hpp"
 #include "hrx_kernel.hpp"
+#include "hrx_error.hpp"
 #include "hrx_arena_alloc.hpp"
 #include "hrx_place_rule.hpp"
 #include "hrx_lane.h"
@@ -36,6 +37,7 @@ static int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+int hrx::set_last_error(int code, const std::string &msg) { return fail(code, msg); }   // hrx_error.hpp: the other translation units of the C ABI
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -94,6 +96,7 @@ struct hrx_ctx {
     int device = 0;          // HRX_DEVICE_NONE: no device, host walk only
     int num_cus = 0;
     uint32_t debug = 0;      // HRX_DEBUG_FLAGS, read once at creation (hrx_kernel.hpp)
+    uint32_t tune = 0;       // hrx_ctx_set_option: kTune* bits (hrx_kernel.hpp)
     size_t host_threshold = HRX_DEFAULT_HOST_THRESHOLD;   // rows (B x M) below which host-buffer batches take the host walk
     hipStream_t stream = nullptr;
     // host-buffer batches of three chunks and more: pipelined (two streams) or one stream, whichever the last comparison on this box found faster (batch_host_locked)
@@ -332,6 +335,7 @@ int hrx_ctx_clone(const hrx_ctx *ctx, int device, hrx_ctx **out) {
     const int rc = ctx_create_from(ctx->s, device == HRX_DEVICE_SAME ? ctx->device : device, &c);
     if (rc != HRX_OK) return rc;
     c->host_threshold = ctx->host_threshold;      // the per-context switches travel with the clone
+    c->tune = ctx->tune;
     c->place_enabled = ctx->place_enabled; c->place_max_bytes = ctx->place_max_bytes; c->place_max_ms = ctx->place_max_ms;
     *out = c;
     return HRX_OK;
@@ -466,7 +470,8 @@ void hrx_ctx_destroy(hrx_ctx *c) {
 
 static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                         uint32_t *records, uint16_t *masked, uint64_t *status, hipStream_t st, size_t rec_pitch = 0,
-                        size_t msk_pitch = 0, int layout = 0) {
+                        size_t msk_pitch = 0, int layout = 0, uint32_t *const *planes = nullptr) {
+    // planes: the D record planes in buffers of their own (hrx_witness_batch_device_planes; position-major outputs, a config that runs as ONE launch); records = planes[0] then
     if (!rec_pitch) rec_pitch = M;
     if (!msk_pitch) msk_pitch = M;
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
@@ -511,9 +516,14 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         a.byte_one_id = (set.defs.size() == 1 && set.defs[0].substrs.size() == 1 && set.consts[0].substr_id_offset >= 1 && set.consts[0].substr_id_offset <= 63) ? set.consts[0].substr_id_offset : 0u;
         a.D = (uint32_t)set.defs.size();
         a.debug = ctx->debug;
+        a.tune = ctx->tune;
 #ifdef HRX_ABLATION
         a.debug = debug_flags_from_env();   // tools/ab_flags.py switches ablations between launches of one process
 #endif
+        if (planes) {   // (the chunked launch's repair reads finished records through the interleaved layout: such batches take the sequential kernels)
+            for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.rec_planes[d] = (unsigned char *)planes[d];
+            a.debug |= kDbgNoSpec;
+        }
         // a summary-writing pass is the loader / walker / finisher kernel: no pair-step or def-parallel variant, no HALF table
         if (pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;
         for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = set.consts[d];
@@ -670,6 +680,8 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         }
         return HRX_OK;
     };
+    if (planes && !ctx->s.groups.empty() && !(ctx->d_cw.p && !ctx->mp_combine))
+        return fail(HRX_ERR_ARG, "record planes: configs that run as one launch (up to three defs, or four to eight defs of at most 32 byte classes each)");
     if (ctx->s.groups.empty()) {
         // string-major outputs of a DFA whose 4-byte table does not fit LDS (cfg 5): the string-major kernels would walk it out of global
         // memory (0.21 of peak); the BYTE / HALF table kernels are position-major — run them into context scratch and turn the rows around
@@ -746,6 +758,8 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
         a.debug = ctx->debug;
         a.cw_image = (const uint8_t *)ctx->d_cw.p; a.cw_lut_off = ctx->s.cw_lut_off; a.table_bytes = (uint32_t)ctx->s.cw_image.size();
         for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.dc[d] = ctx->s.cw_consts[d];
+        if (planes)
+            for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.rec_planes[d] = (unsigned char *)planes[d];
         LaunchInfo li{};
         if (plan_pmd_cw(a, ctx->num_cus, li)) {
             a.nt_mix = plan_nt_mix(a, li);
@@ -757,6 +771,7 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
             return HRX_OK;
         }
     }
+    if (planes) return fail(HRX_ERR_BOUNDS, "record planes: the one-launch def-parallel path does not fit this config");
     // ---- more than eight defs, every def of at most 32 byte classes: passes over CW GROUPS of 4 .. 8 defs (DefsSet::cw_groups), each ONE def-parallel launch that writes its defs' planes of the
     // caller's records and a tile summary; the combine launch forms what needs all defs of a row.  D = 16: two passes instead of six, D = 32: four instead of eleven.
     if ((layout & HRX_LAYOUT_POSITION_MAJOR) && !ctx->cw_groups.empty() && !(ctx->debug & kDbgNoDefParallel)) {
@@ -896,7 +911,41 @@ int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *cha
     return launch_batch(ctx, chars, stride, lens, B, M, records, masked, status, (hipStream_t)stream, 0, 0, layout);
 }
 
-static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int num_cus, std::string &out, bool summary_pass = false) {
+int hrx_witness_batch_device_planes(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                                    uint32_t *const *record_planes, size_t n_planes, uint16_t *masked, uint64_t *status, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (!(layout & HRX_LAYOUT_POSITION_MAJOR)) return fail(HRX_ERR_ARG, "record planes are a position-major layout");
+    if (!record_planes || n_planes != ctx->s.defs.size()) return fail(HRX_ERR_ARG, "record planes: one buffer per RegexDefs of the config");
+    for (size_t d = 0; d < n_planes; ++d)
+        if (!record_planes[d] || ((uintptr_t)record_planes[d] & 15)) return fail(HRX_ERR_ARG, "record planes must be 16-byte aligned device buffers");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    if (ctx->device != HRX_DEVICE_NONE) HIP_TRY(guard.set(ctx->device));
+    // one def: its plane IS the position-major records buffer
+    return launch_batch(ctx, chars, stride, lens, B, M, record_planes[0], masked, status, (hipStream_t)stream, 0, 0, layout, n_planes > 1 ? record_planes : nullptr);
+}
+
+int hrx_ctx_set_option(hrx_ctx *ctx, int option, long value) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    switch (option) {
+        case HRX_OPT_PMD_COMBINER_WAVE:
+            if (value < 0 || value > 2) return fail(HRX_ERR_ARG, "HRX_OPT_PMD_COMBINER_WAVE: 0 (default), 1 (on) or 2 (off)");
+            ctx->tune = (ctx->tune & ~kTunePmdFinMask) | (uint32_t)value;
+            return HRX_OK;
+        default: return fail(HRX_ERR_ARG, "hrx_ctx_set_option: unknown option");
+    }
+}
+
+long hrx_ctx_get_option(const hrx_ctx *ctx, int option) {
+    if (!ctx) return -1;
+    switch (option) {
+        case HRX_OPT_PMD_COMBINER_WAVE: return (long)(ctx->tune & kTunePmdFinMask);
+        default: return -1;
+    }
+}
+
+static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int num_cus, std::string &out, bool summary_pass, const uint32_t dbg, const uint32_t tune) {
     WitnessArgs a{};
     a.layout = (uint32_t)layout; a.B = (uint32_t)B; a.M = (uint32_t)M;
     // the planner only looks at which images exist and how large they are
@@ -908,7 +957,14 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     a.pair_blk_bytes = s.pair.blk_bytes; a.pair_lut_off = s.pair.lut_off;
     a.byte_image = s.byte.image.empty() ? nullptr : s.byte.image.data(); a.byte_bytes = s.byte.bytes; a.byte_dead = s.byte.dead; a.byte16_bytes = s.byte.bytes16;
     a.D = (uint32_t)s.defs.size();
-    a.debug = debug_flags_from_env();   // what a context created now would run with (kernel-selection bits only in a release build)
+    a.debug = dbg;   // hrx_describe_launch: what a context created now would run with (kernel-selection bits only in a release build); hrx_ctx_describe_launch: the context's
+    a.tune = tune;
+    if (layout & HRX_LAYOUT_RECORD_PLANES) {     // the launch hrx_witness_batch_device_planes makes (launch_batch)
+        a.layout &= ~(uint32_t)HRX_LAYOUT_RECORD_PLANES;
+        layout &= ~HRX_LAYOUT_RECORD_PLANES;
+        a.rec_planes[0] = reinterpret_cast<unsigned char *>(16);
+        a.debug |= kDbgNoSpec;
+    }
     if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a pass of a multi-pass config is the loader / walker / finisher kernel)
     LaunchInfo li;
     if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
@@ -920,7 +976,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     const char *tf[2] = {"false", "true"};
     // the names rocprofv3 lists: every template argument spelled out, defaulted ones too (an exact-match join with a kernel_stats.csv works)
     if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
-    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u, %s>", a.D, a.cw_image ? ((a.layout & 1u) ? "true, true, false" : "true, true, true") : "false, false, false");
+    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u, %s>", a.D, a.cw_image ? ((a.layout & 1u) ? "true, true, false" : "true, true, true") : li.pmd_fin ? "false, true, false" : "false, false, false");
     else if (li.split == 2) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, %s, %s, %s, %s, %s>", a.D, tf[li.gtab], tf[li.wide], tf[li.half], tf[!(layout & 1)], tf[li.byte]);
     else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u, %s>", a.D, li.byte ? 32u : 32u / a.D, tf[li.byte]);
     else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
@@ -933,25 +989,20 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
     return HRX_OK;
 }
 
-int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap) {
-    if (!defs || !out || !cap) return fail(HRX_ERR_ARG, "NULL argument");
-    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
-    if (num_cus < 1) return fail(HRX_ERR_ARG, "num_cus must be >= 1");
-    const DefsSet &s = defs->s;
+static int describe_config(const DefsSet &s, const uint32_t dbg, const uint32_t tune, const bool mpc_on, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap) {
     std::string text;
     if (s.groups.empty()) {
-        const bool byte_split = !s.byte.image.empty() && !(debug_flags_from_env() & (kDbgNoByte | kDbgForceHalf));
+        const bool byte_split = !s.byte.image.empty() && !(dbg & (kDbgNoByte | kDbgForceHalf));
         const bool via_tp = layout == HRX_LAYOUT_STRING_MAJOR && M % 8 == 0 && !byte_split &&
                             (!s.byte.image.empty() || !s.half_image.empty()) && s.table_image.size() * 4 + wave_stage_bytes((int)s.defs.size(), 16) > kLdsLimit;
-        const int rc = describe_set(s, via_tp ? HRX_LAYOUT_POSITION_MAJOR : layout, B, M, num_cus, text);
+        const int rc = describe_set(s, via_tp ? HRX_LAYOUT_POSITION_MAJOR : layout, B, M, num_cus, text, false, dbg, tune);
         if (rc != HRX_OK) return rc;
         if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
     } else if ([&] {   // four and five defs, string-major rows in multiples of 16: the def-parallel launch writes them itself
-                   const char *mpc = std::getenv("HRX_MP_COMBINE");
-                   if (s.cw_image.empty() || (mpc && std::atoi(mpc) != 0) || layout != HRX_LAYOUT_STRING_MAJOR) return false;
+                   if (s.cw_image.empty() || mpc_on || layout != HRX_LAYOUT_STRING_MAJOR) return false;
                    WitnessArgs a{};
                    a.layout = HRX_LAYOUT_STRING_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)s.defs.size();
-                   a.debug = debug_flags_from_env();
+                   a.debug = dbg;
                    a.cw_image = s.cw_image.data(); a.table_bytes = (uint32_t)s.cw_image.size();
                    LaunchInfo li{};
                    if (!plan_pmd_cw_sm(a, num_cus, li)) return false;
@@ -961,12 +1012,11 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
                    return true;
                }()) {
     } else if ([&] {   // 6 or 7 defs with CLASS-WIDE tables: one def-parallel launch over the whole config (position-major; string-major rows in multiples of 8 through the transposer)
-                   const char *mpc = std::getenv("HRX_MP_COMBINE");
                    const bool tp = !(layout & 1) && M % 8 == 0;
-                   if (s.cw_image.empty() || (mpc && std::atoi(mpc) != 0) || !((layout & 1) || tp)) return false;
+                   if (s.cw_image.empty() || mpc_on || !((layout & 1) || tp)) return false;
                    WitnessArgs a{};
                    a.layout = HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR); a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)s.defs.size();
-                   a.debug = debug_flags_from_env();
+                   a.debug = dbg;
                    a.cw_image = s.cw_image.data(); a.table_bytes = (uint32_t)s.cw_image.size();
                    LaunchInfo li{};
                    if (!plan_pmd_cw(a, num_cus, li)) return false;
@@ -978,7 +1028,7 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
                }()) {
     } else if ([&] {   // more than eight defs with CW groups: one def-parallel launch per group of 4 .. 8 defs, then the combine launch
                    const bool tp = !(layout & 1) && M % 8 == 0;
-                   if (s.cw_groups.empty() || !((layout & 1) || tp) || (debug_flags_from_env() & kDbgNoDefParallel)) return false;
+                   if (s.cw_groups.empty() || !((layout & 1) || tp) || (dbg & kDbgNoDefParallel)) return false;
                    std::string t2 = "multi-pass, " + std::to_string(s.cw_groups.size()) + " groups: ";
                    for (size_t g = 0; g < s.cw_groups.size(); ++g) {
                        WitnessArgs a{};
@@ -1000,19 +1050,31 @@ int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, in
         for (size_t g = 0; g < s.groups.size(); ++g) {
             std::string one;
             const bool tp = !(layout & 1) && M % 8 == 0;
-            const int rc = describe_set(s.groups[g], HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR), B, M, num_cus, one, (layout & 1) != 0 || tp);
+            const int rc = describe_set(s.groups[g], HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR), B, M, num_cus, one, (layout & 1) != 0 || tp, dbg, tune);
             if (rc != HRX_OK) return rc;
             text += "[defs " + std::to_string(s.group_first[g]) + ".." + std::to_string(s.group_first[g] + s.groups[g].defs.size() - 1) + ": " + one + "] ";
         }
         const bool via_tp = !(layout & 1) && M % 8 == 0;
-        const char *mpc = std::getenv("HRX_MP_COMBINE");
-        const bool merge_last = ((layout & 1) || via_tp) && s.groups.size() - 1 <= kMaxMergeGroups && !(mpc && std::atoi(mpc) != 0);
+        const bool merge_last = ((layout & 1) || via_tp) && s.groups.size() - 1 <= kMaxMergeGroups && !mpc_on;
         text += merge_last ? "(the last pass merges the summaries) + hrx::witness_merge_status_kernel"
                            : (layout & 1) || via_tp ? "+ hrx::witness_combine_summary_kernel" : "+ hrx::witness_combine_kernel<true>";
         if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
     }
     std::snprintf(out, cap, "%s", text.c_str());
     return HRX_OK;
+}
+
+int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap) {
+    if (!defs || !out || !cap) return fail(HRX_ERR_ARG, "NULL argument");
+    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
+    if (num_cus < 1) return fail(HRX_ERR_ARG, "num_cus must be >= 1");
+    const char *mpc = std::getenv("HRX_MP_COMBINE");      // (what hrx_ctx_create would read now)
+    return describe_config(defs->s, debug_flags_from_env(), 0u, mpc && std::atoi(mpc) != 0, layout, B, M, num_cus, out, cap);
+}
+
+int hrx_ctx_describe_launch(const hrx_ctx *ctx, int layout, size_t B, size_t M, char *out, size_t cap) {
+    if (!ctx || !out || !cap) return fail(HRX_ERR_ARG, "NULL argument");
+    return describe_config(ctx->s, ctx->debug, ctx->tune, ctx->mp_combine, layout, B, M, ctx->num_cus > 0 ? ctx->num_cus : 256, out, cap);
 }
 
 size_t hrx_fr_num_columns(size_t D) { return 4 + 4 * D; }
@@ -1390,6 +1452,178 @@ int hrx_traffic_pass_device_layout(hrx_ctx *ctx, int layout, const uint8_t *char
     li.split = 1;
     const uint32_t nt_mix = plan_nt_mix(a, li);
     HIP_TRY(launch_traffic_pass_sm(chars, stride, B, M, (uint32_t)D, records, rec_pitch, masked, msk_pitch, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream));
+    return HRX_OK;
+}
+
+int hrx_traffic_pass_device_planes(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *const *record_planes, size_t n_planes,
+                                   uint16_t *masked, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
+    if (B == 0) return HRX_OK;
+    if (!chars || !record_planes || !masked || n_planes != ctx->s.defs.size() || n_planes > kMaxDefsPerLaunch) return fail(HRX_ERR_ARG, "NULL buffer, or not one plane per def (at most eight)");
+    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)masked & 15)) return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
+    for (size_t d = 0; d < n_planes; ++d)
+        if (!record_planes[d] || ((uintptr_t)record_planes[d] & 15)) return fail(HRX_ERR_ARG, "record planes must be 16-byte aligned device buffers");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    WitnessArgs a{};
+    a.layout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)n_planes;
+    LaunchInfo li{};
+    li.split = 2;
+    const uint32_t nt_mix = plan_nt_mix(a, li);
+    HIP_TRY(launch_traffic_pass(chars, stride, B, M, a.D, record_planes[0], masked, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream, record_planes));
+    return HRX_OK;
+}
+
+void hrx_position_major_plane_sizes(size_t B, size_t M, size_t *plane_u32, size_t *masked_u16) {
+    if (plane_u32) *plane_u32 = (M + 3) / 4 * B * 4;
+    if (masked_u16) *masked_u16 = (M + 7) / 8 * B * 8;
+}
+
+int hrx_rows_of_string_planes(const uint32_t *const *record_planes, const uint16_t *masked_pm, size_t B, size_t M, size_t D, size_t b, uint32_t *records, uint16_t *masked) {
+    if (!record_planes && !masked_pm) return fail(HRX_ERR_ARG, "NULL buffer");
+    if ((record_planes && !records) || (masked_pm && !masked)) return fail(HRX_ERR_ARG, "NULL output");
+    if (b >= B || M == 0 || D == 0 || D > HRX_MAX_DEFS) return fail(HRX_ERR_ARG, "string index or shape out of range");
+    const size_t k = b / HRX_PM_BLOCK, bl = b % HRX_PM_BLOCK, nb = std::min<size_t>(HRX_PM_BLOCK, B - k * HRX_PM_BLOCK);
+    const size_t q4 = (M + 3) / 4;
+    if (record_planes) {
+        for (size_t d = 0; d < D; ++d) {
+            if (!record_planes[d]) return fail(HRX_ERR_ARG, "NULL plane");
+            const uint32_t *base = record_planes[d] + k * HRX_PM_BLOCK * q4 * 4 + bl * 4;       // quad q of this def: base + q * nb * 4
+            for (size_t q = 0; q < q4; ++q) {
+                const size_t rows = std::min<size_t>(4, M - 4 * q);
+                for (size_t i = 0; i < rows; ++i) records[(4 * q + i) * D + d] = base[q * nb * 4 + i];
+            }
+        }
+    }
+    if (masked_pm) return hrx_rows_of_string_position_major(nullptr, masked_pm, B, M, D, b, nullptr, masked);
+    return HRX_OK;
+}
+
+int hrx_probe_write_pair(hrx_ctx *ctx, void *a, void *b, size_t bytes, double *gbs) {
+    if (!ctx || !a || !b || !gbs || bytes < ((size_t)32 << 20)) return fail(HRX_ERR_ARG, "hrx_probe_write_pair: two device buffers of at least 32 MiB each");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to measure on");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    size_t wrote = 0;
+    const double us = hrx::placement_probe_us(a, bytes, b, bytes, 0u, ctx->stream, (unsigned long long *)(ctx->d_group_counter + 4), &wrote);
+    if (us <= 0) return fail(HRX_ERR_HIP, "hrx_probe_write_pair: the probe launch failed");
+    *gbs = (double)wrote / us * 1e-3;
+    return HRX_OK;
+}
+
+// Record planes + masked rows, each in a neighbourhood of its own: the launch's D + 1 write streams spread over the classes of the physical address space instead of 4 D of
+// its 4 D + 2 bytes per row going into one allocation.  A POOL of candidates — D + kPlanesSpare plane-sized buffers, kPlanesMasked masked-row-sized ones, allocated one after the other (they
+// walk down the device memory) — is measured pair by pair with the two-equal-streams probe (~1 ms per pair on the device clock), and the D planes + masked buffer whose SLOWEST pairing is
+// fastest are kept (ties: the larger sum); the rest is freed before the call returns.  No threshold: pairs in one class measure 5.2-5.7 TB/s, in different classes 6.2-7.0
+// (profiles/r06_probes/plane_probe.txt), and both levels move with the box.  Random draws of three 4-GiB planes + masked rows already run cfg 4's no-compute pass at 0.86 of peak in 54 of 60
+// cases, against 0.65 for three planes of one class and 0.74-0.77 for the interleaved buffer: the selection only has to avoid the draws that collide.
+constexpr size_t kPlanesSpare = 4, kPlanesMasked = 3;
+int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_planes, uint16_t **masked) {
+    if (!ctx || !record_planes || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes: bad argument");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
+    const size_t D = ctx->s.defs.size();
+    if (D == 1) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
+    size_t plane_u32 = 0, masked_u16 = 0;
+    hrx_position_major_plane_sizes(B, M, &plane_u32, &masked_u16);
+    const size_t plane_bytes = plane_u32 * 4, masked_bytes = masked_u16 * 2;
+    for (size_t d = 0; d < D; ++d) record_planes[d] = nullptr;
+    *masked = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    hrx_place_report rep{};
+    std::vector<void *> pc, mc;     // plane and masked-row candidates
+    auto free_all = [&]() { for (void *p : pc) (void)hipFree(p); for (void *p : mc) (void)hipFree(p); pc.clear(); mc.clear(); };
+    const bool walk = ctx->place_enabled && plane_bytes >= kPlaceFromBytes;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac), spent = 0;
+    if (ctx->place_max_bytes) budget = std::min(budget, ctx->place_max_bytes);
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    auto take = [&](std::vector<void *> &v, size_t bytes, size_t must, size_t want) -> bool {      // `must` buffers or failure; up to `want` while memory and time allow
+        while (v.size() < want) {
+            const bool extra = v.size() >= must;
+            if (extra && (spent + bytes > budget)) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
+            if (extra && ctx->place_max_ms > 0 && elapsed_ms() > ctx->place_max_ms) { rep.capped |= HRX_PLACE_CAPPED_TIME; break; }
+            void *p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                if (extra) { rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
+                return false;
+            }
+            v.push_back(p);
+            spent += bytes;
+        }
+        rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
+        return true;
+    };
+    if (!take(pc, plane_bytes, D, walk ? D + kPlanesSpare : D) || !take(mc, masked_bytes, 1, walk ? kPlanesMasked : 1)) {
+        free_all();
+        return fail(HRX_ERR_HIP, "hrx_alloc_output_planes: out of device memory");
+    }
+    std::vector<size_t> pick(D);
+    for (size_t d = 0; d < D; ++d) pick[d] = d;
+    size_t pick_m = 0;
+    if (walk && (pc.size() > D || mc.size() > 1)) {
+        rep.searched = 1;
+        unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);
+        const size_t P = pc.size(), Q = mc.size();
+        std::vector<double> pp(P * P, 0.0), pm(Q * P, 0.0);       // bytes per microsecond of every pairing
+        auto probe = [&](void *x, void *y, size_t bytes) {
+            size_t wrote = 0;
+            const double us = hrx::placement_probe_us(x, bytes, y, bytes, 0u, ctx->stream, clk, &wrote);
+            rep.probe_bytes = wrote;
+            ++rep.steps;
+            return us > 0 ? (double)wrote / us : 0.0;
+        };
+        double lo = 1e30, hi = 0.0;
+        for (size_t i = 0; i < P; ++i)
+            for (size_t j = i + 1; j < P; ++j) { pp[i * P + j] = pp[j * P + i] = probe(pc[i], pc[j], plane_bytes); lo = std::min(lo, pp[i * P + j]); hi = std::max(hi, pp[i * P + j]); }
+        for (size_t q = 0; q < Q; ++q)
+            for (size_t i = 0; i < P; ++i) { pm[q * P + i] = probe(mc[q], pc[i], std::min(masked_bytes, plane_bytes)); lo = std::min(lo, pm[q * P + i]); hi = std::max(hi, pm[q * P + i]); }
+        if (ctx->place_trace) {
+            for (size_t i = 0; i < P; ++i) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pp[i * P + j] * 1e-3)); place_trace(ctx, "hrx planes: plane candidate %zu %p vs planes (GB/s):%s\n", i, pc[i], l.c_str()); }
+            for (size_t q = 0; q < Q; ++q) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pm[q * P + j] * 1e-3)); place_trace(ctx, "hrx planes: masked candidate %zu %p vs planes (GB/s):%s\n", q, mc[q], l.c_str()); }
+        }
+        // every D-subset of the plane candidates (in allocation order) x every masked candidate: at most C(12, 8) x 3 score evaluations
+        std::vector<size_t> idx(D);
+        for (size_t d = 0; d < D; ++d) idx[d] = d;
+        double best_min = -1.0, best_sum = -1.0, first_min = 0.0;
+        bool first = true;
+        for (;;) {
+            for (size_t q = 0; q < Q; ++q) {
+                double mn = 1e30, sum = 0.0;
+                for (size_t x = 0; x < D; ++x) {
+                    for (size_t y = x + 1; y < D; ++y) { mn = std::min(mn, pp[idx[x] * P + idx[y]]); sum += pp[idx[x] * P + idx[y]]; }
+                    mn = std::min(mn, pm[q * P + idx[x]]); sum += pm[q * P + idx[x]];
+                }
+                if (first) { first_min = mn; first = false; }      // candidates 0 .. D - 1 + masked candidate 0: what plain allocations would have been
+                if (mn > best_min * 1.01 || (mn > best_min * 0.99 && sum > best_sum)) { best_min = mn; best_sum = sum; pick = idx; pick_m = q; }
+            }
+            size_t k = D;       // next combination
+            while (k > 0 && idx[k - 1] == P - D + k - 1) --k;
+            if (k == 0) break;
+            ++idx[k - 1];
+            for (size_t x = k; x < D; ++x) idx[x] = idx[x - 1] + 1;
+        }
+        rep.ref_gbs = lo * 1e-3;          // the slowest and ...
+        rep.first_gbs = first_min * 1e-3; // (the slowest pairing of the first D + 1 buffers: the plain-allocation draw)
+        rep.best_gbs = best_min * 1e-3;   // ... the kept set's slowest pairing; hi is in the trace
+        rep.accepted = best_min >= 1.08 * lo ? 1 : 0;   // the kept set is clear of the slowest pairing seen (if every pairing measures alike there was nothing to choose)
+        place_trace(ctx, "hrx planes: pairings %.2f .. %.2f TB/s; kept set's slowest %.2f TB/s (the first %zu + 1 buffers: %.2f)\n", lo * 1e-6, hi * 1e-6, best_min * 1e-6, D, first_min * 1e-6);
+    }
+    for (size_t d = 0; d < D; ++d) { record_planes[d] = (uint32_t *)pc[pick[d]]; pc[pick[d]] = nullptr; }
+    *masked = (uint16_t *)mc[pick_m];
+    mc[pick_m] = nullptr;
+    for (void *&p : pc) if (p) { (void)hipFree(p); p = nullptr; }
+    for (void *&p : mc) if (p) { (void)hipFree(p); p = nullptr; }
+    rep.search_ms = elapsed_ms();
+    ctx->last_place = rep;
     return HRX_OK;
 }
 

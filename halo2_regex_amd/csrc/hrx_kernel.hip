@@ -273,12 +273,18 @@ static bool plan_witness_launch_groups(WitnessArgs &a, int num_cus, LaunchInfo &
         a.B <= kPmBlock &&   // one block of the position-major buffers (hrx_lane.h): its strides are the whole batch's
         ((size_t)a.n_groups <= (size_t)num_cus * 2 || (a.debug & kDbgForceDefParallel))) {
         const int G = (size_t)a.n_groups <= (size_t)num_cus && !(a.debug & kDbgForceDefParallel) ? 1 : 2;
+        // a combiner wave of its own (FIN): the last def's walker otherwise carries walk + D - 1 merges + reveal mask + masked rows (2.36 of cfg 4's 2.9 ms with every record store
+        // compiled out).  kTunePmdFin* (hrx_ctx_set_option HRX_OPT_PMD_COMBINER_WAVE) forces it on / off; the default is what profiles/r06_probes/cfg4_fin_ab.txt measured.
+        // Same lease, same input, cfg 4 (tools/planes_ab.py): interleaved records 2.78 ms without / 3.04 with the combiner wave; record planes 2.69 without / 2.53 with — where the records'
+        // write stream is what bounds the launch, two more waves per CU only disturb it; where the planes spread it over the classes, the combiner's chain is the bound that is left.
+        const bool fin = (a.tune & kTunePmdFinMask) == kTunePmdFinOn || ((a.tune & kTunePmdFinMask) == 0u && a.rec_planes[0] != nullptr);
         for (int ns = 4; ns >= 2; --ns) {
-            const size_t lds = a.table_bytes + (size_t)G * pmd_group_bytes((int)a.D, ns);
+            const size_t lds = a.table_bytes + (size_t)G * (fin ? pmd_fin_group_bytes((int)a.D, ns) : pmd_group_bytes((int)a.D, ns));
             if (lds > kLdsLimit) continue;
             out.split = 5;
             out.wide = 1;
-            out.waves_per_wg = G * ((int)a.D + 1);
+            out.pmd_fin = fin ? 1 : 0;
+            out.waves_per_wg = G * ((int)a.D + 1 + (fin ? 1 : 0));
             out.nslots = ns;
             out.lds_bytes = lds;
             const size_t need = ((size_t)a.n_groups + G - 1) / G;

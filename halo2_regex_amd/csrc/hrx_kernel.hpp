@@ -40,6 +40,7 @@ struct WitnessArgs {
     uint32_t gs;                  // strings per wave (64, 32 or 16), set by plan_witness_launch
     uint32_t D;
     uint32_t debug;               // the context's kDbg* bits below (forced kernel / table choices for the tests; ablations only with -DHRX_ABLATION)
+    uint32_t tune;                // the context's kTune* bits (hrx_ctx_set_option, include/hrx.h): choices between variants that compute the same rows
     unsigned long long *stamps;   // profiling only (tools/kbench): per wave and tile 4 s_memtime stamps; NULL in the product
     // dynamic group assignment (position-major kernel, batches of >= 8 long groups per walker pair): after its first group a pair
     // takes the next unclaimed group from a device counter (hrx_kernel_pm.hip); 0 / NULL: groups g_first + j * stride
@@ -51,6 +52,11 @@ struct WitnessArgs {
     // kernel needs — per tile and string 80 bytes: ST / EN bitvectors + one substr-id byte per row, [tile][5][B][16 B]
     uint32_t rec_D, rec_d0;       // 0 / 0: this launch's defs are the whole config
     uint32_t *summary;            // NULL: an ordinary launch
+    // RECORD PLANES (include/hrx.h hrx_witness_batch_device_planes): def d's records in a buffer of its own — per block of kPmBlock strings [ceil(M/4)][nb][4], the
+    // D = 1 position-major layout — instead of plane d of the interleaved [M/4][D][nb][4].  A D = 3 launch writes 12 of its 14 output bytes per row into the records;
+    // as ONE allocation they lie in one class of the physical address space and the launch runs at what one class absorbs (the no-compute pass of cfg 4:
+    // 0.70-0.77 of peak), as separately placed planes at 0.86 (profiles/r06_probes/plane_probe.txt).  rec_planes[0] == NULL: the interleaved layout, `records`.
+    unsigned char *rec_planes[kMaxDefsPerLaunch];
     // the LAST pass of a multi-pass config reads the earlier groups' tile summaries itself (its finisher has everything else in hand: this
     // group's bitvectors and id bytes, the input bytes, the reveal-mask carries) and writes the FINAL masked rows: no combine launch,
     // this group's summary never written, the others' read once.  0: not such a pass.
@@ -124,6 +130,10 @@ enum : uint32_t {
     kDbgHonoured = kDbgForceMask,
 #endif
 };
+// hrx_ctx_set_option (include/hrx.h) -> WitnessArgs::tune
+enum : uint32_t {
+    kTunePmdFinMask = 3u, kTunePmdFinOn = 1u, kTunePmdFinOff = 2u,   // HRX_OPT_PMD_COMBINER_WAVE: the def-parallel kernel on the WIDE table with / without a combiner wave (0: the planner's default)
+};
 // HRX_DEBUG_FLAGS from the environment, reduced to the bits this build honours
 uint32_t debug_flags_from_env();
 
@@ -142,6 +152,7 @@ struct LaunchInfo {
     int dyn;           // 1: dynamic group assignment (position-major loader/walker kernel, >= 8 long groups per walker pair)
     int spec_tiles;    // > 0: CHUNKED launch (hrx_kernel_spec.hip): tiles per chunk; the geometry above is that of the walk over the chunks
     int spec_chunks;   // chunks per string
+    int pmd_fin;       // def-parallel kernel on the WIDE table (two and three defs): 1 = a combiner wave of its own per group (hrx_kernel_pmd.hip FIN)
     size_t lds_bytes;
 };
 
@@ -175,7 +186,7 @@ double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_byt
 hipError_t launch_traffic_pass_sm(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, size_t rec_pitch, uint16_t *masked,
                                   size_t msk_pitch, uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream);
 hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
-                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream);
+                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream, uint32_t *const *planes = nullptr);
 uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li);
 constexpr size_t kPmSummaryBytes = 6144;
 template <bool HALF, bool SM> constexpr bool kPmFinisher = !HALF && !SM;
@@ -186,6 +197,8 @@ constexpr size_t kPpSlotBytes = 8192;   // pair-step kernel: one ring slot = 4 K
 constexpr size_t pp_pair_bytes(size_t nring) { return nring * kPpSlotBytes + kPmSummaryBytes + kPmCounterBytes; }   // + the finisher's tile summary + counters
 // LDS bytes per group of the def-parallel kernel: input ring + (D - 1) x (2 summaries of 5 KiB + a 2-KiB status piece) + counters
 constexpr size_t pmd_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)(D - 1) * (2 * 5120 + 2048) + 192; }
+// ... of the WIDE kernel with a combiner wave (FIN): all D walkers publish, their status pieces lie in their first summary slots (hrx_kernel_pmd.hip PA)
+constexpr size_t pmd_fin_group_bytes(int D, int nring) { return (size_t)nring * 4096 + (size_t)D * (2 * 5120) + 192; }
 
 // Configs of more than kMaxDefsPerPass RegexDefs (hrx_defs.hpp): every group of defs is walked by an ordinary launch into a
 // group-private position-major records buffer [ceil(M/4)][D_g][nb][4] (blocked like every position-major buffer) and its own

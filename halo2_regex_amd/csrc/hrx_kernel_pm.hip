@@ -575,10 +575,16 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             // cover): records [B][pitch][D], masked [B][pitch] — same walk, the lane's own strides
             // a pass of a multi-pass config writes its defs' planes of the caller's [M/4][rec_D][nb][4] buffer (hrx_kernel.hpp)
             const uint32_t RD = a.rec_D ? a.rec_D : (uint32_t)D;
+            // record planes in buffers of their own (WitnessArgs::rec_planes): every def's plane is the D = 1 layout [M/4][nb][4] of its block
+            const bool planes = !SM && a.rec_planes[0] != nullptr;
             unsigned char *rp = SM ? reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * a.rec_pitch * D * 4u
+                                : planes ? a.rec_planes[0] + ((size_t)blk0 * q4 + (bc - blk0)) * 16u
                                    : reinterpret_cast<unsigned char *>(a.records) + (((size_t)blk0 * q4 * RD + (size_t)a.rec_d0 * nb) + (bc - blk0)) * 16u;
+            size_t poff[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) poff[d] = planes ? (size_t)(a.rec_planes[d] - a.rec_planes[0]) : (size_t)d * nb * 16u;
             // (kDbgFixedLines, profiling only: every quad / octet of a string lands on the first one — same store instructions, no new lines or pages)
-            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u * D : (size_t)nb * 16u * RD;  // one quad of rows further: [M/4][D][nb][4]
+            const size_t rstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u * D : planes ? (size_t)nb * 16u : (size_t)nb * 16u * RD;  // one quad of rows further: [M/4][D][nb][4]
             unsigned char *mp = SM ? reinterpret_cast<unsigned char *>(a.masked) + (size_t)bc * a.msk_pitch * 2u
                                    : reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
             const size_t mstep = (a.debug & kDbgFixedLines) ? (size_t)0 : SM ? (size_t)16u : (size_t)nb * 16u;      // 8 rows further: [M/8][nb][8]
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 const bool pend_store = have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
                 // [ceil(M/4)][D][nb][4]: one def's quads of all strings of the block
-                GlobalSink<D, SM> sink{rp, (size_t)nb * 16u, rstep, do_store, nt_rec, nt_msk,
+                GlobalSink<D, SM> sink{rp, poff, rstep, do_store, nt_rec, nt_msk,
                                        pend, pend_mp, mstep, pend_store, {}};
                 if (WIDE) {
                     const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,

@@ -64,8 +64,11 @@ constexpr uint32_t kPmdPiece = 64u * 32u;     // per lane: dead, err_pos, err_st
 // FIN: the combiner is a wave of its own that walks nothing — W = D + 1 walker-like waves per group, all D walkers publish, the last wave merges, runs the reveal mask and stores the masked
 // rows: with the last def's walk on top of D - 1 merges the combiner was the slowest wave of every group and set the launch's pace (0.54-0.65 of peak at 4 .. 7 defs whatever D).
 template <int D, bool CW, bool FIN, bool SMO = false>
-__global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
+__global__ __launch_bounds__(FIN && (D >= 7 || (!CW && D >= 3)) ? 640 : 512) void witness_pmd_kernel(const WitnessArgs a, const uint32_t nring) {
     static_assert(!SMO || (CW && FIN), "string-major outputs: the CLASS-WIDE kernel with a combiner wave");
+    // PA: the WIDE kernel with a combiner wave (cfg 4: three defs, two groups per workgroup, ten waves) has no LDS left for the walkers' 2-KiB status pieces — 75 KiB of tables,
+    // two rings, six walkers' summaries: a walker's piece lies in its first summary slot, written when the combiner has read the group's last summary (pmd_fin_group_bytes)
+    constexpr bool PA = FIN && !CW;
     constexpr uint32_t kSubS = 16u * D + 4u;              // SMO: dwords per string of a sub-tile buffer
     constexpr uint32_t kSubBytes = 64u * kSubS * 4u;
     constexpr int RS = CW ? kCwRowShift : kWideRowShift;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
     // LDS per group: ring | (D - 1) x (2 summaries + piece) | counters: ready, freed[D], per publishing walker sum_prod, sum_cons, piece_prod; merged
-    const uint32_t walker_bytes = 2u * kSumBytes + kPmdPiece;
+    const uint32_t walker_bytes = 2u * kSumBytes + (PA ? 0u : kPmdPiece), piece_at = PA ? 0u : 2u * kSumBytes;
     const uint32_t group_bytes = nring * kPmTileBytes + (W - 1u) * walker_bytes + 192u + (SMO ? a.sm_bufs * kSubBytes + 8192u : 0u);  // the combiner publishes nothing (hrx_kernel.hpp pmd_group_bytes)
     const uint32_t ring_base = a.table_bytes + lg * group_bytes;
     const uint32_t wbase = ring_base + nring * kPmTileBytes;                  // walker areas of this group
@@ -225,8 +228,11 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
         const size_t q4 = (M + 3u) / 4u, q8 = (M + 7u) / 8u;
         // this def's plane of the block's [M/4][RD][nb][4]: a pass of a multi-pass config (CW groups of up to eight defs, hrx_defs.hpp) writes planes rec_d0 .. of the caller's rec_D
         const uint32_t RD = a.rec_D ? a.rec_D : (uint32_t)D;
-        unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * RD + (size_t)(a.rec_d0 + min(d, (uint32_t)D - 1u)) * nb + (bc - blk0)) * 16u;
-        const size_t rstep = (size_t)nb * 16u * RD;
+        const bool planes = a.rec_planes[0] != nullptr;      // ... or a buffer of its own per def (WitnessArgs::rec_planes): the D = 1 layout [M/4][nb][4] of the block
+        unsigned char *rp = planes ? a.rec_planes[min(d, (uint32_t)D - 1u)] + ((size_t)blk0 * q4 + (bc - blk0)) * 16u
+                                   : reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 * RD + (size_t)(a.rec_d0 + min(d, (uint32_t)D - 1u)) * nb + (bc - blk0)) * 16u;
+        const size_t rstep = planes ? (size_t)nb * 16u : (size_t)nb * 16u * RD;
+        const size_t poff1[1] = {0};
         unsigned char *mp = reinterpret_cast<unsigned char *>(a.masked) + ((size_t)blk0 * q8 + (bc - blk0)) * 16u;
         const size_t mstep = (size_t)nb * 16u;
         const uint32_t lut = CW ? a.cw_lut_off + 256u * min(d, (uint32_t)D - 1u) : 0u;     // this def's class LUT
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
             TileBits tb;
             const bool full = (t0 + 64u < min_n);
             uint32_t tile_ov = 0, hb = 0;
-            GlobalSink<1> sink{rp, 0, rstep, !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
+            GlobalSink<1> sink{rp, poff1, rstep, !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
             const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                       cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
             uint4 ccol[4] = {};  // CW: the bytes' columns (class x 8) of this def, packed like the bytes
@@ -432,8 +438,9 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
         if (a.stamps && combiner && lane == 0u && gi == 0u) a.stamps[(size_t)(blockIdx.x * G + lg) * 16u + 8u] = wall_clock64();
 #endif
         // ---------------- per-string status: every def's walker publishes its piece, the combiner merges ----------------
-        const uint32_t pa = my_area + 2u * kSumBytes + lane * 32u;
+        const uint32_t pa = my_area + piece_at + lane * 32u;
         if (!combiner) {
+            if (PA) ring_wait(sum_prod_off(d) + 4u, seq);      // the combiner has read every summary of this group: the slot is free for the piece
             *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)pa = v4u32{dead, err_pos, err_state, err_char};
             *(__attribute__((address_space(3))) v4u32 *)(uintptr_t)(pa + 16u) = v4u32{acc_state[0], 0u, 0u, 0u};
             ring_post_lds(sum_prod_off(d) + 8u, gi + 1u);
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(FIN && D >= 7 ? 640 : 512) void witness_pmd_kernel(
             uint32_t w_dead, w_pos, w_state, w_char, w_acc;
             if (dd + 1u < W) {
                 ring_wait(sum_prod_off(dd) + 8u, gi + 1u);
-                const uint32_t oa = wbase + dd * walker_bytes + 2u * kSumBytes + lane * 32u;
+                const uint32_t oa = wbase + dd * walker_bytes + piece_at + lane * 32u;
                 const uint4 x0 = lds_u128(oa), x1 = lds_u128(oa + 16u);
                 w_dead = x0.x; w_pos = x0.y; w_state = x0.z; w_char = x0.w; w_acc = x1.x;
             } else {
@@ -497,6 +504,7 @@ hipError_t launch_witness_pmd(const WitnessArgs &a, const LaunchInfo &li, hipStr
             default: return hipErrorInvalidValue;
         }
     }
+    if (li.pmd_fin) return a.D == 2 ? launch_pmd<2, false, true>(a, li, stream) : a.D == 3 ? launch_pmd<3, false, true>(a, li, stream) : hipErrorInvalidValue;
     return a.D == 2 ? launch_pmd<2, false, false>(a, li, stream) : a.D == 3 ? launch_pmd<3, false, false>(a, li, stream) : hipErrorInvalidValue;
 }
 

@@ -318,6 +318,7 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
         unsigned char *rp = reinterpret_cast<unsigned char *>(a.records) + ((size_t)blk0 * q4 + (bc - blk0)) * 16u;
         const size_t rstep = (size_t)nb * 16u;   // one quad of rows further: [M/4][1][nb][4]
         uint4 pend[8];                           // (the sink's slot for masked rows in flight: unused here, they are the finisher's)
+        const size_t poff1[1] = {0};             // (one def: its plane is the buffer)
 #pragma unroll
         for (int k = 0; k < 8; ++k) pend[k] = make_uint4(0, 0, 0, 0);
 
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
             for (int i = 0; i < 16; ++i) sidq[i] = 0;
             uint32_t odd_dead = 0;
             const bool full = (t0 + 64u < min_n);
-            GlobalSink<1, false> sink{rp, (size_t)nb * 16u, rstep, !(a.debug & kDbgSkipRecords), !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)),
+            GlobalSink<1, false> sink{rp, poff1, rstep, !(a.debug & kDbgSkipRecords), !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)),
                                       pend, rp, rstep, false, {}};
             TileBits tb;
             if (full) tb = walk_tile_pp<true>(L, iw, a, sink, 0, 0, sidq, acc_state, odd_dead);

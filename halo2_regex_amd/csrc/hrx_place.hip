@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void placement_probe_kernel(unsigned char *rec
 double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_bytes, uint32_t D, hipStream_t st, unsigned long long *clk, size_t *bytes_written) {
     uint32_t msk_waves = (uint32_t)((kProbeWaves * 2u) / (4u * D + 2u) + 64u) / 128u * 128u;   // the streams' byte ratio, in units of 128 waves
     msk_waves = std::min(std::max(msk_waves, 128u), 512u);
+    if (D == 0u) msk_waves = kProbeWaves / 2u;   // two EQUAL streams: one record plane against another (hrx_alloc_output_planes)
     const size_t rec_part = rec_bytes / kProbeParts / 4096 * 4096, msk_part = msk_bytes / kProbeParts / 4096 * 4096;
     const size_t steps = std::min<size_t>({(size_t)128, rec_part / ((size_t)(kProbeWaves - msk_waves) << 10), msk_part / ((size_t)msk_waves << 10)});
     if (steps == 0 || !clk) return -1.0;
@@ -82,6 +83,7 @@ struct TrafficArgs {
     uint32_t nt_mix;
     uint32_t *sink;
     uint32_t spread;
+    unsigned char *planes[kMaxDefsPerLaunch];   // record planes in buffers of their own (WitnessArgs::rec_planes); planes[0] == NULL: the interleaved `records`
 };
 
 __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) 
             const bool wb = wb_k != 0u && (t % wb_k) == wb_k - 1u;
             const uint4 v = make_uint4(q, 1, 2, 3);
             for (uint32_t d = 0; d < a.D; ++d) {
-                unsigned char *p = rp + ((size_t)q * a.D + d) * nb * 16u;
+                unsigned char *p = a.planes[0] ? a.planes[d] + ((size_t)blk0 * q4 + bl + (size_t)q * nb) * 16u : rp + ((size_t)q * a.D + d) * nb * 16u;
                 if (wb) *reinterpret_cast<uint4 *>(p) = v;
                 else store16_nt(p, v);
             }
@@ -194,8 +196,10 @@ hipError_t launch_traffic_pass_sm(const uint8_t *chars, size_t stride, size_t B,
 }
 
 hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
-                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream) {
-    TrafficArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink, 0u};
+                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream, uint32_t *const *planes) {
+    TrafficArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink, 0u, {}};
+    if (planes)
+        for (uint32_t d = 0; d < D && d < kMaxDefsPerLaunch; ++d) a.planes[d] = (unsigned char *)planes[d];
     const size_t n_groups = (B + 63) / 64;
     a.spread = n_groups < (size_t)num_cus * 4 ? 1u : 0u;
     const size_t need = a.spread ? n_groups : (n_groups + 3) / 4;

@@ -50,7 +50,8 @@ template <int D, bool SM = false>
 struct GlobalSink {
     static constexpr bool kSidq = true;
     unsigned char *rp;
-    size_t plane, rstep;
+    const size_t (&poff)[D];   // def d's plane relative to def 0's: d * nb * 16 in the interleaved [M/4][D][nb][4], the distance of the buffers with WitnessArgs::rec_planes
+    size_t rstep;
     bool do_store, nt_rec, nt_msk;
     const uint4 (&pend)[8];
     unsigned char *pend_mp;
@@ -78,7 +79,7 @@ struct GlobalSink {
             return;
         }
         // quads that start at or beyond row M do not exist in [ceil(M/4)][D][B][4]
-        if (do_store && (full || (p & ~3) <= mrem)) store16(rp + (size_t)d * plane, v, nt_rec);
+        if (do_store && (full || (p & ~3) <= mrem)) store16(rp + poff[d], v, nt_rec);
         if (d == D - 1) rp += rstep;
     }
     __device__ __forceinline__ void row(const int p) {

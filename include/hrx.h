@@ -134,6 +134,13 @@ int hrx_ctx_device(const hrx_ctx *ctx);
 #define HRX_DEFAULT_HOST_THRESHOLD 32768
 int hrx_ctx_set_host_threshold(hrx_ctx *ctx, size_t rows);
 size_t hrx_ctx_host_threshold(const hrx_ctx *ctx);
+/* Per-context choices between variants that compute the same rows (what a linking prover sets instead of environment variables).
+ *   HRX_OPT_PMD_COMBINER_WAVE  the def-parallel kernel of two- and three-def configs (batches of at most two groups of 64 strings per CU): 1 = a combiner wave of its own
+ *                              per group (sums over the defs, reveal mask, masked rows), 2 = the last def's walker combines, 0 = the library's default
+ * Applies to later launches; hrx_ctx_clone copies the options.  hrx_ctx_get_option: the value, -1 for an unknown option. */
+enum { HRX_OPT_PMD_COMBINER_WAVE = 1 };
+int hrx_ctx_set_option(hrx_ctx *ctx, int option, long value);
+long hrx_ctx_get_option(const hrx_ctx *ctx, int option);
 /* thread-local text of the last failing call (any entry point) */
 const char *hrx_last_error(void);
 
@@ -188,10 +195,37 @@ void hrx_recommended_pitches(size_t M, size_t *rec_pitch, size_t *msk_pitch, siz
  *       — what a caller that assembles the batch itself should write; `stride` is then only the per-string capacity
  *       (stride % 16 == 0, >= every n_b). */
 #define HRX_PM_BLOCK 65536
-enum { HRX_LAYOUT_STRING_MAJOR = 0, HRX_LAYOUT_POSITION_MAJOR = 1, HRX_LAYOUT_INPUT_POSITION_MAJOR = 2 };
+enum { HRX_LAYOUT_STRING_MAJOR = 0, HRX_LAYOUT_POSITION_MAJOR = 1, HRX_LAYOUT_INPUT_POSITION_MAJOR = 2,
+       HRX_LAYOUT_RECORD_PLANES = 4 /* hrx_describe_launch / hrx_ctx_describe_launch only, or-ed with HRX_LAYOUT_POSITION_MAJOR: the launch of hrx_witness_batch_device_planes */ };
 int hrx_witness_batch_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,
                                     size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status, void *stream);
 void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32, size_t *masked_u16);
+/* RECORD PLANES — HRX_LAYOUT_POSITION_MAJOR with every def's records in a buffer of its own: plane d holds the states / substr_ids / start_enable / end_enable
+ * columns of regex_defs[d] (src/lib.rs:387-519 fills them per def), laid out like the position-major records of a one-def config — per block of HRX_PM_BLOCK
+ * strings [ceil(M/4)][nb][4] u32, blocks back to back: record of (string b, row r) of def d at record_planes[d][k*HRX_PM_BLOCK*ceil(M/4)*4 + ((r/4)*nb + b')*4 + r%4];
+ * masked, status, chars, lens and `layout` (HRX_LAYOUT_POSITION_MAJOR, optionally | HRX_LAYOUT_INPUT_POSITION_MAJOR) as in hrx_witness_batch_device_layout.
+ * Why: a launch of D defs writes 4 D of its 4 D + 2 output bytes per row into the records; as ONE allocation they lie in one class of the MI355X's physical
+ * address space and the launch runs at what one class absorbs, as separately placed planes (hrx_alloc_output_planes) its D + 1 write streams spread over the
+ * classes: the no-compute pass of three defs x 32768 x 32768 rows 0.86 of the HBM peak against 0.70-0.77 (profiles/r06_probes/plane_probe.txt).
+ * n_planes must be the config's number of defs; configs that run as one launch (up to three defs, or four to eight defs of at most 32 byte classes each);
+ * the values equal the interleaved layout's. */
+int hrx_witness_batch_device_planes(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                                    uint32_t *const *record_planes, size_t n_planes, uint16_t *masked, uint64_t *status, void *stream);
+void hrx_position_major_plane_sizes(size_t B, size_t M, size_t *plane_u32, size_t *masked_u16);
+/* The D planes and the masked rows of a batch of B strings x M rows, each allocated on ctx's device in a neighbourhood of its own: a pool of D + 4 plane-sized and 3
+ * masked-row-sized candidates, allocated one after the other (they walk down the device memory), is measured pair by pair (two equal write streams, ~1 ms per pair on the
+ * device clock) and the D planes + masked buffer whose slowest pairing is fastest are kept; everything else is freed before the call returns.  hrx_alloc_last_report: steps =
+ * pairings measured, ref_gbs = the slowest pairing seen, first_gbs = the slowest pairing of the first D + 1 buffers (what plain allocations would have been), best_gbs = the
+ * kept set's.  The pool never takes more than 70 % of the free memory (hrx_ctx_set_placement narrows that).  Planes below 128 MiB, HRX_PLACE_OFF: plain allocations.
+ * record_planes: D pointers out; each buffer is released with hrx_device_free.  One def: hrx_alloc_outputs_position_major.  Takes the context's lock; not inside a stream capture. */
+int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_planes, uint16_t **masked);
+/* The allocator's measurement, for a caller that manages device memory itself (a prover with its own pool): two equal, time-aligned write streams over the first `bytes`
+ * of device buffers a and b (both are OVERWRITTEN), *gbs = bytes written per time.  Pairings in one class of the physical address space measure 5.2-5.9 TB/s, in different
+ * classes 6.7-7.3 (a level per box: compare pairings with each other, not with a constant).  Synchronous; takes the context's lock. */
+int hrx_probe_write_pair(hrx_ctx *ctx, void *a, void *b, size_t bytes, double *gbs);
+/* hrx_rows_of_string_position_major for record planes in HOST memory (each plane copied from the device as it is): records [M][D], masked [M] of string b. */
+int hrx_rows_of_string_planes(const uint32_t *const *record_planes, const uint16_t *masked_pm, size_t B, size_t M, size_t D, size_t b,
+                              uint32_t *records, uint16_t *masked);
 /* One circuit's view of a position-major batch, on the HOST: the rows of string b of a batch of B strings x M rows x D defs that lies in host memory in
  * HRX_LAYOUT_POSITION_MAJOR (e.g. copied from the device as it is) -> records [M][D] u32 and masked [M] u16, the string-major values the fill loops of
  * match_substrs index per string (src/lib.rs:387-519).  A string's consecutive quads are nb*16*D bytes apart, so this is M/4*D + M/8 gathers of 16 bytes:
@@ -274,6 +308,9 @@ int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, s
  * (0 = M).  What the string-major lines of a sweep are measured against (the reference's fill loops index one string: src/lib.rs:387-519). */
 int hrx_traffic_pass_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, size_t rec_pitch,
                                    uint16_t *masked, size_t msk_pitch, void *stream);
+/* ... over record planes (hrx_witness_batch_device_planes): the same traffic with plane d written at record_planes[d]. */
+int hrx_traffic_pass_device_planes(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *const *record_planes, size_t n_planes,
+                                   uint16_t *masked, void *stream);
 /* From the reference's input shape to the coalesced one, on the device: `chars` = B strings of `stride` bytes each, back to back — one contiguous
  * &[u8] per string is what RegexVerifyConfig::match_substrs is handed (src/lib.rs:311-315) — -> `chars_pm` (B * stride bytes, another buffer) in
  * HRX_LAYOUT_INPUT_POSITION_MAJOR.  Pure streaming (2 * stride bytes of traffic per string; measured beside the bench line: bench.py
@@ -289,6 +326,8 @@ int hrx_device_free(void *ptr);
  * waves=12 ring=4 lds=..." — the kernel name a profiler will show, every template argument spelled out (bench.py's roofline.kernel).  Host-only: nothing is
  * launched and no device is touched.  Returns HRX_OK, HRX_ERR_BOUNDS if nothing fits. */
 int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap);
+/* The same for a context: its own device's CU count (256 on a host-only context), the kernel-selection flags it was created with and its hrx_ctx_set_option choices. */
+int hrx_ctx_describe_launch(const hrx_ctx *ctx, int layout, size_t B, size_t M, char *out, size_t cap);
 /* Same with HOST buffers (any alignment/stride >= max len): staged through ctx-owned device buffers, or — below the
  * context's host threshold, and always on a host-only context — walked on the host; synchronous.  This is what an unmodified caller of
  * match_substrs' seam gets (host Vecs in, host Vecs out, src/lib.rs:311-318).  Batches of more than ~100 MiB of rows go one of two ways: pipelined chunk by chunk
@@ -320,6 +359,31 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
                           size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream);
 /* F::from(v) on the host (same arithmetic as the kernel): limbs[4]. */
 void hrx_fr_from_u64(uint64_t v, int flags, uint64_t *limbs);
+
+/* ------------------------------------------------------------------ */
+/* SURVEY §8 f3 — from the compact records to what the reference's fill consumes (host only, no context, re-entrant)   */
+/* ------------------------------------------------------------------ */
+/* One circuit: EXACTLY the Vecs the three derive_* calls at the top of match_substrs return (src/lib.rs:316-318), out of the string's compact records, so that the body
+ * below lib.rs:318 runs unchanged on them (bindings/rust/hrx.rs WitnessOf is this call):
+ *   records    [M][D] u32, string-major rows of ONE string (a row of hrx_witness_batch_host's output, or hrx_rows_of_string_position_major / _planes)
+ *   n          characters.len() <= M
+ *   states     [D][n + 1] u64   derive_states          (lib.rs:804-823); states[d][n] = the state after the last character
+ *   substr_ids [D][n]     usize derive_substr_ids      (lib.rs:825-845)
+ *   is_start   [D][n + 1] bool  derive_is_start_end.0  (lib.rs:847-888); is_start[d][n] = false
+ *   is_end     [D][n + 1] bool  derive_is_start_end.1;                   is_end[d][0] = false
+ * Exact: for i < n the enable cell is 1, so start_enable[i] = is_start[i] and end_enable[i] = is_end[i + 1] (lib.rs:482-519).  When n == M the records have no row n:
+ * states[d][M] is returned as 0 and is_end[d][M] as false — the two values the reference computes and never assigns to a cell (lib.rs:388-418, 501).
+ * Strings whose status word is not ok have no records to decode (the reference panics in derive_states, lib.rs:817). */
+int hrx_witness_of_string(const uint32_t *records, size_t D, size_t n, size_t M, uint64_t *states, size_t *substr_ids, uint8_t *is_start, uint8_t *is_end);
+/* All circuits of a batch, column-major: the integer content of every advice cell the loops of match_substrs assign (lib.rs:339-348 char_enable / characters,
+ * 419-519 states / substr_ids / start_enable / end_enable per def) and of the two result columns (lib.rs:752-771), for strings [b_begin, b_begin + b_count) of a finished
+ * batch that lies in HOST memory in `layout` (string-major with rec_pitch / msk_pitch in rows, 0 = M; or position-major as copied from the device):
+ *   columns  [n_cols][b_count][M] u64, n_cols = hrx_witness_num_columns(D) = 4 + 4 D, in the column order of hrx_fr_columns_device:
+ *            0 char_enable, 1 characters, 2+4d states[d], 3+4d substr_ids[d], 4+4d start_enable[d], 5+4d end_enable[d], 2+4D masked_characters, 3+4D all_substr_ids
+ * — what `Value::known(F::from(v))` is applied to, one contiguous [M] run per circuit and column: a batch fill assigns them without a derive_* call or a gate evaluation per row. */
+size_t hrx_witness_num_columns(size_t D);
+int hrx_witness_columns_host(int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, const uint32_t *records, size_t rec_pitch, const uint16_t *masked,
+                             size_t msk_pitch, size_t B, size_t M, size_t D, size_t b_begin, size_t b_count, uint64_t *columns);
 
 /* ------------------------------------------------------------------ */
 /* Multi-GPU driver for host buffers: strings are independent given the RegexDefs, so a batch shards by string index with

@@ -33,6 +33,15 @@ def test_library_exports_every_declared_symbol():
         assert getattr(hra.lib, s) is not None
 
 
+def test_rust_binding_declares_every_export():
+    """bindings/rust/hrx.rs (uncompiled here: no Rust toolchain in the image) must at least name every entry point of include/hrx.h and nothing else."""
+    hdr = open(os.path.join(ROOT, "include", "hrx.h")).read()
+    rs = open(os.path.join(ROOT, "bindings", "rust", "hrx.rs")).read()
+    declared = set(re.findall(r"\b(hrx_[a-z0-9_]+)\s*\(", hdr))
+    bound = set(re.findall(r"pub fn (hrx_[a-z0-9_]+)\s*\(", rs))
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+
+
 def test_library_is_a_gfx950_hip_build():
     # the product .so carries a gfx950 code object (hipcc --offload-arch=gfx950) and no other target
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", "--input=" + hra.LIB_PATH],

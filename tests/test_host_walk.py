@@ -203,28 +203,10 @@ def test_random_definitions(oracle):
         _check_batch(oracle, None, chars, lens, M, cfg=cfg, o=OracleDefs(oracle, [(a, subs) for a, subs, _ in defs_t]))
 
 
-def _witness_of(rec, D, n, M):
-    """bindings/rust/hrx.rs WitnessOf::new restated: the four values lib.rs:316-318 derive, out of one string's compact records (M x D)."""
-    states = np.zeros((D, n + 1), np.uint64)
-    sids = np.zeros((D, n), np.uint64)
-    st = np.zeros((D, n + 1), bool)
-    en = np.zeros((D, n + 1), bool)
-    for d in range(D):
-        for idx in range(min(n, M)):
-            r = int(rec[idx, d])
-            states[d, idx] = r & 0xffff
-            sids[d, idx] = (r >> 16) & 0xff
-            st[d, idx] = bool((r >> 24) & 1)
-            en[d, idx + 1] = bool((r >> 25) & 1)
-        if n < M:
-            states[d, n] = int(rec[n, d]) & 0xffff
-    return states, sids, st, en
-
-
 @pytest.mark.parametrize("names", [CFG_1, CFG_A, CFG_123], ids=["D1", "D2", "D3"])
 def test_records_decode_to_what_derive_states_ids_flags_return(oracle, names):
     """SURVEY §8 f3, the part that can be pinned without a Rust toolchain: the batch fill feeds lib.rs:339-773 from the compact records instead of the three
-    derive_* calls (bindings/rust/hrx.rs WitnessOf).  The decode must give EXACTLY what derive_states / derive_substr_ids / derive_is_start_end return
+    derive_* calls (hrx_witness_of_string; bindings/rust/hrx.rs WitnessOf is that call).  The decode must give EXACTLY what derive_states / derive_substr_ids / derive_is_start_end return
     (lib.rs:804-888; the oracle's restatement of them) — every reference test string, planted and stress strings, n = 0 and n = M included; the one value
     the records cannot hold (states[d][M] and the last transition's end flag when n == M) is one the reference computes and never assigns (lib.rs:388-418, 501)."""
     M = 160
@@ -251,7 +233,7 @@ def test_records_decode_to_what_derive_states_ids_flags_return(oracle, names):
         want_states = o.derive_states(t)
         want_sids = o.derive_substr_ids(want_states)
         want_st, want_en = o.derive_is_start_end(want_states, want_sids)
-        g_states, g_sids, g_st, g_en = _witness_of(rec[b], D, n, M)
+        g_states, g_sids, g_st, g_en = hra.witness_of_string(rec[b], n)      # hrx_witness_of_string: the C export bindings/rust/hrx.rs WitnessOf::new calls
         if n == M:                                           # what no cell ever holds
             want_states = want_states.copy(); want_states[:, M] = 0
             want_en = want_en.copy(); want_en[:, M] = False
@@ -259,3 +241,43 @@ def test_records_decode_to_what_derive_states_ids_flags_return(oracle, names):
         assert np.array_equal(g_st, want_st) and np.array_equal(g_en, want_en), t
         checked += 1
     assert checked >= 40
+
+
+@pytest.mark.parametrize("names", [CFG_1, CFG_A, CFG_123], ids=["D1", "D2", "D3"])
+def test_batch_columns_are_what_match_substrs_assigns_per_circuit(oracle, names):
+    """hrx_witness_columns_host (the batch form): every advice column of every circuit of a batch, column-major, equals what the single-string surface — the
+    oracle's restatement of lib.rs:339-519, 593-764 — gives for that string; string-major and position-major host buffers, a sub-range of the batch, n = 0 and n = M."""
+    M = 96
+    D = len(names)
+    cfg = _cfg(names, M)
+    o = OracleDefs.from_files(oracle, names)
+    c2, l2 = synth.reveal_stress(150, M, seed=5)
+    c2[3, :] = synth.regex1_planted(1, M, seed=9, stride=M)[0][0, :M]; l2[3] = M      # n == M
+    l2[4] = 0
+    rec, msk, st = cfg.witness_batch_host(c2, l2)
+    ok = (st & np.uint64(0xff)) == 0
+    assert ok.sum() > 100
+    B = len(l2)
+    cols = hra.witness_columns_host(c2, l2, rec, msk, M, D)
+    assert cols.shape == (4 + 4 * D, B, M)
+    names_of = ["enable", "character"] + sum([["state", "substr_id", "start_enable", "end_enable"]] * D, []) + ["masked_char", "masked_substr_id"]
+    for b in range(B):
+        if not ok[b]:
+            continue
+        w = o.match_substrs(bytes(c2[b, :l2[b]]), M)
+        for c, key in enumerate(names_of):
+            want = w[key] if np.ndim(w[key]) == 1 else w[key][(c - 2) // 4]
+            assert np.array_equal(cols[c, b], want), (b, key)
+    # a sub-range, and the same rows out of position-major buffers (what the device writes, copied out as it is)
+    sub = hra.witness_columns_host(c2, l2, rec, msk, M, D, b_begin=17, b_count=40)
+    assert np.array_equal(sub, cols[:, 17:57])
+    q4, q8 = (M + 3) // 4, (M + 7) // 8
+    rec_pm = np.zeros((q4, D, B, 4), np.uint32); msk_pm = np.zeros((q8, B, 8), np.uint16)
+    rec_pm[:] = rec.reshape(B, q4, 4, D).transpose(1, 3, 0, 2)
+    msk_pm[:] = msk.reshape(B, q8, 8).transpose(1, 0, 2)
+    stride = c2.shape[1]
+    c_pm = np.ascontiguousarray(c2.reshape(B, stride // 16, 16).transpose(1, 0, 2))
+    pmc = hra.witness_columns_host(c_pm, l2, rec_pm, msk_pm, M, D, position_major=True, chars_pm_stride=stride, B=B)
+    assert np.array_equal(pmc, cols)
+    with pytest.raises(hra.HrxError):
+        hra.witness_columns_host(c2, l2, rec, msk, M, D, b_begin=140, b_count=20)
