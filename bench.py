@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--distinct", type=int, default=0, help="generate this many DISTINCT strings and build the batch from rotated copies of them, block after block "
                     "(0 = every string of the batch distinct).  Planting text into 2^20 strings on the host takes minutes; the oracle then walks the distinct "
                     "strings once and EVERY string of every buffer set is compared with the rows of the string it is a copy of")
+    ap.add_argument("--planes", action="store_true", help="position-major outputs of two or more defs as RECORD PLANES: every def's records in a buffer of its own "
+                    "(hrx_witness_batch_device_planes, buffers from hrx_alloc_output_planes); the line then also times the interleaved layout over as many buffer sets (interleaved_layout)")
     ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the legs over BASELINE configs[2..4] (other_configs in the line)")
     ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)     # one of the other_configs legs: a child of the default run
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # spawned by a bare --gpus N run
@@ -206,7 +208,10 @@ def verify_timed_buffers(o, hra, sets, shift, chars, lens, M, D, pm, dev, B, sb)
             nb = min(hra.PM_BLOCK, B - blk)
             for a in range(0, nb, step):
                 e = min(nb, a + step)
-                if pm:
+                if pm and isinstance(rec, (list, tuple)):      # record planes: def d's plane is [q4][nb][4] per block
+                    r = torch.stack([p.view(-1)[blk * q4 * 4:][:q4 * nb * 4].view(q4, nb, 4)[:, a:e].permute(1, 0, 2).reshape(e - a, q4 * 4)[:, :M] for p in rec], dim=2)
+                    m = msk.view(-1)[blk * q8 * 8:][:q8 * nb * 8].view(q8, nb, 8)[:, a:e].permute(1, 0, 2).reshape(e - a, q8 * 8)[:, :M]
+                elif pm:
                     r = rec.view(-1)[blk * q4 * D * 4:][:q4 * D * nb * 4].view(q4, D, nb, 4)[:, :, a:e].permute(2, 0, 3, 1).reshape(e - a, q4 * 4, D)[:, :M]
                     m = msk.view(-1)[blk * q8 * 8:][:q8 * nb * 8].view(q8, nb, 8)[:, a:e].permute(1, 0, 2).reshape(e - a, q8 * 8)[:, :M]
                 else:
@@ -405,6 +410,7 @@ def run_rank(args, rank, world, device_index, barrier):
     else:
         b_begin, B = rank * args.batch, args.batch
     pm = args.layout == "position-major"
+    planes = bool(args.planes) and pm and D > 1
     rec_pitch, msk_pitch, rec_stride = hra.recommended_pitches(M)
     if args.dense or pm:
         rec_pitch, msk_pitch, rec_stride = M, M, (max(n, 1) + 15) // 16 * 16
@@ -442,18 +448,20 @@ def run_rank(args, rank, world, device_index, barrier):
                     if keep_sm:
                         sm_sets.append(c_k.contiguous())          # the reference's input shape (one contiguous string per row): for roofline.from_string_major_input
                     c_k = hra.chars_to_position_major(c_k)       # [stride/16][B][16]: done once, outside the timed region
-                    out = cfg.alloc_outputs_position_major(B, dev)
+                    out = cfg.alloc_output_planes(B, dev) if planes else cfg.alloc_outputs_position_major(B, dev)
                 else:
                     c_k = c_k.contiguous()
                     out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
-                rep = cfg.last_placement_report() if out[0].numel() * 4 >= hra.PLACED_FROM else {"searched": 0}
+                rep = cfg.last_placement_report() if (out[0][0] if planes else out[0]).numel() * 4 >= hra.PLACED_FROM else {"searched": 0}
                 placement.append(rep)
                 sets.append((c_k, l_k, out))
             torch.cuda.synchronize()
         if world > 1:
             barrier()
     del d_chars0
-    if pm:
+    if planes:
+        launch = lambda i: cfg.witness_batch_planes(sets[i % nsets][0], sets[i % nsets][1], out=sets[i % nsets][2], chars_pm_stride=stride)
+    elif pm:
         launch = lambda i: cfg.witness_batch_position_major(sets[i % nsets][0], sets[i % nsets][1], out=sets[i % nsets][2], chars_pm_stride=stride)
     else:
         launch = lambda i: cfg.witness_batch(sets[i % nsets][0], sets[i % nsets][1], out=sets[i % nsets][2])
@@ -464,7 +472,7 @@ def run_rank(args, rank, world, device_index, barrier):
         torch.cuda.synchronize()
 
     # the kernel and geometry the planner picks for this shape on this device (what rocprofv3 will list)
-    desc = cfg.describe_launch(B, layout=3 if pm else 0, num_cus=torch.cuda.get_device_properties(dev).multi_processor_count)
+    desc = cfg.describe_launch(B, layout=(3 | (hra.LAYOUT_RECORD_PLANES if planes else 0)) if pm else 0, num_cus=torch.cuda.get_device_properties(dev).multi_processor_count)
 
     def graph_of(fn, count):
         """`count` calls of fn(i) recorded once into a HIP graph (stream capture of the very same calls); None if capture fails"""
@@ -544,7 +552,8 @@ def run_rank(args, rank, world, device_index, barrier):
     # eager sequence) once more.  Every launch of the timed region is one of this replay's launches, with the same arguments.
     for _, _, out in sets:
         if pm:                                 # (prime strides: every string and every row position gets its share of the spots)
-            out[0].view(-1)[::16411].fill_(-1)
+            for r_ in (out[0] if planes else [out[0]]):
+                r_.view(-1)[::16411].fill_(-1)
             out[1].view(-1)[::32771].fill_(-1)
         else:                                  # (string-major outputs are pitched views: every 64th row of every string)
             out[0][:, ::64].fill_(-1)
@@ -584,6 +593,21 @@ def run_rank(args, rank, world, device_index, barrier):
         per = timed_replays(run_steps, reps, args.steps)
         res["spread"] = {"replays": reps, "steps_per_replay": args.steps, "ms_per_step_median": statistics.median(per),
                          "ms_per_step_min": min(per), "ms_per_step_max": max(per)}
+    # per buffer set: three back-to-back launches over set k alone (multi-GB sets: where a set's buffers lie shows here; sets that fit the Infinity Cache: not an HBM figure)
+    if not args.no_spread and world == 1 and nsets > 1 and foot >= (1 << 30):
+        try:
+            pss = []
+            for k in range(nsets):
+                launch(k); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    launch(k)
+                e1.record(); torch.cuda.synchronize()
+                pss.append(e0.elapsed_time(e1) / 3)
+            res["per_set_ms"] = pss
+        except Exception as e:
+            sys.stderr.write("per-set timing failed: %s\n" % e)
     # The complementary figure: the same K launches re-processing ONE batch into ONE set of buffers (round 1 and 2's step).  From the
     # second launch on the 256-MB Infinity Cache holds part of what a launch reads and overwrites — not an HBM figure.
     if not args.no_spread and world == 1 and nsets > 1:
@@ -601,7 +625,8 @@ def run_rank(args, rank, world, device_index, barrier):
     # of one launch — same addresses, same instructions, same store policy — and does no DFA work.
     if not args.no_spread and world == 1 and (pm or M % 8 == 0):
         try:
-            tp = (lambda i: cfg.traffic_pass(sets[i % nsets][0], B, sets[i % nsets][2], stride)) if pm else \
+            tp = (lambda i: cfg.traffic_pass_planes(sets[i % nsets][0], B, sets[i % nsets][2], stride)) if planes else \
+                 (lambda i: cfg.traffic_pass(sets[i % nsets][0], B, sets[i % nsets][2], stride)) if pm else \
                  (lambda i: cfg.traffic_pass_string_major(sets[i % nsets][0], sets[i % nsets][2]))
             gt = graph_of(tp, args.steps) if not args.eager else None
             runt = gt.replay if gt is not None else (lambda: [tp(i) for i in range(args.steps)])
@@ -609,7 +634,8 @@ def run_rank(args, rank, world, device_index, barrier):
             per = timed_replays(runt, 5, args.steps)
             mc = {"rotating_us": statistics.median(per) * 1e3}
             if nsets > 1:
-                tp1 = (lambda i: cfg.traffic_pass(sets[0][0], B, sets[0][2], stride)) if pm else (lambda i: cfg.traffic_pass_string_major(sets[0][0], sets[0][2]))
+                tp1 = (lambda i: cfg.traffic_pass_planes(sets[0][0], B, sets[0][2], stride)) if planes else \
+                      (lambda i: cfg.traffic_pass(sets[0][0], B, sets[0][2], stride)) if pm else (lambda i: cfg.traffic_pass_string_major(sets[0][0], sets[0][2]))
                 gt1 = graph_of(tp1, args.steps) if not args.eager else None
                 runt1 = gt1.replay if gt1 is not None else (lambda: [tp1(i) for i in range(args.steps)])
                 runt1(); torch.cuda.synchronize()
@@ -705,6 +731,26 @@ def run_rank(args, rank, world, device_index, barrier):
             del hrec, hmsk, hst, rp, mp
         except Exception as e:
             sys.stderr.write("end-to-end host probe failed: %s\n" % e)
+    # Record planes: the same K steps over the INTERLEAVED layout ([M/4][D][B][4] in one allocation + placed masked rows: what every earlier round measured), as many buffer
+    # sets, in this process on this box — what the planes buy.  The planes' sets are released first (the verification and the no-compute pass are done with them).
+    if planes and world == 1 and not args.no_spread:
+        try:
+            ins = [(c, l) for c, l, _ in sets]
+            for k in range(len(sets)):
+                sets[k] = (sets[k][0], sets[k][1], None)
+            torch.cuda.empty_cache()
+            il_sets = [cfg.alloc_outputs_position_major(B, dev) for _ in range(nsets)]
+            il = lambda i: cfg.witness_batch_position_major(ins[i % nsets][0], ins[i % nsets][1], out=il_sets[i % nsets], chars_pm_stride=stride)
+            gi = graph_of(il, args.steps) if not args.eager else None
+            runi = gi.replay if gi is not None else (lambda: [il(i) for i in range(args.steps)])
+            runi(); torch.cuda.synchronize()
+            per = timed_replays(runi, 5, args.steps)
+            st_ok = all(((il_sets[k][2].cpu().numpy().view(np.uint64) & np.uint64(0xff)) == 0).all() for k in range(min(nsets, args.steps)))
+            res["interleaved_layout"] = {"ms_per_step_median": statistics.median(per), "ms_per_step_min": min(per), "status_ok": bool(st_ok),
+                                         "kernel": cfg.describe_launch(B, layout=3, num_cus=torch.cuda.get_device_properties(dev).multi_processor_count).split(" grid=")[0]}
+            del gi, il_sets
+        except Exception as e:                                   # a probe must never break the bench line
+            sys.stderr.write("interleaved-layout comparison failed: %s\n" % e)
     res["desc"] = desc
     res["placement"] = placement
     res["library"] = os.path.realpath(hra.LIB_PATH)
@@ -713,7 +759,10 @@ def run_rank(args, rank, world, device_index, barrier):
                                  % (label, D, B, stride, n, M, "uniform noise over the %s%s%s" % (alphabet, " + planted match" if planted else "",
                                     "" if nd == B else "; %d distinct strings, the batch = %d blocks of them, block j rotated by %d j strings" % (nd, (B + nd - 1) // nd, sb))),
                      "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
-                     "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of 65536 strings): chars [%d/16][B][16], records "
+                     "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR with RECORD PLANES (blocks of 65536 strings): chars [%d/16][B][16], every def's records "
+                                 "[M/4][B][4] in a buffer of its own, masked [M/8][B][8] (include/hrx.h hrx_witness_batch_device_planes); the %d + 1 output buffers from "
+                                 "hrx_alloc_output_planes (each in a neighbourhood of the device memory of its own)" % (stride, D)) if planes else
+                                ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of 65536 strings): chars [%d/16][B][16], records "
                                  "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h); outputs from hrx_alloc_outputs_position_major (placement-aware "
                                  "from 128 MiB of records on, two plain allocations below)" % stride) if pm else
                                 ("string-major; input stride %d B, records pitch %d rows, masked pitch %d rows" % (stride, rec_pitch, msk_pitch)),
@@ -791,7 +840,17 @@ def aggregate(per_rank, args):
             "best_gbs": [round(p.get("best_gbs", 0)) for p in srch], "search_ms": [round(p.get("search_ms", 0), 1) for p in srch],
             "capped": [p.get("capped", 0) for p in srch],
             "what": "hrx_alloc_outputs_position_major per buffer set: two-stream probe rates (GB/s written, device clock) of the same-block reference, the first candidate "
-                    "(= two plain allocations) and the kept masked-row buffer; accepted = kept one >= 10 % above the reference (DESIGN.md §6)"}
+                    "(= two plain allocations) and the kept masked-row buffer; accepted = kept one >= 10 % above the reference (DESIGN.md §6).  RECORD PLANES "
+                    "(hrx_alloc_output_planes): steps = pairings measured, ref_gbs / best_gbs = the slowest pairing seen / of the kept set, first_gbs = of the first D + 1 "
+                    "buffers (plain allocations), chosen_step = output bytes per row (of 4 D + 2) in the kept set's busiest class of the address space"}
+    if r0.get("per_set_ms"):
+        line["roofline"]["per_set_ms"] = [round(x, 4) for x in r0["per_set_ms"]]
+    if r0.get("interleaved_layout"):
+        il = r0["interleaved_layout"]
+        gbs = algo_bytes / (il["ms_per_step_median"] * 1e-3) / 1e9
+        line["roofline"]["interleaved_layout"] = dict(il, achieved=gbs, frac=gbs / HBM_PEAK_GBS,
+                                                      what="the same K steps in this process with the records INTERLEAVED in one allocation ([M/4][D][B][4] from "
+                                                           "hrx_alloc_outputs_position_major: every earlier round's layout) over as many buffer sets — what the record planes buy on this box")
     if r0.get("one_buffer_set"):
         ob = r0["one_buffer_set"]
         gbs = algo_bytes / (ob["ms_per_step_median"] * 1e-3) / 1e9
@@ -921,9 +980,9 @@ def spawn_children(args, argv, timeout_s=3600):
 # set compared with the oracle, hrx_traffic_pass_device over the same buffers), and is condensed into the line's `other_configs`.
 OTHER_CONFIGS = [
     ("configs[2]: regex2_test + regex3_test with substr extraction, 2^20 x 2048-byte strings, 1 MI355X",
-     ["--config", "regex23", "--batch", "1048576", "--len", "2047", "--rows", "2048", "--steps", "5", "--warmup", "2", "--distinct", "65536"]),
+     ["--config", "regex23", "--batch", "1048576", "--len", "2047", "--rows", "2048", "--steps", "5", "--warmup", "2", "--distinct", "65536", "--planes"]),
     ("configs[3]: 32-KiB header regexes (D = 3 stand-ins, BASELINE.md), 256K strings over 8 GPUs = 32768 strings per GPU",
-     ["--config", "headers3", "--batch", "32768", "--len", "32767", "--rows", "32768", "--steps", "5", "--warmup", "2", "--distinct", "4096"]),
+     ["--config", "headers3", "--batch", "32768", "--len", "32767", "--rows", "32768", "--steps", "5", "--warmup", "2", "--distinct", "4096", "--planes"]),
     ("configs[4]: synthetic 256-state dense DFA, 4096-byte inputs, >= 1M strings over 8 GPUs = 131072 strings per GPU",
      ["--config", "dfa256", "--batch", "131072", "--len", "4095", "--rows", "4096", "--steps", "10", "--warmup", "3", "--distinct", "65536"]),
 ]
@@ -946,7 +1005,9 @@ def condense_leg(name, line, wall_s):
             "spread_ms_per_step": (line.get("spread") or {}).get("ms_per_step_median"),
             "verified": {"bit_exact": v.get("bit_exact"), "strings": v.get("strings"), "buffer_sets": v.get("buffer_sets"), "distinct_strings": v.get("distinct_strings")},
             "placement": {"best_gbs": pl.get("best_gbs"), "ref_gbs": pl.get("ref_gbs"), "steps": pl.get("steps"), "sets_accepted": pl.get("sets_accepted"), "capped": pl.get("capped"),
-                          "search_ms": pl.get("search_ms")},
+                          "search_ms": pl.get("search_ms"), "busiest_class_bytes_per_row": pl.get("chosen_step") if "RECORD PLANES" in line["config"]["buffers"] else None},
+            "record_planes": "RECORD PLANES" in line["config"]["buffers"], "per_set_ms": r.get("per_set_ms"),
+            "interleaved_layout": ({k: r["interleaved_layout"].get(k) for k in ("ms_per_step_median", "frac", "kernel")} if r.get("interleaved_layout") else None),
             "buffer_sets": line["config"]["buffer_sets"].split(":")[0], "launch_mode": line["config"]["launch_mode"].split(" (")[0], "wall_s": wall_s}
 
 

@@ -2,63 +2,21 @@
 // Batches run on the gfx950 kernels; device-pointer entry points fail with HRX_ERR_HIP without a device.  The one
 // host-side compute path is the native small-batch walk (hrx_host_walk.cpp): single strings and host-buffer batches
 // below the context's threshold — a GPU launch cannot beat a host core on ~1000 rows.
-#include <hip/hip_runtime_api.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <fstream>
-#include <map>
-#include <mutex>
 #include <sstream>
-#include <string>
-#include <thread>
-#include <vector>
 
-#include "../../include/hrx.h"
-#include "hrx_defs.hpp"
+#include "hrx_ctx.hpp"
 #include "hrx_fr.h"
 #include "hrx_host_walk.hpp"
-#include "hrx_kernel.hpp"
-#include "hrx_error.hpp"
-#include "hrx_arena_alloc.hpp"
-#include "hrx_place_rule.hpp"
 #include "hrx_lane.h"
 
 using namespace hrx;
 
 static thread_local std::string g_err;
-
-static int fail(int code, const std::string &msg) {
+int hrx::set_last_error(int code, const std::string &msg) {   // hrx_error.hpp: every translation unit of the C ABI fails through here
     g_err = msg;
     return code;
 }
-int hrx::set_last_error(int code, const std::string &msg) { return fail(code, msg); }   // hrx_error.hpp: the other translation units of the C ABI
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t _e = (expr);                                                                         \
-        if (_e != hipSuccess) return fail(HRX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-    } while (0)
-
-// Entry points select the context's device for their HIP calls and restore the caller's current device on return
-// (a torch process keeps its own notion of the current device).
-struct DeviceGuard {
-    int prev = -1;
-    bool active = false;
-    hipError_t set(int device) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev == device) return hipSuccess;
-        hipError_t e = hipSetDevice(device);
-        active = (e == hipSuccess && prev >= 0);
-        return e;
-    }
-    ~DeviceGuard() { if (active) (void)hipSetDevice(prev); }
-};
 
 namespace hrx {
 uint32_t debug_flags_from_env() {
@@ -67,96 +25,6 @@ uint32_t debug_flags_from_env() {
 }
 }  // namespace hrx
 
-struct hrx_defs {
-    DefsSet s;
-};
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        const size_t want = bytes + bytes / 4 + 4096;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct hrx_place_arena;
-static void arena_retire(hrx_place_arena *a);
-struct hrx_place_pool;
-static hrx_place_pool *pool_acquire(int device);
-static void pool_release(hrx_place_pool *p);
-
-struct hrx_ctx {
-    DefsSet s;  // private copy: the ctx outlives / is independent of the hrx_defs it was made from
-    int device = 0;          // HRX_DEVICE_NONE: no device, host walk only
-    int num_cus = 0;
-    uint32_t debug = 0;      // HRX_DEBUG_FLAGS, read once at creation (hrx_kernel.hpp)
-    uint32_t tune = 0;       // hrx_ctx_set_option: kTune* bits (hrx_kernel.hpp)
-    size_t host_threshold = HRX_DEFAULT_HOST_THRESHOLD;   // rows (B x M) below which host-buffer batches take the host walk
-    hipStream_t stream = nullptr;
-    // host-buffer batches of three chunks and more: pipelined (two streams) or one stream, whichever the last comparison on this box found faster (batch_host_locked)
-    struct HostMode { unsigned calls = 0, until_probe = 0; bool sequential = false; double piped_ns_per_byte = 0.0, seq_ns_per_byte = 0.0; } host_mode;
-    hipStream_t copy_stream = nullptr;   // host-buffer batches: the device-to-host copies of finished chunks run here while the next chunks are staged and walked on `stream`
-    uint32_t *d_table = nullptr;
-    uint64_t *d_wide = nullptr;
-    uint16_t *d_half = nullptr;
-    uint8_t *d_pairtab = nullptr;
-    uint8_t *d_bytetab = nullptr;
-    std::vector<uint16_t *> d_pair;
-    std::vector<uint8_t *> d_member;
-    std::mutex mu;
-    DevBuf chars, lens, records, masked, status, states, tags;
-    // multi-pass configs (more than kMaxDefsPerPass defs, hrx_defs.hpp): per group the device images of its own DefsSet and its
-    // private records / status buffers; one scratch array takes the passes' (meaningless) masked rows
-    struct GroupDev {
-        uint32_t *d_table = nullptr;
-        uint64_t *d_wide = nullptr;
-        uint16_t *d_half = nullptr;
-        uint8_t *d_pairtab = nullptr;
-        uint8_t *d_bytetab = nullptr;
-        DevBuf records, status, summary;
-    };
-    std::vector<GroupDev> groups;
-    struct CwGroupDev { DevBuf d_cw, status, summary; };
-    std::vector<CwGroupDev> cw_groups;   // more than eight defs: the CW groups of DefsSet::cw_groups (position-major passes of up to eight defs each)
-    DevBuf mp_masked;
-    DevBuf mp_ov;          // multi-pass configs whose last pass merges the summaries: its cross-group overlap rows (WitnessArgs::merge_ov)
-    bool mp_combine = false;   // HRX_MP_COMBINE=1: always the separate combine launch
-    DevBuf tp_records, tp_masked;   // string-major callers served by the position-major path + transpose_pm_to_sm_kernel (hrx_kernel_tp.hip)
-    DevBuf spec_cls, spec_ends, spec_fail, spec_init, spec_vstatus, spec_vinfo, spec_work;
-    bool spec_qabs_ready = false;
-    DevBuf spec_cimage;            // the scout's compact tables (class LUTs + class-indexed u16 tables), built with spec_qabs
-    uint32_t spec_cimage_bytes = 0, spec_c_lut[kMaxDefsPerPass] = {}, spec_c_tab[kMaxDefsPerPass] = {}, spec_c_rowb[kMaxDefsPerPass] = {}, spec_c_inv[kMaxDefsPerPass] = {};
-    uint32_t spec_qabs[kMaxDefsPerPass][8];   // chunked launches (hrx_kernel_spec.hip)
-    // dynamic group assignment (hrx_kernel_pm.hip): a device counter, zeroed on the launch's stream right before the launch
-    // (a memset node when the launches are captured into a HIP graph: replay-safe)
-    uint32_t *d_group_counter = nullptr;
-    // context-owned device scratch (the counter above, the group buffers of multi-pass configs) is shared by the launches of this
-    // context: they must not overlap.  Launches on ONE stream are ordered anyway; a launch on another stream first waits (on the
-    // host) for the stream that used the scratch last.  No events: these calls must stay legal inside a stream capture.
-    hipStream_t scratch_stream = nullptr;
-    bool scratch_used = false;
-    // placement-aware output allocation (hrx_alloc_output_pair): tunables read once at creation, the last call's report
-    bool place_enabled = true, place_trace = false;
-    int place_max_steps = 48;
-    bool place_max_steps_set = false;   // HRX_PLACE_MAX_STEPS given: it bounds arena walks too (their own cap is kPlaceArenaHardSteps)
-    double place_seen_rate = 0.0;     // bytes per microsecond of the best candidate any DIRECT walk (records >= 1 GiB) of this context has probed; arena walks keep theirs per device (hrx_place_pool)
-    size_t place_max_bytes = 0;       // hrx_ctx_set_placement: the most device memory a walk may hold at once (0: 70 % of what is free)
-    double place_max_ms = 0.0;        // ... and the wall-clock time a walk may take (0: the rule's own bounds, hrx_place_rule.hpp)
-    hrx_place_report last_place{};
-    struct hrx_place_pool *pool = nullptr;   // bench-sized outputs: the device's measured arena pair, shared by every context of that device in this process
-    DevBuf d_cw;                    // CLASS-WIDE image of a config of 4 .. 7 defs (DefsSet::cw_image): the single-launch def-parallel path
-#ifdef HRX_STAMPS
-    DevBuf stamps;                  // tools-only build: 8 u64 per walker pair of the position-major kernel (hrx_kernel_pm.hip)
-#endif
-};
-
-// device copies of one DefsSet's kernel-side images
 static hipError_t upload_blob(const std::vector<uint8_t> &v, uint8_t *&d) {
     if (v.empty()) return hipSuccess;
     hipError_t e = hipMalloc((void **)&d, v.size());
@@ -468,9 +336,11 @@ void hrx_ctx_destroy(hrx_ctx *c) {
 
 /* ------------------------------ the hot path ------------------------------ */
 
-static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
-                        uint32_t *records, uint16_t *masked, uint64_t *status, hipStream_t st, size_t rec_pitch = 0,
-                        size_t msk_pitch = 0, int layout = 0, uint32_t *const *planes = nullptr) {
+}  // extern "C"
+
+int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                 uint32_t *records, uint16_t *masked, uint64_t *status, hipStream_t st, size_t rec_pitch,
+                 size_t msk_pitch, int layout, uint32_t *const *planes) {
     // planes: the D record planes in buffers of their own (hrx_witness_batch_device_planes; position-major outputs, a config that runs as ONE launch); records = planes[0] then
     if (!rec_pitch) rec_pitch = M;
     if (!msk_pitch) msk_pitch = M;
@@ -870,6 +740,8 @@ static int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const
     return HRX_OK;
 }
 
+extern "C" {
+
 #ifdef HRX_STAMPS
 // tools only (libhrx_stamps.so): the stamps of the LAST position-major launch of this context, 8 u64 per walker pair
 int hrx_debug_read_stamps(hrx_ctx *ctx, unsigned long long *out, size_t n_u64) {
@@ -1123,357 +995,18 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
     }
     return HRX_OK;
 }
-
-// Placement-aware allocation of the two output buffers (hrx_place.hip).
-//
-// Device memory is handed out top-down, so whatever a process allocates next lands right below what it allocated last — in
-// the same class of the physical address space, where the launch's two write streams collide.  The search WALKS down the
-// device memory instead and measures, with the two-stream probe, what lies there against where the records are:
-//   * records >= kPlaceDirectFrom (1 GiB): masked-row candidates are allocated one after the other, each is measured against
-//     the records buffer itself, and a rejected candidate stays allocated as the spacer that pushes the next one further
-//     (round 2's scheme, now bounded by a budget and a relative acceptance rule);
-//   * smaller records (the bench line's 256 MiB): buffers of that size live in the reach of the 256-MB Infinity Cache — a
-//     probe over them measures the cache — and the driver's buddy allocator puts small blocks into whatever hole is highest,
-//     not below the previous allocation.  They are therefore carved out of ARENAS: two 2-GiB blocks per context, one for
-//     records and one for masked rows, the second found by walking 2-GiB blocks down the memory and measuring each, whole,
-//     against the first (2 GiB per probe pass: the HBM regime).  Later requests are served from the same measured pair until
-//     it is full; hrx_device_free returns a sub-buffer to its arena, and an arena is released when its last sub-buffer is
-//     (and the context has moved on to another pair or is gone).
-// Reference time: the same probe over two parts of ONE block (the records arena, or the records buffer): what two streams in
-// one neighbourhood cost on this box.  A candidate is accepted when it is faster than that by kPlaceMargin — no absolute
-// threshold (round 2's 6.9 TB/s did not hold on every box); failing that the fastest measured candidate is kept.  Spacers and
-// rejected candidates are freed before the call returns.  The walk never takes more than kPlaceBudgetFrac of the free memory.
-constexpr size_t kPlaceFromBytes = (size_t)128 << 20;    // below this the whole launch lives in the Infinity Cache: plain allocations
-constexpr size_t kPlaceDirectFrom = (size_t)1 << 30;
-constexpr size_t kPlaceArenaBytes = (size_t)2 << 30, kPlaceArenaAlign = (size_t)2 << 20;
-constexpr double kPlaceBudgetFrac = 0.70;   // (the acceptance rule and its margins: hrx_place_rule.hpp)
-
-struct hrx_place_arena {
-    void *base = nullptr;
-    int device = 0;
-    hrx::ArenaRanges ranges;   // which offsets are handed out (first fit, freed ranges merge: hrx_arena_alloc.hpp) — an alloc / free churn is served from one pair for ever
-    bool retired = false;      // no context serves requests from it any more: released with its last sub-buffer
-};
-static std::mutex g_arena_mu;
-static std::map<uintptr_t, hrx_place_arena *> g_arena_of;   // sub-buffer -> arena (hrx_device_free has no context argument)
-
-// ranges / retired of an arena are only ever touched under g_arena_mu: hrx_device_free (any thread, no context argument — e.g. a finalizer
-// while another thread allocates) releases sub-buffers concurrently with the owning context's takes.
-static inline size_t arena_need(size_t bytes) { return (bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign; }
-// a records and a masked-row sub-buffer out of the pair, or neither: the capacity check and both takes are ONE critical section
-static bool arena_take_pair(hrx_place_arena *ra, size_t r_bytes, hrx_place_arena *ma, size_t m_bytes, void **r, void **m) {
-    std::lock_guard<std::mutex> lk(g_arena_mu);
-    if (!ra->ranges.fits(arena_need(r_bytes)) || !ma->ranges.fits(arena_need(m_bytes))) return false;
-    const size_t ro = ra->ranges.take(arena_need(r_bytes)), mo = ma->ranges.take(arena_need(m_bytes));
-    *r = (unsigned char *)ra->base + ro;
-    *m = (unsigned char *)ma->base + mo;
-    g_arena_of[(uintptr_t)*r] = ra;
-    g_arena_of[(uintptr_t)*m] = ma;
-    return true;
-}
-static void arena_retire(hrx_place_arena *a) {
-    if (!a) return;
-    std::lock_guard<std::mutex> lk(g_arena_mu);
-    a->retired = true;
-    if (a->ranges.live() == 0) { (void)hipFree(a->base); delete a; }
-}
-// true if ptr was a sub-buffer of an arena (and has been returned to it).  hipFree waits for the device before it releases memory, and callers rely on that
-// (a buffer may be freed while the launch that writes it is still in flight; the Python wrapper's finalizers do).  A range handed back to an arena is reusable at
-// once — by another context, thread and stream — so the release waits for the arena's device first, exactly like the plain allocations' hipFree below 128 MiB:
-// the same caller code is safe whatever the buffer size (tests: test_arena_free_waits_for_the_device).
-static bool arena_release(void *ptr) {
-    int device = -1;
-    {
-        std::lock_guard<std::mutex> lk(g_arena_mu);
-        auto it = g_arena_of.find((uintptr_t)ptr);
-        if (it == g_arena_of.end()) return false;
-        device = it->second->device;
-    }
-    {   // (outside the arena mutex: other threads keep allocating while this one waits; ptr is the caller's until the give below)
-        DeviceGuard guard;
-        if (guard.set(device) == hipSuccess) (void)hipDeviceSynchronize();
-        (void)hipGetLastError();
-    }
-    std::lock_guard<std::mutex> lk(g_arena_mu);
-    auto it = g_arena_of.find((uintptr_t)ptr);
-    if (it == g_arena_of.end()) return true;    // (released by a concurrent call with the same pointer: a double free; nothing left to do)
-    hrx_place_arena *a = it->second;
-    g_arena_of.erase(it);
-    a->ranges.give((size_t)((unsigned char *)ptr - (unsigned char *)a->base));
-    if (a->ranges.live() == 0 && a->retired) { (void)hipFree(a->base); delete a; }
-    return true;
-}
-
-// One measured arena pair per DEVICE and process, not per context: a prover that keeps one context per worker thread (a context serves one stream at a time)
-// would otherwise walk once per context and hold 4 GiB of arenas in each.  mu serialises the walks and the replacement of a full pair; it is taken after the
-// context's own mutex and before g_arena_mu (hrx_device_free takes only the latter).
-struct hrx_place_pool {
-    std::mutex mu;
-    hrx_place_arena *rec = nullptr, *msk = nullptr;
-    hrx_place_report report{};     // of the walk that found the pair
-    double seen_rate[HRX_MAX_DEFS + 1] = {};   // per number of defs D (the probe writes its two streams in the launch's ratio 4 D : 2, so rates of different D do not compare):
-                                               // the fastest pairing any arena walk on this device has probed (bytes per microsecond)
-    int users = 0;                 // live contexts of the device (under g_arena_mu)
-};
-static std::map<int, hrx_place_pool *> g_pools;   // under g_arena_mu; entries are never removed (a few dozen bytes per device)
-static hrx_place_pool *pool_acquire(int device) {
-    std::lock_guard<std::mutex> lk(g_arena_mu);
-    hrx_place_pool *&p = g_pools[device];
-    if (!p) p = new hrx_place_pool();
-    ++p->users;
-    return p;
-}
-static void pool_release(hrx_place_pool *p) {
-    if (!p) return;
-    hrx_place_arena *r = nullptr, *m = nullptr;
-    {
-        std::lock_guard<std::mutex> pl(p->mu);
-        std::lock_guard<std::mutex> lk(g_arena_mu);
-        if (--p->users == 0) { r = p->rec; m = p->msk; p->rec = p->msk = nullptr; for (double &v : p->seen_rate) v = 0.0; p->report = hrx_place_report{}; }
-    }
-    arena_retire(r); arena_retire(m);
-}
-
-static void place_trace(const hrx_ctx *ctx, const char *fmt, ...) {
-    if (!ctx->place_trace) return;
-    va_list ap;
-    va_start(ap, fmt);
-    std::vfprintf(stderr, fmt, ap);
-    va_end(ap);
-}
-
-// The walk.  A: the block everything is measured against (a_bytes), cand_bytes: the size of the blocks to walk with.  Returns the
-// kept candidate (NULL: none could be allocated); everything else it allocated is freed.
-static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes, const bool arena_walk, const double seen_before, hrx_place_report &rep, double *best_rate_out) {
-    const uint32_t D = (uint32_t)ctx->s.defs.size();
-    unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);   // 16 bytes of the context's 64-byte scratch word area
-    size_t free_b = 0, total_b = 0;
-    *best_rate_out = 0.0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    // never more than kPlaceBudgetFrac of what is free NOW.  The 2-GiB arena candidates of bench-sized outputs: 24 of them (48 GiB) as a rule — several contexts
-    // or ranks on one device walk at the same time without pushing each other out of memory — and on only while NOTHING clearly above the same-block reference
-    // has turned up (one lease of round 4: 24 candidates between 5.6 and 6.07 TB/s against a reference of 5.9, the bench line at 0.722 instead of 0.76; round 3's
-    // unbounded walk had found a clear partner on every lease, up to ~100 candidates down), re-reading the free memory at every further step.
-    // (arena_walk is the caller's statement, not inferred from the size: a direct walk whose masked buffer happens to measure 2 GiB — 1048576 x 1024 rows — keeps
-    // the direct walk's caps.)  hrx_ctx_set_placement narrows the budget and adds a time cap; rep.capped says which bound ended the walk.
-    size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
-    if (ctx->place_max_bytes) budget = std::min(budget, ctx->place_max_bytes);
-    const int max_steps = arena_walk && !ctx->place_max_steps_set ? std::max(ctx->place_max_steps, hrx::kPlaceArenaHardSteps) : ctx->place_max_steps;
-    rep.searched = 1;
-    double ref_rate = 0.0;   // bytes per microsecond
-    {   // the reference: both streams inside ONE block, in the launch's byte ratio (4 D : 2)
-        const size_t a_rec = a_bytes / (4 * D + 2) * (4 * D) / 4096 * 4096;
-        size_t wrote = 0;
-        rep.ref_us = hrx::placement_probe_us(A, a_rec, (unsigned char *)A + a_rec, a_bytes - a_rec, D, ctx->stream, clk, &wrote);
-        if (rep.ref_us > 0) ref_rate = (double)wrote / rep.ref_us;
-        rep.ref_gbs = ref_rate * 1e-3;
-    }
-    std::vector<void *> spacers;       // rejected candidates: they are what pushes the next candidate further down
-    void *best = nullptr;
-    size_t spent = 0;
-    double best_us = -1.0;
-    hrx::PlaceWalk walk;               // the rates measured and when to stop: hrx_place_rule.hpp
-    walk.ref_rate = ref_rate;
-    walk.seen_before = seen_before;    // the fastest pairing earlier walks of the same kind measured (direct: this context's; arena: this device's)
-    walk.arena = arena_walk;
-    const auto t_walk = std::chrono::steady_clock::now();
-    int i = 0;
-    bool ended_by_rule = false;
-    for (; i < max_steps; ++i) {
-        if (spent + cand_bytes > budget) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
-        if (!walk.may_take_another()) { ended_by_rule = true; break; }   // the arena soft cap: something clear of the reference is in hand
-        if (arena_walk && i >= hrx::kPlaceArenaSoftSteps) {     // beyond it: leave other walkers / contexts of this device their share
-            size_t f2 = 0, t2 = 0;
-            if (hipMemGetInfo(&f2, &t2) != hipSuccess) { (void)hipGetLastError(); rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
-            if ((double)f2 < (1.0 - kPlaceBudgetFrac) * (double)t2) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
-        }
-        void *cand = nullptr;
-        if (hipMalloc(&cand, cand_bytes) != hipSuccess) { (void)hipGetLastError(); rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
-        spent += cand_bytes;
-        rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
-        const double us = hrx::placement_probe_us(A, a_bytes, cand, cand_bytes, D, ctx->stream, clk, &rep.probe_bytes);
-        const double rate = us > 0 ? (double)rep.probe_bytes / us : 0.0;
-        place_trace(ctx, "hrx placement: step %d candidate %p: %.1f us = %.2f TB/s, reference %.2f TB/s, %.1f ms into the walk\n", i, cand, us, rate * 1e-6, ref_rate * 1e-6,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count());
-        ++rep.steps;
-        if (i == 0) { rep.first_us = us; rep.first_gbs = rate * 1e-3; }
-        const bool better = us >= 0 && (best_us < 0 || us < best_us);
-        void *loser = better ? best : cand;
-        if (better) { best = cand; best_us = us; rep.chosen_step = i; }
-        if (loser) spacers.push_back(loser);
-        walk.rates.push_back(rate);
-        const double elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count();
-        const hrx::PlaceVerdict v = walk.decide(elapsed_ms);
-        if (v == hrx::PlaceVerdict::accept) { rep.accepted = 1; ended_by_rule = true; break; }
-        if (v == hrx::PlaceVerdict::settle) {
-            rep.accepted = walk.clear_of_reference() ? 1 : 0; ended_by_rule = true;
-            if (elapsed_ms > (arena_walk ? hrx::kPlaceArenaHardMs : hrx::kPlaceHardMs)) rep.capped |= HRX_PLACE_CAPPED_TIME;   // the rule's own hard bound: whatever it holds
-            break;
-        }
-        if (ctx->place_max_ms > 0 && elapsed_ms > ctx->place_max_ms) { rep.capped |= HRX_PLACE_CAPPED_TIME; break; }   // the caller's bound (hrx_ctx_set_placement)
-    }
-    if (i >= max_steps && !ended_by_rule) rep.capped |= HRX_PLACE_CAPPED_STEPS;
-    const double best_rate = walk.best();
-    *best_rate_out = best_rate;
-    if (!rep.accepted && walk.clear_of_reference()) rep.accepted = 1;   // (a walk that ran into a cap with a pairing >= 10 % above the reference in hand)
-    for (void *p : spacers) (void)hipFree(p);
-    rep.best_us = best_us;
-    rep.best_gbs = best_rate * 1e-3;
-    place_trace(ctx, "hrx placement: kept step %d (%.1f us vs reference %.1f us, %s), %d steps\n", rep.chosen_step, best_us, rep.ref_us,
-                rep.accepted ? "accepted" : "fastest measured", rep.steps);
-    return best;
-}
-
-int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_bytes, void **records, void **masked) {
-    if (!ctx || !records || !masked || records_bytes == 0 || masked_bytes == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_pair: bad argument");
-    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
-    *records = nullptr; *masked = nullptr;
-    std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
-    const auto t_begin = std::chrono::steady_clock::now();
-    hrx_place_report rep{};
-    auto done = [&](void *r, void *m) -> int {
-        *records = r; *masked = m;
-        rep.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-        ctx->last_place = rep;
-        return HRX_OK;
-    };
-    auto plain = [&]() -> int {
-        void *r = nullptr, *m = nullptr;
-        if (hipMalloc(&r, records_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
-        if (hipMalloc(&m, masked_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(r); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
-        return done(r, m);
-    };
-    if (records_bytes < kPlaceFromBytes || !ctx->place_enabled) return plain();
-    if (records_bytes >= kPlaceDirectFrom) {
-        // ---- large outputs: candidates measured against the records buffer itself
-        // (Round 5 also walked the RECORDS side — against one 12-GiB records buffer of cfg 4 all 48 masked-row candidates measure 6.4-6.8 TB/s, against the next one 5.8-6.3: where the records
-        // lie sets the level — trying up to three records buffers and keeping the best pair: the allocation churn of 12-GiB spacers brought multi-second hipMalloc stalls (search_ms 3-4 s per
-        // buffer set) and the launches did not follow the probe level closely enough to pay for it — cfg 4 at 0.655 with all three sets at 6.6-6.75.  Not kept.)
-        void *rec = nullptr;
-        if (hipMalloc(&rec, records_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
-        double walked_best = 0.0;
-        void *best = place_walk(ctx, rec, records_bytes, masked_bytes, /*arena_walk=*/false, ctx->place_seen_rate, rep, &walked_best);
-        ctx->place_seen_rate = std::max(ctx->place_seen_rate, walked_best);
-        if (!best && hipMalloc(&best, masked_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
-        return done(rec, best);
-    }
-    // ---- bench-sized outputs: sub-buffers of the device's measured arena pair
-    if (records_bytes > kPlaceArenaBytes || masked_bytes > kPlaceArenaBytes) return plain();
-    hrx_place_pool *pool = ctx->pool;
-    std::lock_guard<std::mutex> pl(pool->mu);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (pool->rec && pool->msk) {
-            void *r = nullptr, *m = nullptr;
-            if (arena_take_pair(pool->rec, records_bytes, pool->msk, masked_bytes, &r, &m)) {
-                if (attempt == 0) { rep = pool->report; rep.searched = 2; }   // served from the pair an earlier call (of any context of the device) measured
-                return done(r, m);
-            }
-            arena_retire(pool->rec); arena_retire(pool->msk);     // full: a new pair
-            pool->rec = pool->msk = nullptr;
-        }
-        void *A = nullptr;
-        if (hipMalloc(&A, kPlaceArenaBytes) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-        // (the arena walks' own best rate per device and D: a direct walk's rate over other buffer sizes is not comparable — copied in here it could keep the accept
-        // rule `b >= 0.96 seen()` from ever firing and every replacement pair walking to its caps with the pool mutex held)
-        double &pool_seen = pool->seen_rate[std::min<size_t>(ctx->s.defs.size(), HRX_MAX_DEFS)];
-        double walked_best = 0.0;
-        void *X = place_walk(ctx, A, kPlaceArenaBytes, kPlaceArenaBytes, /*arena_walk=*/true, pool_seen, rep, &walked_best);
-        pool_seen = std::max(pool_seen, walked_best);
-        if (!X) { (void)hipFree(A); rep = hrx_place_report{}; return plain(); }
-        pool->rec = new hrx_place_arena(); pool->rec->base = A; pool->rec->device = ctx->device; pool->rec->ranges.reset(kPlaceArenaBytes);
-        pool->msk = new hrx_place_arena(); pool->msk->base = X; pool->msk->device = ctx->device; pool->msk->ranges.reset(kPlaceArenaBytes);
-        pool->report = rep;
-    }
-    return plain();
-}
-
-int hrx_ctx_set_placement(hrx_ctx *ctx, int mode, size_t max_bytes, double max_ms) {
-    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
-    if (mode != HRX_PLACE_OFF && mode != HRX_PLACE_WALK) return fail(HRX_ERR_ARG, "hrx_ctx_set_placement: mode must be HRX_PLACE_OFF or HRX_PLACE_WALK");
-    if (max_ms < 0) return fail(HRX_ERR_ARG, "hrx_ctx_set_placement: max_ms < 0");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->place_enabled = mode == HRX_PLACE_WALK;
-    ctx->place_max_bytes = max_bytes;
-    ctx->place_max_ms = max_ms;
-    return HRX_OK;
-}
-
-int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out) {
-    if (!ctx || !out) return fail(HRX_ERR_ARG, "NULL argument");
-    *out = ctx->last_place;
-    return HRX_OK;
-}
-
-int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, uint16_t *masked, void *stream) {
+int hrx_chars_to_position_major_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, uint8_t *chars_pm, void *stream) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
     if (B == 0) return HRX_OK;
-    if (!chars || !records || !masked) return fail(HRX_ERR_ARG, "NULL buffer");
-    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
-    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)records & 15) || ((uintptr_t)masked & 15))
+    if (!chars || !chars_pm) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (B > 0xffffffffull - 64 || stride / 16 > 0xffffffffull) return fail(HRX_ERR_ARG, "shape out of range");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)chars_pm & 15))
         return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard guard;
+    if (chars == chars_pm) return fail(HRX_ERR_ARG, "in-place conversion is not supported");
+    DeviceGuard guard;      // (stateless: no context scratch, no lock)
     HIP_TRY(guard.set(ctx->device));
-    // the store policy the planner gives the real launch of this shape
-    WitnessArgs a{};
-    a.layout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)ctx->s.defs.size();
-    LaunchInfo li{};
-    li.split = 2;
-    const uint32_t nt_mix = plan_nt_mix(a, li);
-    HIP_TRY(launch_traffic_pass(chars, stride, B, M, a.D, records, masked, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream));
-    return HRX_OK;
-}
-
-int hrx_traffic_pass_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, size_t rec_pitch,
-                                   uint16_t *masked, size_t msk_pitch, void *stream) {
-    if (layout == (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR)) return hrx_traffic_pass_device(ctx, chars, stride, B, M, records, masked, stream);
-    if (layout != HRX_LAYOUT_STRING_MAJOR) return fail(HRX_ERR_ARG, "hrx_traffic_pass_device_layout: HRX_LAYOUT_STRING_MAJOR or HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR");
-    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
-    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
-    if (B == 0) return HRX_OK;
-    if (!chars || !records || !masked) return fail(HRX_ERR_ARG, "NULL buffer");
-    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
-    if (rec_pitch == 0) rec_pitch = M;
-    if (msk_pitch == 0) msk_pitch = M;
-    const size_t D = ctx->s.defs.size();
-    if (rec_pitch < M || msk_pitch < M || (M % 8) || (rec_pitch % 4) || (msk_pitch % 8) || rec_pitch > 0xffffffffull || msk_pitch > 0xffffffffull)
-        return fail(HRX_ERR_ARG, "string-major traffic pass: M % 8 == 0, pitches >= M in multiples of 4 / 8 rows");
-    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)records & 15) || ((uintptr_t)masked & 15))
-        return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
-    WitnessArgs a{};
-    a.layout = HRX_LAYOUT_STRING_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)D;
-    LaunchInfo li{};
-    li.split = 1;
-    const uint32_t nt_mix = plan_nt_mix(a, li);
-    HIP_TRY(launch_traffic_pass_sm(chars, stride, B, M, (uint32_t)D, records, rec_pitch, masked, msk_pitch, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream));
-    return HRX_OK;
-}
-
-int hrx_traffic_pass_device_planes(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *const *record_planes, size_t n_planes,
-                                   uint16_t *masked, void *stream) {
-    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
-    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
-    if (B == 0) return HRX_OK;
-    if (!chars || !record_planes || !masked || n_planes != ctx->s.defs.size() || n_planes > kMaxDefsPerLaunch) return fail(HRX_ERR_ARG, "NULL buffer, or not one plane per def (at most eight)");
-    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
-    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)masked & 15)) return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
-    for (size_t d = 0; d < n_planes; ++d)
-        if (!record_planes[d] || ((uintptr_t)record_planes[d] & 15)) return fail(HRX_ERR_ARG, "record planes must be 16-byte aligned device buffers");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
-    WitnessArgs a{};
-    a.layout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)n_planes;
-    LaunchInfo li{};
-    li.split = 2;
-    const uint32_t nt_mix = plan_nt_mix(a, li);
-    HIP_TRY(launch_traffic_pass(chars, stride, B, M, a.D, record_planes[0], masked, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream, record_planes));
+    HIP_TRY(launch_chars_to_position_major(chars, stride, B, chars_pm, (hipStream_t)stream));
     return HRX_OK;
 }
 
@@ -1499,160 +1032,6 @@ int hrx_rows_of_string_planes(const uint32_t *const *record_planes, const uint16
         }
     }
     if (masked_pm) return hrx_rows_of_string_position_major(nullptr, masked_pm, B, M, D, b, nullptr, masked);
-    return HRX_OK;
-}
-
-int hrx_probe_write_pair(hrx_ctx *ctx, void *a, void *b, size_t bytes, double *gbs) {
-    if (!ctx || !a || !b || !gbs || bytes < ((size_t)32 << 20)) return fail(HRX_ERR_ARG, "hrx_probe_write_pair: two device buffers of at least 32 MiB each");
-    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to measure on");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
-    size_t wrote = 0;
-    const double us = hrx::placement_probe_us(a, bytes, b, bytes, 0u, ctx->stream, (unsigned long long *)(ctx->d_group_counter + 4), &wrote);
-    if (us <= 0) return fail(HRX_ERR_HIP, "hrx_probe_write_pair: the probe launch failed");
-    *gbs = (double)wrote / us * 1e-3;
-    return HRX_OK;
-}
-
-// Record planes + masked rows, each in a neighbourhood of its own: the launch's D + 1 write streams spread over the classes of the physical address space instead of 4 D of
-// its 4 D + 2 bytes per row going into one allocation.  A POOL of candidates — D + kPlanesSpare plane-sized buffers, kPlanesMasked masked-row-sized ones, allocated one after the other (they
-// walk down the device memory) — is measured pair by pair with the two-equal-streams probe (~1 ms per pair on the device clock), and the D planes + masked buffer whose SLOWEST pairing is
-// fastest are kept (ties: the larger sum); the rest is freed before the call returns.  No threshold: pairs in one class measure 5.2-5.7 TB/s, in different classes 6.2-7.0
-// (profiles/r06_probes/plane_probe.txt), and both levels move with the box.  Random draws of three 4-GiB planes + masked rows already run cfg 4's no-compute pass at 0.86 of peak in 54 of 60
-// cases, against 0.65 for three planes of one class and 0.74-0.77 for the interleaved buffer: the selection only has to avoid the draws that collide.
-constexpr size_t kPlanesSpare = 4, kPlanesMasked = 3;
-int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_planes, uint16_t **masked) {
-    if (!ctx || !record_planes || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes: bad argument");
-    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
-    const size_t D = ctx->s.defs.size();
-    if (D == 1) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
-    size_t plane_u32 = 0, masked_u16 = 0;
-    hrx_position_major_plane_sizes(B, M, &plane_u32, &masked_u16);
-    const size_t plane_bytes = plane_u32 * 4, masked_bytes = masked_u16 * 2;
-    for (size_t d = 0; d < D; ++d) record_planes[d] = nullptr;
-    *masked = nullptr;
-    std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
-    const auto t_begin = std::chrono::steady_clock::now();
-    hrx_place_report rep{};
-    std::vector<void *> pc, mc;     // plane and masked-row candidates
-    auto free_all = [&]() { for (void *p : pc) (void)hipFree(p); for (void *p : mc) (void)hipFree(p); pc.clear(); mc.clear(); };
-    const bool walk = ctx->place_enabled && plane_bytes >= kPlaceFromBytes;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-    size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac), spent = 0;
-    if (ctx->place_max_bytes) budget = std::min(budget, ctx->place_max_bytes);
-    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    auto take = [&](std::vector<void *> &v, size_t bytes, size_t must, size_t want) -> bool {      // `must` buffers or failure; up to `want` while memory and time allow
-        while (v.size() < want) {
-            const bool extra = v.size() >= must;
-            if (extra && (spent + bytes > budget)) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
-            if (extra && ctx->place_max_ms > 0 && elapsed_ms() > ctx->place_max_ms) { rep.capped |= HRX_PLACE_CAPPED_TIME; break; }
-            void *p = nullptr;
-            if (hipMalloc(&p, bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                if (extra) { rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
-                return false;
-            }
-            v.push_back(p);
-            spent += bytes;
-        }
-        rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
-        return true;
-    };
-    if (!take(pc, plane_bytes, D, walk ? D + kPlanesSpare : D) || !take(mc, masked_bytes, 1, walk ? kPlanesMasked : 1)) {
-        free_all();
-        return fail(HRX_ERR_HIP, "hrx_alloc_output_planes: out of device memory");
-    }
-    std::vector<size_t> pick(D);
-    for (size_t d = 0; d < D; ++d) pick[d] = d;
-    size_t pick_m = 0;
-    if (walk && (pc.size() > D || mc.size() > 1)) {
-        rep.searched = 1;
-        unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);
-        const size_t P = pc.size(), Q = mc.size();
-        std::vector<double> pp(P * P, 0.0), pm(Q * P, 0.0);       // bytes per microsecond of every pairing
-        auto probe = [&](void *x, void *y, size_t bytes) {
-            size_t wrote = 0;
-            const double us = hrx::placement_probe_us(x, bytes, y, bytes, 0u, ctx->stream, clk, &wrote);
-            rep.probe_bytes = wrote;
-            ++rep.steps;
-            return us > 0 ? (double)wrote / us : 0.0;
-        };
-        double lo = 1e30, hi = 0.0;
-        for (size_t i = 0; i < P; ++i)
-            for (size_t j = i + 1; j < P; ++j) { pp[i * P + j] = pp[j * P + i] = probe(pc[i], pc[j], plane_bytes); lo = std::min(lo, pp[i * P + j]); hi = std::max(hi, pp[i * P + j]); }
-        for (size_t q = 0; q < Q; ++q)
-            for (size_t i = 0; i < P; ++i) { pm[q * P + i] = probe(mc[q], pc[i], std::min(masked_bytes, plane_bytes)); lo = std::min(lo, pm[q * P + i]); hi = std::max(hi, pm[q * P + i]); }
-        if (ctx->place_trace) {
-            for (size_t i = 0; i < P; ++i) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pp[i * P + j] * 1e-3)); place_trace(ctx, "hrx planes: plane candidate %zu %p vs planes (GB/s):%s\n", i, pc[i], l.c_str()); }
-            for (size_t q = 0; q < Q; ++q) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pm[q * P + j] * 1e-3)); place_trace(ctx, "hrx planes: masked candidate %zu %p vs planes (GB/s):%s\n", q, mc[q], l.c_str()); }
-        }
-        // every D-subset of the plane candidates (in allocation order) x every masked candidate: at most C(12, 8) x 3 score evaluations
-        std::vector<size_t> idx(D);
-        for (size_t d = 0; d < D; ++d) idx[d] = d;
-        double best_min = -1.0, best_sum = -1.0, first_min = 0.0;
-        bool first = true;
-        for (;;) {
-            for (size_t q = 0; q < Q; ++q) {
-                double mn = 1e30, sum = 0.0;
-                for (size_t x = 0; x < D; ++x) {
-                    for (size_t y = x + 1; y < D; ++y) { mn = std::min(mn, pp[idx[x] * P + idx[y]]); sum += pp[idx[x] * P + idx[y]]; }
-                    mn = std::min(mn, pm[q * P + idx[x]]); sum += pm[q * P + idx[x]];
-                }
-                if (first) { first_min = mn; first = false; }      // candidates 0 .. D - 1 + masked candidate 0: what plain allocations would have been
-                if (mn > best_min * 1.01 || (mn > best_min * 0.99 && sum > best_sum)) { best_min = mn; best_sum = sum; pick = idx; pick_m = q; }
-            }
-            size_t k = D;       // next combination
-            while (k > 0 && idx[k - 1] == P - D + k - 1) --k;
-            if (k == 0) break;
-            ++idx[k - 1];
-            for (size_t x = k; x < D; ++x) idx[x] = idx[x - 1] + 1;
-        }
-        rep.ref_gbs = lo * 1e-3;          // the slowest and ...
-        rep.first_gbs = first_min * 1e-3; // (the slowest pairing of the first D + 1 buffers: the plain-allocation draw)
-        rep.best_gbs = best_min * 1e-3;   // ... the kept set's slowest pairing; hi is in the trace
-        rep.accepted = best_min >= 1.08 * lo ? 1 : 0;   // the kept set is clear of the slowest pairing seen (if every pairing measures alike there was nothing to choose)
-        place_trace(ctx, "hrx planes: pairings %.2f .. %.2f TB/s; kept set's slowest %.2f TB/s (the first %zu + 1 buffers: %.2f)\n", lo * 1e-6, hi * 1e-6, best_min * 1e-6, D, first_min * 1e-6);
-    }
-    for (size_t d = 0; d < D; ++d) { record_planes[d] = (uint32_t *)pc[pick[d]]; pc[pick[d]] = nullptr; }
-    *masked = (uint16_t *)mc[pick_m];
-    mc[pick_m] = nullptr;
-    for (void *&p : pc) if (p) { (void)hipFree(p); p = nullptr; }
-    for (void *&p : mc) if (p) { (void)hipFree(p); p = nullptr; }
-    rep.search_ms = elapsed_ms();
-    ctx->last_place = rep;
-    return HRX_OK;
-}
-
-int hrx_chars_to_position_major_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, uint8_t *chars_pm, void *stream) {
-    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
-    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
-    if (B == 0) return HRX_OK;
-    if (!chars || !chars_pm) return fail(HRX_ERR_ARG, "NULL buffer");
-    if (B > 0xffffffffull - 64 || stride / 16 > 0xffffffffull) return fail(HRX_ERR_ARG, "shape out of range");
-    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)chars_pm & 15))
-        return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
-    if (chars == chars_pm) return fail(HRX_ERR_ARG, "in-place conversion is not supported");
-    DeviceGuard guard;      // (stateless: no context scratch, no lock)
-    HIP_TRY(guard.set(ctx->device));
-    HIP_TRY(launch_chars_to_position_major(chars, stride, B, chars_pm, (hipStream_t)stream));
-    return HRX_OK;
-}
-
-int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked) {
-    if (!ctx || !records || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_outputs_position_major: bad argument");
-    size_t nr = 0, nm = 0;
-    hrx_position_major_sizes(B, M, ctx->s.defs.size(), &nr, &nm);
-    return hrx_alloc_output_pair(ctx, nr * 4, nm * 2, (void **)records, (void **)masked);
-}
-
-int hrx_device_free(void *ptr) {
-    if (!ptr) return HRX_OK;
-    if (arena_release(ptr)) return HRX_OK;   // a sub-buffer of a measured arena pair (hrx_alloc_output_pair)
-    HIP_TRY(hipFree(ptr));
     return HRX_OK;
 }
 
@@ -1692,272 +1071,6 @@ void hrx_recommended_pitches(size_t M, size_t *rec_pitch, size_t *msk_pitch, siz
     if (rec_pitch) *rec_pitch = m64 + 32;
     if (msk_pitch) *msk_pitch = m64 + 64;
     if (chars_stride) *chars_stride = (M + 127) / 128 * 128 + 128;
-}
-
-static int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
-                             uint32_t *records, uint16_t *masked, uint64_t *status) {
-    if (B == 0) return HRX_OK;
-    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
-    const size_t D = ctx->s.defs.size();
-    const size_t dstride = stride ? (stride + 15) & ~(size_t)15 : 16;
-    HIP_TRY(ctx->chars.reserve(dstride * B + 16));
-    HIP_TRY(ctx->lens.reserve(4 * B));
-    HIP_TRY(ctx->records.reserve(4 * B * M * D));
-    HIP_TRY(ctx->masked.reserve(2 * B * M));
-    HIP_TRY(ctx->status.reserve(8 * B));
-    hipStream_t st = ctx->stream;
-    // Large batches go CHUNK BY CHUNK, two host threads: a producer stages chunk c (host-to-device) and launches its walk on `stream`, the calling thread copies chunk
-    // c - 1's finished rows out on `copy_stream` — the link is full duplex and a copy from or to pageable memory holds its host thread until it has landed, so one thread
-    // cannot have both directions busy.  The rows leave 6 D' bytes per byte that comes in (448 MiB out, 64 MiB in at 65536 x 1024, D = 1): the copy out IS the call
-    // (8.1 of round 4's 8.7 ms: ~55 GB/s, the link's rate in one direction); what the pipeline removes is the staging and the walk in front of it.
-    const size_t out_per_string = M * (4 * D + 2);
-    static const size_t chunk_mib = [] { const char *v = std::getenv("HRX_HOST_CHUNK_MIB"); const long n = v ? std::atol(v) : 0; return (size_t)(n >= 4 && n <= 4096 ? n : 48); }();
-    size_t cb = out_per_string ? (chunk_mib << 20) / out_per_string / 64 * 64 : B;   // ~48 MiB of rows per chunk (HRX_HOST_CHUNK_MIB)
-    if (cb < 1024) cb = 1024;
-    const size_t nchunk = (B + cb - 1) / cb;
-    // HRX_HOST_TRACE=1: one line per call on stderr — which way the call went, how long it took, per chunk when its input was on its way / its walk launched / its copy out began and ended
-    static const bool trace = [] { const char *v = std::getenv("HRX_HOST_TRACE"); return v && std::atoi(v) != 0; }();
-    const auto t_call = std::chrono::steady_clock::now();
-    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
-    // Pipelined or not.  On about every second box of this pool the pipelined call's device-to-host copies run at 25 GB/s instead of 55 for as long as the same call (or process) also
-    // copies host-to-device on the other stream — 16.5 ms per 65536 x 1024 call instead of 8.0, while one stream doing in, walk, out takes 8.6 on every box and a plain copy of the same
-    // bytes 7.2 (per-chunk traces, the variants tried: profiles/r05_probes/host_path_modes.txt).  So a context MEASURES: after its first big call (allocations, first touches) two calls go
-    // pipelined and two on one stream, alternating; the faster way (the better of its two calls, per byte sent back; the pipeline unless the single stream is 10 % faster) takes the next
-    // 62 calls, then the other way gets one call again; a pipelined call a quarter slower than the single stream's figure switches at once.  HRX_HOST_PIPELINE=1 / 0: always / never pipelined.
-    static const int force_pipe = [] { const char *v = std::getenv("HRX_HOST_PIPELINE"); return v ? (std::atoi(v) != 0 ? 1 : 0) : -1; }();
-    hrx_ctx::HostMode &hm = ctx->host_mode;
-    const bool big = nchunk >= 3 && ctx->copy_stream != nullptr;
-    bool sequential = !big, timed = false;
-    if (big) {
-        if (force_pipe >= 0) sequential = force_pipe == 0;
-        else if (hm.calls == 0) sequential = false;                                      // not timed
-        else if (hm.calls <= 4) { sequential = (hm.calls & 1u) == 0u; timed = true; }    // pipelined, one stream, pipelined, one stream
-        else if (hm.until_probe == 0) { sequential = !hm.sequential; timed = true; }     // the other way's turn
-        else { sequential = hm.sequential; timed = true; --hm.until_probe; }
-    }
-    auto account = [&](const bool was_sequential) {
-        if (!big || force_pipe >= 0) return;
-        const double ns_per_byte = ms_now() * 1e6 / (double)(B * out_per_string);
-        const unsigned k = hm.calls++;
-        if (!timed) return;
-        double &fig = was_sequential ? hm.seq_ns_per_byte : hm.piped_ns_per_byte;
-        fig = (k <= 4 && fig > 0.0) ? std::min(fig, ns_per_byte) : ns_per_byte;
-        if (k < 4) return;
-        if (k == 4 || was_sequential != hm.sequential) {       // a comparison is complete: decide
-            hm.sequential = hm.seq_ns_per_byte < 0.9 * hm.piped_ns_per_byte;
-            hm.until_probe = 62;
-        } else if (!was_sequential && ns_per_byte > 1.25 * hm.seq_ns_per_byte) {     // the box has changed its mind
-            hm.sequential = true;
-            hm.until_probe = 62;
-        }
-        if (trace) std::fprintf(stderr, "[hrx host] per byte sent back: pipelined %.4f ns, one stream %.4f ns -> %s\n", hm.piped_ns_per_byte, hm.seq_ns_per_byte, hm.sequential ? "one stream" : "pipelined");
-    };
-    if (sequential) {
-        if (dstride != stride) HIP_TRY(hipMemsetAsync(ctx->chars.p, 0, dstride * B, st));
-        if (stride) HIP_TRY(hipMemcpy2DAsync(ctx->chars.p, dstride, chars, stride, stride, B, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ctx->lens.p, lens, 4 * B, hipMemcpyHostToDevice, st));
-        if (int rc = launch_batch(ctx, (const uint8_t *)ctx->chars.p, dstride, (const uint32_t *)ctx->lens.p, B, M,
-                                  (uint32_t *)ctx->records.p, (uint16_t *)ctx->masked.p, (uint64_t *)ctx->status.p, st))
-            return rc;
-        HIP_TRY(hipMemcpyAsync(records, ctx->records.p, 4 * B * M * D, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(masked, ctx->masked.p, 2 * B * M, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(status, ctx->status.p, 8 * B, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (trace) std::fprintf(stderr, "[hrx host] %zu strings on one stream: %.2f ms\n", B, ms_now());
-        account(true);
-        return HRX_OK;
-    }
-    std::vector<double> t_in(trace ? nchunk : 0), t_launch(trace ? nchunk : 0), t_out0(trace ? nchunk : 0), t_out1(trace ? nchunk : 0);
-    std::vector<hipEvent_t> done(nchunk, nullptr);
-    for (size_t c = 0; c < nchunk; ++c)
-        if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
-            return fail(HRX_ERR_HIP, "hipEventCreate failed");
-        }
-    std::atomic<size_t> staged{0};
-    std::atomic<int> prc{HRX_OK};
-    std::string pmsg;
-    const int device = ctx->device;
-    std::thread producer([&] {
-        DeviceGuard g2;
-        if (g2.set(device) != hipSuccess) { pmsg = "hipSetDevice failed in the staging thread"; prc = HRX_ERR_HIP; staged = nchunk; return; }
-        for (size_t c = 0; c < nchunk; ++c) {
-            const size_t b0 = c * cb, n = std::min(cb, B - b0);
-            unsigned char *dch = (unsigned char *)ctx->chars.p + b0 * dstride;
-            hipError_t e = hipSuccess;
-            if (dstride != stride) e = hipMemsetAsync(dch, 0, dstride * n, st);
-            if (e == hipSuccess && stride) e = hipMemcpy2DAsync(dch, dstride, chars + b0 * stride, stride, stride, n, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync((uint32_t *)ctx->lens.p + b0, lens + b0, 4 * n, hipMemcpyHostToDevice, st);
-            if (trace) t_in[c] = ms_now();
-            int rc = HRX_OK;
-            if (e == hipSuccess)
-                rc = launch_batch(ctx, dch, dstride, (const uint32_t *)ctx->lens.p + b0, n, M, (uint32_t *)ctx->records.p + b0 * M * D,
-                                  (uint16_t *)ctx->masked.p + b0 * M, (uint64_t *)ctx->status.p + b0, st);
-            if (e == hipSuccess && rc == HRX_OK) e = hipEventRecord(done[c], st);
-            if (trace) t_launch[c] = ms_now();
-            if (e != hipSuccess || rc != HRX_OK) {
-                pmsg = e != hipSuccess ? std::string("HIP error while staging a chunk: ") + hipGetErrorString(e) : std::string(hrx_last_error());
-                (void)hipGetLastError();
-                prc = e != hipSuccess ? HRX_ERR_HIP : rc;
-                staged = nchunk;      // release the consumer
-                return;
-            }
-            staged = c + 1;
-        }
-    });
-    int rc = HRX_OK;
-    hipError_t ce = hipSuccess;
-    for (size_t c = 0; c < nchunk && ce == hipSuccess; ++c) {
-        while (staged.load(std::memory_order_acquire) <= c) std::this_thread::yield();
-        if (prc.load() != HRX_OK) break;
-        const size_t b0 = c * cb, n = std::min(cb, B - b0);
-        if (trace) t_out0[c] = ms_now();
-        ce = hipStreamWaitEvent(ctx->copy_stream, done[c], 0);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(records + b0 * M * D, (uint32_t *)ctx->records.p + b0 * M * D, 4 * n * M * D, hipMemcpyDeviceToHost, ctx->copy_stream);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(masked + b0 * M, (uint16_t *)ctx->masked.p + b0 * M, 2 * n * M, hipMemcpyDeviceToHost, ctx->copy_stream);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(status + b0, (uint64_t *)ctx->status.p + b0, 8 * n, hipMemcpyDeviceToHost, ctx->copy_stream);
-        if (trace) t_out1[c] = ms_now();
-    }
-    producer.join();
-    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->copy_stream);
-    (void)hipStreamSynchronize(st);
-    for (hipEvent_t e : done) (void)hipEventDestroy(e);
-    if (trace) {
-        std::string line = "[hrx host] " + std::to_string(nchunk) + " chunks of " + std::to_string(cb) + " strings, pipelined, ms: in/launched/out from-to";
-        char buf[96];
-        for (size_t c = 0; c < nchunk; ++c) { std::snprintf(buf, sizeof buf, " | %.2f/%.2f/%.2f-%.2f", t_in[c], t_launch[c], t_out0[c], t_out1[c]); line += buf; }
-        std::snprintf(buf, sizeof buf, " | end %.2f\n", ms_now());
-        line += buf;
-        std::fputs(line.c_str(), stderr);
-    }
-    if (prc.load() == HRX_OK && ce == hipSuccess) account(false);
-    if (prc.load() != HRX_OK) return fail(prc.load(), pmsg);
-    if (ce != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, std::string("HIP error while copying a chunk out: ") + hipGetErrorString(ce)); }
-    return rc;
-}
-
-// host-buffer batches below the context's threshold (and every batch of a host-only context) take the native host walk
-static bool use_host_walk(const hrx_ctx *ctx, size_t B, size_t M) {
-    if (ctx->device == HRX_DEVICE_NONE) return true;
-    if (ctx->debug & kDbgNoHost) return false;
-    if (ctx->debug & kDbgForceHost) return true;
-    return B * M < ctx->host_threshold;
-}
-
-static int check_host_shape(size_t B, size_t M) {
-    if (M == 0 || M > (1u << 24)) return fail(HRX_ERR_ARG, "max_chars_size must be in 1..2^24");
-    if (B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "batch too large");
-    return HRX_OK;
-}
-
-int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
-                           uint32_t *records, uint16_t *masked, uint64_t *status) {
-    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
-    if (B == 0) return HRX_OK;
-    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
-    if (int rc = check_host_shape(B, M)) return rc;
-    if (use_host_walk(ctx, B, M)) {   // re-entrant: reads the context's tables only
-        for (size_t b = 0; b < B; ++b)
-            if (lens[b] <= M && lens[b] > stride) return fail(HRX_ERR_ARG, "a string is longer than the stride");
-        // one host thread per ~8192 witness rows (~100 us of walk; a thread costs ~30 us to start), up to the machine's cores: a host-only
-        // context walks 4096 x 1024 rows on a 256-core host in ~0.3 ms instead of 15 (NOTES_MEASUREMENTS.md §7c)
-        const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
-        const size_t want = std::max<size_t>(1, B * M / 8192);
-        host_witness_batch(ctx->s, chars, stride, lens, B, M, records, masked, status, (int)std::min(want, hw));
-        return HRX_OK;
-    }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
-    return batch_host_locked(ctx, chars, stride, lens, B, M, records, masked, status);
-}
-
-/* ------------------------------ multi-GPU driver ------------------------------ */
-
-struct hrx_multi {
-    std::vector<hrx_ctx *> ctxs;   // one per shard, in shard order
-    size_t D = 0;
-};
-
-int hrx_multi_create(const hrx_defs *defs, const int *devices, int n_devices, hrx_multi **out) {
-    if (!defs || !devices || !out || n_devices < 1) return fail(HRX_ERR_ARG, "NULL argument or no device");
-    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
-    hrx_multi *m = new hrx_multi();
-    m->D = defs->s.defs.size();
-    for (int i = 0; i < n_devices; ++i) {
-        hrx_ctx *c = nullptr;
-        const int rc = hrx_ctx_create(defs, devices[i], &c);   // restores the caller's current device itself
-        if (rc != HRX_OK) {
-            hrx_multi_destroy(m);
-            return rc;
-        }
-        m->ctxs.push_back(c);
-    }
-    *out = m;
-    return HRX_OK;
-}
-
-void hrx_multi_destroy(hrx_multi *m) {
-    if (!m) return;
-    for (hrx_ctx *c : m->ctxs) hrx_ctx_destroy(c);
-    delete m;
-}
-
-int hrx_multi_num_shards(const hrx_multi *m) { return m ? (int)m->ctxs.size() : 0; }
-int hrx_multi_shard_device(const hrx_multi *m, int shard) { return m && shard >= 0 && shard < (int)m->ctxs.size() ? m->ctxs[(size_t)shard]->device : HRX_DEVICE_NONE; }
-void *hrx_multi_shard_stream(const hrx_multi *m, int shard) { return m && shard >= 0 && shard < (int)m->ctxs.size() ? (void *)m->ctxs[(size_t)shard]->stream : nullptr; }
-
-int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
-                                 uint32_t *records, uint16_t *masked, uint64_t *status) {
-    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
-    if (B == 0) return HRX_OK;
-    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
-    const int world = (int)m->ctxs.size();
-    std::vector<int> rc((size_t)world, HRX_OK);
-    std::vector<std::string> msg((size_t)world);
-    std::vector<std::thread> th;
-    for (int r = 0; r < world; ++r) {
-        th.emplace_back([&, r] {
-            size_t begin = 0, count = 0;
-            hrx_shard_range(B, world, r, &begin, &count);
-            if (count == 0) return;
-            rc[(size_t)r] = hrx_witness_batch_host(m->ctxs[(size_t)r], chars + begin * stride, stride, lens + begin, count, M,
-                                                   records + begin * M * m->D, masked + begin * M, status + begin);
-            if (rc[(size_t)r] != HRX_OK) msg[(size_t)r] = hrx_last_error();   // thread-local: carry it to the caller's thread
-        });
-    }
-    for (std::thread &t : th) t.join();
-    for (int r = 0; r < world; ++r)
-        if (rc[(size_t)r] != HRX_OK) return fail(rc[(size_t)r], "shard " + std::to_string(r) + ": " + msg[(size_t)r]);
-    return HRX_OK;
-}
-
-int hrx_multi_witness_batch_device(hrx_multi *m, int layout, const uint8_t *const *chars, size_t stride, const uint32_t *const *lens,
-                                   const size_t *counts, size_t M, uint32_t *const *records, uint16_t *const *masked,
-                                   uint64_t *const *status) {
-    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
-    if (!chars || !lens || !counts || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL argument");
-    // one kernel per shard on the shard's own stream: the launches are asynchronous, so one host thread keeps all devices busy
-    for (size_t r = 0; r < m->ctxs.size(); ++r) {
-        if (counts[r] == 0) continue;
-        hrx_ctx *c = m->ctxs[r];
-        const int rc = hrx_witness_batch_device_layout(c, layout, chars[r], stride, lens[r], counts[r], M, records[r], masked[r], status[r],
-                                                       (void *)c->stream);
-        if (rc != HRX_OK) return fail(rc, "shard " + std::to_string(r) + ": " + g_err);
-    }
-    return HRX_OK;
-}
-
-int hrx_multi_synchronize(hrx_multi *m) {
-    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
-    for (hrx_ctx *c : m->ctxs) {
-        if (c->device == HRX_DEVICE_NONE) continue;
-        DeviceGuard guard;
-        HIP_TRY(guard.set(c->device));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    return HRX_OK;
 }
 
 /* ------------------------------ single-string entry points ------------------------------ */
@@ -2124,65 +1237,3 @@ int hrx_match_substrs(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t 
 
 }  // extern "C"
 
-// ---------------------------------------------------------------- definition generation (hrx_compile.cpp)
-static int regex_compile_entry(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed, bool json) {
-    if ((!regex && regex_len) || (!out && cap) || !needed) return fail(HRX_ERR_ARG, "null argument");
-    std::string res, err;
-    bool ok = json ? hrx::compile_regex(regex, regex_len, &res, nullptr, err) : hrx::compile_regex(regex, regex_len, nullptr, &res, err);
-    if (!ok) return fail(HRX_ERR_PARSE, err);
-    *needed = res.size();
-    if (out) memcpy(out, res.data(), std::min(cap, res.size()));
-    return HRX_OK;
-}
-extern "C" int hrx_regex_to_allstr_text(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed) {
-    return regex_compile_entry(regex, regex_len, out, cap, needed, false);
-}
-extern "C" int hrx_regex_to_dfa_json(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed) {
-    return regex_compile_entry(regex, regex_len, out, cap, needed, true);
-}
-
-struct hrx_regex_files { hrx::RegexFiles f; };
-extern "C" int hrx_gen_regex_files(const hrx_regex_part *parts, size_t n_parts, size_t max_byte_size, hrx_regex_files **out) {
-    if ((!parts && n_parts) || !out) return fail(HRX_ERR_ARG, "null argument");
-    if (max_byte_size == 0) return fail(HRX_ERR_ARG, "max_byte_size must be positive");
-    std::vector<hrx::RegexPart> ps;
-    for (size_t i = 0; i < n_parts; i++) {
-        if (!parts[i].regex_def && parts[i].regex_len) return fail(HRX_ERR_ARG, "null regex_def");
-        ps.push_back({std::string(parts[i].regex_def ? parts[i].regex_def : "", parts[i].regex_len), parts[i].is_public != 0, parts[i].max_size});
-    }
-    auto *res = new hrx_regex_files();
-    std::string err;
-    if (!hrx::gen_regex_files(ps, max_byte_size, res->f, err)) { delete res; return fail(HRX_ERR_PARSE, err); }
-    *out = res;
-    return HRX_OK;
-}
-extern "C" size_t hrx_regex_files_num_substrs(const hrx_regex_files *files) { return files ? files->f.substrs.size() : 0; }
-extern "C" const char *hrx_regex_files_allstr(const hrx_regex_files *files, size_t *len) {
-    if (!files) return nullptr;
-    if (len) *len = files->f.allstr.size();
-    return files->f.allstr.data();
-}
-extern "C" const char *hrx_regex_files_substr(const hrx_regex_files *files, size_t idx, size_t *len) {
-    if (!files || idx >= files->f.substrs.size()) return nullptr;
-    if (len) *len = files->f.substrs[idx].size();
-    return files->f.substrs[idx].data();
-}
-extern "C" void hrx_regex_files_destroy(hrx_regex_files *files) { delete files; }
-extern "C" int hrx_format_regex_str(const char *regex, size_t regex_len, char *out, size_t cap, size_t *needed) {
-    if ((!regex && regex_len) || (!out && cap) || !needed) return fail(HRX_ERR_ARG, "null argument");
-    std::string res = hrx::format_regex_printable(std::string(regex ? regex : "", regex_len));
-    *needed = res.size();
-    if (out) memcpy(out, res.data(), std::min(cap, res.size()));
-    return HRX_OK;
-}
-extern "C" int hrx_regex_find(const char *pattern, size_t pattern_len, const char *text, size_t text_len, int *found, size_t *start,
-                              size_t *end) {
-    if ((!pattern && pattern_len) || (!text && text_len) || !found || !start || !end) return fail(HRX_ERR_ARG, "null argument");
-    std::string err;
-    bool f = false;
-    size_t s = 0, e = 0;
-    if (!hrx::regex_find(std::string(pattern ? pattern : "", pattern_len), std::string(text ? text : "", text_len), s, e, f, err))
-        return fail(HRX_ERR_PARSE, err);
-    *found = f; *start = s; *end = e;
-    return HRX_OK;
-}

@@ -1,0 +1,279 @@
+// hrx_host_api.cpp — host-buffer batches (hrx_witness_batch_host: what an unmodified caller of match_substrs' seam gets, src/lib.rs:311-318) and the multi-GPU driver
+// (hrx_multi_*: shards by string index, no collective).  DESIGN.md §7, §9.
+#include "hrx_ctx.hpp"
+#include "hrx_host_walk.hpp"
+
+using namespace hrx;
+
+int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                             uint32_t *records, uint16_t *masked, uint64_t *status) {
+    if (B == 0) return HRX_OK;
+    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
+    const size_t D = ctx->s.defs.size();
+    const size_t dstride = stride ? (stride + 15) & ~(size_t)15 : 16;
+    HIP_TRY(ctx->chars.reserve(dstride * B + 16));
+    HIP_TRY(ctx->lens.reserve(4 * B));
+    HIP_TRY(ctx->records.reserve(4 * B * M * D));
+    HIP_TRY(ctx->masked.reserve(2 * B * M));
+    HIP_TRY(ctx->status.reserve(8 * B));
+    hipStream_t st = ctx->stream;
+    // Large batches go CHUNK BY CHUNK, two host threads: a producer stages chunk c (host-to-device) and launches its walk on `stream`, the calling thread copies chunk
+    // c - 1's finished rows out on `copy_stream` — the link is full duplex and a copy from or to pageable memory holds its host thread until it has landed, so one thread
+    // cannot have both directions busy.  The rows leave 6 D' bytes per byte that comes in (448 MiB out, 64 MiB in at 65536 x 1024, D = 1): the copy out IS the call
+    // (8.1 of round 4's 8.7 ms: ~55 GB/s, the link's rate in one direction); what the pipeline removes is the staging and the walk in front of it.
+    const size_t out_per_string = M * (4 * D + 2);
+    static const size_t chunk_mib = [] { const char *v = std::getenv("HRX_HOST_CHUNK_MIB"); const long n = v ? std::atol(v) : 0; return (size_t)(n >= 4 && n <= 4096 ? n : 48); }();
+    size_t cb = out_per_string ? (chunk_mib << 20) / out_per_string / 64 * 64 : B;   // ~48 MiB of rows per chunk (HRX_HOST_CHUNK_MIB)
+    if (cb < 1024) cb = 1024;
+    const size_t nchunk = (B + cb - 1) / cb;
+    // HRX_HOST_TRACE=1: one line per call on stderr — which way the call went, how long it took, per chunk when its input was on its way / its walk launched / its copy out began and ended
+    static const bool trace = [] { const char *v = std::getenv("HRX_HOST_TRACE"); return v && std::atoi(v) != 0; }();
+    const auto t_call = std::chrono::steady_clock::now();
+    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    // Pipelined or not.  On about every second box of this pool the pipelined call's device-to-host copies run at 25 GB/s instead of 55 for as long as the same call (or process) also
+    // copies host-to-device on the other stream — 16.5 ms per 65536 x 1024 call instead of 8.0, while one stream doing in, walk, out takes 8.6 on every box and a plain copy of the same
+    // bytes 7.2 (per-chunk traces, the variants tried: profiles/r05_probes/host_path_modes.txt).  So a context MEASURES: after its first big call (allocations, first touches) two calls go
+    // pipelined and two on one stream, alternating; the faster way (the better of its two calls, per byte sent back; the pipeline unless the single stream is 10 % faster) takes the next
+    // 62 calls, then the other way gets one call again; a pipelined call a quarter slower than the single stream's figure switches at once.  HRX_HOST_PIPELINE=1 / 0: always / never pipelined.
+    static const int force_pipe = [] { const char *v = std::getenv("HRX_HOST_PIPELINE"); return v ? (std::atoi(v) != 0 ? 1 : 0) : -1; }();
+    hrx_ctx::HostMode &hm = ctx->host_mode;
+    const bool big = nchunk >= 3 && ctx->copy_stream != nullptr;
+    bool sequential = !big, timed = false;
+    if (big) {
+        if (force_pipe >= 0) sequential = force_pipe == 0;
+        else if (hm.calls == 0) sequential = false;                                      // not timed
+        else if (hm.calls <= 4) { sequential = (hm.calls & 1u) == 0u; timed = true; }    // pipelined, one stream, pipelined, one stream
+        else if (hm.until_probe == 0) { sequential = !hm.sequential; timed = true; }     // the other way's turn
+        else { sequential = hm.sequential; timed = true; --hm.until_probe; }
+    }
+    auto account = [&](const bool was_sequential) {
+        if (!big || force_pipe >= 0) return;
+        const double ns_per_byte = ms_now() * 1e6 / (double)(B * out_per_string);
+        const unsigned k = hm.calls++;
+        if (!timed) return;
+        double &fig = was_sequential ? hm.seq_ns_per_byte : hm.piped_ns_per_byte;
+        fig = (k <= 4 && fig > 0.0) ? std::min(fig, ns_per_byte) : ns_per_byte;
+        if (k < 4) return;
+        if (k == 4 || was_sequential != hm.sequential) {       // a comparison is complete: decide
+            hm.sequential = hm.seq_ns_per_byte < 0.9 * hm.piped_ns_per_byte;
+            hm.until_probe = 62;
+        } else if (!was_sequential && ns_per_byte > 1.25 * hm.seq_ns_per_byte) {     // the box has changed its mind
+            hm.sequential = true;
+            hm.until_probe = 62;
+        }
+        if (trace) std::fprintf(stderr, "[hrx host] per byte sent back: pipelined %.4f ns, one stream %.4f ns -> %s\n", hm.piped_ns_per_byte, hm.seq_ns_per_byte, hm.sequential ? "one stream" : "pipelined");
+    };
+    if (sequential) {
+        if (dstride != stride) HIP_TRY(hipMemsetAsync(ctx->chars.p, 0, dstride * B, st));
+        if (stride) HIP_TRY(hipMemcpy2DAsync(ctx->chars.p, dstride, chars, stride, stride, B, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->lens.p, lens, 4 * B, hipMemcpyHostToDevice, st));
+        if (int rc = launch_batch(ctx, (const uint8_t *)ctx->chars.p, dstride, (const uint32_t *)ctx->lens.p, B, M,
+                                  (uint32_t *)ctx->records.p, (uint16_t *)ctx->masked.p, (uint64_t *)ctx->status.p, st))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(records, ctx->records.p, 4 * B * M * D, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(masked, ctx->masked.p, 2 * B * M, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(status, ctx->status.p, 8 * B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (trace) std::fprintf(stderr, "[hrx host] %zu strings on one stream: %.2f ms\n", B, ms_now());
+        account(true);
+        return HRX_OK;
+    }
+    std::vector<double> t_in(trace ? nchunk : 0), t_launch(trace ? nchunk : 0), t_out0(trace ? nchunk : 0), t_out1(trace ? nchunk : 0);
+    std::vector<hipEvent_t> done(nchunk, nullptr);
+    for (size_t c = 0; c < nchunk; ++c)
+        if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+            return fail(HRX_ERR_HIP, "hipEventCreate failed");
+        }
+    std::atomic<size_t> staged{0};
+    std::atomic<int> prc{HRX_OK};
+    std::string pmsg;
+    const int device = ctx->device;
+    std::thread producer([&] {
+        DeviceGuard g2;
+        if (g2.set(device) != hipSuccess) { pmsg = "hipSetDevice failed in the staging thread"; prc = HRX_ERR_HIP; staged = nchunk; return; }
+        for (size_t c = 0; c < nchunk; ++c) {
+            const size_t b0 = c * cb, n = std::min(cb, B - b0);
+            unsigned char *dch = (unsigned char *)ctx->chars.p + b0 * dstride;
+            hipError_t e = hipSuccess;
+            if (dstride != stride) e = hipMemsetAsync(dch, 0, dstride * n, st);
+            if (e == hipSuccess && stride) e = hipMemcpy2DAsync(dch, dstride, chars + b0 * stride, stride, stride, n, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync((uint32_t *)ctx->lens.p + b0, lens + b0, 4 * n, hipMemcpyHostToDevice, st);
+            if (trace) t_in[c] = ms_now();
+            int rc = HRX_OK;
+            if (e == hipSuccess)
+                rc = launch_batch(ctx, dch, dstride, (const uint32_t *)ctx->lens.p + b0, n, M, (uint32_t *)ctx->records.p + b0 * M * D,
+                                  (uint16_t *)ctx->masked.p + b0 * M, (uint64_t *)ctx->status.p + b0, st);
+            if (e == hipSuccess && rc == HRX_OK) e = hipEventRecord(done[c], st);
+            if (trace) t_launch[c] = ms_now();
+            if (e != hipSuccess || rc != HRX_OK) {
+                pmsg = e != hipSuccess ? std::string("HIP error while staging a chunk: ") + hipGetErrorString(e) : std::string(hrx_last_error());
+                (void)hipGetLastError();
+                prc = e != hipSuccess ? HRX_ERR_HIP : rc;
+                staged = nchunk;      // release the consumer
+                return;
+            }
+            staged = c + 1;
+        }
+    });
+    int rc = HRX_OK;
+    hipError_t ce = hipSuccess;
+    for (size_t c = 0; c < nchunk && ce == hipSuccess; ++c) {
+        while (staged.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+        if (prc.load() != HRX_OK) break;
+        const size_t b0 = c * cb, n = std::min(cb, B - b0);
+        if (trace) t_out0[c] = ms_now();
+        ce = hipStreamWaitEvent(ctx->copy_stream, done[c], 0);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(records + b0 * M * D, (uint32_t *)ctx->records.p + b0 * M * D, 4 * n * M * D, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(masked + b0 * M, (uint16_t *)ctx->masked.p + b0 * M, 2 * n * M, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(status + b0, (uint64_t *)ctx->status.p + b0, 8 * n, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (trace) t_out1[c] = ms_now();
+    }
+    producer.join();
+    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(st);
+    for (hipEvent_t e : done) (void)hipEventDestroy(e);
+    if (trace) {
+        std::string line = "[hrx host] " + std::to_string(nchunk) + " chunks of " + std::to_string(cb) + " strings, pipelined, ms: in/launched/out from-to";
+        char buf[96];
+        for (size_t c = 0; c < nchunk; ++c) { std::snprintf(buf, sizeof buf, " | %.2f/%.2f/%.2f-%.2f", t_in[c], t_launch[c], t_out0[c], t_out1[c]); line += buf; }
+        std::snprintf(buf, sizeof buf, " | end %.2f\n", ms_now());
+        line += buf;
+        std::fputs(line.c_str(), stderr);
+    }
+    if (prc.load() == HRX_OK && ce == hipSuccess) account(false);
+    if (prc.load() != HRX_OK) return fail(prc.load(), pmsg);
+    if (ce != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, std::string("HIP error while copying a chunk out: ") + hipGetErrorString(ce)); }
+    return rc;
+}
+
+extern "C" {
+
+// host-buffer batches below the context's threshold (and every batch of a host-only context) take the native host walk
+static bool use_host_walk(const hrx_ctx *ctx, size_t B, size_t M) {
+    if (ctx->device == HRX_DEVICE_NONE) return true;
+    if (ctx->debug & kDbgNoHost) return false;
+    if (ctx->debug & kDbgForceHost) return true;
+    return B * M < ctx->host_threshold;
+}
+
+}  // extern "C"
+int check_host_shape(size_t B, size_t M) {
+    if (M == 0 || M > (1u << 24)) return fail(HRX_ERR_ARG, "max_chars_size must be in 1..2^24");
+    if (B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "batch too large");
+    return HRX_OK;
+}
+extern "C" {
+
+int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                           uint32_t *records, uint16_t *masked, uint64_t *status) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (B == 0) return HRX_OK;
+    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (int rc = check_host_shape(B, M)) return rc;
+    if (use_host_walk(ctx, B, M)) {   // re-entrant: reads the context's tables only
+        for (size_t b = 0; b < B; ++b)
+            if (lens[b] <= M && lens[b] > stride) return fail(HRX_ERR_ARG, "a string is longer than the stride");
+        // one host thread per ~8192 witness rows (~100 us of walk; a thread costs ~30 us to start), up to the machine's cores: a host-only
+        // context walks 4096 x 1024 rows on a 256-core host in ~0.3 ms instead of 15 (NOTES_MEASUREMENTS.md §7c)
+        const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+        const size_t want = std::max<size_t>(1, B * M / 8192);
+        host_witness_batch(ctx->s, chars, stride, lens, B, M, records, masked, status, (int)std::min(want, hw));
+        return HRX_OK;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    return batch_host_locked(ctx, chars, stride, lens, B, M, records, masked, status);
+}
+
+/* ------------------------------ multi-GPU driver ------------------------------ */
+
+struct hrx_multi {
+    std::vector<hrx_ctx *> ctxs;   // one per shard, in shard order
+    size_t D = 0;
+};
+
+int hrx_multi_create(const hrx_defs *defs, const int *devices, int n_devices, hrx_multi **out) {
+    if (!defs || !devices || !out || n_devices < 1) return fail(HRX_ERR_ARG, "NULL argument or no device");
+    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
+    hrx_multi *m = new hrx_multi();
+    m->D = defs->s.defs.size();
+    for (int i = 0; i < n_devices; ++i) {
+        hrx_ctx *c = nullptr;
+        const int rc = hrx_ctx_create(defs, devices[i], &c);   // restores the caller's current device itself
+        if (rc != HRX_OK) {
+            hrx_multi_destroy(m);
+            return rc;
+        }
+        m->ctxs.push_back(c);
+    }
+    *out = m;
+    return HRX_OK;
+}
+
+void hrx_multi_destroy(hrx_multi *m) {
+    if (!m) return;
+    for (hrx_ctx *c : m->ctxs) hrx_ctx_destroy(c);
+    delete m;
+}
+
+int hrx_multi_num_shards(const hrx_multi *m) { return m ? (int)m->ctxs.size() : 0; }
+int hrx_multi_shard_device(const hrx_multi *m, int shard) { return m && shard >= 0 && shard < (int)m->ctxs.size() ? m->ctxs[(size_t)shard]->device : HRX_DEVICE_NONE; }
+void *hrx_multi_shard_stream(const hrx_multi *m, int shard) { return m && shard >= 0 && shard < (int)m->ctxs.size() ? (void *)m->ctxs[(size_t)shard]->stream : nullptr; }
+
+int hrx_multi_witness_batch_host(hrx_multi *m, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
+                                 uint32_t *records, uint16_t *masked, uint64_t *status) {
+    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
+    if (B == 0) return HRX_OK;
+    if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
+    const int world = (int)m->ctxs.size();
+    std::vector<int> rc((size_t)world, HRX_OK);
+    std::vector<std::string> msg((size_t)world);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r) {
+        th.emplace_back([&, r] {
+            size_t begin = 0, count = 0;
+            hrx_shard_range(B, world, r, &begin, &count);
+            if (count == 0) return;
+            rc[(size_t)r] = hrx_witness_batch_host(m->ctxs[(size_t)r], chars + begin * stride, stride, lens + begin, count, M,
+                                                   records + begin * M * m->D, masked + begin * M, status + begin);
+            if (rc[(size_t)r] != HRX_OK) msg[(size_t)r] = hrx_last_error();   // thread-local: carry it to the caller's thread
+        });
+    }
+    for (std::thread &t : th) t.join();
+    for (int r = 0; r < world; ++r)
+        if (rc[(size_t)r] != HRX_OK) return fail(rc[(size_t)r], "shard " + std::to_string(r) + ": " + msg[(size_t)r]);
+    return HRX_OK;
+}
+
+int hrx_multi_witness_batch_device(hrx_multi *m, int layout, const uint8_t *const *chars, size_t stride, const uint32_t *const *lens,
+                                   const size_t *counts, size_t M, uint32_t *const *records, uint16_t *const *masked,
+                                   uint64_t *const *status) {
+    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
+    if (!chars || !lens || !counts || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL argument");
+    // one kernel per shard on the shard's own stream: the launches are asynchronous, so one host thread keeps all devices busy
+    for (size_t r = 0; r < m->ctxs.size(); ++r) {
+        if (counts[r] == 0) continue;
+        hrx_ctx *c = m->ctxs[r];
+        const int rc = hrx_witness_batch_device_layout(c, layout, chars[r], stride, lens[r], counts[r], M, records[r], masked[r], status[r],
+                                                       (void *)c->stream);
+        if (rc != HRX_OK) return fail(rc, "shard " + std::to_string(r) + ": " + std::string(hrx_last_error()));
+    }
+    return HRX_OK;
+}
+
+int hrx_multi_synchronize(hrx_multi *m) {
+    if (!m) return fail(HRX_ERR_ARG, "NULL handle");
+    for (hrx_ctx *c : m->ctxs) {
+        if (c->device == HRX_DEVICE_NONE) continue;
+        DeviceGuard guard;
+        HIP_TRY(guard.set(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return HRX_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,560 @@
+// hrx_place_api.cpp — the C ABI's placement-aware output allocation (hrx_alloc_output_pair, hrx_alloc_outputs_position_major, hrx_alloc_output_planes, hrx_device_free, hrx_probe_write_pair,
+// hrx_ctx_set_placement, hrx_alloc_last_report) and the roofline diagnostics that share its measuring kernels (hrx_traffic_pass_device*: csrc/hrx_place.hip).  DESIGN.md §6.
+#include "hrx_ctx.hpp"
+#include "hrx_arena_alloc.hpp"
+#include "hrx_place_rule.hpp"
+
+using namespace hrx;
+
+extern "C" {
+
+// Placement-aware allocation of the two output buffers (hrx_place.hip).
+//
+// Device memory is handed out top-down, so whatever a process allocates next lands right below what it allocated last — in
+// the same class of the physical address space, where the launch's two write streams collide.  The search WALKS down the
+// device memory instead and measures, with the two-stream probe, what lies there against where the records are:
+//   * records >= kPlaceDirectFrom (1 GiB): masked-row candidates are allocated one after the other, each is measured against
+//     the records buffer itself, and a rejected candidate stays allocated as the spacer that pushes the next one further
+//     (round 2's scheme, now bounded by a budget and a relative acceptance rule);
+//   * smaller records (the bench line's 256 MiB): buffers of that size live in the reach of the 256-MB Infinity Cache — a
+//     probe over them measures the cache — and the driver's buddy allocator puts small blocks into whatever hole is highest,
+//     not below the previous allocation.  They are therefore carved out of ARENAS: two 2-GiB blocks per context, one for
+//     records and one for masked rows, the second found by walking 2-GiB blocks down the memory and measuring each, whole,
+//     against the first (2 GiB per probe pass: the HBM regime).  Later requests are served from the same measured pair until
+//     it is full; hrx_device_free returns a sub-buffer to its arena, and an arena is released when its last sub-buffer is
+//     (and the context has moved on to another pair or is gone).
+// Reference time: the same probe over two parts of ONE block (the records arena, or the records buffer): what two streams in
+// one neighbourhood cost on this box.  A candidate is accepted when it is faster than that by kPlaceMargin — no absolute
+// threshold (round 2's 6.9 TB/s did not hold on every box); failing that the fastest measured candidate is kept.  Spacers and
+// rejected candidates are freed before the call returns.  The walk never takes more than kPlaceBudgetFrac of the free memory.
+constexpr size_t kPlaceFromBytes = (size_t)128 << 20;    // below this the whole launch lives in the Infinity Cache: plain allocations
+constexpr size_t kPlaceDirectFrom = (size_t)1 << 30;
+constexpr size_t kPlaceArenaBytes = (size_t)2 << 30, kPlaceArenaAlign = (size_t)2 << 20;
+constexpr double kPlaceBudgetFrac = 0.70;   // (the acceptance rule and its margins: hrx_place_rule.hpp)
+
+struct hrx_place_arena {
+    void *base = nullptr;
+    int device = 0;
+    hrx::ArenaRanges ranges;   // which offsets are handed out (first fit, freed ranges merge: hrx_arena_alloc.hpp) — an alloc / free churn is served from one pair for ever
+    bool retired = false;      // no context serves requests from it any more: released with its last sub-buffer
+};
+static std::mutex g_arena_mu;
+static std::map<uintptr_t, hrx_place_arena *> g_arena_of;   // sub-buffer -> arena (hrx_device_free has no context argument)
+
+// ranges / retired of an arena are only ever touched under g_arena_mu: hrx_device_free (any thread, no context argument — e.g. a finalizer
+// while another thread allocates) releases sub-buffers concurrently with the owning context's takes.
+static inline size_t arena_need(size_t bytes) { return (bytes + kPlaceArenaAlign - 1) / kPlaceArenaAlign * kPlaceArenaAlign; }
+// a records and a masked-row sub-buffer out of the pair, or neither: the capacity check and both takes are ONE critical section
+static bool arena_take_pair(hrx_place_arena *ra, size_t r_bytes, hrx_place_arena *ma, size_t m_bytes, void **r, void **m) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    if (!ra->ranges.fits(arena_need(r_bytes)) || !ma->ranges.fits(arena_need(m_bytes))) return false;
+    const size_t ro = ra->ranges.take(arena_need(r_bytes)), mo = ma->ranges.take(arena_need(m_bytes));
+    *r = (unsigned char *)ra->base + ro;
+    *m = (unsigned char *)ma->base + mo;
+    g_arena_of[(uintptr_t)*r] = ra;
+    g_arena_of[(uintptr_t)*m] = ma;
+    return true;
+}
+}  // extern "C"
+void arena_retire(hrx_place_arena *a) {
+    if (!a) return;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    a->retired = true;
+    if (a->ranges.live() == 0) { (void)hipFree(a->base); delete a; }
+}
+extern "C" {
+// true if ptr was a sub-buffer of an arena (and has been returned to it).  hipFree waits for the device before it releases memory, and callers rely on that
+// (a buffer may be freed while the launch that writes it is still in flight; the Python wrapper's finalizers do).  A range handed back to an arena is reusable at
+// once — by another context, thread and stream — so the release waits for the arena's device first, exactly like the plain allocations' hipFree below 128 MiB:
+// the same caller code is safe whatever the buffer size (tests: test_arena_free_waits_for_the_device).
+static bool arena_release(void *ptr) {
+    int device = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        auto it = g_arena_of.find((uintptr_t)ptr);
+        if (it == g_arena_of.end()) return false;
+        device = it->second->device;
+    }
+    {   // (outside the arena mutex: other threads keep allocating while this one waits; ptr is the caller's until the give below)
+        DeviceGuard guard;
+        if (guard.set(device) == hipSuccess) (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arena_of.find((uintptr_t)ptr);
+    if (it == g_arena_of.end()) return true;    // (released by a concurrent call with the same pointer: a double free; nothing left to do)
+    hrx_place_arena *a = it->second;
+    g_arena_of.erase(it);
+    a->ranges.give((size_t)((unsigned char *)ptr - (unsigned char *)a->base));
+    if (a->ranges.live() == 0 && a->retired) { (void)hipFree(a->base); delete a; }
+    return true;
+}
+
+// One measured arena pair per DEVICE and process, not per context: a prover that keeps one context per worker thread (a context serves one stream at a time)
+// would otherwise walk once per context and hold 4 GiB of arenas in each.  mu serialises the walks and the replacement of a full pair; it is taken after the
+// context's own mutex and before g_arena_mu (hrx_device_free takes only the latter).
+struct hrx_place_pool {
+    std::mutex mu;
+    hrx_place_arena *rec = nullptr, *msk = nullptr;
+    hrx_place_report report{};     // of the walk that found the pair
+    double seen_rate[HRX_MAX_DEFS + 1] = {};   // per number of defs D (the probe writes its two streams in the launch's ratio 4 D : 2, so rates of different D do not compare):
+                                               // the fastest pairing any arena walk on this device has probed (bytes per microsecond)
+    int users = 0;                 // live contexts of the device (under g_arena_mu)
+};
+static std::map<int, hrx_place_pool *> g_pools;   // under g_arena_mu; entries are never removed (a few dozen bytes per device)
+}  // extern "C"
+hrx_place_pool *pool_acquire(int device) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    hrx_place_pool *&p = g_pools[device];
+    if (!p) p = new hrx_place_pool();
+    ++p->users;
+    return p;
+}
+extern "C" {
+}  // extern "C"
+void pool_release(hrx_place_pool *p) {
+    if (!p) return;
+    hrx_place_arena *r = nullptr, *m = nullptr;
+    {
+        std::lock_guard<std::mutex> pl(p->mu);
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        if (--p->users == 0) { r = p->rec; m = p->msk; p->rec = p->msk = nullptr; for (double &v : p->seen_rate) v = 0.0; p->report = hrx_place_report{}; }
+    }
+    arena_retire(r); arena_retire(m);
+}
+extern "C" {
+
+static void place_trace(const hrx_ctx *ctx, const char *fmt, ...) {
+    if (!ctx->place_trace) return;
+    va_list ap;
+    va_start(ap, fmt);
+    std::vfprintf(stderr, fmt, ap);
+    va_end(ap);
+}
+
+// The walk.  A: the block everything is measured against (a_bytes), cand_bytes: the size of the blocks to walk with.  Returns the
+// kept candidate (NULL: none could be allocated); everything else it allocated is freed.
+static void *place_walk(hrx_ctx *ctx, void *A, size_t a_bytes, size_t cand_bytes, const bool arena_walk, const double seen_before, hrx_place_report &rep, double *best_rate_out) {
+    const uint32_t D = (uint32_t)ctx->s.defs.size();
+    unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);   // 16 bytes of the context's 64-byte scratch word area
+    size_t free_b = 0, total_b = 0;
+    *best_rate_out = 0.0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    // never more than kPlaceBudgetFrac of what is free NOW.  The 2-GiB arena candidates of bench-sized outputs: 24 of them (48 GiB) as a rule — several contexts
+    // or ranks on one device walk at the same time without pushing each other out of memory — and on only while NOTHING clearly above the same-block reference
+    // has turned up (one lease of round 4: 24 candidates between 5.6 and 6.07 TB/s against a reference of 5.9, the bench line at 0.722 instead of 0.76; round 3's
+    // unbounded walk had found a clear partner on every lease, up to ~100 candidates down), re-reading the free memory at every further step.
+    // (arena_walk is the caller's statement, not inferred from the size: a direct walk whose masked buffer happens to measure 2 GiB — 1048576 x 1024 rows — keeps
+    // the direct walk's caps.)  hrx_ctx_set_placement narrows the budget and adds a time cap; rep.capped says which bound ended the walk.
+    size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac);
+    if (ctx->place_max_bytes) budget = std::min(budget, ctx->place_max_bytes);
+    const int max_steps = arena_walk && !ctx->place_max_steps_set ? std::max(ctx->place_max_steps, hrx::kPlaceArenaHardSteps) : ctx->place_max_steps;
+    rep.searched = 1;
+    double ref_rate = 0.0;   // bytes per microsecond
+    {   // the reference: both streams inside ONE block, in the launch's byte ratio (4 D : 2)
+        const size_t a_rec = a_bytes / (4 * D + 2) * (4 * D) / 4096 * 4096;
+        size_t wrote = 0;
+        rep.ref_us = hrx::placement_probe_us(A, a_rec, (unsigned char *)A + a_rec, a_bytes - a_rec, D, ctx->stream, clk, &wrote);
+        if (rep.ref_us > 0) ref_rate = (double)wrote / rep.ref_us;
+        rep.ref_gbs = ref_rate * 1e-3;
+    }
+    std::vector<void *> spacers;       // rejected candidates: they are what pushes the next candidate further down
+    void *best = nullptr;
+    size_t spent = 0;
+    double best_us = -1.0;
+    hrx::PlaceWalk walk;               // the rates measured and when to stop: hrx_place_rule.hpp
+    walk.ref_rate = ref_rate;
+    walk.seen_before = seen_before;    // the fastest pairing earlier walks of the same kind measured (direct: this context's; arena: this device's)
+    walk.arena = arena_walk;
+    const auto t_walk = std::chrono::steady_clock::now();
+    int i = 0;
+    bool ended_by_rule = false;
+    for (; i < max_steps; ++i) {
+        if (spent + cand_bytes > budget) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
+        if (!walk.may_take_another()) { ended_by_rule = true; break; }   // the arena soft cap: something clear of the reference is in hand
+        if (arena_walk && i >= hrx::kPlaceArenaSoftSteps) {     // beyond it: leave other walkers / contexts of this device their share
+            size_t f2 = 0, t2 = 0;
+            if (hipMemGetInfo(&f2, &t2) != hipSuccess) { (void)hipGetLastError(); rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
+            if ((double)f2 < (1.0 - kPlaceBudgetFrac) * (double)t2) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
+        }
+        void *cand = nullptr;
+        if (hipMalloc(&cand, cand_bytes) != hipSuccess) { (void)hipGetLastError(); rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
+        spent += cand_bytes;
+        rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
+        const double us = hrx::placement_probe_us(A, a_bytes, cand, cand_bytes, D, ctx->stream, clk, &rep.probe_bytes);
+        const double rate = us > 0 ? (double)rep.probe_bytes / us : 0.0;
+        place_trace(ctx, "hrx placement: step %d candidate %p: %.1f us = %.2f TB/s, reference %.2f TB/s, %.1f ms into the walk\n", i, cand, us, rate * 1e-6, ref_rate * 1e-6,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count());
+        ++rep.steps;
+        if (i == 0) { rep.first_us = us; rep.first_gbs = rate * 1e-3; }
+        const bool better = us >= 0 && (best_us < 0 || us < best_us);
+        void *loser = better ? best : cand;
+        if (better) { best = cand; best_us = us; rep.chosen_step = i; }
+        if (loser) spacers.push_back(loser);
+        walk.rates.push_back(rate);
+        const double elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_walk).count();
+        const hrx::PlaceVerdict v = walk.decide(elapsed_ms);
+        if (v == hrx::PlaceVerdict::accept) { rep.accepted = 1; ended_by_rule = true; break; }
+        if (v == hrx::PlaceVerdict::settle) {
+            rep.accepted = walk.clear_of_reference() ? 1 : 0; ended_by_rule = true;
+            if (elapsed_ms > (arena_walk ? hrx::kPlaceArenaHardMs : hrx::kPlaceHardMs)) rep.capped |= HRX_PLACE_CAPPED_TIME;   // the rule's own hard bound: whatever it holds
+            break;
+        }
+        if (ctx->place_max_ms > 0 && elapsed_ms > ctx->place_max_ms) { rep.capped |= HRX_PLACE_CAPPED_TIME; break; }   // the caller's bound (hrx_ctx_set_placement)
+    }
+    if (i >= max_steps && !ended_by_rule) rep.capped |= HRX_PLACE_CAPPED_STEPS;
+    const double best_rate = walk.best();
+    *best_rate_out = best_rate;
+    if (!rep.accepted && walk.clear_of_reference()) rep.accepted = 1;   // (a walk that ran into a cap with a pairing >= 10 % above the reference in hand)
+    for (void *p : spacers) (void)hipFree(p);
+    rep.best_us = best_us;
+    rep.best_gbs = best_rate * 1e-3;
+    place_trace(ctx, "hrx placement: kept step %d (%.1f us vs reference %.1f us, %s), %d steps\n", rep.chosen_step, best_us, rep.ref_us,
+                rep.accepted ? "accepted" : "fastest measured", rep.steps);
+    return best;
+}
+
+int hrx_alloc_output_pair(hrx_ctx *ctx, size_t records_bytes, size_t masked_bytes, void **records, void **masked) {
+    if (!ctx || !records || !masked || records_bytes == 0 || masked_bytes == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_pair: bad argument");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
+    *records = nullptr; *masked = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    hrx_place_report rep{};
+    auto done = [&](void *r, void *m) -> int {
+        *records = r; *masked = m;
+        rep.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        ctx->last_place = rep;
+        return HRX_OK;
+    };
+    auto plain = [&]() -> int {
+        void *r = nullptr, *m = nullptr;
+        if (hipMalloc(&r, records_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
+        if (hipMalloc(&m, masked_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(r); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
+        return done(r, m);
+    };
+    if (records_bytes < kPlaceFromBytes || !ctx->place_enabled) return plain();
+    if (records_bytes >= kPlaceDirectFrom) {
+        // ---- large outputs: candidates measured against the records buffer itself
+        // (Round 5 also walked the RECORDS side — against one 12-GiB records buffer of cfg 4 all 48 masked-row candidates measure 6.4-6.8 TB/s, against the next one 5.8-6.3: where the records
+        // lie sets the level — trying up to three records buffers and keeping the best pair: the allocation churn of 12-GiB spacers brought multi-second hipMalloc stalls (search_ms 3-4 s per
+        // buffer set) and the launches did not follow the probe level closely enough to pay for it — cfg 4 at 0.655 with all three sets at 6.6-6.75.  Not kept.)
+        void *rec = nullptr;
+        if (hipMalloc(&rec, records_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
+        double walked_best = 0.0;
+        void *best = place_walk(ctx, rec, records_bytes, masked_bytes, /*arena_walk=*/false, ctx->place_seen_rate, rep, &walked_best);
+        ctx->place_seen_rate = std::max(ctx->place_seen_rate, walked_best);
+        if (!best && hipMalloc(&best, masked_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(rec); return fail(HRX_ERR_HIP, "hrx_alloc_output_pair: out of device memory"); }
+        return done(rec, best);
+    }
+    // ---- bench-sized outputs: sub-buffers of the device's measured arena pair
+    if (records_bytes > kPlaceArenaBytes || masked_bytes > kPlaceArenaBytes) return plain();
+    hrx_place_pool *pool = ctx->pool;
+    std::lock_guard<std::mutex> pl(pool->mu);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (pool->rec && pool->msk) {
+            void *r = nullptr, *m = nullptr;
+            if (arena_take_pair(pool->rec, records_bytes, pool->msk, masked_bytes, &r, &m)) {
+                if (attempt == 0) { rep = pool->report; rep.searched = 2; }   // served from the pair an earlier call (of any context of the device) measured
+                return done(r, m);
+            }
+            arena_retire(pool->rec); arena_retire(pool->msk);     // full: a new pair
+            pool->rec = pool->msk = nullptr;
+        }
+        void *A = nullptr;
+        if (hipMalloc(&A, kPlaceArenaBytes) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+        // (the arena walks' own best rate per device and D: a direct walk's rate over other buffer sizes is not comparable — copied in here it could keep the accept
+        // rule `b >= 0.96 seen()` from ever firing and every replacement pair walking to its caps with the pool mutex held)
+        double &pool_seen = pool->seen_rate[std::min<size_t>(ctx->s.defs.size(), HRX_MAX_DEFS)];
+        double walked_best = 0.0;
+        void *X = place_walk(ctx, A, kPlaceArenaBytes, kPlaceArenaBytes, /*arena_walk=*/true, pool_seen, rep, &walked_best);
+        pool_seen = std::max(pool_seen, walked_best);
+        if (!X) { (void)hipFree(A); rep = hrx_place_report{}; return plain(); }
+        pool->rec = new hrx_place_arena(); pool->rec->base = A; pool->rec->device = ctx->device; pool->rec->ranges.reset(kPlaceArenaBytes);
+        pool->msk = new hrx_place_arena(); pool->msk->base = X; pool->msk->device = ctx->device; pool->msk->ranges.reset(kPlaceArenaBytes);
+        pool->report = rep;
+    }
+    return plain();
+}
+
+int hrx_ctx_set_placement(hrx_ctx *ctx, int mode, size_t max_bytes, double max_ms) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (mode != HRX_PLACE_OFF && mode != HRX_PLACE_WALK) return fail(HRX_ERR_ARG, "hrx_ctx_set_placement: mode must be HRX_PLACE_OFF or HRX_PLACE_WALK");
+    if (max_ms < 0) return fail(HRX_ERR_ARG, "hrx_ctx_set_placement: max_ms < 0");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->place_enabled = mode == HRX_PLACE_WALK;
+    ctx->place_max_bytes = max_bytes;
+    ctx->place_max_ms = max_ms;
+    return HRX_OK;
+}
+
+int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out) {
+    if (!ctx || !out) return fail(HRX_ERR_ARG, "NULL argument");
+    *out = ctx->last_place;
+    return HRX_OK;
+}
+
+int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, uint16_t *masked, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
+    if (B == 0) return HRX_OK;
+    if (!chars || !records || !masked) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)records & 15) || ((uintptr_t)masked & 15))
+        return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    // the store policy the planner gives the real launch of this shape
+    WitnessArgs a{};
+    a.layout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)ctx->s.defs.size();
+    LaunchInfo li{};
+    li.split = 2;
+    const uint32_t nt_mix = plan_nt_mix(a, li);
+    HIP_TRY(launch_traffic_pass(chars, stride, B, M, a.D, records, masked, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream));
+    return HRX_OK;
+}
+
+int hrx_traffic_pass_device_layout(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, size_t rec_pitch,
+                                   uint16_t *masked, size_t msk_pitch, void *stream) {
+    if (layout == (HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR)) return hrx_traffic_pass_device(ctx, chars, stride, B, M, records, masked, stream);
+    if (layout != HRX_LAYOUT_STRING_MAJOR) return fail(HRX_ERR_ARG, "hrx_traffic_pass_device_layout: HRX_LAYOUT_STRING_MAJOR or HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR");
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
+    if (B == 0) return HRX_OK;
+    if (!chars || !records || !masked) return fail(HRX_ERR_ARG, "NULL buffer");
+    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
+    if (rec_pitch == 0) rec_pitch = M;
+    if (msk_pitch == 0) msk_pitch = M;
+    const size_t D = ctx->s.defs.size();
+    if (rec_pitch < M || msk_pitch < M || (M % 8) || (rec_pitch % 4) || (msk_pitch % 8) || rec_pitch > 0xffffffffull || msk_pitch > 0xffffffffull)
+        return fail(HRX_ERR_ARG, "string-major traffic pass: M % 8 == 0, pitches >= M in multiples of 4 / 8 rows");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)records & 15) || ((uintptr_t)masked & 15))
+        return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    WitnessArgs a{};
+    a.layout = HRX_LAYOUT_STRING_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)D;
+    LaunchInfo li{};
+    li.split = 1;
+    const uint32_t nt_mix = plan_nt_mix(a, li);
+    HIP_TRY(launch_traffic_pass_sm(chars, stride, B, M, (uint32_t)D, records, rec_pitch, masked, msk_pitch, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream));
+    return HRX_OK;
+}
+
+int hrx_traffic_pass_device_planes(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *const *record_planes, size_t n_planes,
+                                   uint16_t *masked, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
+    if (B == 0) return HRX_OK;
+    if (!chars || !record_planes || !masked || n_planes != ctx->s.defs.size() || n_planes > kMaxDefsPerLaunch) return fail(HRX_ERR_ARG, "NULL buffer, or not one plane per def (at most eight)");
+    if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)masked & 15)) return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
+    for (size_t d = 0; d < n_planes; ++d)
+        if (!record_planes[d] || ((uintptr_t)record_planes[d] & 15)) return fail(HRX_ERR_ARG, "record planes must be 16-byte aligned device buffers");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    WitnessArgs a{};
+    a.layout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)n_planes;
+    LaunchInfo li{};
+    li.split = 2;
+    const uint32_t nt_mix = plan_nt_mix(a, li);
+    HIP_TRY(launch_traffic_pass(chars, stride, B, M, a.D, record_planes[0], masked, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream, record_planes));
+    return HRX_OK;
+}
+
+int hrx_probe_write_pair(hrx_ctx *ctx, void *a, void *b, size_t bytes, double *gbs) {
+    if (!ctx || !a || !b || !gbs || bytes < ((size_t)32 << 20)) return fail(HRX_ERR_ARG, "hrx_probe_write_pair: two device buffers of at least 32 MiB each");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to measure on");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    size_t wrote = 0;
+    const double us = hrx::placement_probe_us(a, bytes, b, bytes, 0u, ctx->stream, (unsigned long long *)(ctx->d_group_counter + 4), &wrote);
+    if (us <= 0) return fail(HRX_ERR_HIP, "hrx_probe_write_pair: the probe launch failed");
+    *gbs = (double)wrote / us * 1e-3;
+    return HRX_OK;
+}
+
+// Record planes + masked rows, each in a neighbourhood of its own: the launch's D + 1 write streams spread over the classes of the physical address space instead of 4 D of
+// its 4 D + 2 bytes per row going into one allocation.  A POOL of candidates — D + kPlanesSpare plane-sized buffers, kPlanesMasked masked-row-sized ones, allocated one after the other (they
+// walk down the device memory) — is measured pair by pair with the two-equal-streams probe (~1 ms per pair on the device clock), and the D planes + masked buffer whose BUSIEST CLASS takes
+// the smallest share of the launch's output bytes (then: the fewest colliding pairings, the largest sum of pairings) are kept; the rest is freed before the call returns.  No absolute threshold: pairings in one class measure 5.2-6.2 TB/s, across classes 6.5-7.3
+// (profiles/r06_probes/plane_probe.txt, plane_select_cfg4.txt), and both levels move with the box: "colliding" = below the midpoint of the two levels of THIS pool.  Random draws of three 4-GiB planes + masked rows already run cfg 4's no-compute pass at 0.86 of peak in 54 of 60
+// cases, against 0.65 for three planes of one class and 0.74-0.77 for the interleaved buffer: the selection only has to avoid the draws that collide.
+constexpr size_t kPlanesSpare = 4, kPlanesMasked = 5, kPlanesGrow = 3, kPlanesMaxSets = 4096;
+int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_planes, uint16_t **masked) {
+    if (!ctx || !record_planes || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes: bad argument");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
+    const size_t D = ctx->s.defs.size();
+    if (D == 1) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
+    size_t plane_u32 = 0, masked_u16 = 0;
+    hrx_position_major_plane_sizes(B, M, &plane_u32, &masked_u16);
+    const size_t plane_bytes = plane_u32 * 4, masked_bytes = masked_u16 * 2;
+    for (size_t d = 0; d < D; ++d) record_planes[d] = nullptr;
+    *masked = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    hrx_place_report rep{};
+    std::vector<void *> pc, mc;     // plane and masked-row candidates
+    auto free_all = [&]() { for (void *p : pc) (void)hipFree(p); for (void *p : mc) (void)hipFree(p); pc.clear(); mc.clear(); };
+    const bool walk = ctx->place_enabled && plane_bytes >= kPlaceFromBytes;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac), spent = 0;
+    if (ctx->place_max_bytes) budget = std::min(budget, ctx->place_max_bytes);
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    auto take = [&](std::vector<void *> &v, size_t bytes, size_t must, size_t want) -> bool {      // `must` buffers or failure; up to `want` while memory and time allow
+        while (v.size() < want) {
+            const bool extra = v.size() >= must;
+            if (extra && (spent + bytes > budget)) { rep.capped |= HRX_PLACE_CAPPED_BYTES; break; }
+            if (extra && ctx->place_max_ms > 0 && elapsed_ms() > ctx->place_max_ms) { rep.capped |= HRX_PLACE_CAPPED_TIME; break; }
+            void *p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                if (extra) { rep.capped |= HRX_PLACE_CAPPED_ALLOC; break; }
+                return false;
+            }
+            v.push_back(p);
+            spent += bytes;
+        }
+        rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
+        return true;
+    };
+    if (!take(pc, plane_bytes, D, walk ? D + kPlanesSpare : D) || !take(mc, masked_bytes, 1, walk ? kPlanesMasked : 1)) {
+        free_all();
+        return fail(HRX_ERR_HIP, "hrx_alloc_output_planes: out of device memory");
+    }
+    std::vector<size_t> pick(D);
+    for (size_t d = 0; d < D; ++d) pick[d] = d;
+    size_t pick_m = 0;
+    if (walk && (pc.size() > D || mc.size() > 1)) {
+        rep.searched = 1;
+        unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);
+        std::vector<std::vector<double>> pp, pm;       // bytes per microsecond of every pairing measured so far: plane x plane, masked x plane
+        auto probe = [&](void *x, void *y, size_t bytes) {
+            size_t wrote = 0;
+            const double us = hrx::placement_probe_us(x, bytes, y, bytes, 0u, ctx->stream, clk, &wrote);
+            rep.probe_bytes = wrote;
+            ++rep.steps;
+            return us > 0 ? (double)wrote / us : 0.0;
+        };
+        double lo = 0, hi = 0, cut = 0, first_low = -1.0, first_sum = 0.0;
+        size_t best_low = ~(size_t)0, best_load = ~(size_t)0;
+        double best_sum = -1.0, best_min = 0.0;
+        for (int round = 0;; ++round) {
+            // ---- measure the pairings of the candidates that are new in this round
+            const size_t P = pc.size(), Q = mc.size(), P0 = pp.size();
+            pp.resize(P);
+            for (auto &r : pp) r.resize(P, 0.0);
+            pm.resize(Q);
+            for (auto &r : pm) r.resize(P, 0.0);
+            for (size_t i = 0; i < P; ++i)
+                for (size_t j = std::max(i + 1, P0); j < P; ++j) pp[i][j] = pp[j][i] = probe(pc[i], pc[j], plane_bytes);
+            for (size_t q = 0; q < Q; ++q)
+                for (size_t i = (round == 0 ? 0 : P0); i < P; ++i) pm[q][i] = probe(mc[q], pc[i], std::min(masked_bytes, plane_bytes));
+            // ---- two levels: pairings in one class of the address space and pairings across classes.  cut = halfway between the levels' means (two-means from the range's middle)
+            std::vector<double> all;
+            for (size_t i = 0; i < P; ++i) for (size_t j = i + 1; j < P; ++j) all.push_back(pp[i][j]);
+            for (size_t q = 0; q < Q; ++q) for (size_t i = 0; i < P; ++i) all.push_back(pm[q][i]);
+            lo = *std::min_element(all.begin(), all.end());
+            hi = *std::max_element(all.begin(), all.end());
+            cut = 0.5 * (lo + hi);
+            for (int it = 0; it < 8; ++it) {
+                double sl = 0, sh = 0; size_t nl = 0, nh = 0;
+                for (double v : all) { if (v < cut) { sl += v; ++nl; } else { sh += v; ++nh; } }
+                if (!nl || !nh) break;
+                cut = 0.5 * (sl / nl + sh / nh);
+            }
+            cut = std::max(cut, 0.88 * hi);     // (one stalled probe — 4.3 TB/s among 5.7 .. 7.3 on one lease — must not drag the cut below the colliding level: pairings across
+                                                //  classes lie within ~10 % of the fastest one)
+            if (hi < 1.08 * lo) cut = 0.0;      // every pairing measures alike: nothing collides (or everything does) — then only the sums rank
+            if (ctx->place_trace) {
+                for (size_t i = P0; i < P; ++i) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pp[i][j] * 1e-3)); place_trace(ctx, "hrx planes: plane candidate %zu %p vs planes (GB/s):%s\n", i, pc[i], l.c_str()); }
+                for (size_t q = 0; q < Q; ++q) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pm[q][j] * 1e-3)); place_trace(ctx, "hrx planes: masked candidate %zu %p vs planes (GB/s):%s\n", q, mc[q], l.c_str()); }
+            }
+            // ---- every D-subset of the plane candidates x every masked candidate: fewest colliding pairings, then the largest sum.  (What the launch time follows, cfg 4 over all
+            // 224 sets of 8 + 4 candidates, profiles/r06_probes/plane_select_cfg4.txt: sets with at most one colliding pairing 2.50-2.53 ms, three — two planes and the masked rows in one
+            // class — 2.64-2.88, all six 3.4-3.8; the slowest pairing alone does not tell these apart.)
+            // The score of a set: the largest share of the launch's output bytes that lands in one class — per buffer its own bytes per row (4 per plane, 2 for the masked rows)
+            // plus those of every buffer it collides with, the maximum over the buffers — then the number of colliding pairings, then the sum of the pairings' rates.  cfg 3 over all 60
+            // sets of 6 + 4 candidates (plane_select_cfg3.txt): nothing collides (largest share 4 of 10 bytes) 3.53 ms; the masked rows with a plane (6 of 10) 3.67-3.77; the two
+            // planes with each other (8 of 10) 3.87-3.89; everything (10 of 10) 4.57-4.69 — the count of colliding pairings alone ranks the second and the third alike.
+            std::vector<size_t> idx(D);
+            for (size_t d = 0; d < D; ++d) idx[d] = d;
+            best_low = ~(size_t)0; best_sum = -1.0; best_load = ~(size_t)0;
+            size_t sets = 0;
+            for (;;) {
+                for (size_t q = 0; q < Q; ++q) {
+                    double mn = 1e30, sum = 0.0; size_t low = 0, load_m = 2, load_max = 0;
+                    for (size_t x = 0; x < D; ++x) {
+                        size_t load_x = 4;
+                        for (size_t y = 0; y < D; ++y) {
+                            if (y == x) continue;
+                            const double v = pp[idx[x]][idx[y]];
+                            if (v < cut) load_x += 4;
+                            if (y > x) { mn = std::min(mn, v); sum += v; low += v < cut; }
+                        }
+                        const double v = pm[q][idx[x]]; mn = std::min(mn, v); sum += v; low += v < cut;
+                        if (v < cut) { load_x += 2; load_m += 4; }
+                        load_max = std::max(load_max, load_x);
+                    }
+                    load_max = std::max(load_max, load_m);
+                    if (first_low < 0) { first_low = (double)low; first_sum = sum; rep.first_gbs = mn * 1e-3; }      // candidates 0 .. D - 1 + masked candidate 0: the plain-allocation draw
+                    if (load_max < best_load || (load_max == best_load && (low < best_low || (low == best_low && sum > best_sum)))) {
+                        best_load = load_max; best_low = low; best_sum = sum; best_min = mn; pick = idx; pick_m = q;
+                    }
+                }
+                if (++sets >= kPlanesMaxSets) break;      // (more than three defs: the first sets in allocation order)
+                size_t k = D;       // next combination
+                while (k > 0 && idx[k - 1] == P - D + k - 1) --k;
+                if (k == 0) break;
+                ++idx[k - 1];
+                for (size_t x = k; x < D; ++x) idx[x] = idx[x - 1] + 1;
+            }
+            place_trace(ctx, "hrx planes: round %d, %zu + %zu candidates: pairings %.2f .. %.2f TB/s, cut %.2f; best set: busiest class %zu of %zu bytes per row, %zu colliding pairings, slowest %.2f TB/s\n",
+                        round, P, Q, lo * 1e-6, hi * 1e-6, cut * 1e-6, best_load, 4 * D + 2, best_low, best_min * 1e-6);
+            // ---- a set whose busiest class takes no more than a plane and the masked rows (6 bytes per row) is what there is to find with three planes; with two, one where nothing
+            // collides; otherwise walk further down the memory, once or twice
+            if (best_load <= (D == 2 ? 4u : 6u) || round >= 2) break;
+            const size_t before = pc.size();
+            if (!take(pc, plane_bytes, before, before + kPlanesGrow) || pc.size() == before) break;
+        }
+        (void)first_sum;
+        rep.ref_gbs = lo * 1e-3;           // the slowest pairing seen (hi is in the trace)
+        rep.best_gbs = best_min * 1e-3;    // the kept set's slowest pairing
+        rep.chosen_step = (int)best_load;  // ... and the output bytes per row (of 4 D + 2) that its busiest class takes
+        rep.accepted = (cut == 0.0 || best_load <= 6) ? 1 : 0;
+    }
+    for (size_t d = 0; d < D; ++d) { record_planes[d] = (uint32_t *)pc[pick[d]]; pc[pick[d]] = nullptr; }
+    *masked = (uint16_t *)mc[pick_m];
+    mc[pick_m] = nullptr;
+    for (void *&p : pc) if (p) { (void)hipFree(p); p = nullptr; }
+    for (void *&p : mc) if (p) { (void)hipFree(p); p = nullptr; }
+    rep.search_ms = elapsed_ms();
+    ctx->last_place = rep;
+    return HRX_OK;
+}
+
+int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked) {
+    if (!ctx || !records || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_outputs_position_major: bad argument");
+    size_t nr = 0, nm = 0;
+    hrx_position_major_sizes(B, M, ctx->s.defs.size(), &nr, &nm);
+    return hrx_alloc_output_pair(ctx, nr * 4, nm * 2, (void **)records, (void **)masked);
+}
+
+int hrx_device_free(void *ptr) {
+    if (!ptr) return HRX_OK;
+    if (arena_release(ptr)) return HRX_OK;   // a sub-buffer of a measured arena pair (hrx_alloc_output_pair)
+    HIP_TRY(hipFree(ptr));
+    return HRX_OK;
+}
+
+
+}  // extern "C"

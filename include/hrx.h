@@ -212,12 +212,16 @@ void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32,
 int hrx_witness_batch_device_planes(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                                     uint32_t *const *record_planes, size_t n_planes, uint16_t *masked, uint64_t *status, void *stream);
 void hrx_position_major_plane_sizes(size_t B, size_t M, size_t *plane_u32, size_t *masked_u16);
-/* The D planes and the masked rows of a batch of B strings x M rows, each allocated on ctx's device in a neighbourhood of its own: a pool of D + 4 plane-sized and 3
+/* The D planes and the masked rows of a batch of B strings x M rows, each allocated on ctx's device in a neighbourhood of its own: a pool of D + 4 plane-sized and 5
  * masked-row-sized candidates, allocated one after the other (they walk down the device memory), is measured pair by pair (two equal write streams, ~1 ms per pair on the
- * device clock) and the D planes + masked buffer whose slowest pairing is fastest are kept; everything else is freed before the call returns.  hrx_alloc_last_report: steps =
- * pairings measured, ref_gbs = the slowest pairing seen, first_gbs = the slowest pairing of the first D + 1 buffers (what plain allocations would have been), best_gbs = the
- * kept set's.  The pool never takes more than 70 % of the free memory (hrx_ctx_set_placement narrows that).  Planes below 128 MiB, HRX_PLACE_OFF: plain allocations.
- * record_planes: D pointers out; each buffer is released with hrx_device_free.  One def: hrx_alloc_outputs_position_major.  Takes the context's lock; not inside a stream capture. */
+ * device clock); pairings fall into two levels — both buffers in one class of the physical address space, or not — and the D planes + masked buffer whose busiest
+ * class takes the fewest of the launch's 4 D + 2 output bytes per row (4 per plane, 2 for the masked rows; then the fewest colliding pairings, the largest sum of
+ * pairings) are kept; a pool whose best set still puts more than 6 bytes per row (two defs: 4) into one class grows by three plane candidates, at most twice;
+ * everything else is freed before the call returns.  hrx_alloc_last_report: steps = pairings measured, ref_gbs = the slowest pairing seen, first_gbs = the slowest
+ * pairing of the first D + 1 buffers (what plain allocations would have been), best_gbs = the kept set's, chosen_step = the bytes per row of the kept set's busiest
+ * class, accepted = at most 6.  The pool never takes more than 70 % of the free memory (hrx_ctx_set_placement narrows that and bounds the time).  Planes below 128 MiB, HRX_PLACE_OFF: plain
+ * allocations.  record_planes: D pointers out; each buffer is released with hrx_device_free.  One def: hrx_alloc_outputs_position_major.  Takes the context's lock; not
+ * inside a stream capture. */
 int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_planes, uint16_t **masked);
 /* The allocator's measurement, for a caller that manages device memory itself (a prover with its own pool): two equal, time-aligned write streams over the first `bytes`
  * of device buffers a and b (both are OVERWRITTEN), *gbs = bytes written per time.  Pairings in one class of the physical address space measure 5.2-5.9 TB/s, in different

@@ -281,3 +281,19 @@ def test_batch_columns_are_what_match_substrs_assigns_per_circuit(oracle, names)
     assert np.array_equal(pmc, cols)
     with pytest.raises(hra.HrxError):
         hra.witness_columns_host(c2, l2, rec, msk, M, D, b_begin=140, b_count=20)
+
+
+def test_a_failed_clone_leaves_the_source_config_usable(oracle):
+    """RegexVerifyConfig.clone made its shallow copy BEFORE hrx_ctx_clone — a failing clone (no such device) left a copy that shared the source's context,
+    and the copy's finalizer destroyed it.  The source must keep working, and destroying it afterwards must be a single free."""
+    import gc
+    cfg = _cfg(CFG_1, 64)
+    with pytest.raises(hra.HrxError):
+        cfg.clone(device=99)
+    gc.collect()
+    r = cfg.match_substrs(b"email was meant for @y.")
+    assert bytes(r.masked_characters[21:22].astype(np.uint8)) == b"y"
+    c2 = cfg.clone()                      # a host-only clone of a host-only context
+    assert np.array_equal(c2.match_substrs(b"email was meant for @y.").masked_characters, r.masked_characters)
+    del cfg, c2
+    gc.collect()
