@@ -208,8 +208,15 @@ def verify_timed_buffers(o, hra, sets, shift, chars, lens, M, D, pm, dev, B, sb)
             nb = min(hra.PM_BLOCK, B - blk)
             for a in range(0, nb, step):
                 e = min(nb, a + step)
-                if pm and isinstance(rec, (list, tuple)):      # record planes: def d's plane is [q4][nb][4] per block
-                    r = torch.stack([p.view(-1)[blk * q4 * 4:][:q4 * nb * 4].view(q4, nb, 4)[:, a:e].permute(1, 0, 2).reshape(e - a, q4 * 4)[:, :M] for p in rec], dim=2)
+                if pm and isinstance(rec, (list, tuple)):      # record planes: def d's plane is [q4][nb][4] per block; one def in R row stripes: quad q in buffer q % R at slot q / R
+                    R = len(rec) // D
+                    slots = (q4 + R - 1) // R
+                    per_def = []
+                    for d_ in range(D):
+                        qs = [rec[r_ * D + d_].view(-1)[blk * slots * 4:][:slots * nb * 4].view(slots, nb, 4)[:, a:e] for r_ in range(R)]
+                        qq = qs[0] if R == 1 else torch.stack(qs, dim=1).reshape(slots * R, e - a, 4)[:q4]
+                        per_def.append(qq.permute(1, 0, 2).reshape(e - a, q4 * 4)[:, :M])
+                    r = torch.stack(per_def, dim=2)
                     m = msk.view(-1)[blk * q8 * 8:][:q8 * nb * 8].view(q8, nb, 8)[:, a:e].permute(1, 0, 2).reshape(e - a, q8 * 8)[:, :M]
                 elif pm:
                     r = rec.view(-1)[blk * q4 * D * 4:][:q4 * D * nb * 4].view(q4, D, nb, 4)[:, :, a:e].permute(2, 0, 3, 1).reshape(e - a, q4 * 4, D)[:, :M]
@@ -410,7 +417,7 @@ def run_rank(args, rank, world, device_index, barrier):
     else:
         b_begin, B = rank * args.batch, args.batch
     pm = args.layout == "position-major"
-    planes = bool(args.planes) and pm and D > 1
+    planes = bool(args.planes) and pm       # (one def: two row stripes)
     rec_pitch, msk_pitch, rec_stride = hra.recommended_pitches(M)
     if args.dense or pm:
         rec_pitch, msk_pitch, rec_stride = M, M, (max(n, 1) + 15) // 16 * 16
@@ -448,11 +455,11 @@ def run_rank(args, rank, world, device_index, barrier):
                     if keep_sm:
                         sm_sets.append(c_k.contiguous())          # the reference's input shape (one contiguous string per row): for roofline.from_string_major_input
                     c_k = hra.chars_to_position_major(c_k)       # [stride/16][B][16]: done once, outside the timed region
-                    out = cfg.alloc_output_planes(B, dev) if planes else cfg.alloc_outputs_position_major(B, dev)
+                    out = cfg.alloc_output_planes(B, dev, stripes=2 if D == 1 else None) if planes else cfg.alloc_outputs_position_major(B, dev)
                 else:
                     c_k = c_k.contiguous()
                     out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
-                rep = cfg.last_placement_report() if (out[0][0] if planes else out[0]).numel() * 4 >= hra.PLACED_FROM else {"searched": 0}
+                rep = cfg.last_placement_report() if (sum(p_.numel() for p_ in out[0]) if planes else out[0].numel()) * 4 >= hra.PLACED_FROM else {"searched": 0}
                 placement.append(rep)
                 sets.append((c_k, l_k, out))
             torch.cuda.synchronize()
@@ -659,6 +666,14 @@ def run_rank(args, rank, world, device_index, barrier):
                 rr = gg.replay if gg is not None else (lambda fn=fn: [fn(i) for i in range(args.steps)])
                 rr(); torch.cuda.synchronize()
                 fsm[key + "_ms"] = statistics.median(timed_replays(rr, 5, args.steps))
+                if key == "string_major_input_launch" and o is not None and not planes:
+                    # the rows this route writes, compared with the oracle like the headline's: outputs poisoned, the same graph replayed once more, every string of every set checked
+                    for _, _, out_ in sets:
+                        out_[0].view(-1)[::16411].fill_(-1); out_[1].view(-1)[::32771].fill_(-1); out_[2].fill_(-1)
+                    torch.cuda.synchronize()
+                    rr(); torch.cuda.synchronize()
+                    v_ = verify_timed_buffers(o, hra, sets[:min(nsets, args.steps)], shift, chars, lens, M, D, pm, dev, B, sb)
+                    fsm["string_major_input_launch_verified"] = {"bit_exact": v_["bit_exact"], "strings": v_["strings"], "buffer_sets": v_["buffer_sets"]}
                 del gg
             # the transposer leaves the very bytes the headline launch read: the outputs after (b) are the verified ones
             st_ok = all(((sets[k][2][2].cpu().numpy().view(np.uint64) & np.uint64(0xff)) == 0).all() for k in range(min(nsets, args.steps)))
@@ -676,30 +691,48 @@ def run_rank(args, rank, world, device_index, barrier):
             hrec, hmsk, hst = np.empty((B, M, D), np.uint32), np.empty((B, M), np.uint16), np.empty(B, np.uint64)
             hc = np.ascontiguousarray(chars[:, :stride])
             cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))          # (first call: the context's staging buffers, first touch of the output pages)
-            explore = []
-            for _ in range(4):        # the context's own comparison: pipelined, one stream, pipelined, one stream (hrx_api.cpp batch_host_locked) — timed, reported apart
-                t0 = time.perf_counter()
-                cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))
-                explore.append((time.perf_counter() - t0) * 1e3)
-            ts = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))
-                ts.append(time.perf_counter() - t0)
+            # The three routes of hrx_witness_batch_host (HRX_OPT_HOST_ROUTE), same batch, same pageable arrays: everything through the device (staged, walked, copied back: the link
+            # bounds it), everything on the host cores (the native walk on every core this process may run on), and the default — both at once, split by the measured rates.
+            def timed_calls(n_warm, n):
+                for _ in range(n_warm):
+                    cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))
+                ts_ = []
+                for _ in range(n):
+                    t0_ = time.perf_counter()
+                    cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))
+                    ts_.append(time.perf_counter() - t0_)
+                return ts_
+            cfg.set_option(hra.OPT_HOST_ROUTE, hra.HOST_ROUTE_DEVICE)
+            explore = [t * 1e3 for t in timed_calls(0, 4)]      # the context's own comparison of its two transfer modes: pipelined, one stream, pipelined, one stream (hrx_host_api.cpp) — timed, reported apart
+            t_dev = timed_calls(0, 5)
+            dev_rep = cfg.host_route_report()
+            cfg.set_option(hra.OPT_HOST_ROUTE, hra.HOST_ROUTE_HOST)
+            t_host = timed_calls(1, 3)
+            host_rep = cfg.host_route_report()
+            cfg.set_option(hra.OPT_HOST_ROUTE, hra.HOST_ROUTE_AUTO)
+            ts = timed_calls(6, 5)                              # (six calls for the split to follow the measured rates)
+            auto_rep = cfg.host_route_report()
             ms = statistics.median(ts) * 1e3
+            best_single = min(statistics.median(t_dev), statistics.median(t_host)) * 1e3
             e2e = {"ms_per_call": ms, "ms_min": min(ts) * 1e3, "rows_per_s": rows_per_step / (ms * 1e-3), "calls": 5,
                    "bytes_out": int(hrec.nbytes + hmsk.nbytes + hst.nbytes), "bytes_in": int(hc.nbytes + 4 * B),
                    "gbs_out": (hrec.nbytes + hmsk.nbytes + hst.nbytes) / (ms * 1e-3) / 1e9,
                    "status_ok": bool(((hst & np.uint64(0xff)) == 0).all()),
+                   "routes": {"auto_ms": ms, "device_ms": statistics.median(t_dev) * 1e3, "host_walk_all_cores_ms": statistics.median(t_host) * 1e3,
+                              "auto_over_best_single_route": ms / best_single,
+                              "auto_split": {k: auto_rep[k] for k in ("route", "device_strings", "host_strings", "device_ms", "host_ms", "device_ns_per_row", "host_ns_per_row", "host_threads", "device_pipelined")},
+                              "host_threads": host_rep["host_threads"], "device_pipelined": dev_rep["device_pipelined"]},
                    "comparison_calls_ms": {"pipelined": [explore[0], explore[2]], "one_stream": [explore[1], explore[3]]},
                    "what": "hrx_witness_batch_host on the same batch: pageable host arrays in (string-major, %d B apart) and out (records [B][M][D] u32, masked [B][M] u16, status), "
-                           "output arrays reused; the five timed calls go the way the context's own comparison (comparison_calls_ms: its calls 2-5) found faster on this box: staged, walked and "
-                           "copied out chunk by chunk on two streams (8.0 ms where the box lets both directions run at once, 16.5 where it does not), or in, walk, out on one stream (8.6 ms "
-                           "everywhere); the call lasts about as long as the copy out over the PCIe link (gbs_out)" % stride}
+                           "output arrays reused.  ms_per_call = the DEFAULT route (HRX_HOST_ROUTE_AUTO: the batch split by string index between the device and the host cores in the ratio of "
+                           "the rates the context measured); routes.device_ms = everything staged, walked and copied back (chunk by chunk on two streams, or in, walk, out on one: "
+                           "comparison_calls_ms are the context's own calls 2-5 that pick; the call lasts about as long as the copy out over the PCIe link); "
+                           "routes.host_walk_all_cores_ms = the native walk on every core this process may run on (a rank is pinned to its GPU's NUMA node)" % stride}
             # what the link gives a plain device-to-host copy of the same bytes into the same (pageable, already touched) arrays on THIS box
             try:
                 tr_, tm_ = torch.from_numpy(hrec.view(np.int32).reshape(-1)), torch.from_numpy(hmsk.view(np.int16).reshape(-1))
-                dr_, dm_ = sets[0][2][0].view(-1)[:tr_.numel()], sets[0][2][1].view(-1)[:tm_.numel()]
+                dr_ = torch.empty(tr_.numel(), dtype=torch.int32, device=dev) if planes else sets[0][2][0].view(-1)[:tr_.numel()]
+                dm_ = sets[0][2][1].view(-1)[:tm_.numel()]
                 tc = []
                 for _ in range(3):
                     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -711,11 +744,18 @@ def run_rank(args, rank, world, device_index, barrier):
                 cfg.witness_batch_host(hc, lens, out=(hrec, hmsk, hst))      # (the arrays hold the host path's rows again: compared with the gather below)
             except Exception as e:
                 sys.stderr.write("copy-out probe failed: %s\n" % e)
-            rp, mp = sets[0][2][0].cpu().numpy().view(np.uint32), sets[0][2][1].cpu().numpy().view(np.uint16)
+            mp = sets[0][2][1].cpu().numpy().view(np.uint16)
             r1, m1 = np.empty((M, D), np.uint32), np.empty(M, np.uint16)
-            fn = hra.lib.hrx_rows_of_string_position_major
             picks = np.random.default_rng(0).integers(0, B, 4000)
-            args_c = (rp.ctypes.data, mp.ctypes.data, B, M, D)
+            if planes:
+                hps = [p_.cpu().numpy().view(np.uint32) for p_ in sets[0][2][0]]
+                arr_ = (C.c_void_p * len(hps))(*[p_.ctypes.data for p_ in hps])
+                fn = hra.lib.hrx_rows_of_string_planes
+                args_c = (arr_, len(hps), mp.ctypes.data, B, M, D)
+            else:
+                rp = sets[0][2][0].cpu().numpy().view(np.uint32)
+                fn = hra.lib.hrx_rows_of_string_position_major
+                args_c = (rp.ctypes.data, mp.ctypes.data, B, M, D)
             same = True
             for b in picks[:64]:
                 fn(*args_c, int(b), r1.ctypes.data, m1.ctypes.data)
@@ -725,12 +765,72 @@ def run_rank(args, rank, world, device_index, barrier):
                 fn(*args_c, int(b), r1.ctypes.data, m1.ctypes.data)
             e2e["gather_us_per_string"] = (time.perf_counter() - t0) / len(picks) * 1e6
             e2e["gather_equals_host_path_rows"] = bool(same)
-            e2e["gather_what"] = ("hrx_rows_of_string_position_major: one circuit's [M][D] records + [M] masked rows gathered on one host core out of position-major HOST "
+            e2e["gather_what"] = ("hrx_rows_of_string_position_major (record planes / row stripes: hrx_rows_of_string_planes): one circuit's [M][D] records + [M] masked rows gathered on one host core out of position-major HOST "
                                   "buffers (the device buffers copied out as they are), random strings, through ctypes")
             res["end_to_end_host"] = e2e
-            del hrec, hmsk, hst, rp, mp
+            del hrec, hmsk, hst, mp
         except Exception as e:
             sys.stderr.write("end-to-end host probe failed: %s\n" % e)
+    # What the placement-aware allocation buys on THIS box: the same K steps, same inputs, into output buffers from two plain allocations per set (HRX_PLACE_OFF).
+    if is_default_workload(args) and world == 1 and not args.no_spread and pm and not planes:
+        try:
+            cfg.set_placement(walk=False)
+            plain_sets = [cfg.alloc_outputs_position_major(B, dev) for _ in range(nsets)]
+            cfg.set_placement(walk=True)
+            pl_fn = lambda i: cfg.witness_batch_position_major(sets[i % nsets][0], sets[i % nsets][1], out=plain_sets[i % nsets], chars_pm_stride=stride)
+            gp = graph_of(pl_fn, args.steps) if not args.eager else None
+            runp = gp.replay if gp is not None else (lambda: [pl_fn(i) for i in range(args.steps)])
+            runp(); torch.cuda.synchronize()
+            for _ in range(max(2, int(0.05 / max(kern_ms * args.steps * 1e-3, 1e-6)))):
+                runp()
+            torch.cuda.synchronize()
+            per = timed_replays(runp, 5, args.steps)
+            st_ok = all(((plain_sets[k][2].cpu().numpy().view(np.uint64) & np.uint64(0xff)) == 0).all() for k in range(min(nsets, args.steps)))
+            res["plain_allocations"] = {"ms_per_step_median": statistics.median(per), "ms_per_step_min": min(per), "status_ok": bool(st_ok)}
+            del gp, plain_sets
+        except Exception as e:
+            sys.stderr.write("plain-allocations probe failed: %s\n" % e)
+    # SURVEY §8 f4 on the headline batch: the compact rows of 8192 strings per call -> bn256::Fr cells (hrx_fr_columns_device), timed; the cells of 64 strings checked against
+    # hrx_fr_from_u64 of the integers hrx_witness_columns_host reads out of the same buffers copied to the host.
+    if is_default_workload(args) and world == 1 and not args.no_spread and pm and not planes:
+        try:
+            NB = min(8192, B)
+            launch(0); torch.cuda.synchronize()
+            c0, l0, o0 = sets[0]
+            for _ in range(2):
+                cells = cfg.fr_columns(c0, l0, o0, b_begin=0, b_count=NB, position_major=True, chars_pm_stride=stride)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record()
+            for i in range(reps):
+                cells = cfg.fr_columns(c0, l0, o0, b_begin=(i * NB) % max(B - NB + 1, 1), b_count=NB, position_major=True, chars_pm_stride=stride)
+            e1.record(); torch.cuda.synchronize()
+            ms_fr = e0.elapsed_time(e1) / reps
+            ncol = 4 + 4 * D
+            nchk = 64
+            mont = cfg.fr_columns(c0, l0, o0, b_begin=0, b_count=nchk, position_major=True, chars_pm_stride=stride).cpu().numpy().view(np.uint64)
+            canon = cfg.fr_columns(c0, l0, o0, b_begin=0, b_count=nchk, position_major=True, chars_pm_stride=stride, canonical=True).cpu().numpy().view(np.uint64)
+            cols = hra.witness_columns_host(c0.cpu().numpy(), l0.cpu().numpy().view(np.uint32), o0[0].cpu().numpy(), o0[1].cpu().numpy(), M, D, b_begin=0, b_count=nchk,
+                                            position_major=True, chars_pm_stride=stride, B=B)
+            ok_int = bool(np.array_equal(canon[..., 0], cols) and not canon[..., 1:].any())
+            vals = np.unique(cols)
+            table = {int(v): hra.fr_from_u64(int(v)) for v in vals}
+            want = np.zeros(mont.shape, np.uint64)
+            for v, limbs in table.items():
+                want[cols == v] = np.asarray(limbs, np.uint64)
+            ok_mont = bool(np.array_equal(mont, want))
+            res["fr_columns"] = {"ms_per_call": ms_fr, "strings_per_call": NB, "cells_per_s": NB * M * ncol / (ms_fr * 1e-3), "written_GBps": NB * M * ncol * 32 / (ms_fr * 1e-3) / 1e9,
+                                 "frac_of_peak": NB * M * (ncol * 32 + BYTES_PER_ROW(D)) / (ms_fr * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "checked_cells": int(mont.size // 4), "distinct_values": int(len(vals)),
+                                 "canonical_cells_equal_hrx_witness_columns_host": ok_int, "montgomery_cells_equal_hrx_fr_from_u64": ok_mont,
+                                 "what": "hrx_fr_columns_device (SURVEY §8 f4) on the headline batch: %d strings x %d rows x %d columns of 32-byte bn256::Fr cells per call out of the "
+                                         "position-major witness buffers; the cells of strings 0..%d compared with hrx_fr_from_u64 of the integers hrx_witness_columns_host gives for the same "
+                                         "buffers copied to the host (parity of the field arithmetic itself: big-integer arithmetic + halo2curves' published constants, tests/test_fr.py)" % (NB, M, ncol, nchk - 1)}
+            del cells, mont, canon
+            torch.cuda.empty_cache()
+        except Exception as e:
+            sys.stderr.write("fr_columns probe failed: %s\n" % e)
     # Record planes: the same K steps over the INTERLEAVED layout ([M/4][D][B][4] in one allocation + placed masked rows: what every earlier round measured), as many buffer
     # sets, in this process on this box — what the planes buy.  The planes' sets are released first (the verification and the no-compute pass are done with them).
     if planes and world == 1 and not args.no_spread:
@@ -759,9 +859,10 @@ def run_rank(args, rank, world, device_index, barrier):
                                  % (label, D, B, stride, n, M, "uniform noise over the %s%s%s" % (alphabet, " + planted match" if planted else "",
                                     "" if nd == B else "; %d distinct strings, the batch = %d blocks of them, block j rotated by %d j strings" % (nd, (B + nd - 1) // nd, sb))),
                      "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
-                     "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR with RECORD PLANES (blocks of 65536 strings): chars [%d/16][B][16], every def's records "
-                                 "[M/4][B][4] in a buffer of its own, masked [M/8][B][8] (include/hrx.h hrx_witness_batch_device_planes); the %d + 1 output buffers from "
-                                 "hrx_alloc_output_planes (each in a neighbourhood of the device memory of its own)" % (stride, D)) if planes else
+                     "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR with RECORD PLANES (blocks of 65536 strings): chars [%d/16][B][16], %s, "
+                                 "masked [M/8][B][8] (include/hrx.h hrx_witness_batch_device_planes); the %d + 1 output buffers from "
+                                 "hrx_alloc_output_planes (each in a neighbourhood of the device memory of its own)" % (stride, "every def's records [M/4][B][4] in a buffer of its own" if D > 1 else
+                                 "the one def's records in two ROW STRIPES [M/8][B][4] (quad q of a string in stripe q % 2 at slot q / 2)", D if D > 1 else 2)) if planes else
                                 ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of 65536 strings): chars [%d/16][B][16], records "
                                  "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h); outputs from hrx_alloc_outputs_position_major (placement-aware "
                                  "from 128 MiB of records on, two plain allocations below)" % stride) if pm else
@@ -845,6 +946,14 @@ def aggregate(per_rank, args):
                     "buffers (plain allocations), chosen_step = output bytes per row (of 4 D + 2) in the kept set's busiest class of the address space"}
     if r0.get("per_set_ms"):
         line["roofline"]["per_set_ms"] = [round(x, 4) for x in r0["per_set_ms"]]
+    if r0.get("plain_allocations"):
+        pa = r0["plain_allocations"]
+        gbs = algo_bytes / (pa["ms_per_step_median"] * 1e-3) / 1e9
+        line["roofline"]["plain_allocations"] = dict(pa, achieved=gbs, frac=gbs / HBM_PEAK_GBS,
+                                                     what="the same K steps in this process into output buffers from two plain allocations per set (hrx_ctx_set_placement HRX_PLACE_OFF) "
+                                                          "instead of the placement-aware ones: what the placement buys on this box")
+    if r0.get("fr_columns"):
+        line["fr_columns"] = r0["fr_columns"]
     if r0.get("interleaved_layout"):
         il = r0["interleaved_layout"]
         gbs = algo_bytes / (il["ms_per_step_median"] * 1e-3) / 1e9
@@ -1035,6 +1144,21 @@ def other_config_legs(dev_index, timeout_s=600):
     return legs
 
 
+def emit(line):
+    """The ONE JSON line on stdout — with the headline's `roofline` block as its LAST key, so that a truncated tail of the output still shows it — and a one-line summary on stderr."""
+    if "roofline" in line:
+        line["roofline"] = line.pop("roofline")
+    print(json.dumps(line), flush=True)
+    try:
+        r = line.get("roofline") or {}
+        legs = " ".join("%s=%.3f" % (o["baseline_config"].split(":")[0], o["frac"]) for o in line.get("other_configs", []) if "frac" in o)
+        sys.stderr.write("bench.py: %s = %.4g %s on %d GPU(s), %.4f ms/step; roofline %.3f of %d GB/s (%s, avg launch %.4f ms, traffic %s); verified %s; cpu_baseline %s %s\n" % (
+            line.get("metric"), line.get("value", 0), line.get("unit"), line.get("n_gpus", 0), line.get("ms_per_step", 0), r.get("frac", 0), r.get("peak", 0), (r.get("kernel") or "")[:60],
+            r.get("avg_launch_ms", 0), r.get("traffic"), (line.get("verified") or {}).get("bit_exact"), (line.get("cpu_baseline") or {}).get("value"), legs))
+    except Exception:
+        pass
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -1050,7 +1174,7 @@ def main(argv=None):
         res = run_rank(args, rank, world, local_rank, dist.barrier)
         line = gather_and_aggregate(res, args)
         if line is not None:
-            print(json.dumps(line), flush=True)
+            emit(line)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -1080,7 +1204,7 @@ def main(argv=None):
     line = aggregate([res], args)
     if is_default_workload(args) and not args.no_other_configs:
         line["other_configs"] = other_config_legs(0)
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 if __name__ == "__main__":

@@ -132,12 +132,14 @@ extern "C" {
                                            record_planes: *const *mut u32, n_planes: usize, masked: *mut u16, status: *mut u64, stream: *mut c_void) -> c_int;
     pub fn hrx_probe_write_pair(ctx: *mut hrx_ctx, a: *mut c_void, b: *mut c_void, bytes: usize, gbs: *mut f64) -> c_int;
     pub fn hrx_position_major_plane_sizes(b: usize, m: usize, plane_u32: *mut usize, masked_u16: *mut usize);
-    pub fn hrx_alloc_output_planes(ctx: *mut hrx_ctx, b: usize, m: usize, record_planes: *mut *mut u32, masked: *mut *mut u16) -> c_int;
-    pub fn hrx_rows_of_string_planes(record_planes: *const *const u32, masked_pm: *const u16, b_total: usize, m: usize, d: usize, b: usize,
+    pub fn hrx_position_major_stripe_sizes(b: usize, m: usize, n_stripes: usize, stripe_u32: *mut usize, masked_u16: *mut usize);
+    pub fn hrx_alloc_output_planes(ctx: *mut hrx_ctx, b: usize, m: usize, n_planes: usize, record_planes: *mut *mut u32, masked: *mut *mut u16) -> c_int;
+    pub fn hrx_rows_of_string_planes(record_planes: *const *const u32, n_planes: usize, masked_pm: *const u16, b_total: usize, m: usize, d: usize, b: usize,
                                      records: *mut u32, masked: *mut u16) -> c_int;
     pub fn hrx_traffic_pass_device_planes(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, m: usize, record_planes: *const *mut u32, n_planes: usize,
                                           masked: *mut u16, stream: *mut c_void) -> c_int;
     /// per-context choices between variants that compute the same rows (HRX_OPT_*)
+    pub fn hrx_ctx_host_route_report(ctx: *const hrx_ctx, out: *mut hrx_host_route_report) -> c_int;
     pub fn hrx_ctx_set_option(ctx: *mut hrx_ctx, option: c_int, value: std::ffi::c_long) -> c_int;
     pub fn hrx_ctx_get_option(ctx: *const hrx_ctx, option: c_int) -> std::ffi::c_long;
     pub fn hrx_describe_launch(defs: *const hrx_defs, layout: c_int, b: usize, m: usize, num_cus: c_int, out: *mut c_char, cap: usize) -> c_int;
@@ -156,6 +158,14 @@ extern "C" {
     pub fn hrx_regex_find(pattern: *const c_char, pattern_len: usize, text: *const c_char, text_len: usize, found: *mut c_int, start: *mut usize, end: *mut usize) -> c_int;
 }
 pub const HRX_OPT_PMD_COMBINER_WAVE: c_int = 1;
+pub const HRX_OPT_HOST_ROUTE: c_int = 2;      // HRX_HOST_ROUTE_AUTO (split between the device and the host cores) / _DEVICE / _HOST
+pub const HRX_OPT_HOST_THREADS: c_int = 3;
+pub const HRX_OPT_HOST_PIPELINE: c_int = 4;
+#[repr(C)] #[derive(Default, Clone, Copy)]
+pub struct hrx_host_route_report {
+    pub route: c_int, pub device_strings: usize, pub host_strings: usize, pub device_ms: f64, pub host_ms: f64, pub call_ms: f64,
+    pub device_ns_per_row: f64, pub host_ns_per_row: f64, pub host_threads: c_int, pub device_pipelined: c_int,
+}
 
 #[repr(C)] pub struct hrx_regex_part { regex_def: *const c_char, regex_len: usize, is_public: c_int, max_size: usize }
 #[repr(C)] pub struct hrx_regex_files { _private: [u8; 0] }

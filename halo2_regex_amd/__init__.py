@@ -36,6 +36,11 @@ class _RegexPartC(C.Structure):      # hrx_regex_part of include/hrx.h
     _fields_ = [("regex_def", C.c_char_p), ("regex_len", C.c_size_t), ("is_public", C.c_int), ("max_size", C.c_size_t)]
 
 
+class _HostRouteReportC(C.Structure):    # hrx_host_route_report of include/hrx.h
+    _fields_ = [("route", C.c_int), ("device_strings", C.c_size_t), ("host_strings", C.c_size_t), ("device_ms", C.c_double), ("host_ms", C.c_double), ("call_ms", C.c_double),
+                ("device_ns_per_row", C.c_double), ("host_ns_per_row", C.c_double), ("host_threads", C.c_int), ("device_pipelined", C.c_int)]
+
+
 class _PlaceReportC(C.Structure):    # hrx_place_report of include/hrx.h
     _fields_ = [("searched", C.c_int), ("steps", C.c_int), ("accepted", C.c_int), ("chosen_step", C.c_int),
                 ("ref_us", C.c_double), ("first_us", C.c_double), ("best_us", C.c_double),
@@ -92,13 +97,15 @@ def _load():
         "hrx_position_major_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_witness_batch_device_planes": (i, [vp, i, vp, sz, vp, sz, sz, C.POINTER(vp), sz, vp, vp, vp]),
         "hrx_position_major_plane_sizes": (None, [sz, sz, C.POINTER(sz), C.POINTER(sz)]),
-        "hrx_alloc_output_planes": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
-        "hrx_rows_of_string_planes": (i, [C.POINTER(vp), vp, sz, sz, sz, sz, vp, vp]),
+        "hrx_position_major_stripe_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "hrx_alloc_output_planes": (i, [vp, sz, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
+        "hrx_rows_of_string_planes": (i, [C.POINTER(vp), sz, vp, sz, sz, sz, sz, vp, vp]),
         "hrx_probe_write_pair": (i, [vp, vp, vp, sz, C.POINTER(C.c_double)]),
         "hrx_traffic_pass_device_planes": (i, [vp, vp, sz, sz, sz, C.POINTER(vp), sz, vp, vp]),
         "hrx_witness_of_string": (i, [vp, sz, sz, sz, vp, vp, vp, vp]),
         "hrx_witness_num_columns": (sz, [sz]),
         "hrx_witness_columns_host": (i, [i, vp, sz, vp, vp, sz, vp, sz, sz, sz, sz, sz, sz, vp]),
+        "hrx_ctx_host_route_report": (i, [vp, C.POINTER(_HostRouteReportC)]),
         "hrx_ctx_set_option": (i, [vp, i, C.c_long]),
         "hrx_ctx_get_option": (C.c_long, [vp, i]),
         "hrx_rows_of_string_position_major": (i, [vp, vp, sz, sz, sz, sz, vp, vp]),
@@ -430,6 +437,8 @@ LAYOUT_RECORD_PLANES = 4      # describe_launch only: the launch witness_batch_p
 
 PLACE_OFF, PLACE_WALK = 0, 1     # hrx_ctx_set_placement modes
 OPT_PMD_COMBINER_WAVE = 1        # hrx_ctx_set_option: 0 default, 1 on, 2 off
+OPT_HOST_ROUTE, OPT_HOST_THREADS, OPT_HOST_PIPELINE = 2, 3, 4
+HOST_ROUTE_AUTO, HOST_ROUTE_DEVICE, HOST_ROUTE_HOST = 0, 1, 2
 PLACE_CAPPED_STEPS, PLACE_CAPPED_BYTES, PLACE_CAPPED_TIME, PLACE_CAPPED_ALLOC = 1, 2, 4, 8      # hrx_place_report.capped
 PLACED_FROM = 128 << 20    # alloc_outputs*: records of this many bytes or more come from the library's placement-aware allocator (kPlaceFromBytes)
 PM_BLOCK = 65536          # kPmBlock of csrc/hrx_lane.h: position-major buffers are blocked by this many strings
@@ -487,26 +496,45 @@ def rows_of_string_position_major(records_pm, masked_pm, B, M, D, b, out=None):
     return rec, msk
 
 
-def planes_to_string_major(planes, masked_pm, B, M):
-    """Inverse of the record-planes layout (include/hrx.h hrx_witness_batch_device_planes): D planes, each per block of PM_BLOCK strings [ceil(M/4)][nb][4], and the
-    position-major masked rows -> (B, M, D) and (B, M); torch tensors or numpy arrays."""
-    D = len(planes)
-    recs = [position_major_to_string_major(p, masked_pm, B, M, 1)[0] for p in planes]
-    msk = position_major_to_string_major(planes[0], masked_pm, B, M, 1)[1]
-    if hasattr(recs[0], "permute"):
-        return torch.cat(recs, dim=2) if D > 1 else recs[0], msk
-    return (np.concatenate(recs, axis=2) if D > 1 else recs[0]), msk
+def planes_to_string_major(planes, masked_pm, B, M, D=None):
+    """Inverse of the record-planes layout (include/hrx.h hrx_witness_batch_device_planes): the D planes — each per block of PM_BLOCK strings [ceil(M/4)][nb][4] — or, D = 1 with two
+    buffers, the two ROW STRIPES of the one def (quad q in buffer q % 2 at slot q / 2), and the position-major masked rows -> (B, M, D) and (B, M); torch tensors or numpy arrays."""
+    D = len(planes) if D is None else D
+    R = len(planes) // D
+    q4, q8 = (M + 3) // 4, (M + 7) // 8
+    slots = (q4 + R - 1) // R
+    is_t = hasattr(planes[0], "permute")
+    recs, msks = [], []
+    for k0 in range(0, B, PM_BLOCK):
+        nb = min(PM_BLOCK, B - k0)
+        per_def = []
+        for d in range(D):
+            quads = []      # (slots, nb, 4) per stripe -> interleave the stripes' slots back into quad order
+            for r in range(R):
+                x = planes[r * D + d][k0 * slots * 4:(k0 + nb) * slots * 4].reshape(slots, nb, 4)
+                quads.append(x)
+            if R == 1:
+                q = quads[0]
+            else:
+                q = (torch.stack(quads, dim=1) if is_t else np.stack(quads, axis=1)).reshape(slots * R, nb, 4)[:q4]
+            q = q.permute(1, 0, 2) if is_t else q.transpose(1, 0, 2)            # (nb, q4, 4)
+            per_def.append(q.reshape(nb, -1)[:, :M])
+        recs.append(torch.stack(per_def, dim=2) if is_t else np.stack(per_def, axis=2))
+        m = masked_pm[k0 * q8 * 8:(k0 + nb) * q8 * 8].reshape(q8, nb, 8)
+        m = m.permute(1, 0, 2) if is_t else m.transpose(1, 0, 2)
+        msks.append(m.reshape(nb, -1)[:, :M])
+    return _cat(recs), _cat(msks)
 
 
-def rows_of_string_planes(planes, masked_pm, B, M, b, out=None):
-    """hrx_rows_of_string_planes: one circuit's rows out of record planes in HOST memory (numpy arrays, each plane copied from the device as it is)."""
-    D = len(planes)
+def rows_of_string_planes(planes, masked_pm, B, M, b, out=None, D=None):
+    """hrx_rows_of_string_planes: one circuit's rows out of record planes (or the two row stripes of one def: D=1) in HOST memory (numpy arrays, each buffer copied from the device as it is)."""
+    D = len(planes) if D is None else D
     rec = np.empty((M, D), np.uint32) if out is None else out[0]
     msk = np.empty(M, np.uint16) if out is None else out[1]
     ps = [np.ascontiguousarray(p).view(np.uint32) for p in planes]
-    arr = (C.c_void_p * D)(*[p.ctypes.data for p in ps])
+    arr = (C.c_void_p * len(ps))(*[p.ctypes.data for p in ps])
     mp = np.ascontiguousarray(masked_pm).view(np.uint16)
-    _check(lib.hrx_rows_of_string_planes(arr, mp.ctypes.data, B, M, D, b, rec.ctypes.data, msk.ctypes.data))
+    _check(lib.hrx_rows_of_string_planes(arr, len(ps), mp.ctypes.data, B, M, D, b, rec.ctypes.data, msk.ctypes.data))
     return rec, msk
 
 
@@ -734,20 +762,24 @@ class RegexVerifyConfig:
         msk = torch.as_tensor(_LibraryOwned(pmk.value, nm.value * 2), device=d).view(torch.int16)
         return rec, msk, st
 
-    def alloc_output_planes(self, B, device=None):
-        """hrx_alloc_output_planes: ([plane_0 .. plane_{D-1}] int32, masked int16, status int64) — every def's records in a buffer of its own, each placed in a neighbourhood
-        of the device memory of its own (include/hrx.h: the launch's D + 1 write streams spread over the classes of the physical address space)."""
+    def alloc_output_planes(self, B, device=None, stripes=None):
+        """hrx_alloc_output_planes: ([record buffers] int32, masked int16, status int64) — every def's records in a buffer of its own (one def: the ordinary records buffer, or with
+        stripes=2 its two row stripes), each placed in a neighbourhood of the device memory of its own (include/hrx.h: the launch's write streams spread over the classes of the
+        physical address space)."""
         dev = torch.device("cuda", self.device) if device is None else device
         D = self.num_defs
+        R = 1 if stripes is None else int(stripes)
+        assert R == 1 or D == 1
+        n = D * R
         npl, nm = C.c_size_t(0), C.c_size_t(0)
-        lib.hrx_position_major_plane_sizes(B, self.max_chars_size, C.byref(npl), C.byref(nm))
+        lib.hrx_position_major_stripe_sizes(B, self.max_chars_size, R, C.byref(npl), C.byref(nm))
         st = torch.empty((B,), dtype=torch.int64, device=dev)
-        if npl.value * 4 < PLACED_FROM or dev.index not in (None, self.device) or torch.cuda.is_current_stream_capturing():
-            return [torch.empty((npl.value,), dtype=torch.int32, device=dev) for _ in range(D)], torch.empty((nm.value,), dtype=torch.int16, device=dev), st
-        arr, pmk = (C.c_void_p * D)(), C.c_void_p()
-        _check(lib.hrx_alloc_output_planes(self._ctx, B, self.max_chars_size, arr, C.byref(pmk)))
+        if npl.value * 4 * n < PLACED_FROM or dev.index not in (None, self.device) or torch.cuda.is_current_stream_capturing():
+            return [torch.empty((npl.value,), dtype=torch.int32, device=dev) for _ in range(n)], torch.empty((nm.value,), dtype=torch.int16, device=dev), st
+        arr, pmk = (C.c_void_p * n)(), C.c_void_p()
+        _check(lib.hrx_alloc_output_planes(self._ctx, B, self.max_chars_size, n, arr, C.byref(pmk)))
         d = torch.device("cuda", self.device)
-        planes = [torch.as_tensor(_LibraryOwned(arr[k], npl.value * 4), device=d).view(torch.int32) for k in range(D)]
+        planes = [torch.as_tensor(_LibraryOwned(arr[k], npl.value * 4), device=d).view(torch.int32) for k in range(n)]
         msk = torch.as_tensor(_LibraryOwned(pmk.value, nm.value * 2), device=d).view(torch.int16)
         return planes, msk, st
 
@@ -785,6 +817,12 @@ class RegexVerifyConfig:
         g = C.c_double(0.0)
         _check(lib.hrx_probe_write_pair(self._need_device(a, b), a.data_ptr(), b.data_ptr(), int(nbytes), C.byref(g)))
         return g.value
+
+    def host_route_report(self):
+        """hrx_ctx_host_route_report: what this config's last witness_batch_host call did (a dict)."""
+        r = _HostRouteReportC()
+        _check(lib.hrx_ctx_host_route_report(self._need_ctx(), C.byref(r)))
+        return {k: getattr(r, k) for k, _ in _HostRouteReportC._fields_}
 
     def set_option(self, option, value):
         """hrx_ctx_set_option (include/hrx.h HRX_OPT_*)."""

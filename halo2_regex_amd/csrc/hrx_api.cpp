@@ -204,6 +204,7 @@ int hrx_ctx_clone(const hrx_ctx *ctx, int device, hrx_ctx **out) {
     if (rc != HRX_OK) return rc;
     c->host_threshold = ctx->host_threshold;      // the per-context switches travel with the clone
     c->tune = ctx->tune;
+    c->host_route = ctx->host_route; c->host_threads = ctx->host_threads; c->host_pipeline = ctx->host_pipeline; c->host_chunk_mib = ctx->host_chunk_mib; c->host_trace = ctx->host_trace;
     c->place_enabled = ctx->place_enabled; c->place_max_bytes = ctx->place_max_bytes; c->place_max_ms = ctx->place_max_ms;
     *out = c;
     return HRX_OK;
@@ -234,6 +235,10 @@ static int ctx_create_from(const DefsSet &set, int device, hrx_ctx **out) {
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     c->debug = debug_flags_from_env();
+    // host-buffer batches (hrx_host_api.cpp): the defaults of HRX_OPT_HOST_PIPELINE and the pipeline's chunk size / trace come from the environment ONCE, here
+    if (const char *v = std::getenv("HRX_HOST_PIPELINE")) c->host_pipeline = std::atoi(v) != 0 ? 1 : 2;
+    if (const char *v = std::getenv("HRX_HOST_CHUNK_MIB")) { const long n = std::atol(v); if (n >= 4 && n <= 4096) c->host_chunk_mib = (size_t)n; }
+    if (const char *v = std::getenv("HRX_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
     // tuning knobs of the placement search: HRX_PLACE=0 switches it off, HRX_PLACE_MAX_STEPS bounds the walk, HRX_PLACE_TRACE=1 prints every measured step to stderr
     if (const char *v = std::getenv("HRX_PLACE")) c->place_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("HRX_MP_COMBINE")) c->mp_combine = std::atoi(v) != 0;
@@ -340,7 +345,7 @@ void hrx_ctx_destroy(hrx_ctx *c) {
 
 int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                  uint32_t *records, uint16_t *masked, uint64_t *status, hipStream_t st, size_t rec_pitch,
-                 size_t msk_pitch, int layout, uint32_t *const *planes) {
+                 size_t msk_pitch, int layout, uint32_t *const *planes, size_t n_planes) {
     // planes: the D record planes in buffers of their own (hrx_witness_batch_device_planes; position-major outputs, a config that runs as ONE launch); records = planes[0] then
     if (!rec_pitch) rec_pitch = M;
     if (!msk_pitch) msk_pitch = M;
@@ -391,8 +396,12 @@ int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32
         a.debug = debug_flags_from_env();   // tools/ab_flags.py switches ablations between launches of one process
 #endif
         if (planes) {   // (the chunked launch's repair reads finished records through the interleaved layout: such batches take the sequential kernels)
-            for (uint32_t d = 0; d < a.D && d < kMaxDefsPerLaunch; ++d) a.rec_planes[d] = (unsigned char *)planes[d];
+            for (uint32_t d = 0; d < n_planes && d < kMaxDefsPerLaunch; ++d) a.rec_planes[d] = (unsigned char *)planes[d];
             a.debug |= kDbgNoSpec;
+            if (n_planes == 2 * (size_t)a.D) {      // one def in two row stripes: the loader / walker / finisher kernel writes them (not the pair-step kernel)
+                a.rec_stripes = 2;
+                a.debug |= kDbgNoPair;
+            }
         }
         // a summary-writing pass is the loader / walker / finisher kernel: no pair-step or def-parallel variant, no HALF table
         if (pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;
@@ -787,14 +796,15 @@ int hrx_witness_batch_device_planes(hrx_ctx *ctx, int layout, const uint8_t *cha
                                     uint32_t *const *record_planes, size_t n_planes, uint16_t *masked, uint64_t *status, void *stream) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     if (!(layout & HRX_LAYOUT_POSITION_MAJOR)) return fail(HRX_ERR_ARG, "record planes are a position-major layout");
-    if (!record_planes || n_planes != ctx->s.defs.size()) return fail(HRX_ERR_ARG, "record planes: one buffer per RegexDefs of the config");
+    const size_t Dn = ctx->s.defs.size();
+    if (!record_planes || !(n_planes == Dn || (Dn == 1 && n_planes == 2))) return fail(HRX_ERR_ARG, "record planes: one buffer per RegexDefs of the config (one def: one buffer, or two row stripes)");
     for (size_t d = 0; d < n_planes; ++d)
         if (!record_planes[d] || ((uintptr_t)record_planes[d] & 15)) return fail(HRX_ERR_ARG, "record planes must be 16-byte aligned device buffers");
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard guard;
     if (ctx->device != HRX_DEVICE_NONE) HIP_TRY(guard.set(ctx->device));
     // one def: its plane IS the position-major records buffer
-    return launch_batch(ctx, chars, stride, lens, B, M, record_planes[0], masked, status, (hipStream_t)stream, 0, 0, layout, n_planes > 1 ? record_planes : nullptr);
+    return launch_batch(ctx, chars, stride, lens, B, M, record_planes[0], masked, status, (hipStream_t)stream, 0, 0, layout, n_planes > 1 ? record_planes : nullptr, n_planes);
 }
 
 int hrx_ctx_set_option(hrx_ctx *ctx, int option, long value) {
@@ -805,6 +815,18 @@ int hrx_ctx_set_option(hrx_ctx *ctx, int option, long value) {
             if (value < 0 || value > 2) return fail(HRX_ERR_ARG, "HRX_OPT_PMD_COMBINER_WAVE: 0 (default), 1 (on) or 2 (off)");
             ctx->tune = (ctx->tune & ~kTunePmdFinMask) | (uint32_t)value;
             return HRX_OK;
+        case HRX_OPT_HOST_ROUTE:
+            if (value < 0 || value > 2) return fail(HRX_ERR_ARG, "HRX_OPT_HOST_ROUTE: HRX_HOST_ROUTE_AUTO, _DEVICE or _HOST");
+            ctx->host_route = (int)value;
+            return HRX_OK;
+        case HRX_OPT_HOST_THREADS:
+            if (value < 0 || value > 4096) return fail(HRX_ERR_ARG, "HRX_OPT_HOST_THREADS: 0 (the calling thread's cores) .. 4096");
+            ctx->host_threads = (int)value;
+            return HRX_OK;
+        case HRX_OPT_HOST_PIPELINE:
+            if (value < 0 || value > 2) return fail(HRX_ERR_ARG, "HRX_OPT_HOST_PIPELINE: 0 (measured), 1 (pipelined) or 2 (one stream)");
+            ctx->host_pipeline = (int)value;
+            return HRX_OK;
         default: return fail(HRX_ERR_ARG, "hrx_ctx_set_option: unknown option");
     }
 }
@@ -813,6 +835,9 @@ long hrx_ctx_get_option(const hrx_ctx *ctx, int option) {
     if (!ctx) return -1;
     switch (option) {
         case HRX_OPT_PMD_COMBINER_WAVE: return (long)(ctx->tune & kTunePmdFinMask);
+        case HRX_OPT_HOST_ROUTE: return ctx->host_route;
+        case HRX_OPT_HOST_THREADS: return ctx->host_threads;
+        case HRX_OPT_HOST_PIPELINE: return ctx->host_pipeline;
         default: return -1;
     }
 }
@@ -836,6 +861,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
         layout &= ~HRX_LAYOUT_RECORD_PLANES;
         a.rec_planes[0] = reinterpret_cast<unsigned char *>(16);
         a.debug |= kDbgNoSpec;
+        if (a.D == 1) { a.rec_stripes = 2; a.debug |= kDbgNoPair; }      // (one def: described with its two row stripes)
     }
     if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a pass of a multi-pass config is the loader / walker / finisher kernel)
     LaunchInfo li;
@@ -1015,21 +1041,22 @@ void hrx_position_major_plane_sizes(size_t B, size_t M, size_t *plane_u32, size_
     if (masked_u16) *masked_u16 = (M + 7) / 8 * B * 8;
 }
 
-int hrx_rows_of_string_planes(const uint32_t *const *record_planes, const uint16_t *masked_pm, size_t B, size_t M, size_t D, size_t b, uint32_t *records, uint16_t *masked) {
+int hrx_rows_of_string_planes(const uint32_t *const *record_planes, size_t n_planes, const uint16_t *masked_pm, size_t B, size_t M, size_t D, size_t b, uint32_t *records, uint16_t *masked) {
     if (!record_planes && !masked_pm) return fail(HRX_ERR_ARG, "NULL buffer");
     if ((record_planes && !records) || (masked_pm && !masked)) return fail(HRX_ERR_ARG, "NULL output");
     if (b >= B || M == 0 || D == 0 || D > HRX_MAX_DEFS) return fail(HRX_ERR_ARG, "string index or shape out of range");
+    if (record_planes && !(n_planes == D || (D == 1 && n_planes == 2))) return fail(HRX_ERR_ARG, "one buffer per def (one def: one buffer or two row stripes)");
     const size_t k = b / HRX_PM_BLOCK, bl = b % HRX_PM_BLOCK, nb = std::min<size_t>(HRX_PM_BLOCK, B - k * HRX_PM_BLOCK);
-    const size_t q4 = (M + 3) / 4;
+    const size_t q4 = (M + 3) / 4, R = record_planes ? n_planes / D : 1, slots = (q4 + R - 1) / R;
     if (record_planes) {
-        for (size_t d = 0; d < D; ++d) {
-            if (!record_planes[d]) return fail(HRX_ERR_ARG, "NULL plane");
-            const uint32_t *base = record_planes[d] + k * HRX_PM_BLOCK * q4 * 4 + bl * 4;       // quad q of this def: base + q * nb * 4
-            for (size_t q = 0; q < q4; ++q) {
+        for (size_t p = 0; p < n_planes; ++p)
+            if (!record_planes[p]) return fail(HRX_ERR_ARG, "NULL plane");
+        for (size_t d = 0; d < D; ++d)
+            for (size_t q = 0; q < q4; ++q) {      // quad q of def d: buffer (q % R) * D + d, slot q / R
+                const uint32_t *src = record_planes[(q % R) * D + d] + k * HRX_PM_BLOCK * slots * 4 + ((q / R) * nb + bl) * 4;
                 const size_t rows = std::min<size_t>(4, M - 4 * q);
-                for (size_t i = 0; i < rows; ++i) records[(4 * q + i) * D + d] = base[q * nb * 4 + i];
+                for (size_t i = 0; i < rows; ++i) records[(4 * q + i) * D + d] = src[i];
             }
-        }
     }
     if (masked_pm) return hrx_rows_of_string_position_major(nullptr, masked_pm, B, M, D, b, nullptr, masked);
     return HRX_OK;

@@ -84,6 +84,13 @@ struct hrx_ctx {
     hipStream_t stream = nullptr;
     // host-buffer batches of three chunks and more: pipelined (two streams) or one stream, whichever the last comparison on this box found faster (batch_host_locked)
     struct HostMode { unsigned calls = 0, until_probe = 0; bool sequential = false; double piped_ns_per_byte = 0.0, seq_ns_per_byte = 0.0; } host_mode;
+    // hrx_witness_batch_host (hrx_host_api.cpp): the route (HRX_OPT_HOST_ROUTE), the host threads of the native walk (HRX_OPT_HOST_THREADS; 0: the cores the calling thread may run on), the
+    // device part's transfer mode (HRX_OPT_HOST_PIPELINE: 0 measured, 1 pipelined, 2 one stream; HRX_HOST_PIPELINE in the environment of hrx_ctx_create sets the default), chunk size and trace
+    int host_route = 0, host_threads = 0, host_pipeline = 0;
+    size_t host_chunk_mib = 48;
+    bool host_trace = false;
+    struct HostRates { double dev_ns_per_row = 0.0, host_ns_per_row = 0.0; unsigned calls = 0; } host_rates;   // what the split calls measured (both parts running at once)
+    hrx_host_route_report last_host{};
     hipStream_t copy_stream = nullptr;   // host-buffer batches: the device-to-host copies of finished chunks run here while the next chunks are staged and walked on `stream`
     uint32_t *d_table = nullptr;
     uint64_t *d_wide = nullptr;
@@ -145,6 +152,6 @@ struct hrx_ctx {
 HRX_INTERNAL int check_host_shape(size_t B, size_t M);
 // hrx_api.cpp: one batch on the context's device (device pointers; the caller holds ctx->mu and has selected the device)
 HRX_INTERNAL int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status,
-                              hipStream_t st, size_t rec_pitch = 0, size_t msk_pitch = 0, int layout = 0, uint32_t *const *planes = nullptr);
+                              hipStream_t st, size_t rec_pitch = 0, size_t msk_pitch = 0, int layout = 0, uint32_t *const *planes = nullptr, size_t n_planes = 0);
 // hrx_host_api.cpp: a host-buffer batch through the device (staged, walked, copied back); the caller holds ctx->mu and has selected the device
 HRX_INTERNAL int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);

@@ -1,6 +1,11 @@
 // hrx_host_api.cpp — host-buffer batches (hrx_witness_batch_host: what an unmodified caller of match_substrs' seam gets, src/lib.rs:311-318) and the multi-GPU driver
 // (hrx_multi_*: shards by string index, no collective).  DESIGN.md §7, §9.
 #include "hrx_ctx.hpp"
+#include <sched.h>
+
+#include <condition_variable>
+#include <system_error>
+
 #include "hrx_host_walk.hpp"
 
 using namespace hrx;
@@ -22,12 +27,11 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
     // cannot have both directions busy.  The rows leave 6 D' bytes per byte that comes in (448 MiB out, 64 MiB in at 65536 x 1024, D = 1): the copy out IS the call
     // (8.1 of round 4's 8.7 ms: ~55 GB/s, the link's rate in one direction); what the pipeline removes is the staging and the walk in front of it.
     const size_t out_per_string = M * (4 * D + 2);
-    static const size_t chunk_mib = [] { const char *v = std::getenv("HRX_HOST_CHUNK_MIB"); const long n = v ? std::atol(v) : 0; return (size_t)(n >= 4 && n <= 4096 ? n : 48); }();
-    size_t cb = out_per_string ? (chunk_mib << 20) / out_per_string / 64 * 64 : B;   // ~48 MiB of rows per chunk (HRX_HOST_CHUNK_MIB)
+    size_t cb = out_per_string ? (ctx->host_chunk_mib << 20) / out_per_string / 64 * 64 : B;   // ~48 MiB of rows per chunk (HRX_HOST_CHUNK_MIB when the context was created)
     if (cb < 1024) cb = 1024;
     const size_t nchunk = (B + cb - 1) / cb;
     // HRX_HOST_TRACE=1: one line per call on stderr — which way the call went, how long it took, per chunk when its input was on its way / its walk launched / its copy out began and ended
-    static const bool trace = [] { const char *v = std::getenv("HRX_HOST_TRACE"); return v && std::atoi(v) != 0; }();
+    const bool trace = ctx->host_trace;
     const auto t_call = std::chrono::steady_clock::now();
     auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     // Pipelined or not.  On about every second box of this pool the pipelined call's device-to-host copies run at 25 GB/s instead of 55 for as long as the same call (or process) also
@@ -35,7 +39,7 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
     // bytes 7.2 (per-chunk traces, the variants tried: profiles/r05_probes/host_path_modes.txt).  So a context MEASURES: after its first big call (allocations, first touches) two calls go
     // pipelined and two on one stream, alternating; the faster way (the better of its two calls, per byte sent back; the pipeline unless the single stream is 10 % faster) takes the next
     // 62 calls, then the other way gets one call again; a pipelined call a quarter slower than the single stream's figure switches at once.  HRX_HOST_PIPELINE=1 / 0: always / never pipelined.
-    static const int force_pipe = [] { const char *v = std::getenv("HRX_HOST_PIPELINE"); return v ? (std::atoi(v) != 0 ? 1 : 0) : -1; }();
+    const int force_pipe = ctx->host_pipeline == 1 ? 1 : ctx->host_pipeline == 2 ? 0 : -1;      // HRX_OPT_HOST_PIPELINE
     hrx_ctx::HostMode &hm = ctx->host_mode;
     const bool big = nchunk >= 3 && ctx->copy_stream != nullptr;
     bool sequential = !big, timed = false;
@@ -56,7 +60,10 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
         if (k < 4) return;
         if (k == 4 || was_sequential != hm.sequential) {       // a comparison is complete: decide
             hm.sequential = hm.seq_ns_per_byte < 0.9 * hm.piped_ns_per_byte;
-            hm.until_probe = 62;
+            // the other way gets a call again after 62 — unless the comparison was lopsided (the slower way more than 1.5x: 16.5 against 8 ms where the pipeline's
+            // copies run at half rate): then only after 1022, so that a long-lived prover does not pay a 2x call every 64th time
+            const double a_ = hm.seq_ns_per_byte, b_ = hm.piped_ns_per_byte;
+            hm.until_probe = (a_ > 0 && b_ > 0 && std::max(a_, b_) > 1.5 * std::min(a_, b_)) ? 1022 : 62;
         } else if (!was_sequential && ns_per_byte > 1.25 * hm.seq_ns_per_byte) {     // the box has changed its mind
             hm.sequential = true;
             hm.until_probe = 62;
@@ -76,6 +83,7 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
         HIP_TRY(hipStreamSynchronize(st));
         if (trace) std::fprintf(stderr, "[hrx host] %zu strings on one stream: %.2f ms\n", B, ms_now());
         account(true);
+        ctx->last_host.device_pipelined = 0;
         return HRX_OK;
     }
     std::vector<double> t_in(trace ? nchunk : 0), t_launch(trace ? nchunk : 0), t_out0(trace ? nchunk : 0), t_out1(trace ? nchunk : 0);
@@ -90,9 +98,12 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
     std::atomic<int> prc{HRX_OK};
     std::string pmsg;
     const int device = ctx->device;
-    std::thread producer([&] {
+    std::mutex smu;                  // the consumer sleeps on `scv` until the chunk it waits for has been staged (it used to spin on `staged`: a core burnt per call)
+    std::condition_variable scv;
+    auto publish = [&](size_t v) { { std::lock_guard<std::mutex> g(smu); staged = v; } scv.notify_one(); };
+    auto producer_body = [&] {
         DeviceGuard g2;
-        if (g2.set(device) != hipSuccess) { pmsg = "hipSetDevice failed in the staging thread"; prc = HRX_ERR_HIP; staged = nchunk; return; }
+        if (g2.set(device) != hipSuccess) { pmsg = "hipSetDevice failed in the staging thread"; prc = HRX_ERR_HIP; publish(nchunk); return; }
         for (size_t c = 0; c < nchunk; ++c) {
             const size_t b0 = c * cb, n = std::min(cb, B - b0);
             unsigned char *dch = (unsigned char *)ctx->chars.p + b0 * dstride;
@@ -111,16 +122,25 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
                 pmsg = e != hipSuccess ? std::string("HIP error while staging a chunk: ") + hipGetErrorString(e) : std::string(hrx_last_error());
                 (void)hipGetLastError();
                 prc = e != hipSuccess ? HRX_ERR_HIP : rc;
-                staged = nchunk;      // release the consumer
+                publish(nchunk);      // release the consumer
                 return;
             }
-            staged = c + 1;
+            publish(c + 1);
         }
-    });
+    };
+    std::thread producer;
+    try {
+        producer = std::thread(producer_body);
+    } catch (const std::system_error &) {      // no thread to be had: stage everything from this one, then copy out (nothing may unwind through the C ABI)
+        producer_body();
+    }
     int rc = HRX_OK;
     hipError_t ce = hipSuccess;
     for (size_t c = 0; c < nchunk && ce == hipSuccess; ++c) {
-        while (staged.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+        {
+            std::unique_lock<std::mutex> g(smu);
+            scv.wait(g, [&] { return staged.load(std::memory_order_acquire) > c; });
+        }
         if (prc.load() != HRX_OK) break;
         const size_t b0 = c * cb, n = std::min(cb, B - b0);
         if (trace) t_out0[c] = ms_now();
@@ -130,7 +150,7 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
         if (ce == hipSuccess) ce = hipMemcpyAsync(status + b0, (uint64_t *)ctx->status.p + b0, 8 * n, hipMemcpyDeviceToHost, ctx->copy_stream);
         if (trace) t_out1[c] = ms_now();
     }
-    producer.join();
+    if (producer.joinable()) producer.join();
     if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamSynchronize(st);
     for (hipEvent_t e : done) (void)hipEventDestroy(e);
@@ -143,6 +163,7 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
         std::fputs(line.c_str(), stderr);
     }
     if (prc.load() == HRX_OK && ce == hipSuccess) account(false);
+    ctx->last_host.device_pipelined = 1;
     if (prc.load() != HRX_OK) return fail(prc.load(), pmsg);
     if (ce != hipSuccess) { (void)hipGetLastError(); return fail(HRX_ERR_HIP, std::string("HIP error while copying a chunk out: ") + hipGetErrorString(ce)); }
     return rc;
@@ -150,12 +171,12 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
 
 extern "C" {
 
-// host-buffer batches below the context's threshold (and every batch of a host-only context) take the native host walk
-static bool use_host_walk(const hrx_ctx *ctx, size_t B, size_t M) {
-    if (ctx->device == HRX_DEVICE_NONE) return true;
-    if (ctx->debug & kDbgNoHost) return false;
-    if (ctx->debug & kDbgForceHost) return true;
-    return B * M < ctx->host_threshold;
+// how many cores the calling thread may run on (its affinity mask: a rank pinned to its GPU's NUMA node walks with that node's cores, not with the machine's)
+static size_t host_threads_available() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (size_t)n; }
+    return std::max<size_t>(1, std::thread::hardware_concurrency());
 }
 
 }  // extern "C"
@@ -166,26 +187,108 @@ int check_host_shape(size_t B, size_t M) {
 }
 extern "C" {
 
+// Batches of at least this many rows are SPLIT between the device and the host cores (HRX_HOST_ROUTE_AUTO): below it the launch + copies of a device part and the thread start-up of a host
+// part are not small against either part's work
+constexpr size_t kHostSplitFromRows = (size_t)1 << 22;
+
 int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                            uint32_t *records, uint16_t *masked, uint64_t *status) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     if (B == 0) return HRX_OK;
     if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
     if (int rc = check_host_shape(B, M)) return rc;
-    if (use_host_walk(ctx, B, M)) {   // re-entrant: reads the context's tables only
+    const size_t D = ctx->s.defs.size();
+    const auto t_call = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const size_t avail = ctx->host_threads > 0 ? (size_t)ctx->host_threads : host_threads_available();
+    // the native walk over strings [b0, b0 + n): one host thread per ~8192 witness rows (~100 us of walk; a thread costs ~30 us to start), up to `threads`
+    auto host_part = [&](size_t b0, size_t n, size_t threads) {
+        const size_t want = std::max<size_t>(1, n * M / 8192);
+        host_witness_batch(ctx->s, chars + b0 * stride, stride, lens + b0, n, M, records + b0 * M * D, masked + b0 * M, status + b0, (int)std::min(want, std::max<size_t>(1, threads)));
+    };
+    auto check_strides = [&]() -> int {
         for (size_t b = 0; b < B; ++b)
             if (lens[b] <= M && lens[b] > stride) return fail(HRX_ERR_ARG, "a string is longer than the stride");
-        // one host thread per ~8192 witness rows (~100 us of walk; a thread costs ~30 us to start), up to the machine's cores: a host-only
-        // context walks 4096 x 1024 rows on a 256-core host in ~0.3 ms instead of 15 (NOTES_MEASUREMENTS.md §7c)
-        const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
-        const size_t want = std::max<size_t>(1, B * M / 8192);
-        host_witness_batch(ctx->s, chars, stride, lens, B, M, records, masked, status, (int)std::min(want, hw));
+        return HRX_OK;
+    };
+    // ---- which way.  A host-only context, a forced route, the debug flags of the tests (AUTO only), small batches: one way; otherwise both at once
+    int route = ctx->host_route;
+    if (ctx->device == HRX_DEVICE_NONE) route = HRX_HOST_ROUTE_HOST;
+    else if (route == HRX_HOST_ROUTE_AUTO) {
+        if (ctx->debug & kDbgNoHost) route = HRX_HOST_ROUTE_DEVICE;
+        else if ((ctx->debug & kDbgForceHost) || B * M < ctx->host_threshold) route = HRX_HOST_ROUTE_HOST;
+        else if (B * M < kHostSplitFromRows) route = HRX_HOST_ROUTE_DEVICE;
+    }
+    if (route == HRX_HOST_ROUTE_HOST) {   // re-entrant: reads the context's tables only (a 256-core host walks 4096 x 1024 rows in ~0.3 ms instead of 15: NOTES_MEASUREMENTS.md §7c)
+        if (int rc = check_strides()) return rc;
+        host_part(0, B, avail);
+        if (ctx->device != HRX_DEVICE_NONE) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            hrx_host_route_report &r = ctx->last_host;
+            r.route = HRX_HOST_ROUTE_HOST; r.device_strings = 0; r.host_strings = B; r.device_ms = 0; r.host_ms = r.call_ms = ms_since(t_call);
+            r.host_threads = (int)std::min(avail, std::max<size_t>(1, B * M / 8192));
+            r.device_ns_per_row = ctx->host_rates.dev_ns_per_row; r.host_ns_per_row = ctx->host_rates.host_ns_per_row;
+        }
         return HRX_OK;
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard guard;
     HIP_TRY(guard.set(ctx->device));
-    return batch_host_locked(ctx, chars, stride, lens, B, M, records, masked, status);
+    hrx_host_route_report &rep = ctx->last_host;
+    if (route == HRX_HOST_ROUTE_DEVICE) {
+        const int rc = batch_host_locked(ctx, chars, stride, lens, B, M, records, masked, status);
+        rep.route = HRX_HOST_ROUTE_DEVICE; rep.device_strings = B; rep.host_strings = 0; rep.host_ms = 0; rep.device_ms = rep.call_ms = ms_since(t_call); rep.host_threads = 0;
+        rep.device_ns_per_row = ctx->host_rates.dev_ns_per_row; rep.host_ns_per_row = ctx->host_rates.host_ns_per_row;
+        return rc;
+    }
+    // ---- both at once: strings [0, bs) through the device, [bs, B) on the host cores (all but two: the staging thread and this one keep the device part fed), in the ratio of the rates
+    // measured so far.  Each part is timed and the estimates follow.
+    if (int rc = check_strides()) return rc;
+    hrx_ctx::HostRates &hr = ctx->host_rates;
+    const double h = hr.host_ns_per_row, d = hr.dev_ns_per_row;
+    double f_dev = (h > 0 && d > 0) ? h / (h + d) : 0.5;
+    const bool refresh = (hr.calls % 64u) == 63u;          // a part that has been getting nothing is measured again on a sixteenth of the batch
+    if (f_dev < 1.0 / 16) f_dev = refresh ? 1.0 / 16 : 0.0;
+    if (f_dev > 15.0 / 16) f_dev = refresh ? 15.0 / 16 : 1.0;
+    size_t bs = (size_t)((double)B * f_dev) / 64 * 64;
+    if (f_dev >= 1.0) bs = B;
+    const size_t hn = B - bs;
+    const size_t hthreads = avail > 3 ? avail - 2 : 1;
+    double host_ms = 0.0, dev_ms = 0.0;
+    std::thread walker;
+    bool walked = hn == 0;
+    if (hn) {
+        try {
+            walker = std::thread([&] { const auto t0 = std::chrono::steady_clock::now(); host_part(bs, hn, hthreads); host_ms = ms_since(t0); });
+        } catch (const std::system_error &) {      // (no thread to be had: the host part follows the device part on this thread)
+        }
+    }
+    int rc = HRX_OK;
+    if (bs) {
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = batch_host_locked(ctx, chars, stride, lens, bs, M, records, masked, status);
+        dev_ms = ms_since(t0);
+    }
+    if (walker.joinable()) { walker.join(); walked = true; }
+    if (!walked) { const auto t0 = std::chrono::steady_clock::now(); host_part(bs, hn, avail); host_ms = ms_since(t0); }
+    if (rc != HRX_OK) return rc;
+    // (mostly the new figure: a part's rate depends on its share — the host cores walk a third of a 65536 x 1024 batch at twice the rate per row of the whole batch — so the split has to follow quickly)
+    if (bs && dev_ms > 0) { const double m = dev_ms * 1e6 / (double)(bs * M); hr.dev_ns_per_row = hr.dev_ns_per_row > 0 ? 0.3 * hr.dev_ns_per_row + 0.7 * m : m; }
+    if (hn && host_ms > 0) { const double m = host_ms * 1e6 / (double)(hn * M); hr.host_ns_per_row = hr.host_ns_per_row > 0 ? 0.3 * hr.host_ns_per_row + 0.7 * m : m; }
+    ++hr.calls;
+    rep.route = bs == 0 ? HRX_HOST_ROUTE_HOST : hn == 0 ? HRX_HOST_ROUTE_DEVICE : HRX_HOST_ROUTE_AUTO;
+    rep.device_strings = bs; rep.host_strings = hn; rep.device_ms = dev_ms; rep.host_ms = host_ms; rep.call_ms = ms_since(t_call);
+    rep.device_ns_per_row = hr.dev_ns_per_row; rep.host_ns_per_row = hr.host_ns_per_row; rep.host_threads = hn ? (int)hthreads : 0;
+    if (ctx->host_trace)
+        std::fprintf(stderr, "[hrx host] split: %zu strings through the device %.2f ms, %zu on %zu host threads %.2f ms; per row %.4f / %.4f ns\n", bs, dev_ms, hn, hthreads, host_ms,
+                     hr.dev_ns_per_row, hr.host_ns_per_row);
+    return HRX_OK;
+}
+
+int hrx_ctx_host_route_report(const hrx_ctx *ctx, hrx_host_route_report *out) {
+    if (!ctx || !out) return fail(HRX_ERR_ARG, "NULL argument");
+    *out = ctx->last_host;
+    return HRX_OK;
 }
 
 /* ------------------------------ multi-GPU driver ------------------------------ */
@@ -209,6 +312,8 @@ int hrx_multi_create(const hrx_defs *defs, const int *devices, int n_devices, hr
         }
         m->ctxs.push_back(c);
     }
+    // (the shards of one host-buffer call run at the same time: each walks with its share of the cores)
+    for (hrx_ctx *c : m->ctxs) c->host_threads = (int)std::max<size_t>(1, host_threads_available() / (size_t)n_devices);
     *out = m;
     return HRX_OK;
 }

@@ -11,8 +11,15 @@
 //   tags / flags    derive_substr_ids, derive_is_start_end   src/lib.rs:825-888
 //   rows, padding   match_substrs        src/lib.rs:339-348, 387-519
 //   reveal mask     match_substrs        src/lib.rs:593-764
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -96,6 +103,86 @@ uint64_t host_witness_one(const DefsSet &s, const uint8_t *chars, size_t n_raw, 
     return status_ok(accept);
 }
 
+// The host threads of host_witness_batch: a process-wide pool of workers that sleep between jobs.  (Until round 6 every call started its threads anew — ~30 us apiece, one after the other:
+// 254 threads for a 65536 x 1024 batch on a 256-core host cost as much as the walk itself, 8.9 ms per call where the pool takes it to what the host's memory gives.)  One job at a time
+// (callers queue on job_mu: the shards of a multi-GPU call, clones on several threads); a job is a range of items handed out in order from an atomic counter, the calling thread works too.
+// A forked child (Python multiprocessing) inherits the pool object without its threads: the pid tells, and the child starts its own.
+class HostPool {
+public:
+    static HostPool &get() {
+        static HostPool *p = new HostPool();      // never destroyed: its workers sleep on it until the process ends
+        return *p;
+    }
+    // fn(lo, hi) over [0, n) in pieces of `grain`, on at most `threads` threads (the caller's included)
+    void run(size_t n, size_t grain, size_t threads, const std::function<void(size_t, size_t)> &fn) {
+        if (n == 0) return;
+        if (grain == 0) grain = 1;
+        const size_t pieces = (n + grain - 1) / grain;
+        if (threads <= 1 || pieces <= 1) { fn(0, n); return; }
+        std::lock_guard<std::mutex> job_lock(job_mu);
+        const size_t helpers = ensure(std::min(threads - 1, pieces - 1));
+        if (helpers == 0) { fn(0, n); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job_fn = &fn; job_n = n; job_grain = grain; next.store(0); wanted = helpers; started = 0; finished = 0; ++generation;
+        }
+        cv_work.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu);
+        wanted = started;                                   // (workers that have not picked the job up yet no longer may: nothing is left)
+        cv_done.wait(lk, [&] { return finished == started; });
+        job_fn = nullptr;
+    }
+
+private:
+    std::mutex job_mu, mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> workers;
+    pid_t owner = 0;
+    const std::function<void(size_t, size_t)> *job_fn = nullptr;
+    size_t job_n = 0, job_grain = 1, wanted = 0, started = 0, finished = 0;
+    uint64_t generation = 0;
+    std::atomic<size_t> next{0};
+
+    void work() {
+        for (;;) {
+            const size_t lo = next.fetch_add(job_grain);
+            if (lo >= job_n) return;
+            (*job_fn)(lo, std::min(job_n, lo + job_grain));
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return generation != seen; });
+            seen = generation;
+            if (job_fn == nullptr || started >= wanted) continue;
+            ++started;
+            lk.unlock();
+            work();
+            lk.lock();
+            if (++finished == started) cv_done.notify_one();
+        }
+    }
+    // at least min(want, what the system gives) sleeping workers; returns how many there are (under job_mu)
+    size_t ensure(size_t want) {
+        if (owner != getpid()) {          // first use, or a forked child: the parent's threads do not exist here
+            for (std::thread &t : workers) t.detach();      // (handles of threads that are not ours)
+            workers.clear();
+            owner = getpid();
+        }
+        while (workers.size() < want) {
+            try {
+                workers.emplace_back([this] { loop(); });
+            } catch (const std::system_error &) {
+                break;
+            }
+        }
+        return std::min(workers.size(), want);
+    }
+};
+
 void host_witness_batch(const DefsSet &s, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                         uint32_t *records, uint16_t *masked, uint64_t *status, int threads) {
     const size_t D = s.defs.size();
@@ -104,10 +191,9 @@ void host_witness_batch(const DefsSet &s, const uint8_t *chars, size_t stride, c
             status[b] = host_witness_one(s, chars + b * stride, lens[b], M, records + b * M * D, masked + b * M);
     };
     if (threads <= 1 || B < 2) { run(0, B); return; }
-    const size_t nt = std::min<size_t>((size_t)threads, B);
-    std::vector<std::thread> th;
-    for (size_t k = 0; k < nt; ++k) th.emplace_back(run, B * k / nt, B * (k + 1) / nt);
-    for (std::thread &x : th) x.join();
+    // pieces of ~32768 rows (~0.1-0.4 ms of walk): small enough to balance ragged strings over the threads, large enough that the counter is not contended
+    const size_t grain = std::max<size_t>(1, 32768 / std::max<size_t>(1, M));
+    HostPool::get().run(B, grain, (size_t)threads, run);
 }
 
 // derive_states (lib.rs:804-823) for one string: states[d * (n + 1) + i]; false + (state, char) of the reference's panic

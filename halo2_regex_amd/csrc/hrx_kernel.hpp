@@ -57,6 +57,10 @@ struct WitnessArgs {
     // as ONE allocation they lie in one class of the physical address space and the launch runs at what one class absorbs (the no-compute pass of cfg 4:
     // 0.70-0.77 of peak), as separately placed planes at 0.86 (profiles/r06_probes/plane_probe.txt).  rec_planes[0] == NULL: the interleaved layout, `records`.
     unsigned char *rec_planes[kMaxDefsPerLaunch];
+    // ... and ONE def's plane in two ROW STRIPES (rec_stripes == 2, D == 1): quad q of a string in buffer q % 2 at slot q / 2 — per block [ceil(ceil(M/4)/2)][nb][4] each — so that even a
+    // one-def launch's 4 record bytes per row spread over two classes of the address space beside the masked rows' third (the no-compute pass of the bench line 0.76 -> 0.805 of peak,
+    // of cfg 5's byte count 0.72-0.80 -> 0.82: profiles/r06_probes/stripe_probe_*.txt).  0 / 1: whole planes.
+    uint32_t rec_stripes;
     // the LAST pass of a multi-pass config reads the earlier groups' tile summaries itself (its finisher has everything else in hand: this
     // group's bitvectors and id bytes, the input bytes, the reveal-mask carries) and writes the FINAL masked rows: no combine launch,
     // this group's summary never written, the others' read once.  0: not such a pass.
@@ -186,7 +190,7 @@ double placement_probe_us(void *rec, size_t rec_bytes, void *msk, size_t msk_byt
 hipError_t launch_traffic_pass_sm(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, size_t rec_pitch, uint16_t *masked,
                                   size_t msk_pitch, uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream);
 hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
-                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream, uint32_t *const *planes = nullptr);
+                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream, uint32_t *const *planes = nullptr, uint32_t stripes = 1);
 uint32_t plan_nt_mix(const WitnessArgs &a, const LaunchInfo &li);
 constexpr size_t kPmSummaryBytes = 6144;
 template <bool HALF, bool SM> constexpr bool kPmFinisher = !HALF && !SM;

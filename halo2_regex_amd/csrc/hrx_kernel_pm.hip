@@ -577,8 +577,10 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
             const uint32_t RD = a.rec_D ? a.rec_D : (uint32_t)D;
             // record planes in buffers of their own (WitnessArgs::rec_planes): every def's plane is the D = 1 layout [M/4][nb][4] of its block
             const bool planes = !SM && a.rec_planes[0] != nullptr;
+            const bool stripes = planes && D == 1 && a.rec_stripes == 2u;      // one def in two row stripes: quad q in buffer q % 2 at slot q / 2
+            const size_t slots = stripes ? (q4 + 1u) / 2u : q4;
             unsigned char *rp = SM ? reinterpret_cast<unsigned char *>(a.records) + (size_t)bc * a.rec_pitch * D * 4u
-                                : planes ? a.rec_planes[0] + ((size_t)blk0 * q4 + (bc - blk0)) * 16u
+                                : planes ? a.rec_planes[0] + ((size_t)blk0 * slots + (bc - blk0)) * 16u
                                    : reinterpret_cast<unsigned char *>(a.records) + (((size_t)blk0 * q4 * RD + (size_t)a.rec_d0 * nb) + (bc - blk0)) * 16u;
             size_t poff[D];
 #pragma unroll
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(pm_max_threads(HALF, SM)) void witness_pm_kernel(co
                 const bool pend_store = have_pend && !(a.debug & kDbgSkipMasked);
                 uint32_t tile_ov = 0, hb = 0;   // WIDE: flag-overlap seen in the tile; bytes >= 128 among the tile's live rows
                 // [ceil(M/4)][D][nb][4]: one def's quads of all strings of the block
-                GlobalSink<D, SM> sink{rp, poff, rstep, do_store, nt_rec, nt_msk,
+                GlobalSink<D, SM> sink{rp, poff, rstep, stripes ? (size_t)0 : rstep, stripes ? (size_t)(a.rec_planes[1] - a.rec_planes[0]) : (size_t)0, do_store, nt_rec, nt_msk,
                                        pend, pend_mp, mstep, pend_store, {}};
                 if (WIDE) {
                     const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(FIN && (D >= 7 || (!CW && D >= 3)) ? 640 : 512) voi
             TileBits tb;
             const bool full = (t0 + 64u < min_n);
             uint32_t tile_ov = 0, hb = 0;
-            GlobalSink<1> sink{rp, poff1, rstep, !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
+            GlobalSink<1> sink{rp, poff1, rstep, rstep, 0, !(a.debug & kDbgSkipRecords), nt_rec, false, no_pend, mp, mstep, false, {}};
             const uint32_t cwl[16] = {cq[0].x, cq[0].y, cq[0].z, cq[0].w, cq[1].x, cq[1].y, cq[1].z, cq[1].w,
                                       cq[2].x, cq[2].y, cq[2].z, cq[2].w, cq[3].x, cq[3].y, cq[3].z, cq[3].w};
             uint4 ccol[4] = {};  // CW: the bytes' columns (class x 8) of this def, packed like the bytes

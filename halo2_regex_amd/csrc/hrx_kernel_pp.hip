@@ -339,7 +339,7 @@ __global__ __launch_bounds__(768) void witness_pp_kernel(const WitnessArgs a, co
             for (int i = 0; i < 16; ++i) sidq[i] = 0;
             uint32_t odd_dead = 0;
             const bool full = (t0 + 64u < min_n);
-            GlobalSink<1, false> sink{rp, poff1, rstep, !(a.debug & kDbgSkipRecords), !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)),
+            GlobalSink<1, false> sink{rp, poff1, rstep, rstep, 0, !(a.debug & kDbgSkipRecords), !(a.debug & (kDbgNoNtStores | kDbgNoNtRecords)), !(a.debug & (kDbgNoNtStores | kDbgNoNtMasked)),
                                       pend, rp, rstep, false, {}};
             TileBits tb;
             if (full) tb = walk_tile_pp<true>(L, iw, a, sink, 0, 0, sidq, acc_state, odd_dead);

@@ -84,6 +84,7 @@ struct TrafficArgs {
     uint32_t *sink;
     uint32_t spread;
     unsigned char *planes[kMaxDefsPerLaunch];   // record planes in buffers of their own (WitnessArgs::rec_planes); planes[0] == NULL: the interleaved `records`
+    uint32_t stripes;                           // 2: one def's plane in two row stripes (WitnessArgs::rec_stripes): quad q in planes[q % 2] at slot q / 2
 };
 
 __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) {
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) 
             const bool wb = wb_k != 0u && (t % wb_k) == wb_k - 1u;
             const uint4 v = make_uint4(q, 1, 2, 3);
             for (uint32_t d = 0; d < a.D; ++d) {
-                unsigned char *p = a.planes[0] ? a.planes[d] + ((size_t)blk0 * q4 + bl + (size_t)q * nb) * 16u : rp + ((size_t)q * a.D + d) * nb * 16u;
+                unsigned char *p = a.stripes == 2u ? a.planes[q & 1u] + ((size_t)blk0 * ((q4 + 1u) / 2u) + bl + (size_t)(q >> 1) * nb) * 16u
+                                 : a.planes[0] ? a.planes[d] + ((size_t)blk0 * q4 + bl + (size_t)q * nb) * 16u : rp + ((size_t)q * a.D + d) * nb * 16u;
                 if (wb) *reinterpret_cast<uint4 *>(p) = v;
                 else store16_nt(p, v);
             }
@@ -196,10 +198,10 @@ hipError_t launch_traffic_pass_sm(const uint8_t *chars, size_t stride, size_t B,
 }
 
 hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t D, uint32_t *records, uint16_t *masked,
-                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream, uint32_t *const *planes) {
-    TrafficArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink, 0u, {}};
+                               uint32_t nt_mix, uint32_t *sink, int num_cus, hipStream_t stream, uint32_t *const *planes, uint32_t stripes) {
+    TrafficArgs a{chars, stride, (uint32_t)B, (uint32_t)M, D, (unsigned char *)records, (unsigned char *)masked, nt_mix, sink, 0u, {}, planes && D == 1 ? stripes : 1u};
     if (planes)
-        for (uint32_t d = 0; d < D && d < kMaxDefsPerLaunch; ++d) a.planes[d] = (unsigned char *)planes[d];
+        for (uint32_t d = 0; d < D * a.stripes && d < kMaxDefsPerLaunch; ++d) a.planes[d] = (unsigned char *)planes[d];
     const size_t n_groups = (B + 63) / 64;
     a.spread = n_groups < (size_t)num_cus * 4 ? 1u : 0u;
     const size_t need = a.spread ? n_groups : (n_groups + 3) / 4;

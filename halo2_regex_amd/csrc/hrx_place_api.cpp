@@ -96,6 +96,9 @@ static bool arena_release(void *ptr) {
 struct hrx_place_pool {
     std::mutex mu;
     hrx_place_arena *rec = nullptr, *msk = nullptr;
+    hrx_place_arena *stripe[4] = {nullptr, nullptr, nullptr, nullptr};   // the device's STRIPE ARENAS (hrx_alloc_output_planes of small buffers): stripe_n of them, mutually non-colliding
+    size_t stripe_n = 0;
+    hrx_place_report stripe_report{};
     hrx_place_report report{};     // of the walk that found the pair
     double seen_rate[HRX_MAX_DEFS + 1] = {};   // per number of defs D (the probe writes its two streams in the launch's ratio 4 D : 2, so rates of different D do not compare):
                                                // the fastest pairing any arena walk on this device has probed (bytes per microsecond)
@@ -110,17 +113,20 @@ hrx_place_pool *pool_acquire(int device) {
     ++p->users;
     return p;
 }
-extern "C" {
-}  // extern "C"
 void pool_release(hrx_place_pool *p) {
     if (!p) return;
-    hrx_place_arena *r = nullptr, *m = nullptr;
+    hrx_place_arena *r = nullptr, *m = nullptr, *st[4] = {nullptr, nullptr, nullptr, nullptr};
     {
         std::lock_guard<std::mutex> pl(p->mu);
         std::lock_guard<std::mutex> lk(g_arena_mu);
-        if (--p->users == 0) { r = p->rec; m = p->msk; p->rec = p->msk = nullptr; for (double &v : p->seen_rate) v = 0.0; p->report = hrx_place_report{}; }
+        if (--p->users == 0) {
+            r = p->rec; m = p->msk; p->rec = p->msk = nullptr; for (double &v : p->seen_rate) v = 0.0; p->report = hrx_place_report{};
+            for (size_t i = 0; i < p->stripe_n; ++i) { st[i] = p->stripe[i]; p->stripe[i] = nullptr; }
+            p->stripe_n = 0;
+        }
     }
     arena_retire(r); arena_retire(m);
+    for (hrx_place_arena *a : st) arena_retire(a);
 }
 extern "C" {
 
@@ -350,7 +356,8 @@ int hrx_traffic_pass_device_planes(hrx_ctx *ctx, const uint8_t *chars, size_t st
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
     if (B == 0) return HRX_OK;
-    if (!chars || !record_planes || !masked || n_planes != ctx->s.defs.size() || n_planes > kMaxDefsPerLaunch) return fail(HRX_ERR_ARG, "NULL buffer, or not one plane per def (at most eight)");
+    const size_t Dn = ctx->s.defs.size();
+    if (!chars || !record_planes || !masked || !(n_planes == Dn || (Dn == 1 && n_planes == 2)) || n_planes > kMaxDefsPerLaunch) return fail(HRX_ERR_ARG, "NULL buffer, or not one plane per def (at most eight; one def: one buffer or two row stripes)");
     if (M == 0 || M > (1u << 24) || B > 0xffffffffull - 64) return fail(HRX_ERR_ARG, "shape out of range");
     if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)masked & 15)) return fail(HRX_ERR_ARG, "buffers must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
     for (size_t d = 0; d < n_planes; ++d)
@@ -359,11 +366,11 @@ int hrx_traffic_pass_device_planes(hrx_ctx *ctx, const uint8_t *chars, size_t st
     DeviceGuard guard;
     HIP_TRY(guard.set(ctx->device));
     WitnessArgs a{};
-    a.layout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)n_planes;
+    a.layout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)Dn;
     LaunchInfo li{};
     li.split = 2;
     const uint32_t nt_mix = plan_nt_mix(a, li);
-    HIP_TRY(launch_traffic_pass(chars, stride, B, M, a.D, record_planes[0], masked, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream, record_planes));
+    HIP_TRY(launch_traffic_pass(chars, stride, B, M, a.D, record_planes[0], masked, nt_mix, ctx->d_group_counter + 8, ctx->num_cus, (hipStream_t)stream, record_planes, (uint32_t)(n_planes / Dn)));
     return HRX_OK;
 }
 
@@ -380,31 +387,24 @@ int hrx_probe_write_pair(hrx_ctx *ctx, void *a, void *b, size_t bytes, double *g
     return HRX_OK;
 }
 
-// Record planes + masked rows, each in a neighbourhood of its own: the launch's D + 1 write streams spread over the classes of the physical address space instead of 4 D of
-// its 4 D + 2 bytes per row going into one allocation.  A POOL of candidates — D + kPlanesSpare plane-sized buffers, kPlanesMasked masked-row-sized ones, allocated one after the other (they
-// walk down the device memory) — is measured pair by pair with the two-equal-streams probe (~1 ms per pair on the device clock), and the D planes + masked buffer whose BUSIEST CLASS takes
-// the smallest share of the launch's output bytes (then: the fewest colliding pairings, the largest sum of pairings) are kept; the rest is freed before the call returns.  No absolute threshold: pairings in one class measure 5.2-6.2 TB/s, across classes 6.5-7.3
-// (profiles/r06_probes/plane_probe.txt, plane_select_cfg4.txt), and both levels move with the box: "colliding" = below the midpoint of the two levels of THIS pool.  Random draws of three 4-GiB planes + masked rows already run cfg 4's no-compute pass at 0.86 of peak in 54 of 60
+// Record planes + masked rows, each in a neighbourhood of its own: the launch's write streams spread over the classes of the physical address space instead of 4 D of
+// its 4 D + 2 bytes per row going into one allocation.  A POOL of candidates — nrec + kPlanesSpare record-sized buffers, kPlanesMasked masked-row-sized ones, allocated one after the other (they
+// walk down the device memory) — is measured pair by pair with the two-equal-streams probe (~1 ms per pair on the device clock), and the nrec record buffers + masked buffer whose BUSIEST CLASS
+// takes the smallest share of the launch's output bytes (then: the fewest colliding pairings, the largest sum of pairings) are kept; the rest is freed before the call returns.  No absolute
+// threshold: pairings in one class measure 5.2-6.2 TB/s, across classes 6.5-7.3 (profiles/r06_probes/plane_probe.txt, plane_select_cfg4.txt), and both levels move with the box: "colliding" =
+// below the cut between the two levels of THIS pool.  Random draws of three 4-GiB planes + masked rows already run cfg 4's no-compute pass at 0.86 of peak in 54 of 60
 // cases, against 0.65 for three planes of one class and 0.74-0.77 for the interleaved buffer: the selection only has to avoid the draws that collide.
 constexpr size_t kPlanesSpare = 4, kPlanesMasked = 5, kPlanesGrow = 3, kPlanesMaxSets = 4096;
-int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_planes, uint16_t **masked) {
-    if (!ctx || !record_planes || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes: bad argument");
-    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
-    const size_t D = ctx->s.defs.size();
-    if (D == 1) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
-    size_t plane_u32 = 0, masked_u16 = 0;
-    hrx_position_major_plane_sizes(B, M, &plane_u32, &masked_u16);
-    const size_t plane_bytes = plane_u32 * 4, masked_bytes = masked_u16 * 2;
-    for (size_t d = 0; d < D; ++d) record_planes[d] = nullptr;
-    *masked = nullptr;
-    std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
+
+}  // extern "C"
+
+// nrec buffers of rec_bytes (each carrying w_rec of the launch's output bytes per row, in any unit) + one of msk_bytes (w_msk).  On success rec_out / msk_out own the kept buffers
+// (hipMalloc'ed; everything else has been freed) and rep says what was measured; false: out of device memory (nothing is held).
+static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nrec, const size_t msk_bytes, const size_t w_rec, const size_t w_msk, const bool walk,
+                           std::vector<void *> &rec_out, void *&msk_out, hrx_place_report &rep) {
     const auto t_begin = std::chrono::steady_clock::now();
-    hrx_place_report rep{};
-    std::vector<void *> pc, mc;     // plane and masked-row candidates
-    auto free_all = [&]() { for (void *p : pc) (void)hipFree(p); for (void *p : mc) (void)hipFree(p); pc.clear(); mc.clear(); };
-    const bool walk = ctx->place_enabled && plane_bytes >= kPlaceFromBytes;
+    std::vector<void *> pc, mc, spacers;     // record and masked-row candidates; blocks that only push the next candidates further down the memory
+    auto free_all = [&]() { for (void *p : pc) if (p) (void)hipFree(p); for (void *p : mc) if (p) (void)hipFree(p); for (void *p : spacers) (void)hipFree(p); pc.clear(); mc.clear(); spacers.clear(); };
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
     size_t budget = (size_t)((double)free_b * kPlaceBudgetFrac), spent = 0;
@@ -427,17 +427,17 @@ int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_
         rep.peak_candidate_bytes = std::max(rep.peak_candidate_bytes, spent);
         return true;
     };
-    if (!take(pc, plane_bytes, D, walk ? D + kPlanesSpare : D) || !take(mc, masked_bytes, 1, walk ? kPlanesMasked : 1)) {
+    if (!take(pc, rec_bytes, nrec, walk ? nrec + kPlanesSpare : nrec) || !take(mc, msk_bytes, 1, walk ? kPlanesMasked : 1)) {
         free_all();
-        return fail(HRX_ERR_HIP, "hrx_alloc_output_planes: out of device memory");
+        return false;
     }
-    std::vector<size_t> pick(D);
-    for (size_t d = 0; d < D; ++d) pick[d] = d;
+    std::vector<size_t> pick(nrec);
+    for (size_t d = 0; d < nrec; ++d) pick[d] = d;
     size_t pick_m = 0;
-    if (walk && (pc.size() > D || mc.size() > 1)) {
+    if (walk && (pc.size() > nrec || mc.size() > 1)) {
         rep.searched = 1;
         unsigned long long *clk = (unsigned long long *)(ctx->d_group_counter + 4);
-        std::vector<std::vector<double>> pp, pm;       // bytes per microsecond of every pairing measured so far: plane x plane, masked x plane
+        std::vector<std::vector<double>> pp, pm;       // bytes per microsecond of every pairing measured so far: record x record, masked x record
         auto probe = [&](void *x, void *y, size_t bytes) {
             size_t wrote = 0;
             const double us = hrx::placement_probe_us(x, bytes, y, bytes, 0u, ctx->stream, clk, &wrote);
@@ -445,20 +445,23 @@ int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_
             ++rep.steps;
             return us > 0 ? (double)wrote / us : 0.0;
         };
-        double lo = 0, hi = 0, cut = 0, first_low = -1.0, first_sum = 0.0;
+        double lo = 0, hi = 0, cut = 0;
+        bool first = true;
         size_t best_low = ~(size_t)0, best_load = ~(size_t)0;
         double best_sum = -1.0, best_min = 0.0;
+        // what there is to find: with up to three buffers, a set in which nothing collides; with more, one whose busiest class takes a record buffer and the masked rows
+        const size_t load_goal = nrec + 1 <= 3 ? std::max(w_rec, w_msk) : w_rec + w_msk;
         for (int round = 0;; ++round) {
             // ---- measure the pairings of the candidates that are new in this round
-            const size_t P = pc.size(), Q = mc.size(), P0 = pp.size();
+            const size_t P = pc.size(), Q = mc.size(), P0 = pp.size(), Q0 = pm.size();
             pp.resize(P);
             for (auto &r : pp) r.resize(P, 0.0);
             pm.resize(Q);
             for (auto &r : pm) r.resize(P, 0.0);
             for (size_t i = 0; i < P; ++i)
-                for (size_t j = std::max(i + 1, P0); j < P; ++j) pp[i][j] = pp[j][i] = probe(pc[i], pc[j], plane_bytes);
+                for (size_t j = std::max(i + 1, P0); j < P; ++j) pp[i][j] = pp[j][i] = probe(pc[i], pc[j], rec_bytes);
             for (size_t q = 0; q < Q; ++q)
-                for (size_t i = (round == 0 ? 0 : P0); i < P; ++i) pm[q][i] = probe(mc[q], pc[i], std::min(masked_bytes, plane_bytes));
+                for (size_t i = (q < Q0 ? P0 : 0); i < P; ++i) pm[q][i] = probe(mc[q], pc[i], std::min(msk_bytes, rec_bytes));      // (new columns of the old rows, whole new rows)
             // ---- two levels: pairings in one class of the address space and pairings across classes.  cut = halfway between the levels' means (two-means from the range's middle)
             std::vector<double> all;
             for (size_t i = 0; i < P; ++i) for (size_t j = i + 1; j < P; ++j) all.push_back(pp[i][j]);
@@ -476,68 +479,155 @@ int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_
                                                 //  classes lie within ~10 % of the fastest one)
             if (hi < 1.08 * lo) cut = 0.0;      // every pairing measures alike: nothing collides (or everything does) — then only the sums rank
             if (ctx->place_trace) {
-                for (size_t i = P0; i < P; ++i) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pp[i][j] * 1e-3)); place_trace(ctx, "hrx planes: plane candidate %zu %p vs planes (GB/s):%s\n", i, pc[i], l.c_str()); }
-                for (size_t q = 0; q < Q; ++q) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pm[q][j] * 1e-3)); place_trace(ctx, "hrx planes: masked candidate %zu %p vs planes (GB/s):%s\n", q, mc[q], l.c_str()); }
+                for (size_t i = P0; i < P; ++i) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pp[i][j] * 1e-3)); place_trace(ctx, "hrx planes: record candidate %zu %p vs records (GB/s):%s\n", i, pc[i], l.c_str()); }
+                for (size_t q = 0; q < Q; ++q) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pm[q][j] * 1e-3)); place_trace(ctx, "hrx planes: masked candidate %zu %p vs records (GB/s):%s\n", q, mc[q], l.c_str()); }
             }
-            // ---- every D-subset of the plane candidates x every masked candidate: fewest colliding pairings, then the largest sum.  (What the launch time follows, cfg 4 over all
-            // 224 sets of 8 + 4 candidates, profiles/r06_probes/plane_select_cfg4.txt: sets with at most one colliding pairing 2.50-2.53 ms, three — two planes and the masked rows in one
-            // class — 2.64-2.88, all six 3.4-3.8; the slowest pairing alone does not tell these apart.)
             // The score of a set: the largest share of the launch's output bytes that lands in one class — per buffer its own bytes per row (4 per plane, 2 for the masked rows)
             // plus those of every buffer it collides with, the maximum over the buffers — then the number of colliding pairings, then the sum of the pairings' rates.  cfg 3 over all 60
             // sets of 6 + 4 candidates (plane_select_cfg3.txt): nothing collides (largest share 4 of 10 bytes) 3.53 ms; the masked rows with a plane (6 of 10) 3.67-3.77; the two
-            // planes with each other (8 of 10) 3.87-3.89; everything (10 of 10) 4.57-4.69 — the count of colliding pairings alone ranks the second and the third alike.
-            std::vector<size_t> idx(D);
-            for (size_t d = 0; d < D; ++d) idx[d] = d;
+            // planes with each other (8 of 10) 3.87-3.89; everything (10 of 10) 4.57-4.69 — the count of colliding pairings alone ranks the second and the third alike.  cfg 4 over all
+            // 224 sets of 8 + 4 (plane_select_cfg4.txt): a plane and the masked rows in one class (6 of 14) 2.50-2.53 ms, two planes and the masked rows 2.64-2.88, everything 3.4-3.8.
+            std::vector<size_t> idx(nrec);
+            for (size_t d = 0; d < nrec; ++d) idx[d] = d;
             best_low = ~(size_t)0; best_sum = -1.0; best_load = ~(size_t)0;
             size_t sets = 0;
             for (;;) {
                 for (size_t q = 0; q < Q; ++q) {
-                    double mn = 1e30, sum = 0.0; size_t low = 0, load_m = 2, load_max = 0;
-                    for (size_t x = 0; x < D; ++x) {
-                        size_t load_x = 4;
-                        for (size_t y = 0; y < D; ++y) {
+                    double mn = 1e30, sum = 0.0; size_t low = 0, load_m = w_msk, load_max = 0;
+                    for (size_t x = 0; x < nrec; ++x) {
+                        size_t load_x = w_rec;
+                        for (size_t y = 0; y < nrec; ++y) {
                             if (y == x) continue;
                             const double v = pp[idx[x]][idx[y]];
-                            if (v < cut) load_x += 4;
+                            if (v < cut) load_x += w_rec;
                             if (y > x) { mn = std::min(mn, v); sum += v; low += v < cut; }
                         }
                         const double v = pm[q][idx[x]]; mn = std::min(mn, v); sum += v; low += v < cut;
-                        if (v < cut) { load_x += 2; load_m += 4; }
+                        if (v < cut) { load_x += w_msk; load_m += w_rec; }
                         load_max = std::max(load_max, load_x);
                     }
                     load_max = std::max(load_max, load_m);
-                    if (first_low < 0) { first_low = (double)low; first_sum = sum; rep.first_gbs = mn * 1e-3; }      // candidates 0 .. D - 1 + masked candidate 0: the plain-allocation draw
+                    if (first) { first = false; rep.first_gbs = mn * 1e-3; }      // candidates 0 .. nrec - 1 + masked candidate 0: the plain-allocation draw
                     if (load_max < best_load || (load_max == best_load && (low < best_low || (low == best_low && sum > best_sum)))) {
                         best_load = load_max; best_low = low; best_sum = sum; best_min = mn; pick = idx; pick_m = q;
                     }
                 }
                 if (++sets >= kPlanesMaxSets) break;      // (more than three defs: the first sets in allocation order)
-                size_t k = D;       // next combination
-                while (k > 0 && idx[k - 1] == P - D + k - 1) --k;
+                size_t k = nrec;       // next combination
+                while (k > 0 && idx[k - 1] == P - nrec + k - 1) --k;
                 if (k == 0) break;
                 ++idx[k - 1];
-                for (size_t x = k; x < D; ++x) idx[x] = idx[x - 1] + 1;
+                for (size_t x = k; x < nrec; ++x) idx[x] = idx[x - 1] + 1;
             }
-            place_trace(ctx, "hrx planes: round %d, %zu + %zu candidates: pairings %.2f .. %.2f TB/s, cut %.2f; best set: busiest class %zu of %zu bytes per row, %zu colliding pairings, slowest %.2f TB/s\n",
-                        round, P, Q, lo * 1e-6, hi * 1e-6, cut * 1e-6, best_load, 4 * D + 2, best_low, best_min * 1e-6);
-            // ---- a set whose busiest class takes no more than a plane and the masked rows (6 bytes per row) is what there is to find with three planes; with two, one where nothing
-            // collides; otherwise walk further down the memory, once or twice
-            if (best_load <= (D == 2 ? 4u : 6u) || round >= 2) break;
+            place_trace(ctx, "hrx planes: round %d, %zu + %zu candidates: pairings %.2f .. %.2f TB/s, cut %.2f; best set: busiest class %zu of %zu output bytes per row, %zu colliding pairings, slowest %.2f TB/s\n",
+                        round, P, Q, lo * 1e-6, hi * 1e-6, cut * 1e-6, best_load, nrec * w_rec + w_msk, best_low, best_min * 1e-6);
+            // otherwise walk further down the memory, once or twice.  (Tried for the 2-GiB stripe arenas of one def's row stripes: four more rounds, each behind a 16-GiB spacer — 24 candidates
+            // over ~120 GiB, 315 pairings, 3-4 s — still found no three mutually non-colliding arenas on a lease whose first 17 candidates showed two classes; not kept:
+            // profiles/r06_probes/stripes_ab_cfg2.txt.)
+            if (best_load <= load_goal || round >= 2) break;
             const size_t before = pc.size();
-            if (!take(pc, plane_bytes, before, before + kPlanesGrow) || pc.size() == before) break;
+            if (!take(pc, rec_bytes, before, before + kPlanesGrow) || pc.size() == before) break;
+            (void)take(mc, msk_bytes, mc.size(), mc.size() + 1);      // (a masked-row candidate of the new neighbourhood as well)
         }
-        (void)first_sum;
-        rep.ref_gbs = lo * 1e-3;           // the slowest pairing seen (hi is in the trace)
+        rep.ref_gbs = lo * 1e-3;           // the slowest pairing seen (the fastest is in the trace)
         rep.best_gbs = best_min * 1e-3;    // the kept set's slowest pairing
-        rep.chosen_step = (int)best_load;  // ... and the output bytes per row (of 4 D + 2) that its busiest class takes
-        rep.accepted = (cut == 0.0 || best_load <= 6) ? 1 : 0;
+        rep.chosen_step = (int)best_load;  // ... and the output bytes per row that its busiest class takes (in units of the weights: planes 4 / masked rows 2; row stripes of one def 2 / 2)
+        rep.accepted = (cut == 0.0 || best_load <= load_goal) ? 1 : 0;
     }
-    for (size_t d = 0; d < D; ++d) { record_planes[d] = (uint32_t *)pc[pick[d]]; pc[pick[d]] = nullptr; }
-    *masked = (uint16_t *)mc[pick_m];
+    rec_out.clear();
+    for (size_t d = 0; d < nrec; ++d) { rec_out.push_back(pc[pick[d]]); pc[pick[d]] = nullptr; }
+    msk_out = mc[pick_m];
     mc[pick_m] = nullptr;
-    for (void *&p : pc) if (p) { (void)hipFree(p); p = nullptr; }
-    for (void *&p : mc) if (p) { (void)hipFree(p); p = nullptr; }
+    free_all();
     rep.search_ms = elapsed_ms();
+    return true;
+}
+
+extern "C" {
+
+void hrx_position_major_stripe_sizes(size_t B, size_t M, size_t n_stripes, size_t *stripe_u32, size_t *masked_u16) {
+    if (n_stripes < 1) n_stripes = 1;
+    if (stripe_u32) *stripe_u32 = ((M + 3) / 4 + n_stripes - 1) / n_stripes * B * 4;
+    if (masked_u16) *masked_u16 = (M + 7) / 8 * B * 8;
+}
+
+// Small record buffers (below kPlaceDirectFrom each: the bench line's 128-MiB row stripes) are carved out of the device's STRIPE ARENAS — up to four 2-GiB blocks per device and process,
+// mutually non-colliding as far as the box has them, found once with choose_buffers over 2-GiB candidates (a probe over buffers that fit the Infinity Cache would measure the cache); record
+// buffer i comes out of arena i, the masked rows out of the last one; hrx_device_free returns a sub-buffer's range to its arena.
+static bool stripe_arenas_take(hrx_ctx *ctx, const size_t nrec, const size_t rec_bytes, const size_t msk_bytes, std::vector<void *> &rec_out, void *&msk_out, hrx_place_report &rep) {
+    hrx_place_pool *pool = ctx->pool;
+    std::lock_guard<std::mutex> pl(pool->mu);
+    const size_t need = nrec + 1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (pool->stripe_n >= need) {
+            std::lock_guard<std::mutex> lk(g_arena_mu);
+            bool fits = pool->stripe[need - 1]->ranges.fits(arena_need(msk_bytes));      // (the masked rows: the last arena of the set that was measured for `need` buffers)
+            for (size_t i = 0; i < nrec && fits; ++i) fits = pool->stripe[i]->ranges.fits(arena_need(rec_bytes));
+            if (fits) {
+                rec_out.clear();
+                for (size_t i = 0; i < nrec; ++i) {
+                    void *p = (unsigned char *)pool->stripe[i]->base + pool->stripe[i]->ranges.take(arena_need(rec_bytes));
+                    g_arena_of[(uintptr_t)p] = pool->stripe[i];
+                    rec_out.push_back(p);
+                }
+                msk_out = (unsigned char *)pool->stripe[need - 1]->base + pool->stripe[need - 1]->ranges.take(arena_need(msk_bytes));
+                g_arena_of[(uintptr_t)msk_out] = pool->stripe[need - 1];
+                if (attempt == 0) { rep = pool->stripe_report; rep.searched = 2; }
+                return true;
+            }
+        }
+        // (full, or fewer arenas than this request needs: a new set)
+        for (size_t i = 0; i < pool->stripe_n; ++i) arena_retire(pool->stripe[i]);
+        pool->stripe_n = 0;
+        std::vector<void *> ar;
+        void *last = nullptr;
+        hrx_place_report r2{};
+        if (!choose_buffers(ctx, kPlaceArenaBytes, need - 1, kPlaceArenaBytes, 2, 2, true, ar, last, r2)) return false;
+        ar.push_back(last);
+        for (size_t i = 0; i < need; ++i) {
+            hrx_place_arena *a = new hrx_place_arena();
+            a->base = ar[i]; a->device = ctx->device; a->ranges.reset(kPlaceArenaBytes);
+            pool->stripe[i] = a;
+        }
+        pool->stripe_n = need;
+        pool->stripe_report = r2;
+        rep = r2;
+    }
+    return false;
+}
+
+int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, uint32_t **record_planes, uint16_t **masked) {
+    if (!ctx || !record_planes || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes: bad argument");
+    if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
+    const size_t D = ctx->s.defs.size();
+    if (!(n_planes == D || (D == 1 && n_planes == 2))) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes: one buffer per RegexDefs of the config (one def: one buffer, or two row stripes)");
+    if (n_planes == 1) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
+    const size_t R = n_planes / D;
+    size_t rec_u32 = 0, masked_u16 = 0;
+    hrx_position_major_stripe_sizes(B, M, R, &rec_u32, &masked_u16);
+    const size_t rec_bytes = rec_u32 * 4, masked_bytes = masked_u16 * 2;
+    for (size_t d = 0; d < n_planes; ++d) record_planes[d] = nullptr;
+    *masked = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
+    DeviceGuard guard;
+    HIP_TRY(guard.set(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    hrx_place_report rep{};
+    std::vector<void *> rec;
+    void *msk = nullptr;
+    const size_t w_rec = 4 / R, w_msk = 2;
+    const bool walk = ctx->place_enabled && rec_bytes * n_planes >= kPlaceFromBytes;
+    bool ok = false;
+    if (walk && rec_bytes < kPlaceDirectFrom && n_planes + 1 <= 4 && rec_bytes <= kPlaceArenaBytes / 2 && masked_bytes <= kPlaceArenaBytes / 2)
+        ok = stripe_arenas_take(ctx, n_planes, rec_bytes, masked_bytes, rec, msk, rep);
+    if (!ok) {
+        rep = hrx_place_report{};
+        ok = choose_buffers(ctx, rec_bytes, n_planes, masked_bytes, w_rec, w_msk, walk && rec_bytes >= kPlaceDirectFrom / 4, rec, msk, rep);
+    }
+    if (!ok) return fail(HRX_ERR_HIP, "hrx_alloc_output_planes: out of device memory");
+    for (size_t d = 0; d < n_planes; ++d) record_planes[d] = (uint32_t *)rec[d];
+    *masked = (uint16_t *)msk;
+    rep.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     ctx->last_place = rep;
     return HRX_OK;
 }

@@ -51,7 +51,8 @@ struct GlobalSink {
     static constexpr bool kSidq = true;
     unsigned char *rp;
     const size_t (&poff)[D];   // def d's plane relative to def 0's: d * nb * 16 in the interleaved [M/4][D][nb][4], the distance of the buffers with WitnessArgs::rec_planes
-    size_t rstep;
+    size_t rstep;              // to the next quad of rows (D == 1: after an ODD quad of the tile; the tile has 16)
+    size_t rstep_even, soff1;  // D == 1: the step after an EVEN quad (= rstep, or 0 with two row stripes) and the second stripe relative to the first (0 without: WitnessArgs::rec_stripes)
     bool do_store, nt_rec, nt_msk;
     const uint4 (&pend)[8];
     unsigned char *pend_mp;
@@ -79,6 +80,12 @@ struct GlobalSink {
             return;
         }
         // quads that start at or beyond row M do not exist in [ceil(M/4)][D][B][4]
+        if (D == 1) {   // (p is a compile-time constant in the unrolled walks: the quad's parity picks the scalars)
+            const bool odd = ((p >> 2) & 1) != 0;
+            if (do_store && (full || (p & ~3) <= mrem)) store16(rp + (odd ? soff1 : (size_t)0), v, nt_rec);
+            rp += odd ? rstep : rstep_even;
+            return;
+        }
         if (do_store && (full || (p & ~3) <= mrem)) store16(rp + poff[d], v, nt_rec);
         if (d == D - 1) rp += rstep;
     }

@@ -137,8 +137,30 @@ size_t hrx_ctx_host_threshold(const hrx_ctx *ctx);
 /* Per-context choices between variants that compute the same rows (what a linking prover sets instead of environment variables).
  *   HRX_OPT_PMD_COMBINER_WAVE  the def-parallel kernel of two- and three-def configs (batches of at most two groups of 64 strings per CU): 1 = a combiner wave of its own
  *                              per group (sums over the defs, reveal mask, masked rows), 2 = the last def's walker combines, 0 = the library's default
- * Applies to later launches; hrx_ctx_clone copies the options.  hrx_ctx_get_option: the value, -1 for an unknown option. */
-enum { HRX_OPT_PMD_COMBINER_WAVE = 1 };
+ *   HRX_OPT_HOST_ROUTE         hrx_witness_batch_host on a device context, batches of at least the host threshold:
+ *                              HRX_HOST_ROUTE_AUTO (0, default) from 2^22 rows on BOTH AT ONCE: the batch is split by string index between the device (staged, walked, copied back)
+ *                                and the host cores (the native walk), in the ratio of the rates this context measured over its earlier calls (the first call: half and half; every
+ *                                call times both parts and the split follows; a part that would get less than a sixteenth of the batch gets nothing, and one call in 64 a sixteenth
+ *                                again) — the copy back over the link bounds the device part (~9e9 rows/s at one def), the host's cores and memory the other; smaller batches: the device;
+ *                              HRX_HOST_ROUTE_DEVICE (1) everything through the device;  HRX_HOST_ROUTE_HOST (2) everything on the host cores.  Results are identical either way.
+ *   HRX_OPT_HOST_THREADS       host threads of the native walk (0, default: as many as the calling thread's affinity mask has cores; hrx_multi_create divides them among its shards)
+ *   HRX_OPT_HOST_PIPELINE      the device part's transfers: 0 (default) the context times both ways over its first calls and keeps the faster (the pipeline's copies out run at half rate
+ *                              on some hosts), 1 pipelined chunk by chunk over two streams, 2 in, walk, out on one stream; HRX_HOST_PIPELINE=1 / 0 in the environment of hrx_ctx_create
+ *                              sets 1 / 2 as the context's default
+ * Applies to later calls; hrx_ctx_clone copies the options.  hrx_ctx_get_option: the value, -1 for an unknown option. */
+enum { HRX_OPT_PMD_COMBINER_WAVE = 1, HRX_OPT_HOST_ROUTE = 2, HRX_OPT_HOST_THREADS = 3, HRX_OPT_HOST_PIPELINE = 4 };
+enum { HRX_HOST_ROUTE_AUTO = 0, HRX_HOST_ROUTE_DEVICE = 1, HRX_HOST_ROUTE_HOST = 2 };
+/* What the context's last hrx_witness_batch_host call did. */
+typedef struct hrx_host_route_report {
+    int route;                    /* 0: split between the device and the host cores, 1: device only, 2: host cores only */
+    size_t device_strings, host_strings;
+    double device_ms, host_ms;    /* wall time of each part (they run at the same time) */
+    double call_ms;
+    double device_ns_per_row, host_ns_per_row;   /* the context's estimates after the call (0: not measured yet): what the next split is made from */
+    int host_threads;
+    int device_pipelined;         /* the device part: 1 chunks pipelined over two streams, 0 one stream */
+} hrx_host_route_report;
+int hrx_ctx_host_route_report(const hrx_ctx *ctx, hrx_host_route_report *out);
 int hrx_ctx_set_option(hrx_ctx *ctx, int option, long value);
 long hrx_ctx_get_option(const hrx_ctx *ctx, int option);
 /* thread-local text of the last failing call (any entry point) */
@@ -206,29 +228,35 @@ void hrx_position_major_sizes(size_t B, size_t M, size_t D, size_t *records_u32,
  * masked, status, chars, lens and `layout` (HRX_LAYOUT_POSITION_MAJOR, optionally | HRX_LAYOUT_INPUT_POSITION_MAJOR) as in hrx_witness_batch_device_layout.
  * Why: a launch of D defs writes 4 D of its 4 D + 2 output bytes per row into the records; as ONE allocation they lie in one class of the MI355X's physical
  * address space and the launch runs at what one class absorbs, as separately placed planes (hrx_alloc_output_planes) its D + 1 write streams spread over the
- * classes: the no-compute pass of three defs x 32768 x 32768 rows 0.86 of the HBM peak against 0.70-0.77 (profiles/r06_probes/plane_probe.txt).
- * n_planes must be the config's number of defs; configs that run as one launch (up to three defs, or four to eight defs of at most 32 byte classes each);
- * the values equal the interleaved layout's. */
+ * classes: three defs x 32768 x 32768 rows 0.78-0.80 of the HBM peak against 0.70-0.72, two defs x 2^20 x 2048 rows 0.81 against 0.75-0.78 (DESIGN.md §6,
+ * profiles/r06_probes/).
+ * n_planes = the config's number of defs.  ONE def may also come in TWO ROW STRIPES (n_planes = 2): quad q = r/4 of a string lies in record_planes[q % 2] at slot q / 2,
+ * each stripe per block [ceil(ceil(M/4)/2)][nb][4] — record of (b, r) at record_planes[(r/4) % 2][k*HRX_PM_BLOCK*ceil(ceil(M/4)/2)*4 + ((r/8)*nb + b')*4 + r%4] — so that
+ * a one-def launch's record bytes spread over two classes beside the masked rows' third (sizes: hrx_position_major_stripe_sizes).
+ * Configs that run as one launch (up to three defs, or four to eight defs of at most 32 byte classes each); the values equal the interleaved layout's. */
 int hrx_witness_batch_device_planes(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
                                     uint32_t *const *record_planes, size_t n_planes, uint16_t *masked, uint64_t *status, void *stream);
 void hrx_position_major_plane_sizes(size_t B, size_t M, size_t *plane_u32, size_t *masked_u16);
-/* The D planes and the masked rows of a batch of B strings x M rows, each allocated on ctx's device in a neighbourhood of its own: a pool of D + 4 plane-sized and 5
- * masked-row-sized candidates, allocated one after the other (they walk down the device memory), is measured pair by pair (two equal write streams, ~1 ms per pair on the
- * device clock); pairings fall into two levels — both buffers in one class of the physical address space, or not — and the D planes + masked buffer whose busiest
- * class takes the fewest of the launch's 4 D + 2 output bytes per row (4 per plane, 2 for the masked rows; then the fewest colliding pairings, the largest sum of
- * pairings) are kept; a pool whose best set still puts more than 6 bytes per row (two defs: 4) into one class grows by three plane candidates, at most twice;
- * everything else is freed before the call returns.  hrx_alloc_last_report: steps = pairings measured, ref_gbs = the slowest pairing seen, first_gbs = the slowest
- * pairing of the first D + 1 buffers (what plain allocations would have been), best_gbs = the kept set's, chosen_step = the bytes per row of the kept set's busiest
- * class, accepted = at most 6.  The pool never takes more than 70 % of the free memory (hrx_ctx_set_placement narrows that and bounds the time).  Planes below 128 MiB, HRX_PLACE_OFF: plain
- * allocations.  record_planes: D pointers out; each buffer is released with hrx_device_free.  One def: hrx_alloc_outputs_position_major.  Takes the context's lock; not
- * inside a stream capture. */
-int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, uint32_t **record_planes, uint16_t **masked);
+void hrx_position_major_stripe_sizes(size_t B, size_t M, size_t n_stripes, size_t *stripe_u32, size_t *masked_u16);
+/* The n_planes record buffers (the D planes; one def: 1, or 2 row stripes) and the masked rows of a batch of B strings x M rows, each allocated on ctx's device in a
+ * neighbourhood of its own: a pool of n_planes + 4 record-sized and 5 masked-row-sized candidates, allocated one after the other (they walk down the device memory), is
+ * measured pair by pair (two equal write streams, ~1 ms per pair on the device clock); pairings fall into two levels — both buffers in one class of the physical address
+ * space, or not — and the buffers whose busiest class takes the fewest of the launch's output bytes per row (4 per plane — 2 per row stripe —, 2 for the masked rows; then
+ * the fewest colliding pairings, the largest sum of pairings) are kept; a pool whose best set still collides (up to three buffers: at all; more: beyond one record buffer +
+ * the masked rows) grows by three record candidates, at most twice; everything else is freed before the call returns.  Record buffers below 1 GiB are carved out of up to
+ * four 2-GiB STRIPE ARENAS per device and process chosen the same way once (a probe over buffers that fit the Infinity Cache would measure the cache); hrx_device_free gives
+ * a sub-buffer's range back.  hrx_alloc_last_report: steps = pairings measured, ref_gbs = the slowest pairing seen, first_gbs = the slowest pairing of the first buffers
+ * (what plain allocations would have been), best_gbs = the kept set's, chosen_step = the bytes per row of the kept set's busiest class, searched = 2: served from arenas
+ * measured earlier.  The pool never takes more than 70 % of the free memory (hrx_ctx_set_placement narrows that and bounds the time).  Less than 128 MiB of records,
+ * HRX_PLACE_OFF: plain allocations.  record_planes: n_planes pointers out; each buffer is released with hrx_device_free.  n_planes = 1: hrx_alloc_outputs_position_major.
+ * Takes the context's lock; not inside a stream capture. */
+int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, uint32_t **record_planes, uint16_t **masked);
 /* The allocator's measurement, for a caller that manages device memory itself (a prover with its own pool): two equal, time-aligned write streams over the first `bytes`
- * of device buffers a and b (both are OVERWRITTEN), *gbs = bytes written per time.  Pairings in one class of the physical address space measure 5.2-5.9 TB/s, in different
- * classes 6.7-7.3 (a level per box: compare pairings with each other, not with a constant).  Synchronous; takes the context's lock. */
+ * of device buffers a and b (both are OVERWRITTEN), *gbs = bytes written per time.  Pairings in one class of the physical address space measure 5.2-6.2 TB/s, in different
+ * classes 6.5-7.3 (a level per box: compare pairings with each other, not with a constant).  Synchronous; takes the context's lock. */
 int hrx_probe_write_pair(hrx_ctx *ctx, void *a, void *b, size_t bytes, double *gbs);
-/* hrx_rows_of_string_position_major for record planes in HOST memory (each plane copied from the device as it is): records [M][D], masked [M] of string b. */
-int hrx_rows_of_string_planes(const uint32_t *const *record_planes, const uint16_t *masked_pm, size_t B, size_t M, size_t D, size_t b,
+/* hrx_rows_of_string_position_major for record planes (or the two row stripes of one def) in HOST memory, each buffer copied from the device as it is: records [M][D], masked [M] of string b. */
+int hrx_rows_of_string_planes(const uint32_t *const *record_planes, size_t n_planes, const uint16_t *masked_pm, size_t B, size_t M, size_t D, size_t b,
                               uint32_t *records, uint16_t *masked);
 /* One circuit's view of a position-major batch, on the HOST: the rows of string b of a batch of B strings x M rows x D defs that lies in host memory in
  * HRX_LAYOUT_POSITION_MAJOR (e.g. copied from the device as it is) -> records [M][D] u32 and masked [M] u16, the string-major values the fill loops of

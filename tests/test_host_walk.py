@@ -297,3 +297,20 @@ def test_a_failed_clone_leaves_the_source_config_usable(oracle):
     assert np.array_equal(c2.match_substrs(b"email was meant for @y.").masked_characters, r.masked_characters)
     del cfg, c2
     gc.collect()
+
+
+def test_host_route_options_on_a_host_only_context(oracle):
+    """hrx_ctx_set_option: a host-only context walks everything on the host whatever HRX_OPT_HOST_ROUTE says; HRX_OPT_HOST_THREADS bounds its threads; results do not depend on either."""
+    M = 128
+    cfg = _cfg(CFG_A, M)
+    chars, lens = synth.reveal_stress(700, M - 8, seed=3)
+    ref = cfg.witness_batch_host(chars, lens)
+    for threads in (1, 3):
+        cfg.set_option(hra.OPT_HOST_THREADS, threads)
+        for route in (hra.HOST_ROUTE_AUTO, hra.HOST_ROUTE_DEVICE, hra.HOST_ROUTE_HOST):
+            cfg.set_option(hra.OPT_HOST_ROUTE, route)
+            got = cfg.witness_batch_host(chars, lens)
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    with pytest.raises(hra.HrxError):
+        cfg.set_option(hra.OPT_HOST_ROUTE, 7)
+    assert cfg.get_option(hra.OPT_HOST_THREADS) == 3

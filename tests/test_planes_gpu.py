@@ -25,6 +25,8 @@ def _planes_rows(hra, cfg, chars, lens, M, pm_input, out=None):
     import torch
     dev = torch.device("cuda", 0)
     B = len(lens)
+    if out is None and cfg.num_defs == 1:
+        out = cfg.alloc_output_planes(B, dev, stripes=2)     # one def: its two row stripes
     stride = (chars.shape[1] + 15) // 16 * 16
     wide = torch.zeros((B, max(stride, 16)), dtype=torch.uint8, device=dev)
     wide[:, :chars.shape[1]] = torch.from_numpy(chars).to(dev)
@@ -34,7 +36,7 @@ def _planes_rows(hra, cfg, chars, lens, M, pm_input, out=None):
     else:
         planes, msk, st = cfg.witness_batch_planes(wide, d_lens, out=out)
     torch.cuda.synchronize()
-    rec, m = hra.planes_to_string_major(planes, msk, B, M)
+    rec, m = hra.planes_to_string_major(planes, msk, B, M, D=cfg.num_defs)
     return rec.cpu().numpy().view(np.uint32), m.cpu().numpy().view(np.uint16), st.cpu().numpy().view(np.uint64), planes, msk
 
 
@@ -52,7 +54,7 @@ def _check_planes(hra, oracle, names, chars, lens, M, cfg=None):
     hm = d_msk.cpu().numpy()
     for b in list(range(0, len(lens), max(1, len(lens) // 17)))[:20]:
         if ok[b]:
-            r1, m1 = hra.rows_of_string_planes(hp, hm, len(lens), M, b)
+            r1, m1 = hra.rows_of_string_planes(hp, hm, len(lens), M, b, D=cfg.num_defs)
             assert np.array_equal(r1, orec[b]) and np.array_equal(m1, omsk[b])
 
 
@@ -137,7 +139,16 @@ def test_record_planes_argument_checks_and_one_def(hra, oracle):
     dev = torch.device("cuda", 0)
     M = 200
     chars, lens = synth.ragged(300, M, seed=3)
-    _check_planes(hra, oracle, CFG_1, chars, lens, M)          # one def: its plane is the position-major records buffer
+    _check_planes(hra, oracle, CFG_1, chars, lens, M)          # one def: two row stripes
+    cfg1 = _cfg(hra, CFG_1, M)
+    one = cfg1.alloc_output_planes(300, dev)                    # ... or one buffer: the position-major records buffer itself
+    assert len(one[0]) == 1 and one[0][0].numel() == (M + 3) // 4 * 300 * 4
+    d_l = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    w = torch.zeros((300, 208), dtype=torch.uint8, device=dev); w[:, :chars.shape[1]] = torch.from_numpy(chars).to(dev)
+    p1, m1, s1 = cfg1.witness_batch_planes(w, d_l, out=one)
+    r0, m0, s0 = cfg1.witness_batch_position_major(w, d_l)
+    torch.cuda.synchronize()
+    assert torch.equal(p1[0], r0) and torch.equal(m1, m0) and torch.equal(s1, s0)
     cfg = _cfg(hra, CFG_A, M)
     planes, msk, st = cfg.alloc_output_planes(300, dev)
     assert len(planes) == 2 and planes[0].numel() == (M + 3) // 4 * 300 * 4
@@ -169,7 +180,7 @@ def test_placed_record_planes_at_a_multi_gigabyte_size(hra, oracle):
     torch.cuda.synchronize()
     o = OracleDefs.from_files(oracle, HDR)
     orec, omsk, ost = o.witness_batch(base_c, base_l, M, threads=os.cpu_count() or 1)
-    rec, m = hra.planes_to_string_major(planes, msk, B, M)
+    rec, m = hra.planes_to_string_major(planes, msk, B, M, D=3)
     t_rec, t_msk = torch.from_numpy(orec.view(np.int32)).to(dev), torch.from_numpy(omsk.view(np.int16)).to(dev)
     assert (ost & np.uint64(0xff) == 0).all()
     for k in range(0, B, 2048):
@@ -178,3 +189,70 @@ def test_placed_record_planes_at_a_multi_gigabyte_size(hra, oracle):
     cfg.set_placement(walk=False)
     out2 = cfg.alloc_output_planes(B, dev)
     assert cfg.last_placement_report()["searched"] == 0 and len(out2[0]) == 3
+
+
+@pytest.mark.parametrize("flags", [0, 0x200000, 0x400000, 0x40000, 0x1000, 0x40000000, 0x2000, 0x8000], ids=["planner", "wide", "half", "global-table", "dynamic-groups", "pair-step-asked", "byte", "no-byte"])
+def test_row_stripes_of_one_def_on_every_table_format(hra, oracle, flags, monkeypatch):
+    """One def in TWO ROW STRIPES (quad q of a string in buffer q % 2 at slot q / 2): every table format of the loader / walker / finisher kernel, odd and even numbers of quads, ragged
+    and failing strings, both input layouts, two blocks of strings; the pair-step kernel does not write stripes (the planner must not pick it even when asked to)."""
+    from halo2_regex_amd import synth
+    from test_parity_gpu import CFG_1, CFG_3
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(flags))
+    for names in (CFG_1, CFG_3):
+        for M in (328, 203, 64, 4, 5):
+            chars, lens = _stress(synth, max(M, 72), seed=41 + M)
+            if M < 72:
+                lens = np.minimum(lens, M + 3)
+            cfg = _cfg(hra, names, M)
+            assert "witness_pp_kernel" not in cfg.describe_launch(len(lens), layout=3 | hra.LAYOUT_RECORD_PLANES)
+            _check_planes(hra, oracle, names, chars, lens, M, cfg=cfg)
+    M, B = 136, 70000
+    chars, lens = synth.ragged(B, M, seed=31)
+    _check_planes(hra, oracle, CFG_1, chars, lens, M)
+
+
+def test_row_stripes_of_a_256_state_dfa(hra, oracle):
+    """cfg 5's table format (BYTE: a 1-byte next-state table + perfect-hash pair tags) with the records in two row stripes, 4096-row strings."""
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    allb = np.arange(256, dtype=np.uint8)
+    a_txt, sub_txt = synth.random_dfa(256, seed=2, alphabet=allb, n_substr_pairs=200)
+    defs = [hra.RegexDefs(hra.AllstrRegexDef(a_txt.encode()), [hra.SubstrRegexDef(sub_txt.encode())])]
+    M, B = 4096, 4096
+    cfg = hra.RegexVerifyConfig.configure(M, defs, device=0)
+    assert "true>" in cfg.describe_launch(B, layout=3 | hra.LAYOUT_RECORD_PLANES).split(" grid=")[0]      # the BYTE kernel
+    chars, lens = synth.noise(B, M - 1, seed=4, alphabet=allb, stride=M)
+    lens[:64] = np.random.default_rng(1).integers(0, M, 64)
+    o = OracleDefs(oracle, [(a_txt.encode(), [sub_txt.encode()])])
+    orec, omsk, ost = o.witness_batch(chars, lens, M, threads=os.cpu_count() or 1)
+    d_chars = hra.chars_to_position_major(torch.from_numpy(chars).to(dev))
+    planes, msk, st = cfg.witness_batch_planes(d_chars, torch.from_numpy(lens.astype(np.int32)).to(dev), chars_pm_stride=M, out=cfg.alloc_output_planes(B, dev, stripes=2))
+    torch.cuda.synchronize()
+    assert len(planes) == 2
+    rec, m = hra.planes_to_string_major(planes, msk, B, M, D=1)
+    assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
+    assert np.array_equal(rec.cpu().numpy().view(np.uint32), orec) and np.array_equal(m.cpu().numpy().view(np.uint16), omsk)
+
+
+def test_small_row_stripes_come_out_of_measured_arenas(hra, oracle):
+    """The bench line's sizes (stripes of 128 MiB): carved out of the device's stripe arenas — three 2-GiB blocks chosen once by their pairings; later requests are served from them
+    (searched = 2), hrx_device_free gives the ranges back."""
+    import torch
+    dev = torch.device("cuda", 0)
+    from test_parity_gpu import CFG_1
+    M, B = 1024, 65536
+    cfg = _cfg(hra, CFG_1, M)
+    outs = [cfg.alloc_output_planes(B, dev, stripes=2) for _ in range(3)]
+    reps = []
+    for _ in range(2):
+        outs.append(cfg.alloc_output_planes(B, dev, stripes=2))
+        reps.append(cfg.last_placement_report())
+    assert all(len(o[0]) == 2 for o in outs) and reps[-1]["searched"] == 2
+    ptrs = sorted(p.data_ptr() for o in outs for p in o[0] + [o[1]])
+    assert len(set(ptrs)) == len(ptrs)
+    first = outs[0][0][0].data_ptr()
+    del outs[0]
+    torch.cuda.synchronize()
+    again = cfg.alloc_output_planes(B, dev, stripes=2)
+    assert first in (again[0][0].data_ptr(), again[0][1].data_ptr(), again[1].data_ptr()) or cfg.last_placement_report()["searched"] == 2

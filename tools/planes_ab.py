@@ -61,7 +61,7 @@ def main():
             cfg.set_option(hra.OPT_PMD_COMBINER_WAVE, fin)
             outs, reps_ = [], []
             for _ in range(a.sets):
-                outs.append(cfg.alloc_output_planes(B, dev) if planes else cfg.alloc_outputs_position_major(B, dev))
+                outs.append(cfg.alloc_output_planes(B, dev, stripes=2 if D == 1 else None) if planes else cfg.alloc_outputs_position_major(B, dev))
                 reps_.append(cfg.last_placement_report())
             if planes:
                 launch = lambda i, cfg=cfg, outs=outs: cfg.witness_batch_planes(c_pm, d_lens, out=outs[i % len(outs)], chars_pm_stride=stride)
@@ -97,6 +97,13 @@ def main():
         q4 = (M + 3) // 4
         for name, cfg, launch, tpass, outs, planes in variants[1:]:
             same = bool(torch.equal(outs[0][1], ref[1])) and bool(torch.equal(outs[0][2], ref[2]))
+            if planes and len(outs[0][0]) != D:      # one def in two row stripes
+                a_r = hra.planes_to_string_major(outs[0][0], outs[0][1], B, M, D=D)[0]
+                b_r = hra.position_major_to_string_major(ref[0], ref[1], B, M, D)[0]
+                same = same and bool(torch.equal(a_r, b_r))
+                print("%s: rows equal to variant 0's: %s" % (name, same), flush=True)
+                assert same
+                continue
             for blk in range(0, B, hra.PM_BLOCK):
                 nb = min(hra.PM_BLOCK, B - blk)
                 r0 = ref[0][blk * q4 * D * 4:][:q4 * D * nb * 4].view(q4, D, nb, 4)
