@@ -81,6 +81,27 @@ def parse_args(argv=None):
 # ----------------------------------------------------------------------------------------------------------------
 # checker / baseline legs (the oracle is never on the product path)
 # ----------------------------------------------------------------------------------------------------------------
+def effective_cores():
+    """Host cores this process can actually keep busy: its affinity mask, capped by the CPU bandwidth its cgroup grants (the GPU boxes of this pool show 256 cores under a quota of 16:
+    256 threads run in a burst and are then throttled for the rest of the period)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        try:
+            q, p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
+
+
 def oracle_handle(names, allow_build=True):
     """the oracle (test infrastructure): None when its library is missing / stale and must not be built here (under a profiler
     no helper process may be started)"""
@@ -144,7 +165,7 @@ def cpu_baseline(o, names, chars, lens, M, budget_s=8.0):
     over all host cores and the oracle's dense-table "best CPU" variant.  Returns (json object, oracle outputs of the sample)."""
     import numpy as np
     nstr = min(len(chars), 16384)
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     ndefs = len(names)
     out = np.zeros((nstr, M, ndefs), np.uint32), np.zeros((nstr, M), np.uint16), np.zeros(nstr, np.uint64)
     rows1 = int(lens[:nstr].sum())
@@ -191,7 +212,7 @@ def verify_timed_buffers(o, hra, sets, shift, chars, lens, M, D, pm, dev, B, sb)
     compared on the device, where it lies, with the rows of the string it is a copy of (chunks of at most 2^28 record words at a time)."""
     import numpy as np
     import torch
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     nd = len(lens)
     orec, omsk, ost = o.witness_batch(chars, lens, M, threads=cores)
     ok = torch.from_numpy(((ost & np.uint64(0xff)) == 0)).to(dev)
@@ -710,8 +731,15 @@ def run_rank(args, rank, world, device_index, barrier):
             t_host = timed_calls(1, 3)
             host_rep = cfg.host_route_report()
             cfg.set_option(hra.OPT_HOST_ROUTE, hra.HOST_ROUTE_AUTO)
-            ts = timed_calls(6, 5)                              # (six calls for the split to follow the measured rates)
-            auto_rep = cfg.host_route_report()
+            cfg_auto = cfg.clone()                              # (a context of its own: its calls 0-4 are the measuring ones — device, device, host cores, split, split)
+            cfg_auto.set_option(hra.OPT_HOST_ROUTE, hra.HOST_ROUTE_AUTO)
+            t_explore = []
+            for _ in range(6):
+                t0_ = time.perf_counter(); cfg_auto.witness_batch_host(hc, lens, out=(hrec, hmsk, hst)); t_explore.append((time.perf_counter() - t0_) * 1e3)
+            ts = []
+            for _ in range(5):
+                t0_ = time.perf_counter(); cfg_auto.witness_batch_host(hc, lens, out=(hrec, hmsk, hst)); ts.append(time.perf_counter() - t0_)
+            auto_rep = cfg_auto.host_route_report()
             ms = statistics.median(ts) * 1e3
             best_single = min(statistics.median(t_dev), statistics.median(t_host)) * 1e3
             e2e = {"ms_per_call": ms, "ms_min": min(ts) * 1e3, "rows_per_s": rows_per_step / (ms * 1e-3), "calls": 5,
@@ -720,12 +748,14 @@ def run_rank(args, rank, world, device_index, barrier):
                    "status_ok": bool(((hst & np.uint64(0xff)) == 0).all()),
                    "routes": {"auto_ms": ms, "device_ms": statistics.median(t_dev) * 1e3, "host_walk_all_cores_ms": statistics.median(t_host) * 1e3,
                               "auto_over_best_single_route": ms / best_single,
-                              "auto_split": {k: auto_rep[k] for k in ("route", "device_strings", "host_strings", "device_ms", "host_ms", "device_ns_per_row", "host_ns_per_row", "host_threads", "device_pipelined")},
+                              "auto_chose": {0: "split", 1: "device", 2: "host cores"}.get(auto_rep["route"]), "auto_measuring_calls_ms": t_explore,
+                              "auto_report": {k: auto_rep[k] for k in ("route", "device_strings", "host_strings", "device_ms", "host_ms", "device_alone_ns_per_row", "host_alone_ns_per_row",
+                                                                       "split_ns_per_row", "device_ns_per_row", "host_ns_per_row", "host_threads", "device_pipelined")},
                               "host_threads": host_rep["host_threads"], "device_pipelined": dev_rep["device_pipelined"]},
                    "comparison_calls_ms": {"pipelined": [explore[0], explore[2]], "one_stream": [explore[1], explore[3]]},
                    "what": "hrx_witness_batch_host on the same batch: pageable host arrays in (string-major, %d B apart) and out (records [B][M][D] u32, masked [B][M] u16, status), "
-                           "output arrays reused.  ms_per_call = the DEFAULT route (HRX_HOST_ROUTE_AUTO: the batch split by string index between the device and the host cores in the ratio of "
-                           "the rates the context measured); routes.device_ms = everything staged, walked and copied back (chunk by chunk on two streams, or in, walk, out on one: "
+                           "output arrays reused.  ms_per_call = the DEFAULT route (HRX_HOST_ROUTE_AUTO: the fastest of device / host cores / both at once by the context's own measurements — "
+                           "its calls 0-4 measure: auto_measuring_calls_ms; auto_chose says which way the timed calls went); routes.device_ms = everything staged, walked and copied back (chunk by chunk on two streams, or in, walk, out on one: "
                            "comparison_calls_ms are the context's own calls 2-5 that pick; the call lasts about as long as the copy out over the PCIe link); "
                            "routes.host_walk_all_cores_ms = the native walk on every core this process may run on (a rank is pinned to its GPU's NUMA node)" % stride}
             # what the link gives a plain device-to-host copy of the same bytes into the same (pageable, already touched) arrays on THIS box

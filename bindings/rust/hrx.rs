@@ -158,12 +158,13 @@ extern "C" {
     pub fn hrx_regex_find(pattern: *const c_char, pattern_len: usize, text: *const c_char, text_len: usize, found: *mut c_int, start: *mut usize, end: *mut usize) -> c_int;
 }
 pub const HRX_OPT_PMD_COMBINER_WAVE: c_int = 1;
-pub const HRX_OPT_HOST_ROUTE: c_int = 2;      // HRX_HOST_ROUTE_AUTO (split between the device and the host cores) / _DEVICE / _HOST
+pub const HRX_OPT_HOST_ROUTE: c_int = 2;      // HRX_HOST_ROUTE_AUTO (the fastest of device / host cores / both at once, by measurement) / _DEVICE / _HOST
 pub const HRX_OPT_HOST_THREADS: c_int = 3;
 pub const HRX_OPT_HOST_PIPELINE: c_int = 4;
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct hrx_host_route_report {
     pub route: c_int, pub device_strings: usize, pub host_strings: usize, pub device_ms: f64, pub host_ms: f64, pub call_ms: f64,
+    pub device_alone_ns_per_row: f64, pub host_alone_ns_per_row: f64, pub split_ns_per_row: f64,
     pub device_ns_per_row: f64, pub host_ns_per_row: f64, pub host_threads: c_int, pub device_pipelined: c_int,
 }
 

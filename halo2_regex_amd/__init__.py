@@ -38,6 +38,7 @@ class _RegexPartC(C.Structure):      # hrx_regex_part of include/hrx.h
 
 class _HostRouteReportC(C.Structure):    # hrx_host_route_report of include/hrx.h
     _fields_ = [("route", C.c_int), ("device_strings", C.c_size_t), ("host_strings", C.c_size_t), ("device_ms", C.c_double), ("host_ms", C.c_double), ("call_ms", C.c_double),
+                ("device_alone_ns_per_row", C.c_double), ("host_alone_ns_per_row", C.c_double), ("split_ns_per_row", C.c_double),
                 ("device_ns_per_row", C.c_double), ("host_ns_per_row", C.c_double), ("host_threads", C.c_int), ("device_pipelined", C.c_int)]
 
 

@@ -89,7 +89,8 @@ struct hrx_ctx {
     int host_route = 0, host_threads = 0, host_pipeline = 0;
     size_t host_chunk_mib = 48;
     bool host_trace = false;
-    struct HostRates { double dev_ns_per_row = 0.0, host_ns_per_row = 0.0; unsigned calls = 0; } host_rates;   // what the split calls measured (both parts running at once)
+    // what the context's big AUTO calls measured, ns per row: each way alone, the split as a whole, and the split's two parts (both running at once: what the next split is made from)
+    struct HostRates { double dev_alone = 0.0, host_alone = 0.0, split_total = 0.0, dev_ns_per_row = 0.0, host_ns_per_row = 0.0; unsigned calls = 0; } host_rates;
     hrx_host_route_report last_host{};
     hipStream_t copy_stream = nullptr;   // host-buffer batches: the device-to-host copies of finished chunks run here while the next chunks are staged and walked on `stream`
     uint32_t *d_table = nullptr;

@@ -3,6 +3,7 @@
 #include "hrx_ctx.hpp"
 #include <sched.h>
 
+#include <cmath>
 #include <condition_variable>
 #include <system_error>
 
@@ -171,12 +172,37 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
 
 extern "C" {
 
-// how many cores the calling thread may run on (its affinity mask: a rank pinned to its GPU's NUMA node walks with that node's cores, not with the machine's)
+// How many host threads a walk may use: the cores of the calling thread's affinity mask (a rank pinned to its GPU's NUMA node walks with that node's cores, not with the machine's) — and
+// no more than the CPU bandwidth the process's cgroup grants.  A container that sees 256 cores under a quota of 16 (cpu.max "1600000 100000": the GPU boxes of this pool) runs 256 threads in
+// a burst and is then throttled for the rest of the period: the 65536 x 1024 walk took 3.7 ms on most calls and 83-92 ms on every third (profiles/r06_probes/host_routes_trace.txt).
+static size_t cgroup_cpu_limit() {
+    static const size_t limit = [] {
+        auto read2 = [](const char *path, double &a, double &b) -> bool {
+            FILE *f = std::fopen(path, "r");
+            if (!f) return false;
+            char x[64] = {0}, y[64] = {0};
+            const int n = std::fscanf(f, "%63s %63s", x, y);
+            std::fclose(f);
+            if (n < 1 || std::strcmp(x, "max") == 0) return false;
+            a = std::atof(x); b = n >= 2 ? std::atof(y) : 0.0;
+            return true;
+        };
+        double quota = 0, period = 0;
+        if (read2("/sys/fs/cgroup/cpu.max", quota, period) && quota > 0 && period > 0) return (size_t)std::max(1.0, std::ceil(quota / period));      // cgroup v2
+        double q1 = 0, p1 = 0, unused = 0;
+        if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q1, unused) && q1 > 0 && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p1, unused) && p1 > 0)
+            return (size_t)std::max(1.0, std::ceil(q1 / p1));                                                                                           // cgroup v1
+        return (size_t)0;      // no limit
+    }();
+    return limit;
+}
 static size_t host_threads_available() {
+    size_t n = std::max<size_t>(1, std::thread::hardware_concurrency());
     cpu_set_t set;
     CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (size_t)n; }
-    return std::max<size_t>(1, std::thread::hardware_concurrency());
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = (size_t)c; }
+    const size_t lim = cgroup_cpu_limit();
+    return lim ? std::min(n, lim) : n;
 }
 
 }  // extern "C"
@@ -219,40 +245,86 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
         else if ((ctx->debug & kDbgForceHost) || B * M < ctx->host_threshold) route = HRX_HOST_ROUTE_HOST;
         else if (B * M < kHostSplitFromRows) route = HRX_HOST_ROUTE_DEVICE;
     }
-    if (route == HRX_HOST_ROUTE_HOST) {   // re-entrant: reads the context's tables only (a 256-core host walks 4096 x 1024 rows in ~0.3 ms instead of 15: NOTES_MEASUREMENTS.md §7c)
-        if (int rc = check_strides()) return rc;
-        host_part(0, B, avail);
-        if (ctx->device != HRX_DEVICE_NONE) {
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            hrx_host_route_report &r = ctx->last_host;
-            r.route = HRX_HOST_ROUTE_HOST; r.device_strings = 0; r.host_strings = B; r.device_ms = 0; r.host_ms = r.call_ms = ms_since(t_call);
-            r.host_threads = (int)std::min(avail, std::max<size_t>(1, B * M / 8192));
-            r.device_ns_per_row = ctx->host_rates.dev_ns_per_row; r.host_ns_per_row = ctx->host_rates.host_ns_per_row;
+    // ---- HRX_HOST_ROUTE_AUTO on a batch of at least kHostSplitFromRows rows: the fastest of THREE ways by this context's own measurements — everything through the device, everything on
+    // the host cores, or both at once (strings [0, bs) through the device, [bs, B) on the host cores, bs from the rates of the two parts).  Which one wins is the host's: on a 256-core box
+    // the host cores alone take 5.4 ms per 65536 x 1024 call, the device 8.0-8.7 (the copy back over the link), the split 6.9 (the parts slow each other down: the copies to and from
+    // pageable memory and 254 walking threads share the host's memory); on a small host the device wins.  The context's calls 0 and 1 go through the device (0: allocations and first touches,
+    // not recorded), 2 on the host cores, 3 and 4 split (half / half, then by the parts' rates); from then on the way with the smallest ns per row, whose figure every call refreshes; every
+    // 64th call re-measures one of the other two ways if its last figure was within 1.5x of the best.
+    enum { kDev = HRX_HOST_ROUTE_DEVICE, kHost = HRX_HOST_ROUTE_HOST, kSplit = 3 };
+    int way = route == HRX_HOST_ROUTE_DEVICE ? kDev : route == HRX_HOST_ROUTE_HOST ? kHost : 0;
+    const bool measured = way == 0;        // an AUTO call of a device context above the split threshold
+    std::unique_lock<std::mutex> lk(ctx->mu, std::defer_lock);
+    if (ctx->device != HRX_DEVICE_NONE) lk.lock();        // (the estimates, the report, the device part)
+    hrx_ctx::HostRates &hr = ctx->host_rates;
+    if (measured) {
+        const unsigned k = hr.calls;
+        if (k <= 1) way = kDev;
+        else if (k == 2) way = kHost;
+        else if (k <= 4) way = kSplit;
+        else {
+            const double d = hr.dev_alone, h = hr.host_alone, sp = hr.split_total;
+            way = (d <= h && d <= sp) ? kDev : (h <= sp ? kHost : kSplit);
+            if ((k % 64u) == 63u) {      // one of the other two gets a call again
+                const double best = std::min(d, std::min(h, sp));
+                const int other[2] = {way == kDev ? kHost : kDev, way == kSplit ? kHost : kSplit};
+                const int cand = other[(k / 64u) & 1u];
+                const double fig = cand == kDev ? d : cand == kHost ? h : sp;
+                if (fig <= 1.5 * best) way = cand;
+            }
         }
+    }
+    hrx_host_route_report &rep = ctx->last_host;
+    auto finish = [&](int did, size_t bs, size_t hn, double dev_ms, double host_ms, size_t hthreads) {
+        if (ctx->device == HRX_DEVICE_NONE) return;
+        const double call_ms = ms_since(t_call), ns_row = call_ms * 1e6 / (double)(B * M);
+        if (measured) {
+            if (hr.calls > 0) {      // (call 0 pays for the allocations)
+                if (did == kDev) hr.dev_alone = ns_row;
+                else if (did == kHost) hr.host_alone = ns_row;
+                else {
+                    hr.split_total = ns_row;
+                    // (mostly the new figure: a part's rate depends on its share, so the split has to follow quickly)
+                    if (bs && dev_ms > 0) { const double m = dev_ms * 1e6 / (double)(bs * M); hr.dev_ns_per_row = hr.dev_ns_per_row > 0 ? 0.3 * hr.dev_ns_per_row + 0.7 * m : m; }
+                    if (hn && host_ms > 0) { const double m = host_ms * 1e6 / (double)(hn * M); hr.host_ns_per_row = hr.host_ns_per_row > 0 ? 0.3 * hr.host_ns_per_row + 0.7 * m : m; }
+                }
+            }
+            ++hr.calls;
+        }
+        rep.route = did == kSplit ? HRX_HOST_ROUTE_AUTO : did;
+        rep.device_strings = bs; rep.host_strings = hn; rep.device_ms = dev_ms; rep.host_ms = host_ms; rep.call_ms = call_ms;
+        rep.device_alone_ns_per_row = hr.dev_alone; rep.host_alone_ns_per_row = hr.host_alone; rep.split_ns_per_row = hr.split_total;
+        rep.device_ns_per_row = hr.dev_ns_per_row; rep.host_ns_per_row = hr.host_ns_per_row; rep.host_threads = (int)hthreads;
+        if (ctx->host_trace)
+            std::fprintf(stderr, "[hrx host] %s: %zu strings through the device %.2f ms, %zu on %zu host threads %.2f ms, call %.2f ms; ns per row: device %.4f host %.4f split %.4f\n",
+                         did == kDev ? "device" : did == kHost ? "host cores" : "split", bs, dev_ms, hn, hthreads, host_ms, call_ms, hr.dev_alone, hr.host_alone, hr.split_total);
+    };
+    if (way == kHost) {   // (the walk itself reads the context's tables only; a host-only context takes no lock and is re-entrant)
+        if (int rc = check_strides()) return rc;
+        const size_t nthreads = std::min(avail, std::max<size_t>(1, B * M / 8192));
+        const auto t0 = std::chrono::steady_clock::now();
+        if (lk.owns_lock() && !measured) lk.unlock();      // (a forced or small host call need not hold other callers of the context up)
+        host_part(0, B, avail);
+        const double host_ms = ms_since(t0);
+        if (ctx->device != HRX_DEVICE_NONE && !lk.owns_lock()) lk.lock();
+        finish(kHost, 0, B, 0.0, host_ms, nthreads);
         return HRX_OK;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard guard;
     HIP_TRY(guard.set(ctx->device));
-    hrx_host_route_report &rep = ctx->last_host;
-    if (route == HRX_HOST_ROUTE_DEVICE) {
+    if (way == kDev) {
+        const auto t0 = std::chrono::steady_clock::now();
         const int rc = batch_host_locked(ctx, chars, stride, lens, B, M, records, masked, status);
-        rep.route = HRX_HOST_ROUTE_DEVICE; rep.device_strings = B; rep.host_strings = 0; rep.host_ms = 0; rep.device_ms = rep.call_ms = ms_since(t_call); rep.host_threads = 0;
-        rep.device_ns_per_row = ctx->host_rates.dev_ns_per_row; rep.host_ns_per_row = ctx->host_rates.host_ns_per_row;
-        return rc;
+        if (rc != HRX_OK) return rc;
+        finish(kDev, B, 0, ms_since(t0), 0.0, 0);
+        return HRX_OK;
     }
-    // ---- both at once: strings [0, bs) through the device, [bs, B) on the host cores (all but two: the staging thread and this one keep the device part fed), in the ratio of the rates
-    // measured so far.  Each part is timed and the estimates follow.
+    // ---- both at once: all host cores but two (the staging thread and this one keep the device part fed)
     if (int rc = check_strides()) return rc;
-    hrx_ctx::HostRates &hr = ctx->host_rates;
     const double h = hr.host_ns_per_row, d = hr.dev_ns_per_row;
     double f_dev = (h > 0 && d > 0) ? h / (h + d) : 0.5;
-    const bool refresh = (hr.calls % 64u) == 63u;          // a part that has been getting nothing is measured again on a sixteenth of the batch
-    if (f_dev < 1.0 / 16) f_dev = refresh ? 1.0 / 16 : 0.0;
-    if (f_dev > 15.0 / 16) f_dev = refresh ? 15.0 / 16 : 1.0;
-    size_t bs = (size_t)((double)B * f_dev) / 64 * 64;
-    if (f_dev >= 1.0) bs = B;
-    const size_t hn = B - bs;
+    f_dev = std::min(15.0 / 16, std::max(1.0 / 16, f_dev));
+    const size_t bs = std::max<size_t>(64, (size_t)((double)B * f_dev) / 64 * 64), hn = B - bs;
     const size_t hthreads = avail > 3 ? avail - 2 : 1;
     double host_ms = 0.0, dev_ms = 0.0;
     std::thread walker;
@@ -264,7 +336,7 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
         }
     }
     int rc = HRX_OK;
-    if (bs) {
+    {
         const auto t0 = std::chrono::steady_clock::now();
         rc = batch_host_locked(ctx, chars, stride, lens, bs, M, records, masked, status);
         dev_ms = ms_since(t0);
@@ -272,16 +344,7 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
     if (walker.joinable()) { walker.join(); walked = true; }
     if (!walked) { const auto t0 = std::chrono::steady_clock::now(); host_part(bs, hn, avail); host_ms = ms_since(t0); }
     if (rc != HRX_OK) return rc;
-    // (mostly the new figure: a part's rate depends on its share — the host cores walk a third of a 65536 x 1024 batch at twice the rate per row of the whole batch — so the split has to follow quickly)
-    if (bs && dev_ms > 0) { const double m = dev_ms * 1e6 / (double)(bs * M); hr.dev_ns_per_row = hr.dev_ns_per_row > 0 ? 0.3 * hr.dev_ns_per_row + 0.7 * m : m; }
-    if (hn && host_ms > 0) { const double m = host_ms * 1e6 / (double)(hn * M); hr.host_ns_per_row = hr.host_ns_per_row > 0 ? 0.3 * hr.host_ns_per_row + 0.7 * m : m; }
-    ++hr.calls;
-    rep.route = bs == 0 ? HRX_HOST_ROUTE_HOST : hn == 0 ? HRX_HOST_ROUTE_DEVICE : HRX_HOST_ROUTE_AUTO;
-    rep.device_strings = bs; rep.host_strings = hn; rep.device_ms = dev_ms; rep.host_ms = host_ms; rep.call_ms = ms_since(t_call);
-    rep.device_ns_per_row = hr.dev_ns_per_row; rep.host_ns_per_row = hr.host_ns_per_row; rep.host_threads = hn ? (int)hthreads : 0;
-    if (ctx->host_trace)
-        std::fprintf(stderr, "[hrx host] split: %zu strings through the device %.2f ms, %zu on %zu host threads %.2f ms; per row %.4f / %.4f ns\n", bs, dev_ms, hn, hthreads, host_ms,
-                     hr.dev_ns_per_row, hr.host_ns_per_row);
+    finish(kSplit, bs, hn, dev_ms, host_ms, hn ? hthreads : 0);
     return HRX_OK;
 }
 

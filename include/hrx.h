@@ -138,10 +138,12 @@ size_t hrx_ctx_host_threshold(const hrx_ctx *ctx);
  *   HRX_OPT_PMD_COMBINER_WAVE  the def-parallel kernel of two- and three-def configs (batches of at most two groups of 64 strings per CU): 1 = a combiner wave of its own
  *                              per group (sums over the defs, reveal mask, masked rows), 2 = the last def's walker combines, 0 = the library's default
  *   HRX_OPT_HOST_ROUTE         hrx_witness_batch_host on a device context, batches of at least the host threshold:
- *                              HRX_HOST_ROUTE_AUTO (0, default) from 2^22 rows on BOTH AT ONCE: the batch is split by string index between the device (staged, walked, copied back)
- *                                and the host cores (the native walk), in the ratio of the rates this context measured over its earlier calls (the first call: half and half; every
- *                                call times both parts and the split follows; a part that would get less than a sixteenth of the batch gets nothing, and one call in 64 a sixteenth
- *                                again) — the copy back over the link bounds the device part (~9e9 rows/s at one def), the host's cores and memory the other; smaller batches: the device;
+ *                              HRX_HOST_ROUTE_AUTO (0, default) from 2^22 rows on the FASTEST OF THREE WAYS by this context's own measurements: everything through the device
+ *                                (staged, walked, copied back: the copy back over the link bounds it, ~9e9 rows/s at one def), everything on the host cores (the native walk: the host's
+ *                                cores and memory bound it), or both at once — the batch split by string index between them in the ratio of the two parts' rates.  The context's calls 0
+ *                                and 1 go through the device (0 pays for allocations and is not recorded), 2 on the host cores, 3 and 4 split; from then on the way with the smallest time
+ *                                per row, whose figure every call refreshes; every 64th call re-measures one of the other two if its last figure was within 1.5x of the best.  Smaller
+ *                                batches: the device; below the host threshold: the host;
  *                              HRX_HOST_ROUTE_DEVICE (1) everything through the device;  HRX_HOST_ROUTE_HOST (2) everything on the host cores.  Results are identical either way.
  *   HRX_OPT_HOST_THREADS       host threads of the native walk (0, default: as many as the calling thread's affinity mask has cores; hrx_multi_create divides them among its shards)
  *   HRX_OPT_HOST_PIPELINE      the device part's transfers: 0 (default) the context times both ways over its first calls and keeps the faster (the pipeline's copies out run at half rate
@@ -152,11 +154,12 @@ enum { HRX_OPT_PMD_COMBINER_WAVE = 1, HRX_OPT_HOST_ROUTE = 2, HRX_OPT_HOST_THREA
 enum { HRX_HOST_ROUTE_AUTO = 0, HRX_HOST_ROUTE_DEVICE = 1, HRX_HOST_ROUTE_HOST = 2 };
 /* What the context's last hrx_witness_batch_host call did. */
 typedef struct hrx_host_route_report {
-    int route;                    /* 0: split between the device and the host cores, 1: device only, 2: host cores only */
+    int route;                    /* what the call did — 0: split between the device and the host cores, 1: device only, 2: host cores only */
     size_t device_strings, host_strings;
     double device_ms, host_ms;    /* wall time of each part (they run at the same time) */
     double call_ms;
-    double device_ns_per_row, host_ns_per_row;   /* the context's estimates after the call (0: not measured yet): what the next split is made from */
+    double device_alone_ns_per_row, host_alone_ns_per_row, split_ns_per_row;   /* the context's figures after the call (0: not measured yet): what HRX_HOST_ROUTE_AUTO picks its way by */
+    double device_ns_per_row, host_ns_per_row;   /* ... of the two parts of a split call (both running at once): what the next split is made from */
     int host_threads;
     int device_pipelined;         /* the device part: 1 chunks pipelined over two streams, 0 one stream */
 } hrx_host_route_report;
