@@ -70,6 +70,8 @@ def parse_args(argv=None):
                     "strings once and EVERY string of every buffer set is compared with the rows of the string it is a copy of")
     ap.add_argument("--planes", action="store_true", help="position-major outputs of two or more defs as RECORD PLANES: every def's records in a buffer of its own "
                     "(hrx_witness_batch_device_planes, buffers from hrx_alloc_output_planes); the line then also times the interleaved layout over as many buffer sets (interleaved_layout)")
+    ap.add_argument("--probes", action="store_true", help="also run the side probes earlier rounds' documents cite (all after the timed region): the same launches over ONE buffer set, "
+                    "tools/mixceil, the input transposer alone and in front of the launch")
     ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the legs over BASELINE configs[2..4] (other_configs in the line)")
     ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)     # one of the other_configs legs: a child of the default run
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # spawned by a bare --gpus N run
@@ -638,7 +640,7 @@ def run_rank(args, rank, world, device_index, barrier):
             sys.stderr.write("per-set timing failed: %s\n" % e)
     # The complementary figure: the same K launches re-processing ONE batch into ONE set of buffers (round 1 and 2's step).  From the
     # second launch on the 256-MB Infinity Cache holds part of what a launch reads and overwrites — not an HBM figure.
-    if not args.no_spread and world == 1 and nsets > 1:
+    if args.probes and not args.no_spread and world == 1 and nsets > 1:
         try:
             one = lambda i: launch(0)
             g1 = graph_of(one, args.steps) if not args.eager else None
@@ -661,7 +663,7 @@ def run_rank(args, rank, world, device_index, barrier):
             runt(); torch.cuda.synchronize()
             per = timed_replays(runt, 5, args.steps)
             mc = {"rotating_us": statistics.median(per) * 1e3}
-            if nsets > 1:
+            if nsets > 1 and args.probes:
                 tp1 = (lambda i: cfg.traffic_pass_planes(sets[0][0], B, sets[0][2], stride)) if planes else \
                       (lambda i: cfg.traffic_pass(sets[0][0], B, sets[0][2], stride)) if pm else (lambda i: cfg.traffic_pass_string_major(sets[0][0], sets[0][2]))
                 gt1 = graph_of(tp1, args.steps) if not args.eager else None
@@ -682,7 +684,7 @@ def run_rank(args, rank, world, device_index, barrier):
             tr = lambda i: cfg.chars_to_position_major_device(sm_sets[i % nsets], out=sets[i % nsets][0])
             both = lambda i: (tr(i), launch(i))
             direct = lambda i: cfg.witness_batch_position_major(sm_sets[i % nsets], sets[i % nsets][1], out=sets[i % nsets][2])
-            for key, fn in (("transpose", tr), ("transpose_plus_launch", both), ("string_major_input_launch", direct)):
+            for key, fn in ((("transpose", tr), ("transpose_plus_launch", both)) if args.probes else ()) + (("string_major_input_launch", direct),):
                 gg = graph_of(fn, args.steps) if not args.eager else None
                 rr = gg.replay if gg is not None else (lambda fn=fn: [fn(i) for i in range(args.steps)])
                 rr(); torch.cuda.synchronize()
@@ -905,7 +907,7 @@ def run_rank(args, rank, world, device_index, barrier):
     if world == 1:
         del sets
         torch.cuda.empty_cache()
-        if args.config == "regex1" and B == 65536 and M == 1024 and pm:
+        if args.probes and args.config == "regex1" and B == 65536 and M == 1024 and pm:
             res["mix_ceiling"] = mix_ceiling(device_index)
         if not args.no_pmc:
             res["traffic"] = measured_traffic(args.argv, device_index)
@@ -1017,7 +1019,8 @@ def aggregate(per_rank, args):
         line["roofline"]["mix_ceiling"] = ceil
     if r0.get("from_string_major_input"):
         f = dict(r0["from_string_major_input"])
-        f["frac_transpose_plus_launch"] = algo_bytes / (f["transpose_plus_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if "transpose_plus_launch_ms" in f:      # (--probes)
+            f["frac_transpose_plus_launch"] = algo_bytes / (f["transpose_plus_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         f["frac_string_major_input_launch"] = algo_bytes / (f["string_major_input_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         f["what"] = ("the same K steps over the same buffer sets starting from the reference's input shape, B contiguous strings (lib.rs:311-315): transpose = "
                      "hrx_chars_to_position_major_device alone; transpose_plus_launch = that followed by the headline's launch (the cost of the fast path for a caller "

@@ -395,12 +395,11 @@ int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32
 #ifdef HRX_ABLATION
         a.debug = debug_flags_from_env();   // tools/ab_flags.py switches ablations between launches of one process
 #endif
-        if (planes) {   // (the chunked launch's repair reads finished records through the interleaved layout: such batches take the sequential kernels)
+        if (planes) {
             for (uint32_t d = 0; d < n_planes && d < kMaxDefsPerLaunch; ++d) a.rec_planes[d] = (unsigned char *)planes[d];
-            a.debug |= kDbgNoSpec;
-            if (n_planes == 2 * (size_t)a.D) {      // one def in two row stripes: the loader / walker / finisher kernel writes them (not the pair-step kernel)
-                a.rec_stripes = 2;
-                a.debug |= kDbgNoPair;
+            if (n_planes == 2 * (size_t)a.D) {      // one def in two row stripes: the loader / walker / finisher kernel writes them (not the pair-step kernel, and not in chunks:
+                a.rec_stripes = 2;                  // a chunk's first tile is not a stripe boundary in general, and the chunked launch's repair reads whole planes)
+                a.debug |= kDbgNoPair | kDbgNoSpec;
             }
         }
         // a summary-writing pass is the loader / walker / finisher kernel: no pair-step or def-parallel variant, no HALF table
@@ -515,6 +514,8 @@ int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32
 #endif
             sp.init = (uint32_t *)ctx->spec_init.p; sp.vinfo = (const uint2 *)ctx->spec_vinfo.p; sp.vstatus = (const uint64_t *)ctx->spec_vstatus.p;
             sp.status = stat; sp.records = rec; sp.masked = msk;
+            if (planes)
+                for (uint32_t d = 0; d < Dn && d < kMaxDefsPerPass; ++d) sp.rec_planes[d] = planes[d];
             sp.work_count = (uint32_t *)ctx->spec_work.p; sp.work = (uint2 *)((unsigned char *)ctx->spec_work.p + 16); sp.work_cap = (uint32_t)(C * B);
             HIP_TRY(launch_spec_scout(sp, ctx->num_cus, st));
             HIP_TRY(launch_spec_compose(sp, st));
@@ -860,8 +861,7 @@ static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int nu
         a.layout &= ~(uint32_t)HRX_LAYOUT_RECORD_PLANES;
         layout &= ~HRX_LAYOUT_RECORD_PLANES;
         a.rec_planes[0] = reinterpret_cast<unsigned char *>(16);
-        a.debug |= kDbgNoSpec;
-        if (a.D == 1) { a.rec_stripes = 2; a.debug |= kDbgNoPair; }      // (one def: described with its two row stripes)
+        if (a.D == 1) { a.rec_stripes = 2; a.debug |= kDbgNoPair | kDbgNoSpec; }      // (one def: described with its two row stripes)
     }
     if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a pass of a multi-pass config is the loader / walker / finisher kernel)
     LaunchInfo li;

@@ -266,6 +266,7 @@ struct SpecArgs {
     const uint64_t *vstatus;                 // [chunk][B] <- WitnessArgs::vs_status
     uint64_t *status;
     const uint32_t *records;
+    const uint32_t *rec_planes[kMaxDefsPerPass];   // record planes (WitnessArgs::rec_planes): def d's records in a buffer of its own; rec_planes[0] == NULL: the interleaved `records`
     uint16_t *masked;
     // chunks whose reveal-mask assumptions were wrong, found by the stitch launch, recomputed by the repair launch (one wave each)
     uint32_t *work_count;                    // [1], zeroed in front of the stitch launch

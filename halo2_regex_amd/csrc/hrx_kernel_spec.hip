@@ -473,7 +473,8 @@ __global__ __launch_bounds__(64) void spec_repair_kernel(const SpecArgs a) {
             sid = 0; st = 0; en1 = 0;
             if (r >= a.M) return;
             for (uint32_t d = 0; d < D; ++d) {
-                const uint32_t w = rec[(((size_t)(r >> 2) * D + d) * nb + bl) * 4u + (r & 3u)];
+                const uint32_t w = a.rec_planes[0] ? a.rec_planes[d][(size_t)blk0 * q4 * 4u + ((size_t)(r >> 2) * nb + bl) * 4u + (r & 3u)]
+                                                   : rec[(((size_t)(r >> 2) * D + d) * nb + bl) * 4u + (r & 3u)];
                 sid += (w >> 16) & 0xffu; st |= (w >> 24) & 1u; en1 |= (w >> 25) & 1u;
             }
         };

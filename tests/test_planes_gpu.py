@@ -256,3 +256,27 @@ def test_small_row_stripes_come_out_of_measured_arenas(hra, oracle):
     torch.cuda.synchronize()
     again = cfg.alloc_output_planes(B, dev, stripes=2)
     assert first in (again[0][0].data_ptr(), again[0][1].data_ptr(), again[1].data_ptr()) or cfg.last_placement_report()["searched"] == 2
+
+
+@pytest.mark.parametrize("names", [CFG_A, CFG_123, HDR], ids=["r1r2", "r1r2r3", "headers3"])
+def test_record_planes_through_the_chunked_launch(hra, oracle, names, monkeypatch):
+    """Few long strings are cut into chunks (scout -> compose -> walk over the chunks -> stitch -> repair: csrc/hrx_kernel_spec.hip); the walk writes record planes like any other
+    launch and the repair reads the finished records out of the planes.  Forced 4-tile chunks over reveal-stress strings (revealed parts straddling chunk borders: the repair runs), and
+    the planner's own choice for a batch of few long strings."""
+    from halo2_regex_amd import synth
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags(0x80))
+    for M in (1024, 2048):
+        chars, lens = synth.reveal_stress(300, M - 8, seed=7 + M)
+        h_c, h_l = synth.headers_planted(100, chars.shape[1] - 3, seed=9, stride=chars.shape[1])
+        chars, lens = np.concatenate([chars, h_c]), np.concatenate([lens, h_l])
+        chars[7, 700] = 250
+        lens[12], lens[13] = 0, min(M, chars.shape[1])
+        cfg = _cfg(hra, names, M)
+        assert "chunked=" in cfg.describe_launch(len(lens), layout=3 | hra.LAYOUT_RECORD_PLANES)
+        _check_planes(hra, oracle, names, chars, lens, M, cfg=cfg)
+    monkeypatch.setenv("HRX_DEBUG_FLAGS", _flags())
+    M = 8192
+    chars, lens = synth.headers_planted(512, M - 1, seed=11, stride=M)
+    cfg = _cfg(hra, names, M)
+    assert "chunked=" in cfg.describe_launch(512, layout=3 | hra.LAYOUT_RECORD_PLANES)
+    _check_planes(hra, oracle, names, chars, lens, M, cfg=cfg)
