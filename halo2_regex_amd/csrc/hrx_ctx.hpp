@@ -155,4 +155,6 @@ HRX_INTERNAL int check_host_shape(size_t B, size_t M);
 HRX_INTERNAL int launch_batch(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status,
                               hipStream_t st, size_t rec_pitch = 0, size_t msk_pitch = 0, int layout = 0, uint32_t *const *planes = nullptr, size_t n_planes = 0);
 // hrx_host_api.cpp: a host-buffer batch through the device (staged, walked, copied back); the caller holds ctx->mu and has selected the device
-HRX_INTERNAL int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status);
+// (one_stream: in, walk, out on one stream whatever HRX_OPT_HOST_PIPELINE says and without taking part in the context's comparison of its two transfer modes: the device part of a split call)
+HRX_INTERNAL int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M, uint32_t *records, uint16_t *masked, uint64_t *status,
+                                   bool one_stream = false);

@@ -12,7 +12,7 @@
 using namespace hrx;
 
 int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M,
-                             uint32_t *records, uint16_t *masked, uint64_t *status) {
+                      uint32_t *records, uint16_t *masked, uint64_t *status, const bool one_stream) {
     if (B == 0) return HRX_OK;
     if (!chars || !lens || !records || !masked || !status) return fail(HRX_ERR_ARG, "NULL buffer");
     const size_t D = ctx->s.defs.size();
@@ -40,7 +40,9 @@ int batch_host_locked(hrx_ctx *ctx, const uint8_t *chars, size_t stride, const u
     // bytes 7.2 (per-chunk traces, the variants tried: profiles/r05_probes/host_path_modes.txt).  So a context MEASURES: after its first big call (allocations, first touches) two calls go
     // pipelined and two on one stream, alternating; the faster way (the better of its two calls, per byte sent back; the pipeline unless the single stream is 10 % faster) takes the next
     // 62 calls, then the other way gets one call again; a pipelined call a quarter slower than the single stream's figure switches at once.  HRX_HOST_PIPELINE=1 / 0: always / never pipelined.
-    const int force_pipe = ctx->host_pipeline == 1 ? 1 : ctx->host_pipeline == 2 ? 0 : -1;      // HRX_OPT_HOST_PIPELINE
+    // HRX_OPT_HOST_PIPELINE; the device part of a split call: one stream (8.6 ms per 65536 x 1024 on every box; the pipeline's 8.0 is 16.5 on every second one, and a measuring call
+    // in the wrong mode made a split call look slower than the device alone: lease b of profiles/r06_leases/)
+    const int force_pipe = one_stream ? 0 : ctx->host_pipeline == 1 ? 1 : ctx->host_pipeline == 2 ? 0 : -1;
     hrx_ctx::HostMode &hm = ctx->host_mode;
     const bool big = nchunk >= 3 && ctx->copy_stream != nullptr;
     bool sequential = !big, timed = false;
@@ -250,7 +252,7 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
     // the host cores alone take 5.4 ms per 65536 x 1024 call, the device 8.0-8.7 (the copy back over the link), the split 6.9 (the parts slow each other down: the copies to and from
     // pageable memory and 254 walking threads share the host's memory); on a small host the device wins.  The context's calls 0 and 1 go through the device (0: allocations and first touches,
     // not recorded), 2 on the host cores, 3 and 4 split (half / half, then by the parts' rates); from then on the way with the smallest ns per row, whose figure every call refreshes; every
-    // 64th call re-measures one of the other two ways if its last figure was within 1.5x of the best.
+    // 32nd call re-measures one of the other two ways if its figure was within 1.5x of the best.
     enum { kDev = HRX_HOST_ROUTE_DEVICE, kHost = HRX_HOST_ROUTE_HOST, kSplit = 3 };
     int way = route == HRX_HOST_ROUTE_DEVICE ? kDev : route == HRX_HOST_ROUTE_HOST ? kHost : 0;
     const bool measured = way == 0;        // an AUTO call of a device context above the split threshold
@@ -265,10 +267,10 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
         else {
             const double d = hr.dev_alone, h = hr.host_alone, sp = hr.split_total;
             way = (d <= h && d <= sp) ? kDev : (h <= sp ? kHost : kSplit);
-            if ((k % 64u) == 63u) {      // one of the other two gets a call again
+            if ((k % 32u) == 31u) {      // one of the other two gets a call again
                 const double best = std::min(d, std::min(h, sp));
                 const int other[2] = {way == kDev ? kHost : kDev, way == kSplit ? kHost : kSplit};
-                const int cand = other[(k / 64u) & 1u];
+                const int cand = other[(k / 32u) & 1u];
                 const double fig = cand == kDev ? d : cand == kHost ? h : sp;
                 if (fig <= 1.5 * best) way = cand;
             }
@@ -279,11 +281,12 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
         if (ctx->device == HRX_DEVICE_NONE) return;
         const double call_ms = ms_since(t_call), ns_row = call_ms * 1e6 / (double)(B * M);
         if (measured) {
-            if (hr.calls > 0) {      // (call 0 pays for the allocations)
-                if (did == kDev) hr.dev_alone = ns_row;
-                else if (did == kHost) hr.host_alone = ns_row;
+            if (hr.calls > 0) {      // (call 0 pays for the allocations).  The mean of the old figure and the new one: one slow call does not dethrone a way
+                auto upd = [&](double &fig) { fig = fig > 0 ? 0.5 * (fig + ns_row) : ns_row; };
+                if (did == kDev) upd(hr.dev_alone);
+                else if (did == kHost) upd(hr.host_alone);
                 else {
-                    hr.split_total = ns_row;
+                    upd(hr.split_total);
                     // (mostly the new figure: a part's rate depends on its share, so the split has to follow quickly)
                     if (bs && dev_ms > 0) { const double m = dev_ms * 1e6 / (double)(bs * M); hr.dev_ns_per_row = hr.dev_ns_per_row > 0 ? 0.3 * hr.dev_ns_per_row + 0.7 * m : m; }
                     if (hn && host_ms > 0) { const double m = host_ms * 1e6 / (double)(hn * M); hr.host_ns_per_row = hr.host_ns_per_row > 0 ? 0.3 * hr.host_ns_per_row + 0.7 * m : m; }
@@ -338,7 +341,7 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
     int rc = HRX_OK;
     {
         const auto t0 = std::chrono::steady_clock::now();
-        rc = batch_host_locked(ctx, chars, stride, lens, bs, M, records, masked, status);
+        rc = batch_host_locked(ctx, chars, stride, lens, bs, M, records, masked, status, /*one_stream=*/true);
         dev_ms = ms_since(t0);
     }
     if (walker.joinable()) { walker.join(); walked = true; }

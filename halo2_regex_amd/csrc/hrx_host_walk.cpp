@@ -106,11 +106,17 @@ uint64_t host_witness_one(const DefsSet &s, const uint8_t *chars, size_t n_raw, 
 // The host threads of host_witness_batch: a process-wide pool of workers that sleep between jobs.  (Until round 6 every call started its threads anew — ~30 us apiece, one after the other:
 // 254 threads for a 65536 x 1024 batch on a 256-core host cost as much as the walk itself, 8.9 ms per call where the pool takes it to what the host's memory gives.)  One job at a time
 // (callers queue on job_mu: the shards of a multi-GPU call, clones on several threads); a job is a range of items handed out in order from an atomic counter, the calling thread works too.
-// A forked child (Python multiprocessing) inherits the pool object without its threads: the pid tells, and the child starts its own.
+// A forked child gets a pool of its own (get()).
 class HostPool {
 public:
     static HostPool &get() {
-        static HostPool *p = new HostPool();      // never destroyed: its workers sleep on it until the process ends
+        // never destroyed: its workers sleep on it until the process ends.  A forked child (Python multiprocessing) inherits the object without its threads — and possibly with its
+        // mutexes held: it gets a pool of its own and the inherited one is left alone (no destructor ever runs on thread handles that do not exist in this process).
+        static std::mutex gm;
+        static HostPool *p = nullptr;
+        static pid_t owner = 0;
+        std::lock_guard<std::mutex> g(gm);
+        if (!p || owner != getpid()) { p = new HostPool(); owner = getpid(); }
         return *p;
     }
     // fn(lo, hi) over [0, n) in pieces of `grain`, on at most `threads` threads (the caller's included)
@@ -138,7 +144,6 @@ private:
     std::mutex job_mu, mu;
     std::condition_variable cv_work, cv_done;
     std::vector<std::thread> workers;
-    pid_t owner = 0;
     const std::function<void(size_t, size_t)> *job_fn = nullptr;
     size_t job_n = 0, job_grain = 1, wanted = 0, started = 0, finished = 0;
     uint64_t generation = 0;
@@ -167,11 +172,6 @@ private:
     }
     // at least min(want, what the system gives) sleeping workers; returns how many there are (under job_mu)
     size_t ensure(size_t want) {
-        if (owner != getpid()) {          // first use, or a forked child: the parent's threads do not exist here
-            for (std::thread &t : workers) t.detach();      // (handles of threads that are not ours)
-            workers.clear();
-            owner = getpid();
-        }
         while (workers.size() < want) {
             try {
                 workers.emplace_back([this] { loop(); });

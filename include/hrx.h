@@ -142,7 +142,7 @@ size_t hrx_ctx_host_threshold(const hrx_ctx *ctx);
  *                                (staged, walked, copied back: the copy back over the link bounds it, ~9e9 rows/s at one def), everything on the host cores (the native walk: the host's
  *                                cores and memory bound it), or both at once — the batch split by string index between them in the ratio of the two parts' rates.  The context's calls 0
  *                                and 1 go through the device (0 pays for allocations and is not recorded), 2 on the host cores, 3 and 4 split; from then on the way with the smallest time
- *                                per row, whose figure every call refreshes; every 64th call re-measures one of the other two if its last figure was within 1.5x of the best.  Smaller
+ *                                per row, whose figure every call refreshes; every 32nd call re-measures one of the other two if its figure was within 1.5x of the best.  Smaller
  *                                batches: the device; below the host threshold: the host;
  *                              HRX_HOST_ROUTE_DEVICE (1) everything through the device;  HRX_HOST_ROUTE_HOST (2) everything on the host cores.  Results are identical either way.
  *   HRX_OPT_HOST_THREADS       host threads of the native walk (0, default: as many as the calling thread's affinity mask has cores; hrx_multi_create divides them among its shards)

@@ -314,3 +314,19 @@ def test_host_route_options_on_a_host_only_context(oracle):
     with pytest.raises(hra.HrxError):
         cfg.set_option(hra.OPT_HOST_ROUTE, 7)
     assert cfg.get_option(hra.OPT_HOST_THREADS) == 3
+
+
+def test_host_walk_threads_survive_a_fork(oracle):
+    """The native walk's worker threads live in a process-wide pool; a forked child (Python multiprocessing) inherits the pool object without its threads and must start its own."""
+    cfg = _cfg(CFG_1, 128)
+    chars, lens = synth.reveal_stress(4000, 120, seed=1)
+    a = cfg.witness_batch_host(chars, lens)        # (the parent's pool has run a job)
+    pid = os.fork()
+    if pid == 0:
+        try:
+            b = cfg.witness_batch_host(chars, lens)
+            os._exit(0 if all(np.array_equal(x, y) for x, y in zip(a, b)) else 3)
+        except BaseException:
+            os._exit(4)
+    _, st = os.waitpid(pid, 0)
+    assert os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0
