@@ -139,7 +139,8 @@ extern "C" {
     pub fn hrx_traffic_pass_device_planes(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, m: usize, record_planes: *const *mut u32, n_planes: usize,
                                           masked: *mut u16, stream: *mut c_void) -> c_int;
     /// per-context choices between variants that compute the same rows (HRX_OPT_*)
-    pub fn hrx_ctx_host_route_report(ctx: *const hrx_ctx, out: *mut hrx_host_route_report) -> c_int;
+    pub fn hrx_ctx_host_route_report(ctx: *const hrx_ctx, out: *mut hrx_host_route_report, out_bytes: usize) -> c_int;
+    pub fn hrx_alloc_last_report_sized(ctx: *const hrx_ctx, out: *mut c_void, out_bytes: usize) -> c_int;
     pub fn hrx_ctx_set_option(ctx: *mut hrx_ctx, option: c_int, value: std::ffi::c_long) -> c_int;
     pub fn hrx_ctx_get_option(ctx: *const hrx_ctx, option: c_int) -> std::ffi::c_long;
     pub fn hrx_describe_launch(defs: *const hrx_defs, layout: c_int, b: usize, m: usize, num_cus: c_int, out: *mut c_char, cap: usize) -> c_int;

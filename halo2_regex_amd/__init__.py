@@ -106,7 +106,8 @@ def _load():
         "hrx_witness_of_string": (i, [vp, sz, sz, sz, vp, vp, vp, vp]),
         "hrx_witness_num_columns": (sz, [sz]),
         "hrx_witness_columns_host": (i, [i, vp, sz, vp, vp, sz, vp, sz, sz, sz, sz, sz, sz, vp]),
-        "hrx_ctx_host_route_report": (i, [vp, C.POINTER(_HostRouteReportC)]),
+        "hrx_ctx_host_route_report": (i, [vp, C.POINTER(_HostRouteReportC), sz]),
+        "hrx_alloc_last_report_sized": (i, [vp, vp, sz]),
         "hrx_ctx_set_option": (i, [vp, i, C.c_long]),
         "hrx_ctx_get_option": (C.c_long, [vp, i]),
         "hrx_rows_of_string_position_major": (i, [vp, vp, sz, sz, sz, sz, vp, vp]),
@@ -822,7 +823,7 @@ class RegexVerifyConfig:
     def host_route_report(self):
         """hrx_ctx_host_route_report: what this config's last witness_batch_host call did (a dict)."""
         r = _HostRouteReportC()
-        _check(lib.hrx_ctx_host_route_report(self._need_ctx(), C.byref(r)))
+        _check(lib.hrx_ctx_host_route_report(self._need_ctx(), C.byref(r), C.sizeof(r)))
         return {k: getattr(r, k) for k, _ in _HostRouteReportC._fields_}
 
     def set_option(self, option, value):
@@ -835,7 +836,7 @@ class RegexVerifyConfig:
     def last_placement_report(self):
         """hrx_alloc_last_report: what the last placement-aware allocation of this config's context did (a dict)."""
         r = _PlaceReportC()
-        _check(lib.hrx_alloc_last_report(self._need_ctx(), C.byref(r)))
+        _check(lib.hrx_alloc_last_report_sized(self._need_ctx(), C.byref(r), C.sizeof(r)))
         return {k: getattr(r, k) for k, _ in _PlaceReportC._fields_}
 
     def traffic_pass(self, chars_pm, B, out, chars_pm_stride, stream=None):

@@ -351,9 +351,9 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
     return HRX_OK;
 }
 
-int hrx_ctx_host_route_report(const hrx_ctx *ctx, hrx_host_route_report *out) {
+int hrx_ctx_host_route_report(const hrx_ctx *ctx, hrx_host_route_report *out, size_t out_bytes) {
     if (!ctx || !out) return fail(HRX_ERR_ARG, "NULL argument");
-    *out = ctx->last_host;
+    std::memcpy(out, &ctx->last_host, std::min(out_bytes, sizeof ctx->last_host));      // (sized: the struct may grow at its end)
     return HRX_OK;
 }
 

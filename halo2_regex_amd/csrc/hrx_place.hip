@@ -87,6 +87,9 @@ struct TrafficArgs {
     uint32_t stripes;                           // 2: one def's plane in two row stripes (WitnessArgs::rec_stripes): quad q in planes[q % 2] at slot q / 2
 };
 
+// MODE 0: the interleaved records (the code of rounds 2-5, untouched: a run-time choice of the address form per store made the pass of the bench line 5 us slower than the launch it is the
+// ceiling of); 1: record planes; 2: one def in two row stripes
+template <int MODE>
 __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t n_groups = (a.B + 63u) / 64u;
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) 
             const bool wb = wb_k != 0u && (t % wb_k) == wb_k - 1u;
             const uint4 v = make_uint4(q, 1, 2, 3);
             for (uint32_t d = 0; d < a.D; ++d) {
-                unsigned char *p = a.stripes == 2u ? a.planes[q & 1u] + ((size_t)blk0 * ((q4 + 1u) / 2u) + bl + (size_t)(q >> 1) * nb) * 16u
-                                 : a.planes[0] ? a.planes[d] + ((size_t)blk0 * q4 + bl + (size_t)q * nb) * 16u : rp + ((size_t)q * a.D + d) * nb * 16u;
+                unsigned char *p = MODE == 2 ? a.planes[q & 1u] + ((size_t)blk0 * ((q4 + 1u) / 2u) + bl + (size_t)(q >> 1) * nb) * 16u
+                                 : MODE == 1 ? a.planes[d] + ((size_t)blk0 * q4 + bl + (size_t)q * nb) * 16u : rp + ((size_t)q * a.D + d) * nb * 16u;
                 if (wb) *reinterpret_cast<uint4 *>(p) = v;
                 else store16_nt(p, v);
             }
@@ -206,7 +209,10 @@ hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, si
     a.spread = n_groups < (size_t)num_cus * 4 ? 1u : 0u;
     const size_t need = a.spread ? n_groups : (n_groups + 3) / 4;
     const int grid = (int)std::min<size_t>(need, (size_t)num_cus);
-    hipLaunchKernelGGL(traffic_pass_kernel, dim3(grid < 1 ? 1 : grid), dim3(512), 0, stream, a);
+    const dim3 g(grid < 1 ? 1 : grid), b(512);
+    if (a.stripes == 2u) hipLaunchKernelGGL(traffic_pass_kernel<2>, g, b, 0, stream, a);
+    else if (a.planes[0]) hipLaunchKernelGGL(traffic_pass_kernel<1>, g, b, 0, stream, a);
+    else hipLaunchKernelGGL(traffic_pass_kernel<0>, g, b, 0, stream, a);
     return hipGetLastError();
 }
 

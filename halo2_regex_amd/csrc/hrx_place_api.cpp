@@ -302,6 +302,12 @@ int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out) {
     return HRX_OK;
 }
 
+int hrx_alloc_last_report_sized(const hrx_ctx *ctx, void *out, size_t out_bytes) {
+    if (!ctx || !out) return fail(HRX_ERR_ARG, "NULL argument");
+    std::memcpy(out, &ctx->last_place, std::min(out_bytes, sizeof ctx->last_place));      // a consumer built against an earlier header gets the fields it knows (the struct only ever grows at its end)
+    return HRX_OK;
+}
+
 int hrx_traffic_pass_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, size_t M, uint32_t *records, uint16_t *masked, void *stream) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to launch on");
@@ -344,6 +350,7 @@ int hrx_traffic_pass_device_layout(hrx_ctx *ctx, int layout, const uint8_t *char
     HIP_TRY(guard.set(ctx->device));
     WitnessArgs a{};
     a.layout = HRX_LAYOUT_STRING_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)D;
+    a.rec_pitch = (uint32_t)rec_pitch; a.msk_pitch = (uint32_t)msk_pitch;      // (plan_nt_mix sizes the records by the pitch: without it the pass streamed every store where the launch writes some back — ADVICE r5)
     LaunchInfo li{};
     li.split = 1;
     const uint32_t nt_mix = plan_nt_mix(a, li);

@@ -163,7 +163,7 @@ typedef struct hrx_host_route_report {
     int host_threads;
     int device_pipelined;         /* the device part: 1 chunks pipelined over two streams, 0 one stream */
 } hrx_host_route_report;
-int hrx_ctx_host_route_report(const hrx_ctx *ctx, hrx_host_route_report *out);
+int hrx_ctx_host_route_report(const hrx_ctx *ctx, hrx_host_route_report *out, size_t out_bytes);   /* out_bytes = sizeof(hrx_host_route_report) of the caller's header: the struct may grow at its end */
 int hrx_ctx_set_option(hrx_ctx *ctx, int option, long value);
 long hrx_ctx_get_option(const hrx_ctx *ctx, int option);
 /* thread-local text of the last failing call (any entry point) */
@@ -322,6 +322,9 @@ enum {
     HRX_PLACE_CAPPED_ALLOC = 8   /* a candidate could not be allocated */
 };
 int hrx_alloc_last_report(const hrx_ctx *ctx, hrx_place_report *out);
+/* The same into a buffer of out_bytes: min(out_bytes, sizeof(hrx_place_report)) bytes are written.  hrx_place_report only ever grows at its end (`capped` came in round 5), so a
+ * consumer built against an earlier header passes the size of ITS struct and gets the fields it knows (hrx_alloc_last_report writes the whole current struct). */
+int hrx_alloc_last_report_sized(const hrx_ctx *ctx, void *out, size_t out_bytes);
 /* Placement per context (a prover that links the library decides per context, not through the environment):
  *   mode       HRX_PLACE_OFF: hrx_alloc_output_pair / hrx_alloc_outputs_position_major are two plain allocations, nothing is measured, no arena is held
  *              on this context's behalf; HRX_PLACE_WALK (the default unless HRX_PLACE=0 was set when the context was created): as described above.
