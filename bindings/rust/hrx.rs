@@ -150,6 +150,8 @@ extern "C" {
     pub fn hrx_witness_num_columns(d: usize) -> usize;
     pub fn hrx_witness_columns_host(layout: c_int, chars: *const u8, stride: usize, lens: *const u32, records: *const u32, rec_pitch: usize, masked: *const u16,
                                     msk_pitch: usize, b: usize, m: usize, d: usize, b_begin: usize, b_count: usize, columns: *mut u64) -> c_int;
+    pub fn hrx_fr_columns_device_planes(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, lens: *const u32, record_planes: *const *const u32, n_planes: usize,
+                                        masked: *const u16, b: usize, m: usize, b_begin: usize, b_count: usize, cells: *mut u64, flags: c_int, stream: *mut c_void) -> c_int;
     pub fn hrx_fr_num_columns(d: usize) -> usize;
     pub fn hrx_fr_from_u64(v: u64, flags: c_int, limbs: *mut u64);
     /// what src/vrm/js_caller.rs:36-48, 127-157 obtain from V8: regexToDfa's JSON, the AllstrRegexDef text, formatRegexPrintable; and the part search of vrm/mod.rs:540-600

@@ -130,6 +130,7 @@ def _load():
         "hrx_multi_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
         "hrx_fr_num_columns": (sz, [sz]),
         "hrx_fr_columns_device": (i, [vp, i, vp, sz, vp, vp, sz, vp, sz, sz, sz, sz, sz, vp, i, vp]),
+        "hrx_fr_columns_device_planes": (i, [vp, i, vp, sz, vp, C.POINTER(vp), sz, vp, sz, sz, sz, sz, vp, i, vp]),
         "hrx_fr_from_u64": (None, [C.c_uint64, i, _u64p]),
         "hrx_witness_batch_host": (i, [vp, _u8p, sz, _u32p, sz, sz, _u32p, _u16p, _u64p]),
         "hrx_shard_range": (None, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
@@ -912,6 +913,11 @@ class RegexVerifyConfig:
         else:
             stride, rp, mp = chars.stride(0), rec.stride(0) // D, msk.stride(0)
         s = torch.cuda.current_stream(lens.device) if stream is None else stream
+        if isinstance(rec, (list, tuple)):      # record planes (or the two row stripes of one def)
+            arr = (C.c_void_p * len(rec))(*[p.data_ptr() for p in rec])
+            _check(lib.hrx_fr_columns_device_planes(self._need_device(chars, lens, msk, cells, *rec), layout, chars.data_ptr(), stride, lens.data_ptr(), arr, len(rec), msk.data_ptr(),
+                                                    B, M, b_begin, b_count, cells.data_ptr(), FR_CANONICAL if canonical else 0, s.cuda_stream))
+            return cells
         _check(lib.hrx_fr_columns_device(self._need_device(chars, lens, rec, msk, cells), layout, chars.data_ptr(), stride, lens.data_ptr(), rec.data_ptr(), rp,
                                          msk.data_ptr(), mp, B, M, b_begin, b_count, cells.data_ptr(),
                                          FR_CANONICAL if canonical else 0, s.cuda_stream))

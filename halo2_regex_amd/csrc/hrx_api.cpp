@@ -989,9 +989,28 @@ void hrx_fr_from_u64(uint64_t v, int flags, uint64_t *limbs) {
     if (limbs) { limbs[0] = w[0]; limbs[1] = w[1]; limbs[2] = w[2]; limbs[3] = w[3]; }
 }
 
+static int fr_columns_any(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, const uint32_t *records, const uint32_t *const *planes, size_t n_planes,
+                          size_t rec_pitch, const uint16_t *masked, size_t msk_pitch, size_t B, size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream);
+
 int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,
                           const uint32_t *records, size_t rec_pitch, const uint16_t *masked, size_t msk_pitch, size_t B,
                           size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream) {
+    return fr_columns_any(ctx, layout, chars, stride, lens, records, nullptr, 0, rec_pitch, masked, msk_pitch, B, M, b_begin, b_count, cells, flags, stream);
+}
+
+int hrx_fr_columns_device_planes(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, const uint32_t *const *record_planes, size_t n_planes,
+                                 const uint16_t *masked, size_t B, size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream) {
+    if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
+    const size_t Dn = ctx->s.defs.size();
+    if (!(layout & HRX_LAYOUT_POSITION_MAJOR)) return fail(HRX_ERR_ARG, "record planes are a position-major layout");
+    if (!record_planes || !(n_planes == Dn || (Dn == 1 && n_planes == 2)) || n_planes > kMaxDefsPerLaunch) return fail(HRX_ERR_ARG, "record planes: one buffer per def (at most eight; one def: one buffer or two row stripes)");
+    for (size_t d = 0; d < n_planes; ++d)
+        if (!record_planes[d]) return fail(HRX_ERR_ARG, "NULL plane");
+    return fr_columns_any(ctx, layout, chars, stride, lens, record_planes[0], record_planes, n_planes, 0, masked, 0, B, M, b_begin, b_count, cells, flags, stream);
+}
+
+static int fr_columns_any(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, const uint32_t *records, const uint32_t *const *planes, size_t n_planes,
+                          size_t rec_pitch, const uint16_t *masked, size_t msk_pitch, size_t B, size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream) {
     if (!ctx) return fail(HRX_ERR_ARG, "NULL ctx");
     if (b_count == 0) return HRX_OK;
     if (!chars || !lens || !records || !masked || !cells) return fail(HRX_ERR_ARG, "NULL buffer");
@@ -1010,6 +1029,10 @@ int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t
     a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)ctx->s.defs.size(); a.layout = (uint32_t)layout;
     a.rec_pitch = (uint32_t)(rec_pitch ? rec_pitch : M); a.msk_pitch = (uint32_t)(msk_pitch ? msk_pitch : M);
     a.canonical = (flags & HRX_FR_CANONICAL) ? 1u : 0u;
+    if (planes) {
+        for (size_t d = 0; d < n_planes && d < kMaxDefsPerLaunch; ++d) a.rec_planes[d] = planes[d];
+        a.rec_stripes = n_planes == 2 * ctx->s.defs.size() ? 2u : 1u;
+    }
     // one launch per 32768 strings (the grid's y dimension); every launch writes its slice of each column
     const size_t total = b_count;
     for (size_t done = 0; done < total; done += 32768) {

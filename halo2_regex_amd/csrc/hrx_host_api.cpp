@@ -286,7 +286,7 @@ int hrx_witness_batch_host(hrx_ctx *ctx, const uint8_t *chars, size_t stride, co
                 if (did == kDev) upd(hr.dev_alone);
                 else if (did == kHost) upd(hr.host_alone);
                 else {
-                    upd(hr.split_total);
+                    if (hr.calls != 3u) upd(hr.split_total);      // (call 3 is the half / half split that only measures the two parts' rates: 11.9 ms where the split made from them takes 6.4)
                     // (mostly the new figure: a part's rate depends on its share, so the split has to follow quickly)
                     if (bs && dev_ms > 0) { const double m = dev_ms * 1e6 / (double)(bs * M); hr.dev_ns_per_row = hr.dev_ns_per_row > 0 ? 0.3 * hr.dev_ns_per_row + 0.7 * m : m; }
                     if (hn && host_ms > 0) { const double m = host_ms * 1e6 / (double)(hn * M); hr.host_ns_per_row = hr.host_ns_per_row > 0 ? 0.3 * hr.host_ns_per_row + 0.7 * m : m; }

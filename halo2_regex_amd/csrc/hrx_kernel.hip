@@ -546,6 +546,10 @@ __global__ __launch_bounds__(256) void fr_columns_kernel(const FrArgs a) {
 #pragma unroll
         for (uint32_t j = 0; j < kFrJ; ++j) {
             const uint32_t r = min(rbase + j * 32u, a.M - 1u);
+            if (a.rec_planes[0]) {      // (position-major) quad q of def d: buffer (q % R) * D + d, slot q / R of the string's block
+                const uint32_t R = a.rec_stripes == 2u ? 2u : 1u, q = r >> 2, q4 = (a.M + 3u) / 4u, slots = (q4 + R - 1u) / R;
+                rec[j] = a.rec_planes[(q % R) * a.D + d][(size_t)blk0 * slots * 4u + ((size_t)(q / R) * nb + bl) * 4u + (r & 3u)];
+            } else
             rec[j] = pm ? a.records[((size_t)blk0 * ((a.M + 3u) / 4u) * a.D + ((size_t)(r >> 2) * a.D + d) * nb + bl) * 4u + (r & 3u)]
                         : a.records[((size_t)b * a.rec_pitch + r) * a.D + d];
         }

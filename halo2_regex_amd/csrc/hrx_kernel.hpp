@@ -316,6 +316,8 @@ struct FrArgs {
     uint32_t B, M, D, layout, rec_pitch, msk_pitch;
     uint32_t b_begin, b_count;
     uint32_t canonical;   // 1: plain integers instead of Montgomery form
+    const uint32_t *rec_planes[kMaxDefsPerLaunch];   // record planes / the two row stripes of one def (WitnessArgs::rec_planes, ::rec_stripes); rec_planes[0] == NULL: `records`
+    uint32_t rec_stripes;
     uint64_t *cells;      // first cell of string b_begin in column 0
     uint64_t col_cells;   // cells between consecutive columns (= strings of the whole request x M)
 };

@@ -4,6 +4,8 @@
 #include "hrx_arena_alloc.hpp"
 #include "hrx_place_rule.hpp"
 
+#include <functional>
+
 using namespace hrx;
 
 extern "C" {
@@ -401,14 +403,17 @@ int hrx_probe_write_pair(hrx_ctx *ctx, void *a, void *b, size_t bytes, double *g
 // threshold: pairings in one class measure 5.2-6.2 TB/s, across classes 6.5-7.3 (profiles/r06_probes/plane_probe.txt, plane_select_cfg4.txt), and both levels move with the box: "colliding" =
 // below the cut between the two levels of THIS pool.  Random draws of three 4-GiB planes + masked rows already run cfg 4's no-compute pass at 0.86 of peak in 54 of 60
 // cases, against 0.65 for three planes of one class and 0.74-0.77 for the interleaved buffer: the selection only has to avoid the draws that collide.
-constexpr size_t kPlanesSpare = 4, kPlanesMasked = 5, kPlanesGrow = 3, kPlanesMaxSets = 4096;
+constexpr size_t kPlanesSpare = 4, kPlanesMasked = 5, kPlanesGrow = 3, kPlanesMaxSets = 4096, kPlanesDry = 6;
 
 }  // extern "C"
 
 // nrec buffers of rec_bytes (each carrying w_rec of the launch's output bytes per row, in any unit) + one of msk_bytes (w_msk).  On success rec_out / msk_out own the kept buffers
 // (hipMalloc'ed; everything else has been freed) and rep says what was measured; false: out of device memory (nothing is held).
+// dry (optional): the REAL launch over a candidate set, milliseconds (< 0: could not run) — the best sets by the pairings' score are timed and the fastest is kept: the pairwise probe does
+// not see everything (cfg 4: sets with the same pairings differ by 7 %, plane_select_cfg4.txt; a lease whose every set scored alike ran at 0.756 where others reach 0.80).
 static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nrec, const size_t msk_bytes, const size_t w_rec, const size_t w_msk, const bool walk,
-                           std::vector<void *> &rec_out, void *&msk_out, hrx_place_report &rep) {
+                           std::vector<void *> &rec_out, void *&msk_out, hrx_place_report &rep,
+                           const std::function<double(const std::vector<void *> &, void *)> &dry = nullptr) {
     const auto t_begin = std::chrono::steady_clock::now();
     std::vector<void *> pc, mc, spacers;     // record and masked-row candidates; blocks that only push the next candidates further down the memory
     auto free_all = [&]() { for (void *p : pc) if (p) (void)hipFree(p); for (void *p : mc) if (p) (void)hipFree(p); for (void *p : spacers) (void)hipFree(p); pc.clear(); mc.clear(); spacers.clear(); };
@@ -454,6 +459,8 @@ static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nr
         };
         double lo = 0, hi = 0, cut = 0;
         bool first = true;
+        struct Scored { size_t load, low; double sum, mn; std::vector<size_t> idx; size_t q; };
+        std::vector<Scored> scored;
         size_t best_low = ~(size_t)0, best_load = ~(size_t)0;
         double best_sum = -1.0, best_min = 0.0;
         // what there is to find: with up to three buffers, a set in which nothing collides; with more, one whose busiest class takes a record buffer and the masked rows
@@ -498,6 +505,7 @@ static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nr
             for (size_t d = 0; d < nrec; ++d) idx[d] = d;
             best_low = ~(size_t)0; best_sum = -1.0; best_load = ~(size_t)0;
             size_t sets = 0;
+            scored.clear();
             for (;;) {
                 for (size_t q = 0; q < Q; ++q) {
                     double mn = 1e30, sum = 0.0; size_t low = 0, load_m = w_msk, load_max = 0;
@@ -518,6 +526,7 @@ static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nr
                     if (load_max < best_load || (load_max == best_load && (low < best_low || (low == best_low && sum > best_sum)))) {
                         best_load = load_max; best_low = low; best_sum = sum; best_min = mn; pick = idx; pick_m = q;
                     }
+                    if (dry) scored.push_back(Scored{load_max, low, sum, mn, idx, q});
                 }
                 if (++sets >= kPlanesMaxSets) break;      // (more than three defs: the first sets in allocation order)
                 size_t k = nrec;       // next combination
@@ -535,6 +544,25 @@ static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nr
             const size_t before = pc.size();
             if (!take(pc, rec_bytes, before, before + kPlanesGrow) || pc.size() == before) break;
             (void)take(mc, msk_bytes, mc.size(), mc.size() + 1);      // (a masked-row candidate of the new neighbourhood as well)
+        }
+        // ---- the real launch over the best sets by score (at most kPlanesDry of them, no two sharing all their record buffers twice over): the fastest is kept
+        if (dry && !scored.empty()) {
+            std::sort(scored.begin(), scored.end(), [](const Scored &x, const Scored &y) { return x.load != y.load ? x.load < y.load : x.low != y.low ? x.low < y.low : x.sum > y.sum; });
+            double best_ms = -1.0;
+            size_t tried = 0;
+            for (size_t k = 0; k < scored.size() && tried < kPlanesDry; ++k) {
+                const Scored &c = scored[k];
+                if (c.load > scored[0].load + std::max(w_rec, w_msk)) break;      // (only sets about as good as the best by score)
+                std::vector<void *> rs;
+                for (size_t d = 0; d < nrec; ++d) rs.push_back(pc[c.idx[d]]);
+                const double ms = dry(rs, mc[c.q]);
+                ++tried;
+                if (ms <= 0) break;
+                place_trace(ctx, "hrx planes: dry launch over set %zu (busiest class %zu, %zu colliding, sum %.1f TB/s): %.4f ms\n", k, c.load, c.low, c.sum * 1e-6, ms);
+                if (tried == 1) rep.first_us = ms * 1e3;
+                if (best_ms < 0 || ms < best_ms) { best_ms = ms; pick = c.idx; pick_m = c.q; best_load = c.load; best_low = c.low; best_min = c.mn; }
+            }
+            if (best_ms > 0) rep.best_us = best_ms * 1e3;
         }
         rep.ref_gbs = lo * 1e-3;           // the slowest pairing seen (the fastest is in the trace)
         rep.best_gbs = best_min * 1e-3;    // the kept set's slowest pairing
@@ -629,7 +657,41 @@ int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, u
         ok = stripe_arenas_take(ctx, n_planes, rec_bytes, masked_bytes, rec, msk, rep);
     if (!ok) {
         rep = hrx_place_report{};
-        ok = choose_buffers(ctx, rec_bytes, n_planes, masked_bytes, w_rec, w_msk, walk && rec_bytes >= kPlaceDirectFrom / 4, rec, msk, rep);
+        // the dry launch: this context's own launch of B strings x M rows over a candidate set, on a constant input (every string M - 1 times the byte 'a': what the walk finds there does not
+        // matter to where its bytes go), timed with events on the context's stream — one warm-up, the faster of two
+        const bool direct_walk = walk && rec_bytes >= kPlaceDirectFrom / 4;
+        const size_t dstride = (M + 15) / 16 * 16;
+        DevBuf d_chars, d_lens, d_status;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool dry_ok = direct_walk && D <= kMaxDefsPerLaunch;
+        if (dry_ok) {
+            size_t fb = 0, tb = 0;
+            dry_ok = hipMemGetInfo(&fb, &tb) == hipSuccess && (double)(B * dstride) < 0.05 * (double)fb;      // (the input of the dry launch: at most a twentieth of what is free)
+            dry_ok = dry_ok && d_chars.reserve(B * dstride) == hipSuccess && d_lens.reserve(B * 4) == hipSuccess && d_status.reserve(B * 8) == hipSuccess;
+            dry_ok = dry_ok && hipMemsetAsync(d_chars.p, 'a', B * dstride, ctx->stream) == hipSuccess && hipMemsetD32Async((hipDeviceptr_t)d_lens.p, (int)(M - 1), B, ctx->stream) == hipSuccess;
+            dry_ok = dry_ok && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+            if (!dry_ok) (void)hipGetLastError();
+        }
+        auto dry = [&](const std::vector<void *> &rs, void *mk) -> double {
+            std::vector<uint32_t *> pl;
+            for (void *p : rs) pl.push_back((uint32_t *)p);
+            float best = -1.0f;
+            for (int it = 0; it < 3; ++it) {
+                if (hipEventRecord(e0, ctx->stream) != hipSuccess) return -1.0;
+                if (launch_batch(ctx, (const uint8_t *)d_chars.p, dstride, (const uint32_t *)d_lens.p, B, M, pl[0], (uint16_t *)mk, (uint64_t *)d_status.p, ctx->stream, 0, 0,
+                                 HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR, pl.data(), pl.size()) != HRX_OK) return -1.0;
+                if (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.0;
+                float t = 0.0f;
+                if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return -1.0;
+                if (it > 0 && (best < 0 || t < best)) best = t;
+            }
+            return (double)best;
+        };
+        ok = choose_buffers(ctx, rec_bytes, n_planes, masked_bytes, w_rec, w_msk, direct_walk, rec, msk, rep,
+                            dry_ok ? std::function<double(const std::vector<void *> &, void *)>(dry) : std::function<double(const std::vector<void *> &, void *)>());
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        d_chars.release(); d_lens.release(); d_status.release();
     }
     if (!ok) return fail(HRX_ERR_HIP, "hrx_alloc_output_planes: out of device memory");
     for (size_t d = 0; d < n_planes; ++d) record_planes[d] = (uint32_t *)rec[d];

@@ -246,7 +246,9 @@ void hrx_position_major_stripe_sizes(size_t B, size_t M, size_t n_stripes, size_
  * measured pair by pair (two equal write streams, ~1 ms per pair on the device clock); pairings fall into two levels — both buffers in one class of the physical address
  * space, or not — and the buffers whose busiest class takes the fewest of the launch's output bytes per row (4 per plane — 2 per row stripe —, 2 for the masked rows; then
  * the fewest colliding pairings, the largest sum of pairings) are kept; a pool whose best set still collides (up to three buffers: at all; more: beyond one record buffer +
- * the masked rows) grows by three record candidates, at most twice; everything else is freed before the call returns.  Record buffers below 1 GiB are carved out of up to
+ * the masked rows) grows by three record candidates, at most twice; then the context's own launch of B strings x M rows runs over the (at most six) best sets by that
+ * score, on a constant input, and the fastest is kept (the pairwise probe does not see everything: 2.5 ms against 2.9 per launch for sets it ranks alike); everything else
+ * is freed before the call returns.  Record buffers below 1 GiB are carved out of up to
  * four 2-GiB STRIPE ARENAS per device and process chosen the same way once (a probe over buffers that fit the Infinity Cache would measure the cache); hrx_device_free gives
  * a sub-buffer's range back.  hrx_alloc_last_report: steps = pairings measured, ref_gbs = the slowest pairing seen, first_gbs = the slowest pairing of the first buffers
  * (what plain allocations would have been), best_gbs = the kept set's, chosen_step = the bytes per row of the kept set's busiest class, searched = 2: served from arenas
@@ -395,6 +397,9 @@ size_t hrx_fr_num_columns(size_t D);
 int hrx_fr_columns_device(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens,
                           const uint32_t *records, size_t rec_pitch, const uint16_t *masked, size_t msk_pitch, size_t B,
                           size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream);
+/* The same out of RECORD PLANES (hrx_witness_batch_device_planes: the D planes, or the two row stripes of one def); `layout` position-major, optionally | HRX_LAYOUT_INPUT_POSITION_MAJOR. */
+int hrx_fr_columns_device_planes(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, const uint32_t *const *record_planes, size_t n_planes,
+                                 const uint16_t *masked, size_t B, size_t M, size_t b_begin, size_t b_count, uint64_t *cells, int flags, void *stream);
 /* F::from(v) on the host (same arithmetic as the kernel): limbs[4]. */
 void hrx_fr_from_u64(uint64_t v, int flags, uint64_t *limbs);
 

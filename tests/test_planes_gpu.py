@@ -280,3 +280,31 @@ def test_record_planes_through_the_chunked_launch(hra, oracle, names, monkeypatc
     cfg = _cfg(hra, names, M)
     assert "chunked=" in cfg.describe_launch(512, layout=3 | hra.LAYOUT_RECORD_PLANES)
     _check_planes(hra, oracle, names, chars, lens, M, cfg=cfg)
+
+
+@pytest.mark.parametrize("names,stripes", [(CFG_A, None), (CFG_123, None), (None, 2)], ids=["D2-planes", "D3-planes", "D1-stripes"])
+def test_field_cells_out_of_record_planes(hra, oracle, names, stripes):
+    """hrx_fr_columns_device_planes (SURVEY §8 f4 for the planes layout): the cells equal the ones hrx_fr_columns_device makes out of the interleaved buffers of the same batch."""
+    import torch
+    from halo2_regex_amd import synth
+    from test_parity_gpu import CFG_1
+    names = names or CFG_1
+    dev = torch.device("cuda", 0)
+    M, B = 200, 700
+    chars, lens = synth.reveal_stress(B, M - 8, seed=21)
+    cfg = _cfg(hra, names, M)
+    stride = (chars.shape[1] + 15) // 16 * 16
+    wide = torch.zeros((B, stride), dtype=torch.uint8, device=dev)
+    wide[:, :chars.shape[1]] = torch.from_numpy(chars).to(dev)
+    d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    c_pm = hra.chars_to_position_major(wide)
+    out_i = cfg.witness_batch_position_major(c_pm, d_lens, chars_pm_stride=stride)
+    out_p = cfg.witness_batch_planes(c_pm, d_lens, chars_pm_stride=stride, out=cfg.alloc_output_planes(B, dev, stripes=stripes))
+    torch.cuda.synchronize()
+    assert torch.equal(out_i[2], out_p[2])
+    for canonical in (False, True):
+        a = cfg.fr_columns(c_pm, d_lens, out_i, b_begin=37, b_count=500, position_major=True, chars_pm_stride=stride, canonical=canonical)
+        b = cfg.fr_columns(c_pm, d_lens, out_p, b_begin=37, b_count=500, position_major=True, chars_pm_stride=stride, canonical=canonical)
+        torch.cuda.synchronize()
+        ok = ((out_i[2][37:537] & 0xff) == 0)
+        assert ok.sum() > 400 and torch.equal(a[:, ok], b[:, ok])
