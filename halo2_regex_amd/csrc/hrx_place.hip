@@ -133,6 +133,39 @@ __global__ __launch_bounds__(512) void traffic_pass_kernel(const TrafficArgs a) 
     }
 }
 
+// Record planes of a batch that leaves walker slots empty (at most two groups per CU: cfg 4) are written by the DEF-PARALLEL kernel: a wave per def stores its def's plane, the combiner wave
+// the masked rows, a loader reads the input.  The pass for that launch deals its waves the same way — G groups per workgroup x (D plane writers + a masked-row writer + a reader) —
+// because WHO issues the stores matters here: one wave storing all planes of a group in row order reads 0.75 of peak over planes on which the launch itself runs at 0.80
+// (profiles/r06_probes/plane_select_cfg4.txt), and over interleaved records the per-plane dealing reads 0.68 where the one-wave pass reads 0.75 (plane_probe.txt).
+__global__ __launch_bounds__(640) void traffic_pass_planes_pmd_kernel(const TrafficArgs a, const uint32_t G) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t W = a.D + 2u;                         // waves per group
+    const uint32_t lg = wave / W, role = wave % W;        // role d < D: plane d; D: the masked rows; D + 1: the reader
+    const uint32_t n_groups = (a.B + 63u) / 64u;
+    const size_t q4 = (a.M + 3u) / 4u, q8 = (a.M + 7u) / 8u;
+    for (uint32_t g = blockIdx.x * G + lg; g < n_groups; g += gridDim.x * G) {
+        const uint32_t b = min(g * 64u + lane, a.B - 1u);
+        const uint32_t blk0 = (g * 64u / kPmBlock) * kPmBlock, nb = min(kPmBlock, a.B - blk0), bl = b - blk0;
+        if (role == a.D + 1u) {
+            const unsigned char *cp = a.chars + (size_t)blk0 * a.stride + (size_t)bl * 16u;
+            uint4 acc = make_uint4(0, 0, 0, 0);
+            const uint32_t nchunk = (uint32_t)(a.stride / 16u);
+#pragma unroll 8
+            for (uint32_t c = 0; c < nchunk; ++c) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(cp + (size_t)c * nb * 16u);
+                acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+            }
+            if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) a.sink[0] = acc.z ^ acc.w;
+        } else if (role == a.D) {
+            unsigned char *mp = a.masked + ((size_t)blk0 * q8 + bl) * 16u;
+            for (uint32_t o = 0; o < (uint32_t)q8; ++o) store16_nt(mp + (size_t)o * nb * 16u, make_uint4(0, 0, 0, o));
+        } else {
+            unsigned char *p = a.planes[role] + ((size_t)blk0 * q4 + bl) * 16u;
+            for (uint32_t q = 0; q < (uint32_t)q4; ++q) store16_nt(p + (size_t)q * nb * 16u, make_uint4(q, 1, 2, 3));
+        }
+    }
+}
+
 // The same for STRING-MAJOR outputs, the way the walker/storer kernel (hrx_kernel_sm.hip) moves them: a store instruction writes the 128-byte lines of EIGHT strings
 // (lane = string it * 8 + lane / 8, 16-byte piece lane % 8 of the line), 2 D lines of records and one line of masked rows per string and 64 rows; the input is read
 // one string per lane, 16 bytes at a time, a stride apart.  rec_pitch / msk_pitch in rows.
@@ -210,6 +243,14 @@ hipError_t launch_traffic_pass(const uint8_t *chars, size_t stride, size_t B, si
     const size_t need = a.spread ? n_groups : (n_groups + 3) / 4;
     const int grid = (int)std::min<size_t>(need, (size_t)num_cus);
     const dim3 g(grid < 1 ? 1 : grid), b(512);
+    // (what launches this shape with record planes: the def-parallel kernel — two and three defs at up to two groups per CU, four to eight defs always; hrx_kernel.hip)
+    const bool pmd = a.planes[0] && a.stripes != 2u && D >= 2u && ((D <= 3u && n_groups <= (size_t)num_cus * 2 && B <= kPmBlock) || D >= 4u);
+    if (pmd) {
+        const uint32_t G = (D <= 3u && n_groups > (size_t)num_cus) ? 2u : 1u;
+        const size_t needg = (n_groups + G - 1) / G;
+        hipLaunchKernelGGL(traffic_pass_planes_pmd_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>(needg, 1), (size_t)num_cus)), dim3(64u * G * (D + 2u)), 0, stream, a, G);
+        return hipGetLastError();
+    }
     if (a.stripes == 2u) hipLaunchKernelGGL(traffic_pass_kernel<2>, g, b, 0, stream, a);
     else if (a.planes[0]) hipLaunchKernelGGL(traffic_pass_kernel<1>, g, b, 0, stream, a);
     else hipLaunchKernelGGL(traffic_pass_kernel<0>, g, b, 0, stream, a);

@@ -186,6 +186,11 @@ def test_placed_record_planes_at_a_multi_gigabyte_size(hra, oracle):
     for k in range(0, B, 2048):
         assert torch.equal(rec[k:k + 2048], t_rec) and torch.equal(m[k:k + 2048], t_msk)
     assert (st.cpu().numpy().view(np.uint64) == np.tile(ost, B // 2048)).all()
+    # the no-compute pass over the planes (dealt like the def-parallel kernel for this shape): runs, and overwrites what it is pointed at
+    cfg.traffic_pass_planes(d_chars, B, out, M)
+    torch.cuda.synchronize()
+    rec2, _ = hra.planes_to_string_major(planes, msk, B, M, D=3)
+    assert not torch.equal(rec2[:2048], t_rec)
     cfg.set_placement(walk=False)
     out2 = cfg.alloc_output_planes(B, dev)
     assert cfg.last_placement_report()["searched"] == 0 and len(out2[0]) == 3

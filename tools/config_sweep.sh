@@ -1,7 +1,8 @@
 #!/bin/bash
-# One bench line per BASELINE config shape (per-GPU sizes) -> gpurun_out/r05_config_sweep/*.json; copied to profiles/r05_config_sweep/.
+# One bench line per BASELINE config shape (per-GPU sizes) -> gpurun_out/r06_config_sweep/*.json; copied to profiles/r06_config_sweep/.
+# Round 6: every position-major line of two or more defs twice — interleaved records and RECORD PLANES (--planes).
 # Every line in the HBM-only regime (the timed steps rotate over as many buffer sets as fit 48 GiB, up to 8) and verified over every string.
-cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r05_config_sweep; rm -rf $O; mkdir -p $O
+cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r06_config_sweep; rm -rf $O; mkdir -p $O
 B="python3 bench.py --no-cpu-baseline --no-pmc"
 $B                                                                                   > $O/cfg2_regex1_65536x1024.json
 $B --layout string-major                                                             > $O/cfg2_regex1_65536x1024_string_major.json
@@ -26,6 +27,15 @@ $B --batch 8192 --len 32767 --rows 32768 --steps 10 --warmup 2 --distinct 2048  
 $B --batch 16384 --len 32767 --rows 32768 --steps 10 --warmup 2 --distinct 2048                      > $O/regex1_16384x32768_long.json
 $B --config headers3 --batch 8192 --len 32767 --rows 32768 --steps 5 --warmup 2 --distinct 2048      > $O/headers3_8192x32768_long.json
 $B --config regex23 --batch 8192 --len 32767 --rows 32768 --steps 5 --warmup 2 --distinct 2048       > $O/regex23_8192x32768_long.json
+$B --config regex23 --batch 262144 --len 2047 --rows 2048 --steps 20 --warmup 3 --planes      > $O/cfg3_regex23_262144x2048_planes.json
+$B --config regex23 --batch 1048576 --len 2047 --rows 2048 --steps 5 --warmup 2 --distinct 65536 --planes > $O/cfg3_regex23_1048576x2048_full_planes.json
+$B --config headers3 --batch 32768 --len 32767 --rows 32768 --steps 5 --warmup 2 --distinct 4096 --planes > $O/cfg4_headers3_32768x32768_planes.json
+$B --config headers3 --batch 65536 --len 2047 --rows 2048 --steps 20 --warmup 3 --planes      > $O/headers3_65536x2048_planes.json
+$B --config headers5 --batch 65536 --len 2047 --rows 2048 --steps 20 --warmup 3 --planes      > $O/headers5_65536x2048_planes.json
+$B --config headers4 --batch 65536 --len 2047 --rows 2048 --steps 20 --warmup 3 --planes      > $O/headers4_65536x2048_planes.json
+$B --config regex123 --steps 50 --planes                                                      > $O/regex123_65536x1024_planes.json
+$B --config headers3 --batch 8192 --len 32767 --rows 32768 --steps 5 --warmup 2 --distinct 2048 --planes > $O/headers3_8192x32768_long_planes.json
+$B --config regex23 --batch 8192 --len 32767 --rows 32768 --steps 5 --warmup 2 --distinct 2048 --planes  > $O/regex23_8192x32768_long_planes.json
 HRX_DEBUG_FLAGS=0x80000000 $B --allow-debug-flags --batch 8192 --len 32767 --rows 32768 --steps 10 --warmup 2 --distinct 2048 > $O/regex1_8192x32768_long_sequential.json
 HRX_DEBUG_FLAGS=0x80000000 $B --allow-debug-flags --config headers3 --batch 8192 --len 32767 --rows 32768 --steps 5 --warmup 2 --distinct 2048 > $O/headers3_8192x32768_long_sequential.json
 for f in $O/*.json; do python3 -c "
