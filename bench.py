@@ -68,8 +68,10 @@ def parse_args(argv=None):
     ap.add_argument("--distinct", type=int, default=0, help="generate this many DISTINCT strings and build the batch from rotated copies of them, block after block "
                     "(0 = every string of the batch distinct).  Planting text into 2^20 strings on the host takes minutes; the oracle then walks the distinct "
                     "strings once and EVERY string of every buffer set is compared with the rows of the string it is a copy of")
-    ap.add_argument("--planes", action="store_true", help="position-major outputs of two or more defs as RECORD PLANES: every def's records in a buffer of its own "
-                    "(hrx_witness_batch_device_planes, buffers from hrx_alloc_output_planes); the line then also times the interleaved layout over as many buffer sets (interleaved_layout)")
+    ap.add_argument("--planes", action="store_true", help="position-major outputs as RECORD PLANES: every def's records in a buffer of its own "
+                    "(hrx_witness_batch_device_planes, buffers from hrx_alloc_output_planes: a pool of candidates, their pairings, a dry launch); the line then also times the interleaved "
+                    "layout / the pair walk's buffers over as many buffer sets (interleaved_layout).  One def: one records buffer from the same allocator (--stripes 2: two row stripes)")
+    ap.add_argument("--stripes", type=int, default=1, choices=[1, 2], help="--planes with one def: the records in this many row stripes")
     ap.add_argument("--probes", action="store_true", help="also run the side probes earlier rounds' documents cite (all after the timed region): the same launches over ONE buffer set, "
                     "tools/mixceil, the input transposer alone and in front of the launch")
     ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the legs over BASELINE configs[2..4] (other_configs in the line)")
@@ -440,7 +442,7 @@ def run_rank(args, rank, world, device_index, barrier):
     else:
         b_begin, B = rank * args.batch, args.batch
     pm = args.layout == "position-major"
-    planes = bool(args.planes) and pm       # (one def: two row stripes)
+    planes = bool(args.planes) and pm       # (one def: one records buffer from the planes allocator, or --stripes 2)
     rec_pitch, msk_pitch, rec_stride = hra.recommended_pitches(M)
     if args.dense or pm:
         rec_pitch, msk_pitch, rec_stride = M, M, (max(n, 1) + 15) // 16 * 16
@@ -478,7 +480,7 @@ def run_rank(args, rank, world, device_index, barrier):
                     if keep_sm:
                         sm_sets.append(c_k.contiguous())          # the reference's input shape (one contiguous string per row): for roofline.from_string_major_input
                     c_k = hra.chars_to_position_major(c_k)       # [stride/16][B][16]: done once, outside the timed region
-                    out = cfg.alloc_output_planes(B, dev, stripes=2 if D == 1 else None) if planes else cfg.alloc_outputs_position_major(B, dev)
+                    out = cfg.alloc_output_planes(B, dev, stripes=args.stripes if D == 1 else None) if planes else cfg.alloc_outputs_position_major(B, dev)
                 else:
                     c_k = c_k.contiguous()
                     out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
@@ -894,7 +896,8 @@ def run_rank(args, rank, world, device_index, barrier):
                      "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR with RECORD PLANES (blocks of 65536 strings): chars [%d/16][B][16], %s, "
                                  "masked [M/8][B][8] (include/hrx.h hrx_witness_batch_device_planes); the %d + 1 output buffers from "
                                  "hrx_alloc_output_planes (each in a neighbourhood of the device memory of its own)" % (stride, "every def's records [M/4][B][4] in a buffer of its own" if D > 1 else
-                                 "the one def's records in two ROW STRIPES [M/8][B][4] (quad q of a string in stripe q % 2 at slot q / 2)", D if D > 1 else 2)) if planes else
+                                 ("the one def's records in two ROW STRIPES [M/8][B][4] (quad q of a string in stripe q % 2 at slot q / 2)" if args.stripes == 2 else "the one def's records [M/4][B][4]"),
+                                 D if D > 1 else args.stripes)) if planes else
                                 ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR (blocks of 65536 strings): chars [%d/16][B][16], records "
                                  "[M/4][D][B][4], masked [M/8][B][8] (include/hrx.h); outputs from hrx_alloc_outputs_position_major (placement-aware "
                                  "from 128 MiB of records on, two plain allocations below)" % stride) if pm else

@@ -779,6 +779,7 @@ class RegexVerifyConfig:
         st = torch.empty((B,), dtype=torch.int64, device=dev)
         if npl.value * 4 * n < PLACED_FROM or dev.index not in (None, self.device) or torch.cuda.is_current_stream_capturing():
             return [torch.empty((npl.value,), dtype=torch.int32, device=dev) for _ in range(n)], torch.empty((nm.value,), dtype=torch.int16, device=dev), st
+        # (one def, one buffer: the library's pool of record AND masked-row candidates + a dry launch from 1 GiB of records on, its measured arena pair below)
         arr, pmk = (C.c_void_p * n)(), C.c_void_p()
         _check(lib.hrx_alloc_output_planes(self._ctx, B, self.max_chars_size, n, arr, C.byref(pmk)))
         d = torch.device("cuda", self.device)

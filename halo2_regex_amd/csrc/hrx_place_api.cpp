@@ -636,11 +636,14 @@ int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, u
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
     const size_t D = ctx->s.defs.size();
     if (!(n_planes == D || (D == 1 && n_planes == 2))) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes: one buffer per RegexDefs of the config (one def: one buffer, or two row stripes)");
-    if (n_planes == 1) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
     const size_t R = n_planes / D;
     size_t rec_u32 = 0, masked_u16 = 0;
     hrx_position_major_stripe_sizes(B, M, R, &rec_u32, &masked_u16);
     const size_t rec_bytes = rec_u32 * 4, masked_bytes = masked_u16 * 2;
+    // one def, one buffer: the pair walk of hrx_alloc_output_pair.  (Tried: cfg 5's 2-GiB records + 1-GiB masked rows through the pool below — record AND masked-row candidates, pairings,
+    // dry launch: every kept set scored "nothing collides" and dry-launched at 0.61-0.63 ms, yet two of eight sets then ran the real batch at 0.81-0.83 ms where the pair walk's sets run at
+    // 0.63-0.67 (profiles/r06_probes/cfg5_pool_dry.txt): with one def the INPUT is a seventh of the traffic, and the dry launch reads a stand-in buffer, not the caller's.)
+    if (n_planes == 1) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
     for (size_t d = 0; d < n_planes; ++d) record_planes[d] = nullptr;
     *masked = nullptr;
     std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
