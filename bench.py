@@ -72,6 +72,8 @@ def parse_args(argv=None):
                     "(hrx_witness_batch_device_planes, buffers from hrx_alloc_output_planes: a pool of candidates, their pairings, a dry launch); the line then also times the interleaved "
                     "layout / the pair walk's buffers over as many buffer sets (interleaved_layout).  One def: one records buffer from the same allocator (--stripes 2: two row stripes)")
     ap.add_argument("--stripes", type=int, default=1, choices=[1, 2], help="--planes with one def: the records in this many row stripes")
+    ap.add_argument("--planes-stand-in", action="store_true", help="--planes: the allocator chooses with launches over a constant stand-in input (hrx_alloc_output_planes) instead of this "
+                    "run's batch (hrx_alloc_output_planes_for_batch)")
     ap.add_argument("--probes", action="store_true", help="also run the side probes earlier rounds' documents cite (all after the timed region): the same launches over ONE buffer set, "
                     "tools/mixceil, the input transposer alone and in front of the launch")
     ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the legs over BASELINE configs[2..4] (other_configs in the line)")
@@ -480,7 +482,9 @@ def run_rank(args, rank, world, device_index, barrier):
                     if keep_sm:
                         sm_sets.append(c_k.contiguous())          # the reference's input shape (one contiguous string per row): for roofline.from_string_major_input
                     c_k = hra.chars_to_position_major(c_k)       # [stride/16][B][16]: done once, outside the timed region
-                    out = cfg.alloc_output_planes(B, dev, stripes=args.stripes if D == 1 else None) if planes else cfg.alloc_outputs_position_major(B, dev)
+                    # (--planes: the allocator's choosing launches run this very set's batch — hrx_alloc_output_planes_for_batch)
+                    out = (cfg.alloc_output_planes(B, dev, stripes=args.stripes if D == 1 else None, chars=None if args.planes_stand_in else c_k, lens=l_k.contiguous(), chars_pm_stride=stride)
+                           if planes else cfg.alloc_outputs_position_major(B, dev))
                 else:
                     c_k = c_k.contiguous()
                     out = cfg.alloc_outputs(B, dev, pitched=not args.dense)
@@ -1125,11 +1129,11 @@ def spawn_children(args, argv, timeout_s=3600):
 # set compared with the oracle, hrx_traffic_pass_device over the same buffers), and is condensed into the line's `other_configs`.
 OTHER_CONFIGS = [
     ("configs[2]: regex2_test + regex3_test with substr extraction, 2^20 x 2048-byte strings, 1 MI355X",
-     ["--config", "regex23", "--batch", "1048576", "--len", "2047", "--rows", "2048", "--steps", "5", "--warmup", "2", "--distinct", "65536", "--planes"]),
+     ["--config", "regex23", "--batch", "1048576", "--len", "2047", "--rows", "2048", "--steps", "10", "--warmup", "3", "--distinct", "65536", "--planes"]),
     ("configs[3]: 32-KiB header regexes (D = 3 stand-ins, BASELINE.md), 256K strings over 8 GPUs = 32768 strings per GPU",
-     ["--config", "headers3", "--batch", "32768", "--len", "32767", "--rows", "32768", "--steps", "5", "--warmup", "2", "--distinct", "4096", "--planes"]),
+     ["--config", "headers3", "--batch", "32768", "--len", "32767", "--rows", "32768", "--steps", "10", "--warmup", "3", "--distinct", "4096", "--planes"]),
     ("configs[4]: synthetic 256-state dense DFA, 4096-byte inputs, >= 1M strings over 8 GPUs = 131072 strings per GPU",
-     ["--config", "dfa256", "--batch", "131072", "--len", "4095", "--rows", "4096", "--steps", "10", "--warmup", "3", "--distinct", "65536"]),
+     ["--config", "dfa256", "--batch", "131072", "--len", "4095", "--rows", "4096", "--steps", "40", "--warmup", "8", "--distinct", "65536", "--planes"]),
 ]
 
 

@@ -134,6 +134,8 @@ extern "C" {
     pub fn hrx_position_major_plane_sizes(b: usize, m: usize, plane_u32: *mut usize, masked_u16: *mut usize);
     pub fn hrx_position_major_stripe_sizes(b: usize, m: usize, n_stripes: usize, stripe_u32: *mut usize, masked_u16: *mut usize);
     pub fn hrx_alloc_output_planes(ctx: *mut hrx_ctx, b: usize, m: usize, n_planes: usize, record_planes: *mut *mut u32, masked: *mut *mut u16) -> c_int;
+    pub fn hrx_alloc_output_planes_for_batch(ctx: *mut hrx_ctx, layout: c_int, chars: *const u8, stride: usize, lens: *const u32, b: usize, m: usize, n_planes: usize,
+                                             record_planes: *mut *mut u32, masked: *mut *mut u16) -> c_int;
     pub fn hrx_rows_of_string_planes(record_planes: *const *const u32, n_planes: usize, masked_pm: *const u16, b_total: usize, m: usize, d: usize, b: usize,
                                      records: *mut u32, masked: *mut u16) -> c_int;
     pub fn hrx_traffic_pass_device_planes(ctx: *mut hrx_ctx, chars: *const u8, stride: usize, b: usize, m: usize, record_planes: *const *mut u32, n_planes: usize,

@@ -100,6 +100,7 @@ def _load():
         "hrx_position_major_plane_sizes": (None, [sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_position_major_stripe_sizes": (None, [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "hrx_alloc_output_planes": (i, [vp, sz, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
+        "hrx_alloc_output_planes_for_batch": (i, [vp, i, vp, sz, vp, sz, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
         "hrx_rows_of_string_planes": (i, [C.POINTER(vp), sz, vp, sz, sz, sz, sz, vp, vp]),
         "hrx_probe_write_pair": (i, [vp, vp, vp, sz, C.POINTER(C.c_double)]),
         "hrx_traffic_pass_device_planes": (i, [vp, vp, sz, sz, sz, C.POINTER(vp), sz, vp, vp]),
@@ -765,10 +766,11 @@ class RegexVerifyConfig:
         msk = torch.as_tensor(_LibraryOwned(pmk.value, nm.value * 2), device=d).view(torch.int16)
         return rec, msk, st
 
-    def alloc_output_planes(self, B, device=None, stripes=None):
+    def alloc_output_planes(self, B, device=None, stripes=None, chars=None, lens=None, chars_pm_stride=None):
         """hrx_alloc_output_planes: ([record buffers] int32, masked int16, status int64) — every def's records in a buffer of its own (one def: the ordinary records buffer, or with
         stripes=2 its two row stripes), each placed in a neighbourhood of the device memory of its own (include/hrx.h: the launch's write streams spread over the classes of the
-        physical address space)."""
+        physical address space).  chars / lens (as witness_batch_planes takes them): hrx_alloc_output_planes_for_batch — the launches that choose among the candidate sets run this
+        batch, not a stand-in."""
         dev = torch.device("cuda", self.device) if device is None else device
         D = self.num_defs
         R = 1 if stripes is None else int(stripes)
@@ -781,7 +783,20 @@ class RegexVerifyConfig:
             return [torch.empty((npl.value,), dtype=torch.int32, device=dev) for _ in range(n)], torch.empty((nm.value,), dtype=torch.int16, device=dev), st
         # (one def, one buffer: the library's pool of record AND masked-row candidates + a dry launch from 1 GiB of records on, its measured arena pair below)
         arr, pmk = (C.c_void_p * n)(), C.c_void_p()
-        _check(lib.hrx_alloc_output_planes(self._ctx, B, self.max_chars_size, n, arr, C.byref(pmk)))
+        if chars is not None:
+            assert lens is not None and chars.is_cuda and lens.is_cuda and chars.dtype == torch.uint8 and lens.dtype == torch.int32 and lens.numel() == B
+            layout = LAYOUT_POSITION_MAJOR
+            if chars_pm_stride is None:
+                assert chars.stride(1) == 1 and lens.is_contiguous() and chars.shape[0] == B
+                stride = chars.stride(0)
+            else:
+                assert chars.is_contiguous() and chars.numel() == B * chars_pm_stride
+                stride = int(chars_pm_stride)
+                layout |= LAYOUT_INPUT_POSITION_MAJOR
+            torch.cuda.current_stream(chars.device).synchronize()       # (the library's launches run on the context's stream)
+            _check(lib.hrx_alloc_output_planes_for_batch(self._need_device(chars, lens), layout, chars.data_ptr(), stride, lens.data_ptr(), B, self.max_chars_size, n, arr, C.byref(pmk)))
+        else:
+            _check(lib.hrx_alloc_output_planes(self._ctx, B, self.max_chars_size, n, arr, C.byref(pmk)))
         d = torch.device("cuda", self.device)
         planes = [torch.as_tensor(_LibraryOwned(arr[k], npl.value * 4), device=d).view(torch.int32) for k in range(n)]
         msk = torch.as_tensor(_LibraryOwned(pmk.value, nm.value * 2), device=d).view(torch.int16)

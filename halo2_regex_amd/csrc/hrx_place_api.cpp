@@ -4,6 +4,7 @@
 #include "hrx_arena_alloc.hpp"
 #include "hrx_place_rule.hpp"
 
+#include <atomic>
 #include <functional>
 
 using namespace hrx;
@@ -104,6 +105,8 @@ struct hrx_place_pool {
     hrx_place_report report{};     // of the walk that found the pair
     double seen_rate[HRX_MAX_DEFS + 1] = {};   // per number of defs D (the probe writes its two streams in the launch's ratio 4 D : 2, so rates of different D do not compare):
                                                // the fastest pairing any arena walk on this device has probed (bytes per microsecond)
+    std::atomic<double> equal_level{0.0};      // choose_buffers' probe (two EQUAL streams): the mean of the faster level of pairings — across classes — in the last pool of this device that showed
+                                               // two levels (bytes per microsecond; 0: none yet)
     int users = 0;                 // live contexts of the device (under g_arena_mu)
 };
 static std::map<int, hrx_place_pool *> g_pools;   // under g_arena_mu; entries are never removed (a few dozen bytes per device)
@@ -458,7 +461,8 @@ static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nr
             return us > 0 ? (double)wrote / us : 0.0;
         };
         double lo = 0, hi = 0, cut = 0;
-        bool first = true;
+        bool first = true, all_collide = false;
+        int far_rounds = 0;
         struct Scored { size_t load, low; double sum, mn; std::vector<size_t> idx; size_t q; };
         std::vector<Scored> scored;
         size_t best_low = ~(size_t)0, best_load = ~(size_t)0;
@@ -489,9 +493,21 @@ static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nr
                 if (!nl || !nh) break;
                 cut = 0.5 * (sl / nl + sh / nh);
             }
+            double upper = 0.0;      // the mean of the faster level
+            { double sh = 0; size_t nh = 0; for (double v : all) if (v >= cut) { sh += v; ++nh; } upper = nh ? sh / nh : hi; }
             cut = std::max(cut, 0.88 * hi);     // (one stalled probe — 4.3 TB/s among 5.7 .. 7.3 on one lease — must not drag the cut below the colliding level: pairings across
                                                 //  classes lie within ~10 % of the fastest one)
-            if (hi < 1.08 * lo) cut = 0.0;      // every pairing measures alike: nothing collides (or everything does) — then only the sums rank
+            // Pairings that all lie at ONE level: nothing collides — or everything does (a pool of 15 GiB inside one class: classes are 8 to 64 GiB wide; seen on cfg 5's buffer sets on two
+            // leases, every pairing 5.8-6.4 TB/s where the sets before it had 7.1-7.2 across classes, every launch over the pool 0.79-0.83 ms instead of 0.64-0.66).  Which of the two, only a
+            // level measured elsewhere can say: the faster level of this device's last pool that showed both, failing that 6.9 TB/s (seen on every lease so far: 5.2-6.4 within a class,
+            // 6.5-7.4 across).  A pool whose FASTER level is below 0.93 of that lies in one class: everything collides, and the next candidates come from behind a spacer.
+            {
+                const double known = ctx->pool ? ctx->pool->equal_level.load() : 0.0;
+                all_collide = upper < 0.93 * (known > 0 ? known : 6.9e6);
+                if (all_collide) cut = 2.0 * hi;
+                else if (hi < 1.08 * lo) cut = 0.0;       // (nothing collides: only the sums rank)
+                else if (ctx->pool) ctx->pool->equal_level.store(upper);
+            }
             if (ctx->place_trace) {
                 for (size_t i = P0; i < P; ++i) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pp[i][j] * 1e-3)); place_trace(ctx, "hrx planes: record candidate %zu %p vs records (GB/s):%s\n", i, pc[i], l.c_str()); }
                 for (size_t q = 0; q < Q; ++q) { std::string l; for (size_t j = 0; j < P; ++j) l += " " + std::to_string((int)(pm[q][j] * 1e-3)); place_trace(ctx, "hrx planes: masked candidate %zu %p vs records (GB/s):%s\n", q, mc[q], l.c_str()); }
@@ -540,7 +556,14 @@ static bool choose_buffers(hrx_ctx *ctx, const size_t rec_bytes, const size_t nr
             // otherwise walk further down the memory, once or twice.  (Tried for the 2-GiB stripe arenas of one def's row stripes: four more rounds, each behind a 16-GiB spacer — 24 candidates
             // over ~120 GiB, 315 pairings, 3-4 s — still found no three mutually non-colliding arenas on a lease whose first 17 candidates showed two classes; not kept:
             // profiles/r06_probes/stripes_ab_cfg2.txt.)
-            if (best_load <= load_goal || round >= 2) break;
+            if (best_load <= load_goal || round >= (far_rounds ? 4 : 2)) break;
+            if (all_collide) {
+                // the whole pool in one class: the next candidates from further down the memory, behind a block that is allocated and never touched (at most a third of what the budget has left)
+                size_t sp = std::min<size_t>((size_t)12 << 30, budget > spent ? (budget - spent) / 3 : 0) & ~(((size_t)1 << 30) - 1);
+                void *p = nullptr;
+                if (sp && hipMalloc(&p, sp) == hipSuccess) { spacers.push_back(p); spent += sp; ++far_rounds; place_trace(ctx, "hrx planes: every pairing collides: %zu GiB spacer before the next candidates\n", sp >> 30); }
+                else (void)hipGetLastError();
+            }
             const size_t before = pc.size();
             if (!take(pc, rec_bytes, before, before + kPlanesGrow) || pc.size() == before) break;
             (void)take(mc, msk_bytes, mc.size(), mc.size() + 1);      // (a masked-row candidate of the new neighbourhood as well)
@@ -631,7 +654,11 @@ static bool stripe_arenas_take(hrx_ctx *ctx, const size_t nrec, const size_t rec
     return false;
 }
 
-int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, uint32_t **record_planes, uint16_t **masked) {
+}  // extern "C"
+
+// hrx_alloc_output_planes / hrx_alloc_output_planes_for_batch: `chars` != nullptr = the caller's batch (device pointers, `layout` as hrx_witness_batch_device_planes takes it) is what the dry
+// launch runs
+static int alloc_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, uint32_t **record_planes, uint16_t **masked, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens) {
     if (!ctx || !record_planes || !masked || B == 0 || M == 0) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes: bad argument");
     if (ctx->device == HRX_DEVICE_NONE) return fail(HRX_ERR_HIP, "host-only context (HRX_DEVICE_NONE): no device to allocate on");
     const size_t D = ctx->s.defs.size();
@@ -640,10 +667,10 @@ int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, u
     size_t rec_u32 = 0, masked_u16 = 0;
     hrx_position_major_stripe_sizes(B, M, R, &rec_u32, &masked_u16);
     const size_t rec_bytes = rec_u32 * 4, masked_bytes = masked_u16 * 2;
-    // one def, one buffer: the pair walk of hrx_alloc_output_pair.  (Tried: cfg 5's 2-GiB records + 1-GiB masked rows through the pool below — record AND masked-row candidates, pairings,
-    // dry launch: every kept set scored "nothing collides" and dry-launched at 0.61-0.63 ms, yet two of eight sets then ran the real batch at 0.81-0.83 ms where the pair walk's sets run at
-    // 0.63-0.67 (profiles/r06_probes/cfg5_pool_dry.txt): with one def the INPUT is a seventh of the traffic, and the dry launch reads a stand-in buffer, not the caller's.)
-    if (n_planes == 1) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
+    // one def, one buffer, no batch to measure with: the pair walk of hrx_alloc_output_pair.  (Tried: cfg 5's 2-GiB records + 1-GiB masked rows through the pool below — record AND masked-row
+    // candidates, pairings, dry launch on a stand-in input: every kept set scored "nothing collides" and dry-launched at 0.61-0.63 ms, yet two of eight sets then ran the real batch at
+    // 0.81-0.83 ms where the pair walk's sets run at 0.63-0.67 (profiles/r06_probes/cfg5_pool_dry.txt): with one def the INPUT is a seventh of the traffic, and where IT lies counts.)
+    if (n_planes == 1 && !chars) return hrx_alloc_outputs_position_major(ctx, B, M, record_planes, masked);
     for (size_t d = 0; d < n_planes; ++d) record_planes[d] = nullptr;
     *masked = nullptr;
     std::lock_guard<std::mutex> lk(ctx->mu);   // the probe launches on the context's stream and uses its scratch
@@ -663,26 +690,34 @@ int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, u
         // the dry launch: this context's own launch of B strings x M rows over a candidate set, on a constant input (every string M - 1 times the byte 'a': what the walk finds there does not
         // matter to where its bytes go), timed with events on the context's stream — one warm-up, the faster of two
         const bool direct_walk = walk && rec_bytes >= kPlaceDirectFrom / 4;
-        const size_t dstride = (M + 15) / 16 * 16;
+        size_t dstride = (M + 15) / 16 * 16;
+        int dlayout = HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR;
         DevBuf d_chars, d_lens, d_status;
+        const uint8_t *dry_chars = chars;
+        const uint32_t *dry_lens = lens;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         bool dry_ok = direct_walk && D <= kMaxDefsPerLaunch;
-        if (dry_ok) {
+        if (dry_ok && chars) {       // the caller's batch: what the buffers are for
+            dstride = stride;
+            dlayout = layout;
+            dry_ok = d_status.reserve(B * 8) == hipSuccess;
+        } else if (dry_ok) {
             size_t fb = 0, tb = 0;
             dry_ok = hipMemGetInfo(&fb, &tb) == hipSuccess && (double)(B * dstride) < 0.05 * (double)fb;      // (the input of the dry launch: at most a twentieth of what is free)
             dry_ok = dry_ok && d_chars.reserve(B * dstride) == hipSuccess && d_lens.reserve(B * 4) == hipSuccess && d_status.reserve(B * 8) == hipSuccess;
             dry_ok = dry_ok && hipMemsetAsync(d_chars.p, 'a', B * dstride, ctx->stream) == hipSuccess && hipMemsetD32Async((hipDeviceptr_t)d_lens.p, (int)(M - 1), B, ctx->stream) == hipSuccess;
-            dry_ok = dry_ok && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-            if (!dry_ok) (void)hipGetLastError();
+            dry_chars = (const uint8_t *)d_chars.p;
+            dry_lens = (const uint32_t *)d_lens.p;
         }
+        if (dry_ok) dry_ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        if (direct_walk && D <= kMaxDefsPerLaunch && !dry_ok) (void)hipGetLastError();
         auto dry = [&](const std::vector<void *> &rs, void *mk) -> double {
             std::vector<uint32_t *> pl;
             for (void *p : rs) pl.push_back((uint32_t *)p);
             float best = -1.0f;
             for (int it = 0; it < 3; ++it) {
                 if (hipEventRecord(e0, ctx->stream) != hipSuccess) return -1.0;
-                if (launch_batch(ctx, (const uint8_t *)d_chars.p, dstride, (const uint32_t *)d_lens.p, B, M, pl[0], (uint16_t *)mk, (uint64_t *)d_status.p, ctx->stream, 0, 0,
-                                 HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR, pl.data(), pl.size()) != HRX_OK) return -1.0;
+                if (launch_batch(ctx, dry_chars, dstride, dry_lens, B, M, pl[0], (uint16_t *)mk, (uint64_t *)d_status.p, ctx->stream, 0, 0, dlayout, pl.size() > 1 ? pl.data() : nullptr, pl.size()) != HRX_OK) return -1.0;
                 if (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.0;
                 float t = 0.0f;
                 if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return -1.0;
@@ -702,6 +737,21 @@ int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, u
     rep.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     ctx->last_place = rep;
     return HRX_OK;
+}
+
+extern "C" {
+
+int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, uint32_t **record_planes, uint16_t **masked) {
+    return alloc_planes(ctx, B, M, n_planes, record_planes, masked, 0, nullptr, 0, nullptr);
+}
+
+int hrx_alloc_output_planes_for_batch(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M, size_t n_planes, uint32_t **record_planes,
+                                      uint16_t **masked) {
+    if (!chars || !lens) return fail(HRX_ERR_ARG, "hrx_alloc_output_planes_for_batch: chars and lens are the batch the buffers are for (device pointers)");
+    if (!(layout & HRX_LAYOUT_POSITION_MAJOR) || (layout & ~(HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR)))
+        return fail(HRX_ERR_ARG, "hrx_alloc_output_planes_for_batch: layout = HRX_LAYOUT_POSITION_MAJOR, optionally | HRX_LAYOUT_INPUT_POSITION_MAJOR");
+    if ((stride & 15) || stride < 16 || ((uintptr_t)chars & 15) || ((uintptr_t)lens & 3)) return fail(HRX_ERR_ARG, "chars must be 16-byte aligned with stride % 16 == 0 and stride >= 16");
+    return alloc_planes(ctx, B, M, n_planes, record_planes, masked, layout, chars, stride, lens);
 }
 
 int hrx_alloc_outputs_position_major(hrx_ctx *ctx, size_t B, size_t M, uint32_t **records, uint16_t **masked) {

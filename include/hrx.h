@@ -256,6 +256,14 @@ void hrx_position_major_stripe_sizes(size_t B, size_t M, size_t n_stripes, size_
  * HRX_PLACE_OFF: plain allocations.  record_planes: n_planes pointers out; each buffer is released with hrx_device_free.  n_planes = 1: hrx_alloc_outputs_position_major.
  * Takes the context's lock; not inside a stream capture. */
 int hrx_alloc_output_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, uint32_t **record_planes, uint16_t **masked);
+/* The same for a batch that already lies on the device: the launches that choose among the best sets run THE CALLER'S batch (chars, stride, lens, layout as
+ * hrx_witness_batch_device_planes takes them: HRX_LAYOUT_POSITION_MAJOR, optionally | HRX_LAYOUT_INPUT_POSITION_MAJOR) instead of a constant stand-in, so where the input lies
+ * and what the walk does with it are part of what is measured — the choice for a prover that keeps its input buffer and launches batch after batch into the outputs.  With it
+ * one def's single buffer (n_planes = 1) also goes through the pool (on a stand-in input that lost against the pair walk: with one def the input is a seventh of the traffic,
+ * profiles/r06_probes/cfg5_pool_dry.txt).  chars / lens must be complete on the device before the call (the launches run on the context's stream); the outputs they write are
+ * the candidates', the batch itself is only read. */
+int hrx_alloc_output_planes_for_batch(hrx_ctx *ctx, int layout, const uint8_t *chars, size_t stride, const uint32_t *lens, size_t B, size_t M, size_t n_planes,
+                                      uint32_t **record_planes, uint16_t **masked);
 /* The allocator's measurement, for a caller that manages device memory itself (a prover with its own pool): two equal, time-aligned write streams over the first `bytes`
  * of device buffers a and b (both are OVERWRITTEN), *gbs = bytes written per time.  Pairings in one class of the physical address space measure 5.2-6.2 TB/s, in different
  * classes 6.5-7.3 (a level per box: compare pairings with each other, not with a constant).  Synchronous; takes the context's lock. */

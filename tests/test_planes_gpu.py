@@ -196,6 +196,45 @@ def test_placed_record_planes_at_a_multi_gigabyte_size(hra, oracle):
     assert cfg.last_placement_report()["searched"] == 0 and len(out2[0]) == 3
 
 
+@pytest.mark.parametrize("names", ["HDR", "ONE"])
+def test_buffers_chosen_with_the_callers_batch(hra, oracle, names):
+    """hrx_alloc_output_planes_for_batch: the choosing launches run the caller's batch (which they only read); three defs and — through the same pool — one def's single buffer; the
+    launch into the kept buffers writes the oracle's rows.  Wrong arguments are refused before anything is allocated."""
+    import ctypes as C
+    import torch
+    from halo2_regex_amd import synth
+    from test_parity_gpu import CFG_1
+    dev = torch.device("cuda", 0)
+    names = HDR if names == "HDR" else CFG_1
+    D = len(names)
+    M, B = (4096, 65536) if D == 3 else (8192, 65536)
+    base_c, base_l = synth.headers_planted(1024, M - 1, seed=5, stride=M)
+    chars, lens = np.tile(base_c, (B // 1024, 1)), np.tile(base_l, B // 1024)
+    cfg = _cfg(hra, names, M)
+    d_chars = hra.chars_to_position_major(torch.from_numpy(chars).to(dev))
+    d_lens = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    before = d_chars.clone()
+    out = cfg.alloc_output_planes(B, dev, chars=d_chars, lens=d_lens, chars_pm_stride=M)
+    rep = cfg.last_placement_report()
+    assert rep["searched"] == 1 and rep["steps"] >= 3 and len({p.data_ptr() for p in out[0]}) == D
+    assert torch.equal(before, d_chars)
+    planes, msk, st = cfg.witness_batch_planes(d_chars, d_lens, out=out, chars_pm_stride=M)
+    torch.cuda.synchronize()
+    o = OracleDefs.from_files(oracle, names)
+    orec, omsk, ost = o.witness_batch(base_c, base_l, M, threads=os.cpu_count() or 1)
+    rec, m = hra.planes_to_string_major(planes, msk, B, M, D=D)
+    t_rec, t_msk = torch.from_numpy(orec.view(np.int32)).to(dev), torch.from_numpy(omsk.view(np.int16)).to(dev)
+    for k in range(0, B, 1024):
+        assert torch.equal(rec[k:k + 1024], t_rec) and torch.equal(m[k:k + 1024], t_msk)
+    assert (st.cpu().numpy().view(np.uint64) == np.tile(ost, B // 1024)).all()
+    arr, pmk = (C.c_void_p * D)(), C.c_void_p()
+    lib = hra.lib
+    assert lib.hrx_alloc_output_planes_for_batch(cfg._ctx, 3, None, M, d_lens.data_ptr(), B, M, D, arr, C.byref(pmk)) == hra.HRX_ERR_ARG
+    assert lib.hrx_alloc_output_planes_for_batch(cfg._ctx, 2, d_chars.data_ptr(), M, d_lens.data_ptr(), B, M, D, arr, C.byref(pmk)) == hra.HRX_ERR_ARG
+    assert lib.hrx_alloc_output_planes_for_batch(cfg._ctx, 3, d_chars.data_ptr(), M + 8, d_lens.data_ptr(), B, M, D, arr, C.byref(pmk)) == hra.HRX_ERR_ARG
+    assert lib.hrx_alloc_output_planes_for_batch(cfg._ctx, 3, d_chars.data_ptr(), M, d_lens.data_ptr(), B, M, D + 2, arr, C.byref(pmk)) == hra.HRX_ERR_ARG
+
+
 @pytest.mark.parametrize("flags", [0, 0x200000, 0x400000, 0x40000, 0x1000, 0x40000000, 0x2000, 0x8000], ids=["planner", "wide", "half", "global-table", "dynamic-groups", "pair-step-asked", "byte", "no-byte"])
 def test_row_stripes_of_one_def_on_every_table_format(hra, oracle, flags, monkeypatch):
     """One def in TWO ROW STRIPES (quad q of a string in buffer q % 2 at slot q / 2): every table format of the loader / walker / finisher kernel, odd and even numbers of quads, ragged
