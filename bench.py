@@ -451,6 +451,8 @@ def run_rank(args, rank, world, device_index, barrier):
     stride = rec_stride
     defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in names]
     cfg = hra.RegexVerifyConfig.configure(M, defs, device=device_index)
+    if under_profiler():
+        cfg.set_option(hra.OPT_PLACE_DRY_LAUNCH, 0)      # the profiler's per-kernel averages then cover this script's launches only, not the allocator's launches into candidate sets
 
     # this rank's shard of the job: independent strings, seeded per rank (strong scaling: per shard start).  --distinct nd: nd generated strings,
     # the batch = ceil(B / nd) blocks of them, block j rotated by j * sb strings (built on the device)

@@ -166,6 +166,7 @@ pub const HRX_OPT_PMD_COMBINER_WAVE: c_int = 1;
 pub const HRX_OPT_HOST_ROUTE: c_int = 2;      // HRX_HOST_ROUTE_AUTO (the fastest of device / host cores / both at once, by measurement) / _DEVICE / _HOST
 pub const HRX_OPT_HOST_THREADS: c_int = 3;
 pub const HRX_OPT_HOST_PIPELINE: c_int = 4;
+pub const HRX_OPT_PLACE_DRY_LAUNCH: c_int = 5;
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct hrx_host_route_report {
     pub route: c_int, pub device_strings: usize, pub host_strings: usize, pub device_ms: f64, pub host_ms: f64, pub call_ms: f64,

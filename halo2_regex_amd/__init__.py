@@ -441,7 +441,7 @@ LAYOUT_RECORD_PLANES = 4      # describe_launch only: the launch witness_batch_p
 
 PLACE_OFF, PLACE_WALK = 0, 1     # hrx_ctx_set_placement modes
 OPT_PMD_COMBINER_WAVE = 1        # hrx_ctx_set_option: 0 default, 1 on, 2 off
-OPT_HOST_ROUTE, OPT_HOST_THREADS, OPT_HOST_PIPELINE = 2, 3, 4
+OPT_HOST_ROUTE, OPT_HOST_THREADS, OPT_HOST_PIPELINE, OPT_PLACE_DRY_LAUNCH = 2, 3, 4, 5
 HOST_ROUTE_AUTO, HOST_ROUTE_DEVICE, HOST_ROUTE_HOST = 0, 1, 2
 PLACE_CAPPED_STEPS, PLACE_CAPPED_BYTES, PLACE_CAPPED_TIME, PLACE_CAPPED_ALLOC = 1, 2, 4, 8      # hrx_place_report.capped
 PLACED_FROM = 128 << 20    # alloc_outputs*: records of this many bytes or more come from the library's placement-aware allocator (kPlaceFromBytes)

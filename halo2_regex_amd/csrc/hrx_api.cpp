@@ -204,7 +204,7 @@ int hrx_ctx_clone(const hrx_ctx *ctx, int device, hrx_ctx **out) {
     if (rc != HRX_OK) return rc;
     c->host_threshold = ctx->host_threshold;      // the per-context switches travel with the clone
     c->tune = ctx->tune;
-    c->host_route = ctx->host_route; c->host_threads = ctx->host_threads; c->host_pipeline = ctx->host_pipeline; c->host_chunk_mib = ctx->host_chunk_mib; c->host_trace = ctx->host_trace;
+    c->place_dry = ctx->place_dry; c->host_route = ctx->host_route; c->host_threads = ctx->host_threads; c->host_pipeline = ctx->host_pipeline; c->host_chunk_mib = ctx->host_chunk_mib; c->host_trace = ctx->host_trace;
     c->place_enabled = ctx->place_enabled; c->place_max_bytes = ctx->place_max_bytes; c->place_max_ms = ctx->place_max_ms;
     *out = c;
     return HRX_OK;
@@ -828,6 +828,10 @@ int hrx_ctx_set_option(hrx_ctx *ctx, int option, long value) {
             if (value < 0 || value > 2) return fail(HRX_ERR_ARG, "HRX_OPT_HOST_PIPELINE: 0 (measured), 1 (pipelined) or 2 (one stream)");
             ctx->host_pipeline = (int)value;
             return HRX_OK;
+        case HRX_OPT_PLACE_DRY_LAUNCH:
+            if (value < 0 || value > 1) return fail(HRX_ERR_ARG, "HRX_OPT_PLACE_DRY_LAUNCH: 0 or 1");
+            ctx->place_dry = value != 0;
+            return HRX_OK;
         default: return fail(HRX_ERR_ARG, "hrx_ctx_set_option: unknown option");
     }
 }
@@ -839,6 +843,7 @@ long hrx_ctx_get_option(const hrx_ctx *ctx, int option) {
         case HRX_OPT_HOST_ROUTE: return ctx->host_route;
         case HRX_OPT_HOST_THREADS: return ctx->host_threads;
         case HRX_OPT_HOST_PIPELINE: return ctx->host_pipeline;
+        case HRX_OPT_PLACE_DRY_LAUNCH: return ctx->place_dry ? 1 : 0;
         default: return -1;
     }
 }

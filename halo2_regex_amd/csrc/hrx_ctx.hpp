@@ -133,7 +133,7 @@ struct hrx_ctx {
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
     // placement-aware output allocation (hrx_alloc_output_pair): tunables read once at creation, the last call's report
-    bool place_enabled = true, place_trace = false;
+    bool place_enabled = true, place_trace = false, place_dry = true;     // (place_dry: HRX_OPT_PLACE_DRY_LAUNCH)
     int place_max_steps = 48;
     bool place_max_steps_set = false;   // HRX_PLACE_MAX_STEPS given: it bounds arena walks too (their own cap is kPlaceArenaHardSteps)
     double place_seen_rate = 0.0;     // bytes per microsecond of the best candidate any DIRECT walk (records >= 1 GiB) of this context has probed; arena walks keep theirs per device (hrx_place_pool)

@@ -696,7 +696,7 @@ static int alloc_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, uint3
         const uint8_t *dry_chars = chars;
         const uint32_t *dry_lens = lens;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        bool dry_ok = direct_walk && D <= kMaxDefsPerLaunch;
+        bool dry_ok = direct_walk && D <= kMaxDefsPerLaunch && ctx->place_dry;
         if (dry_ok && chars) {       // the caller's batch: what the buffers are for
             dstride = stride;
             dlayout = layout;
@@ -710,7 +710,7 @@ static int alloc_planes(hrx_ctx *ctx, size_t B, size_t M, size_t n_planes, uint3
             dry_lens = (const uint32_t *)d_lens.p;
         }
         if (dry_ok) dry_ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-        if (direct_walk && D <= kMaxDefsPerLaunch && !dry_ok) (void)hipGetLastError();
+        if (direct_walk && D <= kMaxDefsPerLaunch && ctx->place_dry && !dry_ok) (void)hipGetLastError();
         auto dry = [&](const std::vector<void *> &rs, void *mk) -> double {
             std::vector<uint32_t *> pl;
             for (void *p : rs) pl.push_back((uint32_t *)p);

@@ -149,8 +149,10 @@ size_t hrx_ctx_host_threshold(const hrx_ctx *ctx);
  *   HRX_OPT_HOST_PIPELINE      the device part's transfers: 0 (default) the context times both ways over its first calls and keeps the faster (the pipeline's copies out run at half rate
  *                              on some hosts), 1 pipelined chunk by chunk over two streams, 2 in, walk, out on one stream; HRX_HOST_PIPELINE=1 / 0 in the environment of hrx_ctx_create
  *                              sets 1 / 2 as the context's default
+ *   HRX_OPT_PLACE_DRY_LAUNCH   hrx_alloc_output_planes / _for_batch: 1 (default) the best candidate sets by the pairings' score are each launched into and the fastest is kept, 0 the best
+ *                              by score is kept unlaunched (a profiler's kernel list then holds the caller's launches only)
  * Applies to later calls; hrx_ctx_clone copies the options.  hrx_ctx_get_option: the value, -1 for an unknown option. */
-enum { HRX_OPT_PMD_COMBINER_WAVE = 1, HRX_OPT_HOST_ROUTE = 2, HRX_OPT_HOST_THREADS = 3, HRX_OPT_HOST_PIPELINE = 4 };
+enum { HRX_OPT_PMD_COMBINER_WAVE = 1, HRX_OPT_HOST_ROUTE = 2, HRX_OPT_HOST_THREADS = 3, HRX_OPT_HOST_PIPELINE = 4, HRX_OPT_PLACE_DRY_LAUNCH = 5 };
 enum { HRX_HOST_ROUTE_AUTO = 0, HRX_HOST_ROUTE_DEVICE = 1, HRX_HOST_ROUTE_HOST = 2 };
 /* What the context's last hrx_witness_batch_host call did. */
 typedef struct hrx_host_route_report {

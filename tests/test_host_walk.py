@@ -314,6 +314,12 @@ def test_host_route_options_on_a_host_only_context(oracle):
     with pytest.raises(hra.HrxError):
         cfg.set_option(hra.OPT_HOST_ROUTE, 7)
     assert cfg.get_option(hra.OPT_HOST_THREADS) == 3
+    # the allocator's option: on by default, copied by a clone, 0 / 1 only
+    assert cfg.get_option(hra.OPT_PLACE_DRY_LAUNCH) == 1
+    cfg.set_option(hra.OPT_PLACE_DRY_LAUNCH, 0)
+    assert cfg.clone().get_option(hra.OPT_PLACE_DRY_LAUNCH) == 0
+    with pytest.raises(hra.HrxError):
+        cfg.set_option(hra.OPT_PLACE_DRY_LAUNCH, 2)
 
 
 def test_host_walk_threads_survive_a_fork(oracle):

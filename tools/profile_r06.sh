@@ -5,4 +5,4 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 bash tools/profile_cfg.sh r06_cfg3 --config regex23 --batch 1048576 --len 2047 --rows 2048 --steps 5 --warmup 2 --distinct 65536 --planes
 bash tools/profile_cfg.sh r06_cfg4 --config headers3 --batch 32768 --len 32767 --rows 32768 --steps 5 --warmup 2 --distinct 4096 --planes
 bash tools/profile_cfg.sh r06_cfg4i --config headers3 --batch 32768 --len 32767 --rows 32768 --steps 5 --warmup 2 --distinct 4096
-bash tools/profile_cfg.sh r06_cfg5 --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 10 --warmup 3 --distinct 65536
+bash tools/profile_cfg.sh r06_cfg5 --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 40 --warmup 8 --distinct 65536 --planes
