@@ -1,6 +1,7 @@
 #!/bin/bash
 # One bench line per BASELINE config shape (per-GPU sizes) -> gpurun_out/r06_config_sweep/*.json; copied to profiles/r06_config_sweep/.
-# Round 6: every position-major line of two or more defs twice — interleaved records and RECORD PLANES (--planes).
+# Round 6: every position-major line of two or more defs twice — interleaved records and RECORD PLANES (--planes: buffers from hrx_alloc_output_planes_for_batch); cfg 5 also
+# on its one records buffer chosen the same way.
 # Every line in the HBM-only regime (the timed steps rotate over as many buffer sets as fit 48 GiB, up to 8) and verified over every string.
 cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r06_config_sweep; rm -rf $O; mkdir -p $O
 B="python3 bench.py --no-cpu-baseline --no-pmc"
@@ -20,8 +21,9 @@ $B --config headers4 --batch 65536 --len 1023 --rows 1024 --steps 20 --warmup 3 
 $B --config headers4 --batch 65536 --len 2047 --rows 2048 --steps 20 --warmup 3                      > $O/headers4_65536x2048.json
 $B --config regex123 --steps 50                                                      > $O/regex123_65536x1024.json
 $B --config dfa256 --len 4095 --rows 4096 --steps 20 --warmup 3                      > $O/cfg5_dfa256_65536x4096.json
-$B --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 10 --warmup 3 --distinct 65536 > $O/cfg5_dfa256_131072x4096.json
-$B --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 10 --warmup 3 --distinct 65536 --substr-defs 2 --substr-pairs 100 > $O/cfg5_dfa256_two_substr_defs_131072x4096.json
+$B --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 40 --warmup 8 --distinct 65536 > $O/cfg5_dfa256_131072x4096.json
+$B --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 40 --warmup 8 --distinct 65536 --planes > $O/cfg5_dfa256_131072x4096_chosen_with_the_batch.json
+$B --config dfa256 --batch 131072 --len 4095 --rows 4096 --steps 40 --warmup 8 --distinct 65536 --substr-defs 2 --substr-pairs 100 > $O/cfg5_dfa256_two_substr_defs_131072x4096.json
 $B --config dfa256 --len 4095 --rows 4096 --steps 20 --warmup 3 --layout string-major > $O/cfg5_dfa256_65536x4096_string_major.json
 $B --batch 8192 --len 32767 --rows 32768 --steps 10 --warmup 2 --distinct 2048                       > $O/regex1_8192x32768_long.json
 $B --batch 16384 --len 32767 --rows 32768 --steps 10 --warmup 2 --distinct 2048                      > $O/regex1_16384x32768_long.json
