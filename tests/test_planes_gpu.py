@@ -233,6 +233,12 @@ def test_buffers_chosen_with_the_callers_batch(hra, oracle, names):
     assert lib.hrx_alloc_output_planes_for_batch(cfg._ctx, 2, d_chars.data_ptr(), M, d_lens.data_ptr(), B, M, D, arr, C.byref(pmk)) == hra.HRX_ERR_ARG
     assert lib.hrx_alloc_output_planes_for_batch(cfg._ctx, 3, d_chars.data_ptr(), M + 8, d_lens.data_ptr(), B, M, D, arr, C.byref(pmk)) == hra.HRX_ERR_ARG
     assert lib.hrx_alloc_output_planes_for_batch(cfg._ctx, 3, d_chars.data_ptr(), M, d_lens.data_ptr(), B, M, D + 2, arr, C.byref(pmk)) == hra.HRX_ERR_ARG
+    # a batch too small to be worth a walk: plain allocations, the batch is not launched (256 strings of it)
+    assert lib.hrx_alloc_output_planes_for_batch(cfg._ctx, 3, d_chars.data_ptr(), M, d_lens.data_ptr(), 256, M, D, arr, C.byref(pmk)) == 0
+    assert cfg.last_placement_report()["searched"] == 0 and all(arr[d] for d in range(D)) and pmk.value
+    for d in range(D):
+        lib.hrx_device_free(arr[d])
+    lib.hrx_device_free(pmk)
 
 
 @pytest.mark.parametrize("flags", [0, 0x200000, 0x400000, 0x40000, 0x1000, 0x40000000, 0x2000, 0x8000], ids=["planner", "wide", "half", "global-table", "dynamic-groups", "pair-step-asked", "byte", "no-byte"])
