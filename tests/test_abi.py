@@ -253,3 +253,16 @@ def test_planner_picks_the_documented_kernel_per_config(monkeypatch):
     a_txt, sub_txt = synth.random_dfa(300, seed=2)
     cfg = RegexVerifyConfig.configure(1024, [RegexDefs(AllstrRegexDef(a_txt), [SubstrRegexDef(sub_txt)])], device=None)
     assert cfg.describe_launch(65536, layout=1).startswith("hrx::witness_pm_kernel<1, true, false, false, false, false> ")
+
+
+def test_readme_quick_start_runs():
+    """The README's quick start is executed as written (from the repo root, host-only context)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "README.md")).read()
+    block = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    r = subprocess.run([sys.executable, "-c", block], cwd=root, capture_output=True, text=True, timeout=120, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr
+    assert "b'vitalik'" in r.stdout
