@@ -266,3 +266,11 @@ def test_readme_quick_start_runs():
     r = subprocess.run([sys.executable, "-c", block], cwd=root, capture_output=True, text=True, timeout=120, env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0, r.stderr
     assert "b'vitalik'" in r.stdout
+
+
+def test_header_is_plain_c99():
+    """include/hrx.h is the boundary a cgo / bindgen / ctypes consumer reads: it must compile as C (no C++ in it), warnings included."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = '#include "include/hrx.h"\nint main(void) { return hrx_last_error() == 0; }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", root, "-x", "c", "-"], input=src, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr
