@@ -40,9 +40,38 @@ struct hrx_place_arena {
     int device = 0;
     hrx::ArenaRanges ranges;   // which offsets are handed out (first fit, freed ranges merge: hrx_arena_alloc.hpp) — an alloc / free churn is served from one pair for ever
     bool retired = false;      // no context serves requests from it any more: released with its last sub-buffer
+    size_t pending_n = 0;      // of its live ranges, how many the caller has freed already (g_pending): not handed out again before the device has drained
 };
 static std::mutex g_arena_mu;
 static std::map<uintptr_t, hrx_place_arena *> g_arena_of;   // sub-buffer -> arena (hrx_device_free has no context argument)
+// DEFERRED REUSE.  hipFree waits for the device before the memory can be handed out again, and callers rely on that (a buffer may be freed while the launch that writes it is
+// still in flight; the Python wrapper's finalizers do).  A freed arena range gets the same guarantee without a wait inside the free: it is parked here and becomes reusable
+// only behind a device-wide wait that an ALLOCATION performs when its request does not fit otherwise (arena_reclaim_locked) — allocation is a synchronous call that is not legal
+// inside a stream capture anyway, while a free may come from a finalizer thread at any time: a device-wide wait there stalled that thread for every stream of the device, and
+// while another thread captured a graph in the global capture mode the runtime refused the wait (the free returned at once, the range was reusable with launches into it still
+// in flight) or, in the relaxed mode, invalidated that capture (round 5's advisor; tests: test_freed_arena_range_is_not_reused_before_the_device_has_drained, test_arena_free_does_not_disturb_a_capture_in_another_thread).
+static std::vector<std::pair<hrx_place_arena *, size_t>> g_pending;   // (arena, offset), under g_arena_mu
+
+// under g_arena_mu: drops a's parked ranges (the arena itself goes: hipFree waits for the device)
+static void arena_forget_pending(hrx_place_arena *a) {
+    for (auto it = g_pending.begin(); it != g_pending.end();) it = it->first == a ? g_pending.erase(it) : it + 1;
+    a->pending_n = 0;
+}
+// under g_arena_mu: one device-wide wait, then every parked range of that device is free again.  false: nothing was parked, or the wait was refused (a capture elsewhere)
+static bool arena_reclaim_locked(int device) {
+    bool any = false;
+    for (const auto &e : g_pending) any = any || e.first->device == device;
+    if (!any) return false;
+    DeviceGuard guard;
+    if (guard.set(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (auto it = g_pending.begin(); it != g_pending.end();) {
+        if (it->first->device != device) { ++it; continue; }
+        it->first->ranges.give(it->second);
+        --it->first->pending_n;
+        it = g_pending.erase(it);
+    }
+    return true;
+}
 
 // ranges / retired of an arena are only ever touched under g_arena_mu: hrx_device_free (any thread, no context argument — e.g. a finalizer
 // while another thread allocates) releases sub-buffers concurrently with the owning context's takes.
@@ -50,7 +79,8 @@ static inline size_t arena_need(size_t bytes) { return (bytes + kPlaceArenaAlign
 // a records and a masked-row sub-buffer out of the pair, or neither: the capacity check and both takes are ONE critical section
 static bool arena_take_pair(hrx_place_arena *ra, size_t r_bytes, hrx_place_arena *ma, size_t m_bytes, void **r, void **m) {
     std::lock_guard<std::mutex> lk(g_arena_mu);
-    if (!ra->ranges.fits(arena_need(r_bytes)) || !ma->ranges.fits(arena_need(m_bytes))) return false;
+    auto fits = [&]() { return ra->ranges.fits(arena_need(r_bytes)) && ma->ranges.fits(arena_need(m_bytes)); };
+    if (!fits() && !(arena_reclaim_locked(ra->device) && fits())) return false;
     const size_t ro = ra->ranges.take(arena_need(r_bytes)), mo = ma->ranges.take(arena_need(m_bytes));
     *r = (unsigned char *)ra->base + ro;
     *m = (unsigned char *)ma->base + mo;
@@ -63,33 +93,19 @@ void arena_retire(hrx_place_arena *a) {
     if (!a) return;
     std::lock_guard<std::mutex> lk(g_arena_mu);
     a->retired = true;
-    if (a->ranges.live() == 0) { (void)hipFree(a->base); delete a; }
+    if (a->ranges.live() == a->pending_n) { arena_forget_pending(a); (void)hipFree(a->base); delete a; }
 }
 extern "C" {
-// true if ptr was a sub-buffer of an arena (and has been returned to it).  hipFree waits for the device before it releases memory, and callers rely on that
-// (a buffer may be freed while the launch that writes it is still in flight; the Python wrapper's finalizers do).  A range handed back to an arena is reusable at
-// once — by another context, thread and stream — so the release waits for the arena's device first, exactly like the plain allocations' hipFree below 128 MiB:
-// the same caller code is safe whatever the buffer size (tests: test_arena_free_waits_for_the_device).
+// true if ptr was a sub-buffer of an arena: its range is parked (DEFERRED REUSE above), nothing waits here
 static bool arena_release(void *ptr) {
-    int device = -1;
-    {
-        std::lock_guard<std::mutex> lk(g_arena_mu);
-        auto it = g_arena_of.find((uintptr_t)ptr);
-        if (it == g_arena_of.end()) return false;
-        device = it->second->device;
-    }
-    {   // (outside the arena mutex: other threads keep allocating while this one waits; ptr is the caller's until the give below)
-        DeviceGuard guard;
-        if (guard.set(device) == hipSuccess) (void)hipDeviceSynchronize();
-        (void)hipGetLastError();
-    }
     std::lock_guard<std::mutex> lk(g_arena_mu);
     auto it = g_arena_of.find((uintptr_t)ptr);
-    if (it == g_arena_of.end()) return true;    // (released by a concurrent call with the same pointer: a double free; nothing left to do)
+    if (it == g_arena_of.end()) return false;
     hrx_place_arena *a = it->second;
     g_arena_of.erase(it);
-    a->ranges.give((size_t)((unsigned char *)ptr - (unsigned char *)a->base));
-    if (a->ranges.live() == 0 && a->retired) { (void)hipFree(a->base); delete a; }
+    g_pending.emplace_back(a, (size_t)((unsigned char *)ptr - (unsigned char *)a->base));
+    ++a->pending_n;
+    if (a->retired && a->ranges.live() == a->pending_n) { arena_forget_pending(a); (void)hipFree(a->base); delete a; }     // (its last sub-buffer: hipFree waits for the device itself)
     return true;
 }
 
@@ -619,8 +635,12 @@ static bool stripe_arenas_take(hrx_ctx *ctx, const size_t nrec, const size_t rec
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (pool->stripe_n >= need) {
             std::lock_guard<std::mutex> lk(g_arena_mu);
-            bool fits = pool->stripe[need - 1]->ranges.fits(arena_need(msk_bytes));      // (the masked rows: the last arena of the set that was measured for `need` buffers)
-            for (size_t i = 0; i < nrec && fits; ++i) fits = pool->stripe[i]->ranges.fits(arena_need(rec_bytes));
+            auto all_fit = [&]() {
+                bool f = pool->stripe[need - 1]->ranges.fits(arena_need(msk_bytes));      // (the masked rows: the last arena of the set that was measured for `need` buffers)
+                for (size_t i = 0; i < nrec && f; ++i) f = pool->stripe[i]->ranges.fits(arena_need(rec_bytes));
+                return f;
+            };
+            const bool fits = all_fit() || (arena_reclaim_locked(ctx->device) && all_fit());      // (ranges the caller has freed come back behind a device-wide wait)
             if (fits) {
                 rec_out.clear();
                 for (size_t i = 0; i < nrec; ++i) {

@@ -366,10 +366,10 @@ int hrx_traffic_pass_device_planes(hrx_ctx *ctx, const uint8_t *chars, size_t st
  * HRX_LAYOUT_INPUT_POSITION_MAJOR.  Pure streaming (2 * stride bytes of traffic per string; measured beside the bench line: bench.py
  * roofline.from_string_major_input).  Asynchronous on `stream`; no context state is touched. */
 int hrx_chars_to_position_major_device(hrx_ctx *ctx, const uint8_t *chars, size_t stride, size_t B, uint8_t *chars_pm, void *stream);
-/* Releases a buffer of hrx_alloc_output_pair / hrx_alloc_outputs_position_major (NULL: nothing).  Like hipFree it WAITS for the buffer's device to
- * finish everything in flight before the memory can be handed out again — a sub-buffer of the shared arena pair included (its range is reusable by
- * any context of the device right after the call) — so a buffer may be freed while the launch that writes it is still running.  Not inside a
- * stream capture. */
+/* Releases a buffer of hrx_alloc_output_pair / hrx_alloc_outputs_position_major / hrx_alloc_output_planes (NULL: nothing).  As with hipFree, the memory is not
+ * handed out again before the buffer's device has finished everything in flight, so a buffer may be freed while the launch that writes it is still running.  A buffer of
+ * its own: hipFree (which waits).  A sub-buffer of a shared arena: the call returns at once — from any thread, also while another thread captures a stream — and the range
+ * is parked; a later allocation whose request does not fit otherwise waits for the device once and takes the parked ranges back. */
 int hrx_device_free(void *ptr);
 /* Which kernel and launch geometry the planner picks for a batch of B strings x M rows in `layout` on a gfx950 device
  * with `num_cus` compute units (MI355X: 256), as text: "hrx::witness_pm_kernel<1, false, false, false, false, false> grid=256

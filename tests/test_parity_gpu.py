@@ -1313,11 +1313,11 @@ def test_context_clones_run_side_by_side(hra, oracle):
     assert np.array_equal(one.masked_characters.astype(np.uint16) | (one.all_substr_ids.astype(np.uint16) << 8), omsk[0])
 
 
-def test_arena_free_waits_for_the_device(hra, oracle):
-    """hrx_device_free on a sub-buffer of the shared arena pair waits for the device like hipFree does (include/hrx.h): the range is reusable by any
-    context right after the call, so a buffer freed while its launch is still in flight must not be handed to a second context that writes it on
-    another stream.  Context a queues launches into arena buffers on its own stream and frees them WITHOUT syncing; when the free returns that stream
-    has drained; context b then gets the very same ranges (first fit) and its rows — written on another stream — are the oracle's."""
+def test_freed_arena_range_is_not_reused_before_the_device_has_drained(hra, oracle):
+    """hrx_device_free on a sub-buffer of the shared arena pair (include/hrx.h): the range is not handed out again before the device has drained, so a buffer freed while
+    its launch is still in flight never reaches a second context that writes it on another stream.  Context a queues launches into arena buffers on its own stream and frees
+    them WITHOUT syncing: the free returns at once (the range is parked); context b allocates until the arena has nothing else left — the allocation that takes the parked
+    range back has waited for the device — and its rows, written on another stream, are the oracle's."""
     import gc
     import torch
     from halo2_regex_amd import synth
@@ -1338,9 +1338,17 @@ def test_arena_free_waits_for_the_device(hra, oracle):
     assert not s1.query()                                               # still in flight
     del out_a
     gc.collect()                                                        # -> hrx_device_free of both sub-buffers, no sync by the caller
-    assert s1.query(), "hrx_device_free returned while launches into the freed arena range were still running"
-    out_b = b.alloc_outputs_position_major(B, dev)
-    assert (out_b[0].data_ptr(), out_b[1].data_ptr()) == ptr_a          # the freed ranges, handed to another context at once
+    held, out_b = [], None
+    for _ in range(16):                                                 # (a 2-GiB arena has eight 256-MiB ranges)
+        o = b.alloc_outputs_position_major(B, dev)
+        if o[0].data_ptr() == ptr_a[0]:
+            out_b = o
+            break
+        assert s1.query() or o[0].data_ptr() != ptr_a[0]
+        held.append(o)
+    assert out_b is not None, "the freed range never came back: the arena pair was replaced instead"
+    assert s1.query(), "a freed arena range was handed out while launches into it were still running"
+    del held
     with torch.cuda.stream(s2):
         rec, msk, st = b.witness_batch_position_major(d_c, d_l, out=out_b, chars_pm_stride=chars.shape[1])
     torch.cuda.synchronize()
@@ -1349,6 +1357,67 @@ def test_arena_free_waits_for_the_device(hra, oracle):
     ok = torch.from_numpy((ost & np.uint64(0xff)) == 0).to(dev)
     assert np.array_equal(st.cpu().numpy().view(np.uint64), ost)
     assert torch.equal(r2[ok], torch.from_numpy(orec.view(np.int32)).to(dev)[ok]) and torch.equal(m2[ok], torch.from_numpy(omsk.view(np.int16)).to(dev)[ok])
+    del keep
+
+
+def test_arena_free_does_not_disturb_a_capture_in_another_thread(hra, oracle):
+    """While any thread captures a stream in the global capture mode (torch.cuda.graph's default) the runtime refuses a device-wide wait — and in the relaxed mode the wait
+    invalidates that capture: hrx_device_free of an arena sub-buffer from another thread therefore does not wait at all (the range is parked), and the capture survives it."""
+    import gc
+    import threading
+    import torch
+    from halo2_regex_amd import synth
+    dev = torch.device("cuda", 0)
+    M, B = 1024, 65536
+    chars, lens = synth.reveal_stress(B, M - 1, seed=33)
+    d_c, d_l = hra.chars_to_position_major(torch.from_numpy(chars).to(dev)), torch.from_numpy(lens.astype(np.int32)).to(dev)
+    a, c = _cfg(hra, CFG_1, M), _cfg(hra, CFG_1, M)
+    keep = a.alloc_outputs_position_major(B, dev)
+    out_a = a.alloc_outputs_position_major(B, dev)
+    out_c = c.alloc_outputs_position_major(B, dev)
+    s1 = torch.cuda.Stream(device=dev)
+    inside, freed, result = threading.Event(), threading.Event(), {}
+
+    def capturer():
+        try:
+            torch.cuda.set_device(0)
+            side = torch.cuda.Stream(device=dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="global"):
+                    c.witness_batch_position_major(d_c, d_l, out=out_c, chars_pm_stride=chars.shape[1])
+                    inside.set()
+                    freed.wait(60)
+                    c.witness_batch_position_major(d_c, d_l, out=out_c, chars_pm_stride=chars.shape[1])
+            g.replay()
+            torch.cuda.synchronize()
+            result["ok"] = True
+        except Exception as e:      # noqa: BLE001
+            result["error"] = repr(e)
+            inside.set()
+
+    with torch.cuda.stream(s1):       # (first launches allocate the contexts' scratch, and a context that changes streams waits for the old one on the host: not while a capture is open)
+        a.witness_batch_position_major(d_c, d_l, out=out_a, chars_pm_stride=chars.shape[1])
+    c.witness_batch_position_major(d_c, d_l, out=out_c, chars_pm_stride=chars.shape[1])
+    torch.cuda.synchronize()
+    t = threading.Thread(target=capturer)
+    t.start()
+    assert inside.wait(60) and "error" not in result, result
+    import time
+    t0 = time.perf_counter()
+    with torch.cuda.stream(s1):
+        for _ in range(100):          # ~8 ms of queued work writing out_a (a stream query is itself refused while the other thread captures: the clock tells)
+            a.witness_batch_position_major(d_c, d_l, out=out_a, chars_pm_stride=chars.shape[1])
+    t_queued = time.perf_counter() - t0
+    del out_a                         # hrx_device_free of both sub-buffers while the other thread's capture is open (the collector's own pass below is not on the clock)
+    t_freed = time.perf_counter() - t0
+    gc.collect()
+    assert t_freed < 0.006, "hrx_device_free waited (queued %.4f s, freed %.4f s)" % (t_queued, t_freed)
+    freed.set()
+    t.join(120)
+    assert result.get("ok"), result
+    orec, omsk, ost = OracleDefs.from_files(oracle, CFG_1).witness_batch(chars[:2048], lens[:2048], M, threads=os.cpu_count() or 8)
+    assert np.array_equal(out_c[2].cpu().numpy().view(np.uint64)[:2048], ost)
     del keep
 
 
