@@ -72,6 +72,8 @@ def parse_args(argv=None):
                     "(hrx_witness_batch_device_planes, buffers from hrx_alloc_output_planes: a pool of candidates, their pairings, a dry launch); the line then also times the interleaved "
                     "layout / the pair walk's buffers over as many buffer sets (interleaved_layout).  One def: one records buffer from the same allocator (--stripes 2: two row stripes)")
     ap.add_argument("--stripes", type=int, default=1, choices=[1, 2], help="--planes with one def: the records in this many row stripes")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="N=V", help="hrx_ctx_set_option(N, V) on the context before anything runs (include/hrx.h HRX_OPT_*), e.g. 6=2: four defs "
+                    "with one group per workgroup; the line carries it in config.ctx_options")
     ap.add_argument("--planes-stand-in", action="store_true", help="--planes: the allocator chooses with launches over a constant stand-in input (hrx_alloc_output_planes) instead of this "
                     "run's batch (hrx_alloc_output_planes_for_batch)")
     ap.add_argument("--probes", action="store_true", help="also run the side probes earlier rounds' documents cite (all after the timed region): the same launches over ONE buffer set, "
@@ -451,6 +453,8 @@ def run_rank(args, rank, world, device_index, barrier):
     stride = rec_stride
     defs = [hra.RegexDefs(hra.AllstrRegexDef(a), [hra.SubstrRegexDef(t) for t in subs]) for a, subs in names]
     cfg = hra.RegexVerifyConfig.configure(M, defs, device=device_index)
+    for kv in args.ctx_option:
+        cfg.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     if under_profiler():
         cfg.set_option(hra.OPT_PLACE_DRY_LAUNCH, 0)      # the profiler's per-kernel averages then cover this script's launches only, not the allocator's launches into candidate sets
 
@@ -898,7 +902,7 @@ def run_rank(args, rank, world, device_index, barrier):
     res["config"] = {"workload": "%s DFA (D=%d), %d x %d-byte strings per GPU (n=%d chars, M=%d witness rows), %s"
                                  % (label, D, B, stride, n, M, "uniform noise over the %s%s%s" % (alphabet, " + planted match" if planted else "",
                                     "" if nd == B else "; %d distinct strings, the batch = %d blocks of them, block j rotated by %d j strings" % (nd, (B + nd - 1) // nd, sb))),
-                     "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)",
+                     "batch_per_gpu": B, "n": n, "max_chars_size": M, "defs": D, "rows_counted": "sum of n (character positions)", "ctx_options": list(args.ctx_option),
                      "buffers": ("HRX_LAYOUT_POSITION_MAJOR | HRX_LAYOUT_INPUT_POSITION_MAJOR with RECORD PLANES (blocks of 65536 strings): chars [%d/16][B][16], %s, "
                                  "masked [M/8][B][8] (include/hrx.h hrx_witness_batch_device_planes); the %d + 1 output buffers from "
                                  "hrx_alloc_output_planes (each in a neighbourhood of the device memory of its own)" % (stride, "every def's records [M/4][B][4] in a buffer of its own" if D > 1 else
