@@ -848,138 +848,6 @@ long hrx_ctx_get_option(const hrx_ctx *ctx, int option) {
     }
 }
 
-static int describe_set(const DefsSet &s, int layout, size_t B, size_t M, int num_cus, std::string &out, bool summary_pass, const uint32_t dbg, const uint32_t tune) {
-    WitnessArgs a{};
-    a.layout = (uint32_t)layout; a.B = (uint32_t)B; a.M = (uint32_t)M;
-    // the planner only looks at which images exist and how large they are
-    a.table_image = s.table_image.data(); a.table_bytes = (uint32_t)(s.table_image.size() * 4);
-    a.wide_image = s.wide_image.empty() ? nullptr : s.wide_image.data();
-    a.half_image = s.half_image.empty() ? nullptr : s.half_image.data();
-    a.half_bytes = (uint32_t)(s.half_image.size() * 2);
-    a.pair_image = s.pair.image.empty() ? nullptr : s.pair.image.data(); a.pair_bytes = s.pair.bytes; a.pair_classes = s.pair.n_classes;
-    a.pair_blk_bytes = s.pair.blk_bytes; a.pair_lut_off = s.pair.lut_off;
-    a.byte_image = s.byte.image.empty() ? nullptr : s.byte.image.data(); a.byte_bytes = s.byte.bytes; a.byte_dead = s.byte.dead; a.byte16_bytes = s.byte.bytes16;
-    a.D = (uint32_t)s.defs.size();
-    a.debug = dbg;   // hrx_describe_launch: what a context created now would run with (kernel-selection bits only in a release build); hrx_ctx_describe_launch: the context's
-    a.tune = tune;
-    if (layout & HRX_LAYOUT_RECORD_PLANES) {     // the launch hrx_witness_batch_device_planes makes (launch_batch)
-        a.layout &= ~(uint32_t)HRX_LAYOUT_RECORD_PLANES;
-        layout &= ~HRX_LAYOUT_RECORD_PLANES;
-        a.rec_planes[0] = reinterpret_cast<unsigned char *>(16);
-        if (a.D == 1) { a.rec_stripes = 2; a.debug |= kDbgNoPair | kDbgNoSpec; }      // (one def: described with its two row stripes)
-    }
-    if (summary_pass) a.debug |= kDbgNoPair | kDbgNoDefParallel;   // (launch_batch: a pass of a multi-pass config is the loader / walker / finisher kernel)
-    LaunchInfo li;
-    if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
-    if (summary_pass && li.half) {
-        a.debug |= kDbgForceGlobalTable;
-        if (!plan_witness_launch(a, num_cus, li)) return fail(HRX_ERR_BOUNDS, "tables + staging do not fit the 160 KiB LDS");
-    }
-    char name[128], line[256];
-    const char *tf[2] = {"false", "true"};
-    // the names rocprofv3 lists: every template argument spelled out, defaulted ones too (an exact-match join with a kernel_stats.csv works)
-    if (li.split == 6) std::snprintf(name, sizeof name, "hrx::witness_pp_kernel");
-    else if (li.split == 5) std::snprintf(name, sizeof name, "hrx::witness_pmd_kernel<%u, %s>", a.D, a.cw_image ? ((a.layout & 1u) ? "true, true, false" : "true, true, true") : li.pmd_fin ? "false, true, false" : "false, false, false");
-    else if (li.split == 2) std::snprintf(name, sizeof name, "hrx::witness_pm_kernel<%u, %s, %s, %s, %s, %s>", a.D, tf[li.gtab], tf[li.wide], tf[li.half], tf[!(layout & 1)], tf[li.byte]);
-    else if (li.split == 1) std::snprintf(name, sizeof name, "hrx::witness_split_kernel<%u, %u, %s>", a.D, li.byte ? 32u : 32u / a.D, tf[li.byte]);
-    else std::snprintf(name, sizeof name, "hrx::witness_kernel<%u, %s, %s>", a.D, tf[(M % 8) == 0], tf[li.gtab]);
-    std::snprintf(line, sizeof line, "%s grid=%d waves=%d ring=%d lds=%zu%s", name, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes, li.dyn ? " groups=dynamic" : "");
-    out = line;
-    if (li.spec_tiles) {
-        std::snprintf(line, sizeof line, " chunked=%dx%d tiles: hrx::spec_scout_kernel + hrx::spec_compose_kernel before, hrx::spec_stitch_kernel behind", li.spec_chunks, li.spec_tiles);
-        out += line;
-    }
-    return HRX_OK;
-}
-
-static int describe_config(const DefsSet &s, const uint32_t dbg, const uint32_t tune, const bool mpc_on, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap) {
-    std::string text;
-    if (s.groups.empty()) {
-        const bool byte_split = !s.byte.image.empty() && !(dbg & (kDbgNoByte | kDbgForceHalf));
-        const bool via_tp = layout == HRX_LAYOUT_STRING_MAJOR && M % 8 == 0 && !byte_split &&
-                            (!s.byte.image.empty() || !s.half_image.empty()) && s.table_image.size() * 4 + wave_stage_bytes((int)s.defs.size(), 16) > kLdsLimit;
-        const int rc = describe_set(s, via_tp ? HRX_LAYOUT_POSITION_MAJOR : layout, B, M, num_cus, text, false, dbg, tune);
-        if (rc != HRX_OK) return rc;
-        if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
-    } else if ([&] {   // four and five defs, string-major rows in multiples of 16: the def-parallel launch writes them itself
-                   if (s.cw_image.empty() || mpc_on || layout != HRX_LAYOUT_STRING_MAJOR) return false;
-                   WitnessArgs a{};
-                   a.layout = HRX_LAYOUT_STRING_MAJOR; a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)s.defs.size();
-                   a.debug = dbg;
-                   a.cw_image = s.cw_image.data(); a.table_bytes = (uint32_t)s.cw_image.size();
-                   LaunchInfo li{};
-                   if (!plan_pmd_cw_sm(a, num_cus, li)) return false;
-                   char buf[256];
-                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true, true> grid=%d waves=%d ring=%d sub-tiles=%u lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, a.sm_bufs, li.lds_bytes);
-                   text = buf;
-                   return true;
-               }()) {
-    } else if ([&] {   // 6 or 7 defs with CLASS-WIDE tables: one def-parallel launch over the whole config (position-major; string-major rows in multiples of 8 through the transposer)
-                   const bool tp = !(layout & 1) && M % 8 == 0;
-                   if (s.cw_image.empty() || mpc_on || !((layout & 1) || tp)) return false;
-                   WitnessArgs a{};
-                   a.layout = HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR); a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)s.defs.size();
-                   a.debug = dbg;
-                   a.cw_image = s.cw_image.data(); a.table_bytes = (uint32_t)s.cw_image.size();
-                   LaunchInfo li{};
-                   if (!plan_pmd_cw(a, num_cus, li)) return false;
-                   char buf[256];
-                   std::snprintf(buf, sizeof buf, "hrx::witness_pmd_kernel<%u, true, true, false> grid=%d waves=%d ring=%d lds=%zu", a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
-                   text = buf;
-                   if (tp) text += " + hrx::transpose_pm_to_sm_kernel";
-                   return true;
-               }()) {
-    } else if ([&] {   // more than eight defs with CW groups: one def-parallel launch per group of 4 .. 8 defs, then the combine launch
-                   const bool tp = !(layout & 1) && M % 8 == 0;
-                   if (s.cw_groups.empty() || !((layout & 1) || tp) || (dbg & kDbgNoDefParallel)) return false;
-                   std::string t2 = "multi-pass, " + std::to_string(s.cw_groups.size()) + " groups: ";
-                   for (size_t g = 0; g < s.cw_groups.size(); ++g) {
-                       WitnessArgs a{};
-                       a.layout = HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR); a.B = (uint32_t)B; a.M = (uint32_t)M; a.D = (uint32_t)s.cw_groups[g].defs.size();
-                       a.cw_image = s.cw_groups[g].cw_image.data(); a.table_bytes = (uint32_t)s.cw_groups[g].cw_image.size();
-                       LaunchInfo li{};
-                       if (!plan_pmd_cw(a, num_cus, li)) return false;
-                       char buf[256];
-                       std::snprintf(buf, sizeof buf, "[defs %u..%zu: hrx::witness_pmd_kernel<%u, true, true, false> grid=%d waves=%d ring=%d lds=%zu] ", s.cw_group_first[g],
-                                     s.cw_group_first[g] + s.cw_groups[g].defs.size() - 1, a.D, li.grid, li.waves_per_wg, li.nslots, li.lds_bytes);
-                       t2 += buf;
-                   }
-                   text = t2 + "+ hrx::witness_combine_summary_kernel";
-                   if (tp) text += " + hrx::transpose_pm_to_sm_kernel";
-                   return true;
-               }()) {
-    } else {   // one launch per group of defs (position-major, the caller's input layout), then the combine kernel
-        text = "multi-pass, " + std::to_string(s.groups.size()) + " groups: ";
-        for (size_t g = 0; g < s.groups.size(); ++g) {
-            std::string one;
-            const bool tp = !(layout & 1) && M % 8 == 0;
-            const int rc = describe_set(s.groups[g], HRX_LAYOUT_POSITION_MAJOR | (layout & HRX_LAYOUT_INPUT_POSITION_MAJOR), B, M, num_cus, one, (layout & 1) != 0 || tp, dbg, tune);
-            if (rc != HRX_OK) return rc;
-            text += "[defs " + std::to_string(s.group_first[g]) + ".." + std::to_string(s.group_first[g] + s.groups[g].defs.size() - 1) + ": " + one + "] ";
-        }
-        const bool via_tp = !(layout & 1) && M % 8 == 0;
-        const bool merge_last = ((layout & 1) || via_tp) && s.groups.size() - 1 <= kMaxMergeGroups && !mpc_on;
-        text += merge_last ? "(the last pass merges the summaries) + hrx::witness_merge_status_kernel"
-                           : (layout & 1) || via_tp ? "+ hrx::witness_combine_summary_kernel" : "+ hrx::witness_combine_kernel<true>";
-        if (via_tp) text += " + hrx::transpose_pm_to_sm_kernel";
-    }
-    std::snprintf(out, cap, "%s", text.c_str());
-    return HRX_OK;
-}
-
-int hrx_describe_launch(const hrx_defs *defs, int layout, size_t B, size_t M, int num_cus, char *out, size_t cap) {
-    if (!defs || !out || !cap) return fail(HRX_ERR_ARG, "NULL argument");
-    if (!defs->s.finalized) return fail(HRX_ERR_STATE, "call hrx_defs_finalize first");
-    if (num_cus < 1) return fail(HRX_ERR_ARG, "num_cus must be >= 1");
-    const char *mpc = std::getenv("HRX_MP_COMBINE");      // (what hrx_ctx_create would read now)
-    return describe_config(defs->s, debug_flags_from_env(), 0u, mpc && std::atoi(mpc) != 0, layout, B, M, num_cus, out, cap);
-}
-
-int hrx_ctx_describe_launch(const hrx_ctx *ctx, int layout, size_t B, size_t M, char *out, size_t cap) {
-    if (!ctx || !out || !cap) return fail(HRX_ERR_ARG, "NULL argument");
-    return describe_config(ctx->s, ctx->debug, ctx->tune, ctx->mp_combine, layout, B, M, ctx->num_cus > 0 ? ctx->num_cus : 256, out, cap);
-}
-
 size_t hrx_fr_num_columns(size_t D) { return 4 + 4 * D; }
 
 void hrx_fr_from_u64(uint64_t v, int flags, uint64_t *limbs) {
@@ -1126,168 +994,6 @@ void hrx_recommended_pitches(size_t M, size_t *rec_pitch, size_t *msk_pitch, siz
     if (rec_pitch) *rec_pitch = m64 + 32;
     if (msk_pitch) *msk_pitch = m64 + 64;
     if (chars_stride) *chars_stride = (M + 127) / 128 * 128 + 128;
-}
-
-/* ------------------------------ single-string entry points ------------------------------ */
-
-static int status_to_error(uint64_t sw) {
-    switch (sw & 0xff) {
-        case kStatusOk: return HRX_OK;
-        case kStatusInvalidTransition: {
-            char buf[96];
-            // the reference's panic text, lib.rs:817
-            std::snprintf(buf, sizeof buf, "The transition from %u by %u is invalid!", (unsigned)((sw >> 24) & 0xffff),
-                          (unsigned)((sw >> 16) & 0xff));
-            return fail(HRX_ERR_INVALID_TRANSITION, buf);
-        }
-        case kStatusFlagOverlap:
-            return fail(HRX_ERR_OUT_OF_CONTRACT, "two regex defs raise a start/end flag on row " + std::to_string(sw >> 40));
-        default: return fail(HRX_ERR_OUT_OF_CONTRACT, "input longer than max_chars_size");
-    }
-}
-
-// One string with M rows -> host copies of the compact outputs.  A single string is the host walk's case (one GPU lane
-// needs ~50 ns per row, a host core ~3); the batch kernel serves it only when HRX_DEBUG_FLAGS says so (the GPU tests).
-static int run_one(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t M, std::vector<uint32_t> &rec,
-                   std::vector<uint16_t> &msk, uint64_t &sw) {
-    const size_t D = ctx->s.defs.size();
-    rec.assign(M * D, 0);
-    msk.assign(M, 0);
-    if (int rc = check_host_shape(1, M)) return rc;
-    if (ctx->device == HRX_DEVICE_NONE || !(ctx->debug & kDbgNoHost)) {
-        sw = host_witness_one(ctx->s, characters, n, M, rec.data(), msk.data());
-        return HRX_OK;
-    }
-    const uint32_t len = (uint32_t)n;
-    std::vector<uint8_t> tmp((n + 15) & ~(size_t)15, 0);
-    if (n) std::memcpy(tmp.data(), characters, n);
-    if (tmp.empty()) tmp.resize(16, 0);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
-    return batch_host_locked(ctx, tmp.data(), tmp.size(), &len, 1, M, rec.data(), msk.data(), &sw);
-}
-
-static bool single_on_device(const hrx_ctx *ctx) { return ctx->device != HRX_DEVICE_NONE && (ctx->debug & kDbgNoHost); }
-
-int hrx_derive_states(hrx_ctx *ctx, const uint8_t *characters, size_t n, uint64_t *states) {
-    if (!ctx || (!characters && n) || !states) return fail(HRX_ERR_ARG, "NULL argument");
-    const size_t D = ctx->s.defs.size();
-    if (!single_on_device(ctx)) {
-        uint32_t bs = 0, bc = 0;
-        if (!host_derive_states(ctx->s, characters, n, states, bs, bc)) return status_to_error(status_invalid(0, 0, bs, bc));
-        return HRX_OK;
-    }
-    const size_t M = n + 1;  // row n holds states[d][n] (lib.rs:406-411)
-    std::vector<uint32_t> rec;
-    std::vector<uint16_t> msk;
-    uint64_t sw = 0;
-    if (int rc = run_one(ctx, characters, n, M, rec, msk, sw)) return rc;
-    if ((sw & 0xff) == kStatusInvalidTransition) return status_to_error(sw);   // (records of such a string are unspecified)
-    for (size_t d = 0; d < D; ++d)
-        for (size_t i = 0; i <= n; ++i) states[d * (n + 1) + i] = rec[i * D + d] & 0xffffu;
-    return HRX_OK;
-}
-
-static int pair_tags_any(hrx_ctx *ctx, const uint64_t *states, size_t n, std::vector<uint16_t> &tags) {
-    const size_t D = ctx->s.defs.size();
-    tags.assign(n * D, 0);
-    if (n == 0) return HRX_OK;
-    if (!single_on_device(ctx)) {
-        host_pair_tags(ctx->s, states, n, tags.data());
-        return HRX_OK;
-    }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard guard;
-    HIP_TRY(guard.set(ctx->device));
-    HIP_TRY(ctx->states.reserve(8 * D * (n + 1)));
-    HIP_TRY(ctx->tags.reserve(2 * D * n));
-    HIP_TRY(hipMemcpyAsync(ctx->states.p, states, 8 * D * (n + 1), hipMemcpyHostToDevice, ctx->stream));
-    std::vector<uint32_t> ns(D);
-    std::vector<const uint16_t *> pt(D);
-    for (size_t d = 0; d < D; ++d) { ns[d] = (uint32_t)ctx->s.defs[d].allstr.largest_state_val + 1; pt[d] = ctx->d_pair[d]; }
-    HIP_TRY(launch_pair_tags((const uint64_t *)ctx->states.p, n, (uint32_t)D, pt.data(), ns.data(), (uint16_t *)ctx->tags.p, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(tags.data(), ctx->tags.p, 2 * D * n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return HRX_OK;
-}
-
-int hrx_derive_substr_ids(hrx_ctx *ctx, const uint64_t *states, size_t n, uint64_t *substr_ids) {
-    if (!ctx || !states || (!substr_ids && n)) return fail(HRX_ERR_ARG, "NULL argument");
-    std::vector<uint16_t> tags;
-    if (int rc = pair_tags_any(ctx, states, n, tags)) return rc;
-    for (size_t i = 0; i < tags.size(); ++i) substr_ids[i] = tags[i] & 0xffu;
-    return HRX_OK;
-}
-
-int hrx_derive_is_start_end(hrx_ctx *ctx, const uint64_t *states, const uint64_t *substr_ids, size_t n,
-                            uint8_t *is_start, uint8_t *is_end) {
-    if (!ctx || !states || !is_start || !is_end || (!substr_ids && n)) return fail(HRX_ERR_ARG, "NULL argument");
-    const size_t D = ctx->s.defs.size();
-    std::vector<uint8_t> flags(n * D, 0);
-    if (n && !single_on_device(ctx)) {
-        host_endpoint_flags(ctx->s, states, substr_ids, n, flags.data());
-    } else if (n) {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        DeviceGuard guard;
-        HIP_TRY(guard.set(ctx->device));
-        HIP_TRY(ctx->states.reserve(8 * D * (n + 1)));
-        HIP_TRY(ctx->tags.reserve(8 * D * n + D * n));
-        uint64_t *d_sids = (uint64_t *)ctx->tags.p;
-        uint8_t *d_flags = (uint8_t *)ctx->tags.p + 8 * D * n;
-        HIP_TRY(hipMemcpyAsync(ctx->states.p, states, 8 * D * (n + 1), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_sids, substr_ids, 8 * D * n, hipMemcpyHostToDevice, ctx->stream));
-        EndpointArgs a{};
-        a.states = (const uint64_t *)ctx->states.p; a.substr_ids = d_sids; a.n = n; a.D = (uint32_t)D; a.flags = d_flags;
-        std::vector<const uint8_t *> member(D);
-        std::vector<uint32_t> dims(3 * D);
-        for (size_t d = 0; d < D; ++d) {
-            member[d] = ctx->d_member[d];
-            dims[3 * d] = (uint32_t)ctx->s.defs[d].allstr.largest_state_val + 1;
-            dims[3 * d + 1] = (uint32_t)ctx->s.defs[d].substrs.size();
-            dims[3 * d + 2] = ctx->s.consts[d].substr_id_offset;
-        }
-        HIP_TRY(launch_endpoint_flags(a, member.data(), dims.data(), ctx->stream));
-        HIP_TRY(hipMemcpyAsync(flags.data(), d_flags, D * n, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    for (size_t d = 0; d < D; ++d) {
-        for (size_t i = 0; i < n; ++i) {
-            is_start[d * (n + 1) + i] = flags[d * n + i] & 1;
-            is_end[d * (n + 1) + i + 1] = (flags[d * n + i] >> 1) & 1;
-        }
-        is_start[d * (n + 1) + n] = 0;  // lib.rs:869
-        is_end[d * (n + 1)] = 0;        // lib.rs:882
-    }
-    return HRX_OK;
-}
-
-int hrx_match_substrs(hrx_ctx *ctx, const uint8_t *characters, size_t n, size_t M, uint64_t *enable, uint64_t *character,
-                      uint64_t *state, uint64_t *substr_id, uint64_t *start_enable, uint64_t *end_enable,
-                      uint64_t *masked_char, uint64_t *masked_substr_id, uint64_t *status) {
-    if (!ctx || (!characters && n)) return fail(HRX_ERR_ARG, "NULL argument");
-    if (n > M) return fail(HRX_ERR_OUT_OF_CONTRACT, "input longer than max_chars_size");
-    const size_t D = ctx->s.defs.size();
-    std::vector<uint32_t> rec;
-    std::vector<uint16_t> msk;
-    uint64_t sw = 0;
-    if (int rc = run_one(ctx, characters, n, M, rec, msk, sw)) return rc;
-    if (status) *status = sw;
-    if (int rc = status_to_error(sw)) return rc;
-    for (size_t r = 0; r < M; ++r) {
-        if (enable) enable[r] = r < n ? 1 : 0;                          // lib.rs:339-348
-        if (character) character[r] = r < n ? characters[r] : 0;
-        for (size_t d = 0; d < D; ++d) {
-            const uint32_t w = rec[r * D + d];
-            if (state) state[d * M + r] = w & 0xffffu;
-            if (substr_id) substr_id[d * M + r] = (w >> 16) & 0xffu;
-            if (start_enable) start_enable[d * M + r] = (w >> 24) & 1u;
-            if (end_enable) end_enable[d * M + r] = (w >> 25) & 1u;
-        }
-        if (masked_char) masked_char[r] = msk[r] & 0xffu;
-        if (masked_substr_id) masked_substr_id[r] = msk[r] >> 8;
-    }
-    return HRX_OK;
 }
 
 }  // extern "C"

@@ -1,4 +1,4 @@
-// hrx_ctx.hpp — what the translation units of the C ABI share (hrx_api.cpp: data model, contexts, the device entry points; hrx_place_api.cpp: placement-aware allocation and
+// hrx_ctx.hpp — what the translation units of the C ABI share (hrx_api.cpp: data model, contexts, the device entry points; hrx_describe_api.cpp, hrx_single_api.cpp: what their names say; hrx_place_api.cpp: placement-aware allocation and
 // the roofline diagnostics; hrx_host_api.cpp: host-buffer batches and the multi-GPU driver; hrx_regex_api.cpp: definition generation): the handle structs, the error / device
 // helpers and the few internal functions that cross the files.  Not installed, not part of include/hrx.h.
 #pragma once
