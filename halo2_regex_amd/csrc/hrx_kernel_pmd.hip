@@ -69,6 +69,7 @@ __global__ __launch_bounds__(FIN && (D >= 7 || (!CW && D >= 3)) ? 640 : 512) voi
     // PA: the WIDE kernel with a combiner wave (cfg 4: three defs, two groups per workgroup, ten waves) has no LDS left for the walkers' 2-KiB status pieces — 75 KiB of tables,
     // two rings, six walkers' summaries: a walker's piece lies in its first summary slot, written when the combiner has read the group's last summary (pmd_fin_group_bytes)
     constexpr bool PA = FIN && !CW;
+    constexpr int kMergeUnroll = D >= 7 ? 1 : 8;      // (the combiner's merge loop: rolled at seven and eight defs, see there)
     constexpr uint32_t kSubS = 16u * D + 4u;              // SMO: dwords per string of a sub-tile buffer
     constexpr uint32_t kSubBytes = 64u * kSubS * 4u;
     constexpr int RS = CW ? kCwRowShift : kWideRowShift;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(FIN && (D >= 7 || (!CW && D >= 3)) ? 640 : 512) voi
                 __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll(D >= 7 ? 1 : 8)
+#pragma unroll kMergeUnroll
             for (uint32_t dd = 0; dd + 1u < W; ++dd) {
                 const uint32_t sa = wbase + dd * walker_bytes + (seq & 1u) * kSumBytes + lane * 80u;
                 const uint4 h = lds_u128(sa);
