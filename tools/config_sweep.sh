@@ -3,7 +3,7 @@
 # Round 6: every position-major line of two or more defs twice — interleaved records and RECORD PLANES (--planes: buffers from hrx_alloc_output_planes_for_batch); cfg 5 also
 # on its one records buffer chosen the same way.
 # Every line in the HBM-only regime (the timed steps rotate over as many buffer sets as fit 48 GiB, up to 8) and verified over every string.
-cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r06_config_sweep; rm -rf $O; mkdir -p $O
+cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r06_config_sweep${SWEEP_TAG:-}; rm -rf $O; mkdir -p $O
 B="python3 bench.py --no-cpu-baseline --no-pmc"
 $B                                                                                   > $O/cfg2_regex1_65536x1024.json
 $B --layout string-major                                                             > $O/cfg2_regex1_65536x1024_string_major.json
